@@ -1,0 +1,86 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Loads the *real* reference (dfm/george) for oracle pinning:
+
+* ``load_kernel_interface()`` -- the reference's own C++ kernel evaluator
+  (``/root/reference/src/george/kernel_interface.cpp``), compiled by
+  ``oracle/Makefile`` into ``oracle/_ref/``.  The shared object travels to the
+  GPU box, so this works there too (it only needs a *spec object* exposing the
+  attributes ``parser.h:14-35,344-403`` reads -- our own host classes do).
+* ``load_reference()`` -- the full reference Python package, assembled from
+  the sources where they lie under ``/root/reference`` (nothing is copied)
+  plus the compiled ``kernel_interface``.  Only possible in the build
+  container; returns ``None`` when ``/root/reference`` is absent.
+
+The reference's ``_hodlr`` extension cannot be built (Eigen submodule is
+empty), so it is replaced by a stub whose solver raises on construction.
+"""
+import glob
+import importlib.util
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_ROOT = os.environ.get("GEORGE_REFERENCE", "/root/reference")
+REF_SRC = os.path.join(REF_ROOT, "src", "george")
+
+
+def _so_path():
+    hits = glob.glob(os.path.join(HERE, "_ref", "kernel_interface*.so"))
+    return hits[0] if hits else None
+
+
+def load_kernel_interface():
+    """Return the reference ``KernelInterface`` class, or None if not built."""
+    if "george.kernel_interface" in sys.modules:
+        return sys.modules["george.kernel_interface"].KernelInterface
+    if "_george_ref_kernel_interface" in sys.modules:
+        return sys.modules["_george_ref_kernel_interface"].KernelInterface
+    so = _so_path()
+    if so is None:
+        return None
+    # PyInit_kernel_interface is looked up from the last dotted component.
+    spec = importlib.util.spec_from_file_location("kernel_interface", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["_george_ref_kernel_interface"] = mod
+    return mod.KernelInterface
+
+
+def load_reference():
+    """Import the reference package as ``george`` (build container only)."""
+    if "george" in sys.modules and getattr(sys.modules["george"], "_is_oracle_ref", False):
+        return sys.modules["george"]
+    if not os.path.isdir(REF_SRC):
+        return None
+    KI = load_kernel_interface()
+    if KI is None:
+        return None
+
+    init = os.path.join(REF_SRC, "__init__.py")
+    spec = importlib.util.spec_from_file_location(
+        "george", init, submodule_search_locations=[REF_SRC])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["george"] = pkg
+
+    # normally written by setuptools_scm (pyproject.toml:27-28)
+    ver = types.ModuleType("george.george_version")
+    ver.version = "0.4.0+oracle"
+    sys.modules["george.george_version"] = ver
+
+    ki = types.ModuleType("george.kernel_interface")
+    ki.KernelInterface = KI
+    sys.modules["george.kernel_interface"] = ki
+
+    class _NoHODLR(object):
+        def __init__(self, *a, **k):
+            raise ImportError("reference _hodlr needs Eigen (un-vendored submodule); not buildable here")
+
+    hod = types.ModuleType("george.solvers._hodlr")
+    hod.HODLRSolver = _NoHODLR
+    sys.modules["george.solvers._hodlr"] = hod
+
+    spec.loader.exec_module(pkg)
+    pkg._is_oracle_ref = True
+    return pkg
