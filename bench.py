@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Headline benchmark: GP ``compute()`` + ``log_likelihood()`` (BASELINE.json metric).
+
+One "step" = one full pass of the hot path on synthetic inputs that are already resident in HBM:
+build K(x, x) + diag(yerr^2) on the device, blocked fp64 Cholesky, log-det, forward solve and
+r^T K^-1 r -> log-likelihood.  Inputs follow the reference's only benchmark
+(docs/tutorials/scaling.rst:56-59,67 / SURVEY.md 8d).
+
+    python bench.py --gpus N --steps K --warmup W [--n 65536] [--nb 512]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL): the dense factorisation is
+sharded block-cyclically over the ranks (george_amd/distributed.py) -- same N, strong scaling.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X datasheet fp64 matrix peak; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+
+
+def flops_alg(n):
+    return n ** 3 / 3.0 + 2.0 * n ** 2           # potrf + potrs
+
+
+def make_inputs(n, seed=1234):
+    rng = np.random.RandomState(seed)
+    x = np.sort(rng.uniform(0, 10, n))
+    return x, 0.1 * np.ones(n), np.sin(x)
+
+
+def cpu_baseline(n_cpu):
+    """The reference's CPU path on this host, bounded sample: its own compiled C++ kernel
+    evaluator (oracle/_ref) when present + the same SciPy LAPACK calls as basic.py:64-70,102."""
+    import george_amd.kernels as K
+    from oracle import solver_np
+    x, yerr, y = make_inputs(n_cpu)
+    kernel = np.var(y) * K.ExpSquaredKernel(1.0)
+    kind = solver_np.evaluator_kind()
+    t0 = time.perf_counter()
+    solver = solver_np.DenseOracle(kernel)
+    ll = solver_np.gp_log_likelihood(solver, x[:, None], yerr, y)
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {
+        "value": flops_alg(n_cpu) / dt * 1e-12, "unit": "TFLOP/s", "seconds": dt, "cores": int(threads),
+        "kind": kind,
+        "sample": "same workload at N=%d (one compute()+log_likelihood(); kernel build 1 thread, "
+                  "LAPACK dpotrf/dpotrs %d threads); loglike=%.10g" % (n_cpu, threads, ll),
+    }
+
+
+class DenseJob(object):
+    """compute()+log_likelihood() straight through the C ABI with device-resident inputs."""
+
+    def __init__(self, n, nb, device, profile=True):
+        import torch
+        import george_amd.kernels as K
+        from george_amd import _native as N
+        from george_amd.program import DeviceKernel
+        self.N, self.torch, self.n = N, torch, n
+        x, yerr, y = make_inputs(n)
+        self.amp = float(np.var(y))
+        self.dk = DeviceKernel(self.amp * K.ExpSquaredKernel(1.0))
+        dev = torch.device("cuda", device)
+        self.x = torch.from_numpy(x).to(dev)
+        self.yerr = torch.from_numpy(np.sqrt(yerr ** 2 + 1.25e-12)).to(dev)     # gp.py:330 with default white noise
+        self.y = torch.from_numpy(y).to(dev)
+        torch.cuda.synchronize(dev)
+        o = N.gh_chol_opts()
+        o.device, o.nb, o.profile, o.lookahead = device, nb, int(profile), 1
+        self.h = N._vp()
+        N.check(N.lib.gh_chol_create(C.byref(o), C.byref(self.h)))
+
+    def step(self):
+        N = self.N
+        logdet, q = C.c_double(0.0), C.c_double(0.0)
+        N.check(N.lib.gh_chol_compute(self.h, self.dk.handle, self.x.data_ptr(), self.n, 1,
+                                      self.yerr.data_ptr(), C.byref(logdet)))
+        N.check(N.lib.gh_chol_dot_solve(self.h, self.y.data_ptr(), C.byref(q)))
+        return -0.5 * (self.n * np.log(2 * np.pi) + logdet.value) - 0.5 * q.value    # gp.py:333-335,396
+
+    def profile(self):
+        p = self.N.gh_chol_profile()
+        self.N.check(self.N.lib.gh_chol_get_profile(self.h, C.byref(p)))
+        return p
+
+    def close(self):
+        self.N.lib.gh_chol_destroy(self.h)
+
+
+def run_timed(job, steps, warmup, barrier):
+    import torch
+    ll = None
+    for _ in range(warmup):
+        ll = job.step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ll = job.step()
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0, ll
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=65536, help="N (north-star target config: 65536, 1-D ExpSquared)")
+    ap.add_argument("--nb", type=int, default=0, help="outer panel width (0 = library default)")
+    ap.add_argument("--cpu-n", type=int, default=12288, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary N=16384 (configs[1]) measurement")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+        from george_amd.distributed import DistributedDenseJob
+        job = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs)
+        barrier = dist.barrier
+    else:
+        job = DenseJob(args.n, args.nb, local_rank, profile=True)
+        barrier = lambda: None
+
+    elapsed, ll = run_timed(job, args.steps, args.warmup, barrier)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        sec = elapsed / args.steps
+        value = flops_alg(args.n) / sec * 1e-12
+        out = {
+            "metric": "gp_compute_plus_log_likelihood_effective_tflops",
+            "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec * 1e3, "seconds_per_step": sec, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "N=%d 1-D sorted uniform(0,10) x, var(y)*ExpSquaredKernel(1.0), yerr=0.1, "
+                            "dense Cholesky fp64 (BasicSolver path): compute()+log_likelihood()" % args.n,
+                "N": args.n, "ndim": 1, "kernel": "ExpSquared", "solver": "dense-cholesky",
+                "parallelism": "1gpu" if world == 1 else "block-cyclic-%d" % world,
+                "flops_model": "N^3/3 + 2 N^2",
+            },
+            "log_likelihood": ll,
+            "frac_of_fp64_mfma_peak": value / (PEAK_FP64_MFMA_TFLOPS * world),
+        }
+        if world == 1:
+            p = job.profile()
+            if p.n_trailing > 0 and p.ms_trailing > 0:
+                ach = p.trailing_flops / (p.ms_trailing * 1e-3) * 1e-12
+                out["roofline"] = {
+                    "kernel": "gemm_f64_mfma<k-major,k-major> (trailing SYRK update, lower tiles)",
+                    "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "launches": int(p.n_trailing), "avg_launch_ms": p.ms_trailing / p.n_trailing,
+                    "algorithmic_flops_per_launch": p.trailing_flops / p.n_trailing,
+                }
+            out["phases_ms"] = {"total_compute": p.ms_total, "kernel_matrix_build": p.ms_build,
+                                "panel_factor_trsm": p.ms_panel, "trailing_syrk": p.ms_trailing,
+                                "forward_solve": p.ms_solve}
+            job.close()
+            if not args.no_extra and args.n != 16384:
+                j2 = DenseJob(16384, args.nb, local_rank, profile=False)
+                e2, ll2 = run_timed(j2, 3, 1, lambda: None)
+                j2.close()
+                out["config"]["also_configs1_N16384"] = {
+                    "seconds_per_step": e2 / 3, "value_tflops": flops_alg(16384) / (e2 / 3) * 1e-12,
+                    "log_likelihood": ll2}
+            if not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

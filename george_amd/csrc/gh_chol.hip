@@ -1,0 +1,699 @@
+// gh_chol.hip -- dense blocked Cholesky solver on one MI355X.
+//
+// Replaces BasicSolver (reference src/george/solvers/basic.py:51-121) and the
+// SciPy/LAPACK dpotrf/dpotrs behind it.  The covariance matrix is built on the
+// device (gh_kmat.hip), lives in HBM as one row-major Np x Np array (Np = N
+// rounded up to 128, identity-padded) of which only the LOWER triangle is ever
+// touched (K = L L^T; the reference's upper factor U is L^T), and is factorised
+// in place:
+//
+//   for each outer panel of NB columns:
+//     for each 128-column step of the panel:
+//        potf2_inv   : 128x128 diagonal block -> L_jj and L_jj^-1 (one workgroup, all in LDS)
+//        trsm (gemm) : rows below <- rows * L_jj^-T            (MFMA, in place)
+//        update(gemm): remaining panel columns -= ...          (MFMA)
+//     trailing SYRK   : A22 -= L21 L21^T, K = NB, lower tiles  (MFMA; >95 % of the flops)
+//
+// Solves are blocked substitutions that multiply by the stored 128x128 diagonal
+// inverses: TRSV kernels for one right-hand side, the same MFMA GEMM for many.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include "gh_common.h"
+
+#define T 128                 // tile edge
+#define LP 129                // LDS row pitch of the potf2 tile (odd -> conflict-free columns)
+
+// ============================================================= potf2 + inverse
+// One workgroup factorises a 128x128 block held entirely in LDS (129 KiB) and
+// inverts the triangular factor; `dinv` receives L^-1 (row-major 128x128, zeros
+// above the diagonal).  info: 0 = ok so far; set to base+j+1 at the first
+// non-positive pivot (LAPACK dpotrf `info`), after which every later call is a no-op.
+__global__ __launch_bounds__(256) void potf2_inv_kernel(double* A, long lda, double* dinv,
+                                                        long long* info, long long base) {
+  __shared__ double s[T * LP];
+  __shared__ int fail_at;
+  const int tid = threadIdx.x;
+  if (*info != 0) return;               // uniform: an earlier block already failed
+  if (tid == 0) fail_at = -1;
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;
+    s[i * LP + j] = A[(long)i * lda + j];
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;       // 16x16 cyclic ownership of the trailing block
+  for (int j = 0; j < T; ++j) {
+    const double d = s[j * LP + j];
+    if (!(d > 0.0)) {                            // also catches NaN
+      if (tid == 0) fail_at = j;
+      break;                                     // uniform: every thread read the same d
+    }
+    const double ajj = sqrt(d);
+    __syncthreads();                             // everyone has read d before it is overwritten
+    if (tid < T) {
+      if (tid > j) s[tid * LP + j] /= ajj;
+      else if (tid == j) s[j * LP + j] = ajj;
+    }
+    __syncthreads();
+    // rank-1 update of the trailing lower triangle
+    for (int i = j + 1 + ((ty - (j + 1)) & 15); i < T; i += 16) {
+      const double lij = s[i * LP + j];
+      for (int k = j + 1 + ((tx - (j + 1)) & 15); k <= i; k += 16)
+        s[i * LP + k] -= lij * s[k * LP + j];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (fail_at >= 0) {
+    if (tid == 0) *info = base + fail_at + 1;
+    return;
+  }
+  // write the factor back, zeroing the strict upper triangle of the tile
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;
+    A[(long)i * lda + j] = (j <= i) ? s[i * LP + j] : 0.0;
+  }
+  __syncthreads();
+  // L^-1, column by column: lane pair (c, h) owns column c, h splits the dot product by
+  // k parity; x_i (i > c) is kept in the unused upper triangle at s[c][i].  No workgroup
+  // barrier: a column only depends on itself, and the two lanes sit in one wavefront
+  // (LDS operations of a wavefront execute in program order; volatile stops the compiler
+  // from caching or reordering them).
+  {
+    volatile double* vs = s;
+    const int c = tid >> 1, h = tid & 1;
+    const double xc = 1.0 / vs[c * LP + c];
+    for (int i = c + 1; i < T; ++i) {
+      double acc = (h == 0) ? vs[i * LP + c] * xc : 0.0;
+      for (int k = c + 1 + h; k < i; k += 2) acc += vs[i * LP + k] * vs[c * LP + k];
+      acc += __shfl_xor(acc, 1, 64);
+      const double xi = -acc / vs[i * LP + i];
+      if (h == 0) vs[c * LP + i] = xi;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;       // dinv[i][j] = x_i of column j
+    double v;
+    if (j < i) v = s[j * LP + i];
+    else if (j == i) v = 1.0 / s[i * LP + i];
+    else v = 0.0;
+    dinv[idx] = v;
+  }
+}
+
+// ================================================================= reductions
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum_256(double v, double* sh /* >= 4 */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// out[0] (+)= 2 * sum_i log(A[i][i])   (basic.py:69); one workgroup, fixed order
+__global__ __launch_bounds__(256) void logdet_kernel(const double* A, long lda, long n, double* out, int accumulate) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) v += log(A[i * lda + i]);
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + 2.0 * v;
+}
+// out[0] = sum_i a[i] * b[i]
+__global__ __launch_bounds__(256) void dot_kernel(const double* a, const double* b, long n, double* out) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) v += a[i] * b[i];
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) out[0] = v;
+}
+
+// ======================================================== single-RHS solves
+// Forward step j of L z = y (right-looking).  Every workgroup recomputes
+// z_j = L_jj^-1 w_j from the current working vector w (128x128 mat-vec from L2), workgroup 0
+// publishes it into z, workgroups b >= 1 update their 128 rows: w[i] -= L[i, jblock] . z_j.
+__global__ __launch_bounds__(256) void trsv_fwd_step(const double* L, long ld, const double* dinv_j,
+                                                     long j0, double* w, double* z) {
+  __shared__ double zj[T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double2 wv = *reinterpret_cast<const double2*>(w + j0 + 2 * lane);
+  for (int r = wave; r < T; r += 4) {
+    const double2 a = *reinterpret_cast<const double2*>(dinv_j + r * T + 2 * lane);
+    const double v = wave_sum(a.x * wv.x + a.y * wv.y);
+    if (lane == 0) zj[r] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid < T) z[j0 + tid] = zj[tid];
+    return;
+  }
+  const long row0 = j0 + (long)blockIdx.x * T;
+  const double zx = zj[2 * lane], zy = zj[2 * lane + 1];
+  for (int r = wave; r < T; r += 4) {
+    const double2 a = *reinterpret_cast<const double2*>(L + (row0 + r) * ld + j0 + 2 * lane);
+    const double v = wave_sum(a.x * zx + a.y * zy);
+    if (lane == 0) w[row0 + r] -= v;
+  }
+}
+// Backward step j of L^T x = z.  x_j = L_jj^-T w_j; columns c < j0: w[c] -= sum_r L[j0+r][c] x_j[r].
+// Workgroup j0/128 (the last one) publishes x_j; workgroup b < j0/128 updates columns [128b, 128b+128).
+__global__ __launch_bounds__(256) void trsv_bwd_step(const double* L, long ld, const double* dinv_j,
+                                                     long j0, double* w, double* x) {
+  __shared__ double xj[T];
+  __shared__ double part[2][T];
+  const int tid = threadIdx.x, c = tid & 127, h = tid >> 7;
+  double acc = 0.0;
+  for (int r = h * 64; r < h * 64 + 64; ++r) acc += dinv_j[r * T + c] * w[j0 + r];
+  part[h][c] = acc;
+  __syncthreads();
+  if (tid < T) xj[tid] = part[0][tid] + part[1][tid];
+  __syncthreads();
+  const long nb = j0 / T;
+  if ((long)blockIdx.x == nb) {
+    if (tid < T) x[j0 + tid] = xj[tid];
+    return;
+  }
+  const long col0 = (long)blockIdx.x * T;
+  acc = 0.0;
+  for (int r = h * 64; r < h * 64 + 64; ++r) acc += L[(j0 + r) * ld + col0 + c] * xj[r];
+  __syncthreads();
+  part[h][c] = acc;
+  __syncthreads();
+  if (tid < T) w[col0 + tid] -= part[0][tid] + part[1][tid];
+}
+
+// ========================================================= predict reductions
+// partial[s][c] = sum over the s-th row chunk of V[r][c] * z[r]  and of V[r][c]^2
+__global__ __launch_bounds__(256) void colreduce_kernel(const double* V, long ldv, long nrows, long rows_per,
+                                                        const double* z, double* pmu, double* pvar, long ncols_p) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols_p) return;
+  const long r0 = (long)blockIdx.y * rows_per;
+  const long r1 = r0 + rows_per < nrows ? r0 + rows_per : nrows;
+  double am = 0.0, av = 0.0;
+  for (long r = r0; r < r1; ++r) {
+    const double v = V[r * ldv + c];
+    am += v * z[r];
+    av += v * v;
+  }
+  pmu[(long)blockIdx.y * ncols_p + c] = am;
+  pvar[(long)blockIdx.y * ncols_p + c] = av;
+}
+__global__ void colfinal_kernel(const double* pmu, const double* pvar, long nchunks, long ncols_p, long m,
+                                double* mu, double* var /* in: k(xs,xs) diag; may be NULL */) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  double am = 0.0, av = 0.0;
+  for (long s = 0; s < nchunks; ++s) { am += pmu[s * ncols_p + c]; av += pvar[s * ncols_p + c]; }
+  mu[c] = am;
+  if (var) var[c] -= av;
+}
+__global__ void fill_kernel(double* p, long n, double v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void eye_kernel(double* p, long n, long ld) {   // p must be pre-zeroed
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i * ld + i] = 1.0;
+}
+// mirror the lower triangle of an n x n matrix into the upper one (out may be != in)
+__global__ void symmetrize_kernel(const double* in, long ldi, double* out, long ldo, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  const long i = idx / n, j = idx % n;
+  out[i * ldo + j] = (j <= i) ? in[i * ldi + j] : in[j * ldi + i];
+}
+__global__ void copy2d_kernel(const double* in, long ldi, double* out, long ldo, long rows, long cols) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const long i = idx / cols, j = idx % cols;
+  out[i * ldo + j] = in[i * ldi + j];
+}
+
+// ================================================================= the solver
+struct EvPair { hipEvent_t a, b; };
+
+struct gh_chol {
+  gh_chol_opts opts;
+  hipStream_t st = nullptr;
+  int64_t n = 0, np = 0;
+  int ndim = 0;
+  bool computed = false;
+  int64_t info = 0;
+  double logdet = 0.0;
+  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch;
+  long long* d_info = nullptr;
+  gh_chol_profile prof;
+  std::vector<EvPair> ev_pool;
+  size_t ev_used = 0;
+  std::vector<size_t> ev_trailing, ev_panel;
+  // returns an index into ev_pool (the vector may grow, so never keep pointers), or -1
+  long next_ev() {
+    if (ev_used == ev_pool.size()) {
+      EvPair p;
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+      ev_pool.push_back(p);
+    }
+    return (long)ev_used++;
+  }
+  ~gh_chol() {
+    for (auto& p : ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (d_info) (void)hipFree(d_info);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+static int set_device(gh_chol* s) {
+  if (gh_device_count() <= 0) { gh_set_error("no HIP device available: the george_amd solver needs an MI355X"); return GH_ERR_HIP; }
+  GH_HIP(hipSetDevice(s->opts.device));
+  return GH_OK;
+}
+
+extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
+  if (!out) { gh_set_error("null output"); return GH_ERR_BAD_ARG; }
+  gh_chol* s = new gh_chol();
+  memset(&s->opts, 0, sizeof(s->opts));
+  memset(&s->prof, 0, sizeof(s->prof));
+  if (opts) s->opts = *opts;
+  if (s->opts.nb <= 0) s->opts.nb = 512;
+  if (s->opts.nb % T) { delete s; gh_set_error("nb must be a multiple of 128"); return GH_ERR_BAD_ARG; }
+  int rc = set_device(s);
+  if (rc != GH_OK) { delete s; return rc; }
+  if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  if (hipMalloc((void**)&s->d_info, sizeof(long long)) != hipSuccess) { delete s; gh_set_error("hipMalloc failed"); return GH_ERR_HIP; }
+  *out = s;
+  return GH_OK;
+}
+extern "C" void gh_chol_destroy(gh_chol* s) { if (s) { (void)hipSetDevice(s->opts.device); delete s; } }
+extern "C" int64_t gh_chol_info(const gh_chol* s) { return s ? s->info : 0; }
+extern "C" int64_t gh_chol_size(const gh_chol* s) { return s ? s->n : 0; }
+extern "C" int gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out) {
+  if (!s || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  *out = s->prof;
+  return GH_OK;
+}
+
+static inline double* blk(double* A, int64_t ld, int64_t r, int64_t c) { return A + r * ld + c; }
+
+// C = A * B^T (alpha=1,beta=0) or C -= A * B^T helpers on k-major operands
+static int gemm_nt(hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                   int64_t M, int64_t N, int64_t K, double alpha, double beta, bool lower) {
+  GhGemm g{};
+  g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  g.alpha = alpha; g.beta = beta; g.a_km = true; g.b_km = true; g.lower = lower;
+  return gh_launch_gemm(g, st);
+}
+
+// in-place lower Cholesky of the n x n block at A (n multiple of 128) + diagonal-block inverses
+static int potrf_block(hipStream_t st, double* A, int64_t ld, int64_t n, double* dinv, long long* d_info, long long base) {
+  for (int64_t j0 = 0; j0 < n; j0 += T) {
+    double* dj = dinv + (j0 / T) * T * T;
+    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, blk(A, ld, j0, j0), (long)ld, dj, d_info, base + j0);
+    GH_HIP(hipGetLastError());
+    const int64_t rem = n - (j0 + T);
+    if (rem > 0) {
+      double* P = blk(A, ld, j0 + T, j0);
+      GH_CHECK(gemm_nt(st, P, ld, P, ld, dj, T, rem, T, T, 1.0, 0.0, false));          // P <- P L_jj^-T (in place)
+      GH_CHECK(gemm_nt(st, blk(A, ld, j0 + T, j0 + T), ld, P, ld, P, ld, rem, rem, T, -1.0, 1.0, true));
+    }
+  }
+  return GH_OK;
+}
+// A21 (m x n) <- A21 L11^-T, L11 n x n lower with diagonal-block inverses dinv
+static int trsm_right(hipStream_t st, const double* L11, int64_t ld11, const double* dinv, double* A21, int64_t lda, int64_t m, int64_t n) {
+  for (int64_t j0 = 0; j0 < n; j0 += T) {
+    double* Xj = A21 + j0;
+    if (j0 > 0)
+      GH_CHECK(gemm_nt(st, Xj, lda, A21, lda, L11 + j0 * ld11, ld11, m, T, j0, -1.0, 1.0, false));
+    GH_CHECK(gemm_nt(st, Xj, lda, Xj, lda, dinv + (j0 / T) * T * T, T, m, T, T, 1.0, 0.0, false));
+  }
+  return GH_OK;
+}
+
+extern "C" int gh_dev_potrf_block(double* a, int64_t lda, int64_t n, double* dinv, int64_t* info_dev, int64_t base_index, void* stream) {
+  if (n % T) { gh_set_error("potrf_block: n must be a multiple of 128"); return GH_ERR_BAD_ARG; }
+  return potrf_block((hipStream_t)stream, a, lda, n, dinv, (long long*)info_dev, base_index);
+}
+extern "C" int gh_dev_trsm_right(const double* l11, int64_t ld11, const double* dinv, double* a21, int64_t lda, int64_t m, int64_t n, void* stream) {
+  if (n % T || m % T) { gh_set_error("trsm_right: sizes must be multiples of 128"); return GH_ERR_BAD_ARG; }
+  return trsm_right((hipStream_t)stream, l11, ld11, dinv, a21, lda, m, n);
+}
+extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, double* out_dev, void* stream) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (long)lda, (long)n, out_dev, 1);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+static int factor(gh_chol* s) {
+  hipStream_t st = s->st;
+  double* A = s->A.d();
+  const int64_t np = s->np, ld = np, NB = s->opts.nb;
+  const bool prof = s->opts.profile != 0;
+  for (int64_t k0 = 0; k0 < np; k0 += NB) {
+    const int64_t nb = std::min<int64_t>(NB, np - k0);
+    const long ep = prof ? s->next_ev() : -1;
+    if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, st)); s->ev_panel.push_back((size_t)ep); }
+    GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, s->dinv.d() + (k0 / T) * T * T, s->d_info, k0));
+    const int64_t m = np - (k0 + nb);
+    if (m > 0)
+      GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, s->dinv.d() + (k0 / T) * T * T, blk(A, ld, k0 + nb, k0), ld, m, nb));
+    if (ep >= 0) GH_HIP(hipEventRecord(s->ev_pool[ep].b, st));
+    if (m > 0) {
+      const long et = prof ? s->next_ev() : -1;
+      if (et >= 0) { GH_HIP(hipEventRecord(s->ev_pool[et].a, st)); s->ev_trailing.push_back((size_t)et); }
+      const double* P = blk(A, ld, k0 + nb, k0);
+      GH_CHECK(gemm_nt(st, blk(A, ld, k0 + nb, k0 + nb), ld, P, ld, P, ld, m, m, nb, -1.0, 1.0, true));
+      if (et >= 0) GH_HIP(hipEventRecord(s->ev_pool[et].b, st));
+      const double tiles = (double)(m / T) * (m / T + 1) / 2.0;
+      s->prof.trailing_flops += tiles * 2.0 * T * T * (double)nb;
+      s->prof.n_trailing += 1;
+    }
+  }
+  return GH_OK;
+}
+
+extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                               const double* yerr, double* logdet_out) {
+  if (!s || !k || !x || !yerr || n <= 0) { gh_set_error("bad argument to compute"); return GH_ERR_BAD_ARG; }
+  if (ndim != k->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
+  GH_CHECK(set_device(s));
+  GH_CHECK(k->upload());
+  s->computed = false;
+  s->info = 0;
+  const int64_t np = gh_round_up(n, T);
+  s->n = n; s->np = np; s->ndim = ndim;
+  GH_CHECK(s->A.ensure((size_t)np * np * sizeof(double)));
+  GH_CHECK(s->dinv.ensure((size_t)(np / T) * T * T * sizeof(double)));
+  GH_CHECK(s->x.ensure((size_t)n * ndim * sizeof(double)));
+  GH_CHECK(s->yerr.ensure((size_t)n * sizeof(double)));
+  GH_CHECK(s->scal.ensure(64));
+  hipStream_t st = s->st;
+  memset(&s->prof, 0, sizeof(s->prof));
+  s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear();
+  const bool prof = s->opts.profile != 0;
+  const long e_all = prof ? s->next_ev() : -1;
+  const long e_build = prof ? s->next_ev() : -1;
+  if (e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_all].a, st));
+  GH_CHECK(gh_to_device(s->x.d(), x, (size_t)n * ndim, st));
+  GH_CHECK(gh_to_device(s->yerr.d(), yerr, (size_t)n, st));
+  GH_HIP(hipMemsetAsync(s->d_info, 0, sizeof(long long), st));
+  if (e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_build].a, st));
+  GH_CHECK(gh_launch_kmat(k, s->x.d(), n, s->x.d(), n, s->yerr.d(), s->A.d(), np, np, np, 0, 0, true, true, st));
+  if (e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_build].b, st));
+  GH_CHECK(factor(s));
+  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, s->A.d(), (long)np, (long)np, s->scal.d(), 0);
+  GH_HIP(hipGetLastError());
+  if (e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_all].b, st));
+  double ld_host = 0.0;
+  long long info_host = 0;
+  GH_HIP(hipMemcpyAsync(&ld_host, s->scal.d(), sizeof(double), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipMemcpyAsync(&info_host, s->d_info, sizeof(long long), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipStreamSynchronize(st));
+  if (prof && e_all >= 0 && e_build >= 0) {
+    float ms = 0;
+    GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[e_all].a, s->ev_pool[e_all].b)); s->prof.ms_total = ms;
+    GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[e_build].a, s->ev_pool[e_build].b)); s->prof.ms_build = ms;
+    for (size_t i : s->ev_trailing) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_trailing += ms; }
+    for (size_t i : s->ev_panel) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_panel += ms; }
+  }
+  if (info_host != 0) {
+    s->info = info_host;
+    gh_set_error("%lld-th leading minor of the array is not positive definite", info_host);
+    return GH_ERR_NOT_PD;
+  }
+  s->logdet = ld_host;
+  s->computed = true;
+  if (logdet_out) *logdet_out = ld_host;
+  return GH_OK;
+}
+
+static int need_computed(gh_chol* s) {
+  if (!s) { gh_set_error("null solver"); return GH_ERR_BAD_ARG; }
+  if (!s->computed) { gh_set_error("you must call 'compute' first"); return GH_ERR_NOT_COMPUTED; }
+  return set_device(s);
+}
+
+// load a length-n vector (host or device) into a zero-padded device vector of length np
+static int load_vec(gh_chol* s, GhBuf& buf, const double* src) {
+  GH_CHECK(buf.ensure((size_t)s->np * sizeof(double)));
+  if (s->np > s->n) GH_HIP(hipMemsetAsync(buf.d() + s->n, 0, (size_t)(s->np - s->n) * sizeof(double), s->st));
+  return gh_to_device(buf.d(), src, (size_t)s->n, s->st);
+}
+// z = L^-1 w  (w is destroyed)
+static int trsv_forward(gh_chol* s, double* w, double* z) {
+  const int64_t nt = s->np / T;
+  for (int64_t j = 0; j < nt; ++j) {
+    hipLaunchKernelGGL(trsv_fwd_step, dim3((unsigned)(nt - j)), dim3(256), 0, s->st,
+                       s->A.d(), (long)s->np, s->dinv.d() + j * T * T, (long)(j * T), w, z);
+  }
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+// x = L^-T w  (w is destroyed)
+static int trsv_backward(gh_chol* s, double* w, double* x) {
+  const int64_t nt = s->np / T;
+  for (int64_t j = nt - 1; j >= 0; --j) {
+    hipLaunchKernelGGL(trsv_bwd_step, dim3((unsigned)(j + 1)), dim3(256), 0, s->st,
+                       s->A.d(), (long)s->np, s->dinv.d() + j * T * T, (long)(j * T), w, x);
+  }
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
+  GH_CHECK(need_computed(s));
+  if (!y || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  // y^T K^-1 y = || L^-1 y ||^2 : one forward sweep (the reference does both, basic.py:102)
+  GH_CHECK(load_vec(s, s->v0, y));
+  GH_CHECK(s->v1.ensure((size_t)s->np * sizeof(double)));
+  const long e = s->opts.profile ? s->next_ev() : -1;
+  if (e >= 0) GH_HIP(hipEventRecord(s->ev_pool[e].a, s->st));
+  GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d()));
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s->st, s->v1.d(), s->v1.d(), (long)s->np, s->scal.d() + 1);
+  GH_HIP(hipGetLastError());
+  if (e >= 0) GH_HIP(hipEventRecord(s->ev_pool[e].b, s->st));
+  double v = 0.0;
+  GH_HIP(hipMemcpyAsync(&v, s->scal.d() + 1, sizeof(double), hipMemcpyDeviceToHost, s->st));
+  GH_HIP(hipStreamSynchronize(s->st));
+  if (e >= 0) { float ms = 0; GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[e].a, s->ev_pool[e].b)); s->prof.ms_solve = ms; }
+  *out = v;
+  return GH_OK;
+}
+
+// B (np x rp, row-major, zero padded) <- L^-1 B  (forward) and optionally L^-T (backward)
+static int trsm_multi(gh_chol* s, double* B, int64_t rp, bool forward, bool backward) {
+  const int64_t np = s->np, nt = np / T;
+  const double* L = s->A.d();
+  if (forward) {
+    for (int64_t j = 0; j < nt; ++j) {
+      double* Bj = B + j * T * rp;
+      GhGemm g{};
+      g.C = Bj; g.ldc = rp; g.A = s->dinv.d() + j * T * T; g.lda = T; g.B = Bj; g.ldb = rp;
+      g.M = T; g.N = rp; g.K = T; g.alpha = 1.0; g.beta = 0.0; g.a_km = true; g.b_km = false;
+      GH_CHECK(gh_launch_gemm(g, s->st));
+      const int64_t rem = np - (j + 1) * T;
+      if (rem > 0) {
+        GhGemm u{};
+        u.C = B + (j + 1) * T * rp; u.ldc = rp; u.A = L + (j + 1) * T * np + j * T; u.lda = np; u.B = Bj; u.ldb = rp;
+        u.M = rem; u.N = rp; u.K = T; u.alpha = -1.0; u.beta = 1.0; u.a_km = true; u.b_km = false;
+        GH_CHECK(gh_launch_gemm(u, s->st));
+      }
+    }
+  }
+  if (backward) {
+    for (int64_t j = nt - 1; j >= 0; --j) {
+      double* Bj = B + j * T * rp;
+      GhGemm g{};
+      g.C = Bj; g.ldc = rp; g.A = s->dinv.d() + j * T * T; g.lda = T; g.B = Bj; g.ldb = rp;
+      g.M = T; g.N = rp; g.K = T; g.alpha = 1.0; g.beta = 0.0; g.a_km = false; g.b_km = false;
+      GH_CHECK(gh_launch_gemm(g, s->st));
+      if (j > 0) {
+        GhGemm u{};
+        u.C = B; u.ldc = rp; u.A = L + j * T * np; u.lda = np; u.B = Bj; u.ldb = rp;
+        u.M = j * T; u.N = rp; u.K = T; u.alpha = -1.0; u.beta = 1.0; u.a_km = false; u.b_km = false;
+        GH_CHECK(gh_launch_gemm(u, s->st));
+      }
+    }
+  }
+  return GH_OK;
+}
+
+extern "C" int gh_chol_solve(gh_chol* s, const double* b, int64_t nrhs, double* out) {
+  GH_CHECK(need_computed(s));
+  if (!b || !out || nrhs <= 0) { gh_set_error("bad argument to solve"); return GH_ERR_BAD_ARG; }
+  const int64_t n = s->n, np = s->np;
+  if (nrhs == 1) {
+    GH_CHECK(load_vec(s, s->v0, b));
+    GH_CHECK(s->v1.ensure((size_t)np * sizeof(double)));
+    GH_CHECK(s->v2.ensure((size_t)np * sizeof(double)));
+    GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d()));
+    GH_CHECK(trsv_backward(s, s->v1.d(), s->v2.d()));
+    return gh_from_device(out, s->v2.d(), (size_t)n, s->st);
+  }
+  const int64_t rp = gh_round_up(nrhs, T);
+  GH_CHECK(s->rhs.ensure((size_t)np * rp * sizeof(double)));
+  GH_HIP(hipMemsetAsync(s->rhs.d(), 0, (size_t)np * rp * sizeof(double), s->st));
+  GH_HIP(hipMemcpy2DAsync(s->rhs.d(), rp * sizeof(double), b, nrhs * sizeof(double), nrhs * sizeof(double), n,
+                          gh_is_device_ptr(b) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st));
+  GH_CHECK(trsm_multi(s, s->rhs.d(), rp, true, true));
+  GH_HIP(hipMemcpy2DAsync(out, nrhs * sizeof(double), s->rhs.d(), rp * sizeof(double), nrhs * sizeof(double), n,
+                          gh_is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->st));
+  GH_HIP(hipStreamSynchronize(s->st));
+  return GH_OK;
+}
+
+extern "C" int gh_chol_apply_sqrt(gh_chol* s, const double* r, int64_t nrows, double* out) {
+  GH_CHECK(need_computed(s));
+  if (!r || !out || nrows <= 0) { gh_set_error("bad argument to apply_sqrt"); return GH_ERR_BAD_ARG; }
+  // out = r @ U with U = L^T (basic.py:114):  out[s][j] = sum_{k <= j} r[s][k] L[j][k]
+  const int64_t n = s->n, np = s->np, rr = gh_round_up(nrows, T);
+  GH_CHECK(s->rhs.ensure((size_t)rr * np * sizeof(double)));
+  GH_CHECK(s->work.ensure((size_t)rr * np * sizeof(double)));
+  GH_HIP(hipMemsetAsync(s->rhs.d(), 0, (size_t)rr * np * sizeof(double), s->st));
+  GH_HIP(hipMemcpy2DAsync(s->rhs.d(), np * sizeof(double), r, n * sizeof(double), n * sizeof(double), nrows,
+                          gh_is_device_ptr(r) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st));
+  GhGemm g{};
+  g.C = s->work.d(); g.ldc = np; g.A = s->rhs.d(); g.lda = np; g.B = s->A.d(); g.ldb = np;
+  g.M = rr; g.N = np; g.K = np; g.alpha = 1.0; g.beta = 0.0; g.a_km = true; g.b_km = true; g.khi_col = true;
+  GH_CHECK(gh_launch_gemm(g, s->st));
+  GH_HIP(hipMemcpy2DAsync(out, n * sizeof(double), s->work.d(), np * sizeof(double), n * sizeof(double), nrows,
+                          gh_is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->st));
+  GH_HIP(hipStreamSynchronize(s->st));
+  return GH_OK;
+}
+
+// W (np x np) <- K^-1, lower triangle valid.  Uses K^-1 = L^-T L^-1:
+//   Linv = L^-1 (forward substitution on the identity), K^-1 = Linv^T Linv (k >= max(i, j)).
+static int inverse_lower(gh_chol* s, double* W /* np*np */, double* Linv /* np*np scratch */) {
+  const int64_t np = s->np, nt = np / T;
+  const double* L = s->A.d();
+  GH_HIP(hipMemsetAsync(Linv, 0, (size_t)np * np * sizeof(double), s->st));
+  hipLaunchKernelGGL(eye_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s->st, Linv, (long)np, (long)np);
+  GH_HIP(hipGetLastError());
+  // forward substitution exploiting the lower-triangular right-hand side: at step j only
+  // columns [0, (j+1)*128) of block row j are non-zero
+  for (int64_t j = 0; j < nt; ++j) {
+    double* Bj = Linv + j * T * np;
+    const int64_t ncols = (j + 1) * T;
+    GhGemm g{};
+    g.C = Bj; g.ldc = np; g.A = s->dinv.d() + j * T * T; g.lda = T; g.B = Bj; g.ldb = np;
+    g.M = T; g.N = ncols; g.K = T; g.alpha = 1.0; g.beta = 0.0; g.a_km = true; g.b_km = false;
+    GH_CHECK(gh_launch_gemm(g, s->st));
+    const int64_t rem = np - (j + 1) * T;
+    if (rem > 0) {
+      GhGemm u{};
+      u.C = Linv + (j + 1) * T * np; u.ldc = np; u.A = L + (j + 1) * T * np + j * T; u.lda = np; u.B = Bj; u.ldb = np;
+      u.M = rem; u.N = ncols; u.K = T; u.alpha = -1.0; u.beta = 1.0; u.a_km = true; u.b_km = false;
+      GH_CHECK(gh_launch_gemm(u, s->st));
+    }
+  }
+  GhGemm q{};
+  q.C = W; q.ldc = np; q.A = Linv; q.lda = np; q.B = Linv; q.ldb = np;
+  q.M = np; q.N = np; q.K = np; q.alpha = 1.0; q.beta = 0.0; q.a_km = false; q.b_km = false;
+  q.lower = true; q.klo_max = true;
+  return gh_launch_gemm(q, s->st);
+}
+
+extern "C" int gh_chol_get_inverse(gh_chol* s, double* out) {
+  GH_CHECK(need_computed(s));
+  if (!out) { gh_set_error("null output"); return GH_ERR_BAD_ARG; }
+  const int64_t n = s->n, np = s->np;
+  GH_CHECK(s->work.ensure((size_t)np * np * sizeof(double)));
+  GH_CHECK(s->work2.ensure((size_t)np * np * sizeof(double)));
+  GH_CHECK(inverse_lower(s, s->work.d(), s->work2.d()));
+  // full symmetric n x n result (work2 is free again)
+  double* full = s->work2.d();
+  const long tot = (long)n * n;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->st, s->work.d(), (long)np, full, (long)n, (long)n);
+  GH_HIP(hipGetLastError());
+  return gh_from_device(out, full, (size_t)tot, s->st);
+}
+
+extern "C" int gh_chol_predict(gh_chol* s, gh_kernel* k, const double* r, const double* xs, int64_t m,
+                               double* mu, double* var, double* cov) {
+  GH_CHECK(need_computed(s));
+  if (!k || !r || !xs || !mu || m <= 0) { gh_set_error("bad argument to predict"); return GH_ERR_BAD_ARG; }
+  if (k->ndim != s->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
+  GH_CHECK(k->upload());
+  const int64_t n = s->n, np = s->np, mp = gh_round_up(m, T);
+  hipStream_t st = s->st;
+  // z = L^-1 r
+  GH_CHECK(load_vec(s, s->v0, r));
+  GH_CHECK(s->v1.ensure((size_t)np * sizeof(double)));
+  GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d()));
+  // V = L^-1 K(x, xs)   (np x mp): built on the device, forward substitution only, because
+  // K*s K^-1 K*s^T = V^T V and K*s K^-1 r = V^T z  (gp.py:532-545 does both sweeps on the host)
+  GhBuf xsd;
+  const double* xs_dev = xs;
+  if (!gh_is_device_ptr(xs)) {
+    GH_CHECK(xsd.ensure((size_t)m * s->ndim * sizeof(double)));
+    GH_CHECK(gh_to_device(xsd.d(), xs, (size_t)m * s->ndim, st));
+    xs_dev = xsd.d();
+  }
+  GH_CHECK(s->rhs.ensure((size_t)np * mp * sizeof(double)));
+  GH_CHECK(gh_launch_kmat(k, s->x.d(), n, xs_dev, m, nullptr, s->rhs.d(), mp, np, mp, 0, 0, false, false, st));
+  GH_CHECK(trsm_multi(s, s->rhs.d(), mp, true, false));
+  // column reductions
+  const int64_t nchunks = std::min<int64_t>(64, np / T);
+  const int64_t rows_per = gh_round_up((np + nchunks - 1) / nchunks, 1);
+  GH_CHECK(s->scratch.ensure((size_t)(2 * nchunks * mp + 2 * mp) * sizeof(double)));
+  double* pmu = s->scratch.d();
+  double* pvar = pmu + nchunks * mp;
+  double* dmu = pvar + nchunks * mp;
+  double* dvar = dmu + mp;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((mp + 255) / 256), (unsigned)nchunks), dim3(256), 0, st,
+                     s->rhs.d(), (long)mp, (long)np, (long)rows_per, s->v1.d(), pmu, pvar, (long)mp);
+  GH_HIP(hipGetLastError());
+  if (var) GH_CHECK(gh_launch_kdiag(k, xs_dev, xs_dev, m, dvar, st));           // gp.py:539
+  hipLaunchKernelGGL(colfinal_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st,
+                     pmu, pvar, (long)nchunks, (long)mp, (long)m, dmu, var ? dvar : nullptr);
+  GH_HIP(hipGetLastError());
+  GH_CHECK(gh_from_device(mu, dmu, (size_t)m, st));
+  if (var) GH_CHECK(gh_from_device(var, dvar, (size_t)m, st));
+  if (cov) {
+    // cov = K(xs, xs) - V^T V      (gp.py:543-545)
+    GH_CHECK(s->work.ensure((size_t)mp * mp * sizeof(double)));
+    GH_CHECK(gh_launch_kmat(k, xs_dev, m, xs_dev, m, nullptr, s->work.d(), mp, mp, mp, 0, 0, true, false, st));
+    GhGemm g{};
+    g.C = s->work.d(); g.ldc = mp; g.A = s->rhs.d(); g.lda = mp; g.B = s->rhs.d(); g.ldb = mp;
+    g.M = mp; g.N = mp; g.K = np; g.alpha = -1.0; g.beta = 1.0; g.a_km = false; g.b_km = false;
+    GH_CHECK(gh_launch_gemm(g, st));
+    GH_HIP(hipMemcpy2DAsync(cov, m * sizeof(double), s->work.d(), mp * sizeof(double), m * sizeof(double), m,
+                            gh_is_device_ptr(cov) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+  }
+  GH_HIP(hipStreamSynchronize(st));
+  return GH_OK;
+}
+
+extern "C" int gh_chol_grad(gh_chol* s, gh_kernel* k, const uint32_t* which, const double* r,
+                            double* grad, double* alpha, double* diagA) {
+  GH_CHECK(need_computed(s));
+  if (!k || !which || !r || !grad) { gh_set_error("bad argument to grad"); return GH_ERR_BAD_ARG; }
+  if (k->ndim != s->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
+  GH_CHECK(k->upload());
+  const int64_t n = s->n, np = s->np;
+  hipStream_t st = s->st;
+  // alpha = K^-1 r                       (gp.py:429)
+  GH_CHECK(load_vec(s, s->v0, r));
+  GH_CHECK(s->v1.ensure((size_t)np * sizeof(double)));
+  GH_CHECK(s->v2.ensure((size_t)np * sizeof(double)));
+  GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d()));
+  GH_CHECK(trsv_backward(s, s->v1.d(), s->v2.d()));
+  // K^-1 (lower)                         (gp.py:436)
+  GH_CHECK(s->work.ensure((size_t)np * np * sizeof(double)));
+  GH_CHECK(s->work2.ensure((size_t)np * np * sizeof(double)));
+  GH_CHECK(inverse_lower(s, s->work.d(), s->work2.d()));
+  // 1/2 sum_ij A_ij dK_ij/dtheta, A = alpha alpha^T - K^-1   (gp.py:437,465-466), fused
+  GH_CHECK(s->v0.ensure((size_t)std::max<int64_t>(np, GH_MAX_GRAD) * sizeof(double)));
+  double* dgrad = s->v0.d();                       // v0 is free again
+  double* ddiag = s->v1.d();                       // so is v1
+  GH_CHECK(gh_launch_kgrad_reduce(k, which, s->x.d(), n, s->v2.d(), s->work.d(), np, dgrad, ddiag, s->scratch, st));
+  if (k->size > 0) GH_CHECK(gh_from_device(grad, dgrad, (size_t)k->size, st));
+  if (alpha) GH_CHECK(gh_from_device(alpha, s->v2.d(), (size_t)n, st));
+  if (diagA) GH_CHECK(gh_from_device(diagA, ddiag, (size_t)n, st));
+  GH_HIP(hipStreamSynchronize(st));
+  return GH_OK;
+}

@@ -1,0 +1,103 @@
+// gh_common.h -- shared host-side plumbing for libgeorge_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/george_amd.h"
+#include "gh_eval.h"
+
+#define GH_TILE 128             // tile edge of every blocked kernel; device matrices are padded to it
+
+void gh_set_error(const char* fmt, ...);
+
+#define GH_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      gh_set_error("HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),   \
+                   __FILE__, __LINE__, #expr);                                         \
+      return GH_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#define GH_CHECK(expr)                 \
+  do {                                 \
+    int rc_ = (expr);                  \
+    if (rc_ != GH_OK) return rc_;      \
+  } while (0)
+
+static inline int64_t gh_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// true when p is device (HBM) memory
+bool gh_is_device_ptr(const void* p);
+
+// RAII device buffer
+struct GhBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~GhBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  int ensure(size_t nbytes) {
+    if (nbytes <= bytes && p) return GH_OK;
+    release();
+    hipError_t e = hipMalloc(&p, nbytes ? nbytes : 8);
+    if (e != hipSuccess) { p = nullptr; gh_set_error("hipMalloc of %zu bytes failed: %s", nbytes, hipGetErrorString(e)); return GH_ERR_NOMEM; }
+    bytes = nbytes;
+    return GH_OK;
+  }
+  double* d() const { return (double*)p; }
+};
+
+// copy `count` doubles from src (host or device) into device memory dst
+int gh_to_device(double* dst, const double* src, size_t count, hipStream_t st);
+// copy `count` doubles from device src into dst (host or device)
+int gh_from_device(double* dst, const double* src, size_t count, hipStream_t st);
+
+// --------------------------------------------------------------- kernel handle
+struct gh_kernel {
+  std::vector<GhNode> nodes;   // postfix program (host copy)
+  int ndim = 0;
+  int size = 0;                // full parameter count
+  int device = -1;
+  GhNode* d_nodes = nullptr;   // device copy (lazily uploaded per device)
+  ~gh_kernel() { if (d_nodes) (void)hipFree(d_nodes); }
+  int upload();                // ensure d_nodes valid on the current device
+};
+
+// ----------------------------------------------------------------- launchers
+// (all device pointers; sizes need not be tile multiples unless noted)
+// out[r*ldo + c] = k(x1[r], x2[c]) for r < n1, c < n2; rows/cols up to (rows_p, cols_p) are
+// zero-filled (identity when `sym`).  sym: x1 == x2, evaluate with ordered arguments
+// (k(x_min, x_max), mirroring kernel_interface.cpp:62-77), add yerr[r]^2 on the diagonal when
+// yerr != NULL; lower_only: build only 128-tiles on/below the diagonal.
+int gh_launch_kmat(const gh_kernel* k, const double* x1, int64_t n1, const double* x2, int64_t n2,
+                   const double* yerr, double* out, int64_t ldo, int64_t rows_p, int64_t cols_p,
+                   int64_t row0, int64_t col0, bool sym, bool lower_only, hipStream_t st);
+int gh_launch_kdiag(const gh_kernel* k, const double* x1, const double* x2, int64_t n, double* out, hipStream_t st);
+int gh_launch_kgrad(const gh_kernel* k, const uint32_t* which_host, const double* x1, int64_t n1,
+                    const double* x2, int64_t n2, bool sym, double* out, hipStream_t st);
+int gh_launch_kxgrad(const gh_kernel* k, int which_arg, const double* x1, int64_t n1,
+                     const double* x2, int64_t n2, double* out, hipStream_t st);
+// grad[p] = sum_{i>=j} w_ij (alpha_i alpha_j - Kinv[i][j]) dK_ij/dtheta_p, w = 1/2 on the diagonal, 1 below
+// (== 1/2 sum_ij A_ij dK_ij/dtheta_p, gp.py:437,465-466); diagA[i] = alpha_i^2 - Kinv[i][i].
+int gh_launch_kgrad_reduce(const gh_kernel* k, const uint32_t* which_host, const double* x, int64_t n,
+                           const double* alpha, const double* kinv, int64_t ld, double* grad_dev /* size */,
+                           double* diagA /* n or NULL */, GhBuf& scratch, hipStream_t st);
+
+// fp64 GEMM family on the MFMA pipe:  C = beta*C + alpha * op(A) * op(B)^T-ish.  See gh_gemm.hip.
+struct GhGemm {
+  double* C; int64_t ldc;
+  const double* A; int64_t lda;   // a_km: A(m,k) at A[m*lda + k];  else at A[k*lda + m]
+  const double* B; int64_t ldb;   // b_km: B(n,k) at B[n*ldb + k];  else at B[k*ldb + n]
+  int64_t M, N, K;                // M, N multiples of 128; K multiple of 16
+  double alpha, beta;
+  bool a_km, b_km;
+  bool lower;                     // square C: only tiles with tile_row >= tile_col
+  bool klo_max;                   // k starts at max(row0, col0) of the tile (operands lower-triangular in k)
+  bool khi_col;                   // k ends at col0 + 128            (B lower-triangular: B(n,k) = 0 for k > n)
+  bool khi_row;                   // k ends at row0 + 128            (A lower-triangular: A(m,k) = 0 for k > m)
+};
+int gh_launch_gemm(const GhGemm& g, hipStream_t st);
+bool gh_use_mfma();               // false when GEORGE_AMD_NO_MFMA=1 (VALU validation path)

@@ -1,0 +1,338 @@
+// gh_gemm.hip -- fp64 GEMM / SYRK family on the CDNA4 matrix pipe.
+//
+// One kernel template serves every O(N^3) step of the solver (trailing SYRK
+// update, panel updates, TRSM-by-inverse multiplies, multi-RHS solves, K^-1):
+//     C[m][n] = beta * C[m][n] + alpha * sum_k A(m,k) * B(n,k)
+// with each operand either "k-major" (row-major, k contiguous) or "m-major"
+// (k strided); both are staged into LDS in the same [row][k] image so the MFMA
+// fragment reads are identical.
+//
+// Tiling (gfx950): 128x128 C tile per 256-thread workgroup = 2x2 wavefronts,
+// each wavefront a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators
+// (64 f64 = 128 VGPRs/lane).  K is consumed in slabs of 16 through a
+// double-buffered LDS image (2 x 2 x 128 x 18 doubles = 72 KiB -> 2 workgroups
+// per CU); global loads for slab t+1 are issued before the 64 MFMAs of slab t
+// and written to the other buffer after them, one barrier per slab.  LDS rows
+// are padded to 18 doubles so the fragment read (16 rows x 4 k per wavefront,
+// ds_read_b64) hits 32 distinct even banks per 32-lane half: conflict-free.
+//
+// fp64 MFMA issue is 2048 flop / 64 cycles / SIMD: per 16 MFMAs a wavefront needs
+// only 8 fragment reads, so the kernel is MFMA-issue bound, not LDS bound.
+#include <stdlib.h>
+#include "gh_common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LS 18
+
+struct GemmDev {
+  double* C; long ldc;
+  const double* A; long lda;
+  const double* B; long ldb;
+  long K;
+  double alpha, beta;
+  int tiles_m, tiles_n;
+  int lower, klo_max, khi_col, khi_row;
+  long nblk;
+};
+
+// XCD-aware remap (bijective for any nblk): workgroup b runs on XCD b % 8; give each XCD
+// a contiguous range of logical tiles so neighbours share operand panels in one L2.
+__device__ __forceinline__ long xcd_remap(long bid, long nblk) {
+  const long q = nblk / 8, r = nblk % 8;
+  const long xcd = bid % 8, idx = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void tile_of(const GemmDev& g, int& tm, int& tn) {
+  const long l = xcd_remap(blockIdx.x, g.nblk);
+  if (g.lower) {
+    long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
+    while (t * (t + 1) / 2 > l) --t;
+    while ((t + 1) * (t + 2) / 2 <= l) ++t;
+    tm = (int)t;
+    tn = (int)(l - t * (t + 1) / 2);
+  } else {
+    tm = (int)(l / g.tiles_n);
+    tn = (int)(l % g.tiles_n);
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ void stage_load(const double* base, long ld, long r0, long k0, int tid, double2 (&v)[4]) {
+  if (KM) {        // element (row, k) at base[row*ld + k]
+    const int row = tid >> 3, kc = (tid & 7) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = *reinterpret_cast<const double2*>(base + (r0 + row + 32 * i) * ld + k0 + kc);
+  } else {         // element (row, k) at base[k*ld + row]
+    const int k = tid >> 6, m = (tid & 63) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = *reinterpret_cast<const double2*>(base + (k0 + k + 4 * i) * ld + r0 + m);
+  }
+}
+template <bool KM>
+__device__ __forceinline__ void stage_store(double* s, int tid, const double2 (&v)[4]) {
+  if (KM) {
+    const int row = tid >> 3, kc = (tid & 7) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<double2*>(s + (row + 32 * i) * LS + kc) = v[i];
+  } else {
+    const int k = tid >> 6, m = (tid & 63) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[m * LS + k + 4 * i] = v[i].x;
+      s[(m + 1) * LS + k + 4 * i] = v[i].y;
+    }
+  }
+}
+
+__device__ __forceinline__ void k_range(const GemmDev& g, long row0, long col0, long& kbeg, long& kend) {
+  kbeg = 0; kend = g.K;
+  if (g.klo_max) kbeg = row0 > col0 ? row0 : col0;
+  if (g.khi_col && col0 + BN < kend) kend = col0 + BN;
+  if (g.khi_row && row0 + BM < kend) kend = row0 + BM;
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
+  __shared__ double sA[2][BM * LS];
+  __shared__ double sB[2][BN * LS];
+  int tm, tn;
+  tile_of(g, tm, tn);
+  const long row0 = (long)tm * BM, col0 = (long)tn * BN;
+  long kbeg, kend;
+  k_range(g, row0, col0, kbeg, kend);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  const long nk = (kend - kbeg) / BK;
+  double2 ra[4], rb[4];
+  if (nk > 0) {
+    stage_load<A_KM>(g.A, g.lda, row0, kbeg, tid, ra);
+    stage_load<B_KM>(g.B, g.ldb, col0, kbeg, tid, rb);
+    stage_store<A_KM>(sA[0], tid, ra);
+    stage_store<B_KM>(sB[0], tid, rb);
+  }
+  __syncthreads();
+  for (long kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      stage_load<A_KM>(g.A, g.lda, row0, kbeg + (kt + 1) * BK, tid, ra);
+      stage_load<B_KM>(g.B, g.ldb, col0, kbeg + (kt + 1) * BK, tid, rb);
+    }
+    const double* pa = sA[cur] + (wm * 64 + fr) * LS + fk;
+    const double* pb = sB[cur] + (wn * 64 + fr) * LS + fk;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = pa[i * 16 * LS + kk * 4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = pb[j * 16 * LS + kk * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      stage_store<A_KM>(sA[cur ^ 1], tid, ra);
+      stage_store<B_KM>(sB[cur ^ 1], tid, rb);
+    }
+    __syncthreads();
+  }
+  // epilogue.  f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = row0 + wm * 64 + i * 16 + fk + 4 * r;
+      double* crow = g.C + row * g.ldc + col0 + wn * 64 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = alpha * acc[i][j][r];
+        crow[j * 16] = (beta == 0.0) ? v : beta * crow[j * 16] + v;
+      }
+    }
+  }
+}
+
+// Plain-VALU kernel with identical semantics: validation arm for the MFMA lane maps
+// (GEORGE_AMD_NO_MFMA=1) -- each thread owns an 8x8 micro-tile of the 128x128 C tile.
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f64_valu(GemmDev g) {
+  __shared__ double sA[BM * LS];
+  __shared__ double sB[BN * LS];
+  int tm, tn;
+  tile_of(g, tm, tn);
+  const long row0 = (long)tm * BM, col0 = (long)tn * BN;
+  long kbeg, kend;
+  k_range(g, row0, col0, kbeg, kend);
+  const int tid = threadIdx.x;
+  const int tr = (tid >> 4) * 8, tc = (tid & 15) * 8;
+  double acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+  double2 ra[4], rb[4];
+  for (long k0 = kbeg; k0 < kend; k0 += BK) {
+    stage_load<A_KM>(g.A, g.lda, row0, k0, tid, ra);
+    stage_load<B_KM>(g.B, g.ldb, col0, k0, tid, rb);
+    __syncthreads();
+    stage_store<A_KM>(sA, tid, ra);
+    stage_store<B_KM>(sB, tid, rb);
+    __syncthreads();
+    for (int k = 0; k < BK; ++k) {
+      double a[8], b[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = sA[(tr + i) * LS + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = sB[(tc + j) * LS + k];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+  }
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) {
+      double* c = g.C + (row0 + tr + i) * g.ldc + col0 + tc + j;
+      const double v = g.alpha * acc[i][j];
+      *c = (g.beta == 0.0) ? v : g.beta * (*c) + v;
+    }
+}
+
+static int g_mfma = -1;
+bool gh_use_mfma() {
+  if (g_mfma < 0) { const char* e = getenv("GEORGE_AMD_NO_MFMA"); g_mfma = (e && e[0] == '1') ? 0 : 1; }
+  return g_mfma == 1;
+}
+extern "C" int gh_debug_set_mfma(int enabled) {
+  const int prev = gh_use_mfma() ? 1 : 0;
+  g_mfma = enabled ? 1 : 0;
+  return prev;
+}
+
+int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
+  if (h.M <= 0 || h.N <= 0) return GH_OK;
+  if (h.M % BM || h.N % BN || h.K % BK) { gh_set_error("gemm: sizes must be multiples of the tile (%ld %ld %ld)", (long)h.M, (long)h.N, (long)h.K); return GH_ERR_BAD_ARG; }
+  if (h.lower && h.M != h.N) { gh_set_error("gemm: lower needs a square C"); return GH_ERR_BAD_ARG; }
+  GemmDev g;
+  g.C = h.C; g.ldc = h.ldc; g.A = h.A; g.lda = h.lda; g.B = h.B; g.ldb = h.ldb; g.K = h.K;
+  g.alpha = h.alpha; g.beta = h.beta;
+  g.tiles_m = (int)(h.M / BM); g.tiles_n = (int)(h.N / BN);
+  g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
+  g.nblk = h.lower ? (long)g.tiles_m * (g.tiles_m + 1) / 2 : (long)g.tiles_m * g.tiles_n;
+  if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
+  const dim3 grid((unsigned)g.nblk), block(256);
+  const bool mfma = gh_use_mfma();
+#define GH_GEMM_LAUNCH(AK, BKM)                                                             \
+  do {                                                                                      \
+    if (mfma) hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM>), grid, block, 0, st, g);          \
+    else      hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g);          \
+  } while (0)
+  if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
+  else if (h.a_km && !h.b_km) GH_GEMM_LAUNCH(true, false);
+  else if (!h.a_km && !h.b_km) GH_GEMM_LAUNCH(false, false);
+  else GH_GEMM_LAUNCH(false, true);
+#undef GH_GEMM_LAUNCH
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+extern "C" int gh_dev_gemm_nt(double* c, int64_t ldc, const double* a, int64_t lda,
+                              const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k,
+                              int32_t lower, void* stream) {
+  GhGemm g{};
+  g.C = c; g.ldc = ldc; g.A = a; g.lda = lda; g.B = b; g.ldb = ldb;
+  g.M = m; g.N = n; g.K = k; g.alpha = -1.0; g.beta = 1.0;
+  g.a_km = true; g.b_km = true; g.lower = lower != 0;
+  return gh_launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int gh_dev_gemm(double* c, int64_t ldc, const double* a, int64_t lda,
+                           const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k,
+                           double alpha, double beta, int32_t flags, void* stream) {
+  GhGemm g{};
+  g.C = c; g.ldc = ldc; g.A = a; g.lda = lda; g.B = b; g.ldb = ldb;
+  g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta;
+  g.a_km = !(flags & GH_GEMM_A_MMAJOR); g.b_km = !(flags & GH_GEMM_B_NMAJOR);
+  g.lower = (flags & GH_GEMM_LOWER) != 0; g.klo_max = (flags & GH_GEMM_KLO_MAX) != 0;
+  g.khi_col = (flags & GH_GEMM_KHI_COL) != 0; g.khi_row = (flags & GH_GEMM_KHI_ROW) != 0;
+  return gh_launch_gemm(g, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------ micro-benchmarks
+// fp64 MFMA issue-rate ceiling: 4 independent accumulators per wavefront, 8 waves/CU.
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
+  v4d acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc3, 0, 0, 0);
+  }
+  const v4d s = acc0 + acc1 + acc2 + acc3;
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];   // keep the chain live
+}
+extern "C" int gh_microbench_mfma_f64(double* tflops_out) {
+  if (gh_device_count() <= 0) { gh_set_error("no HIP device"); return GH_ERR_HIP; }
+  double* d = nullptr;
+  GH_HIP(hipMalloc((void**)&d, 64));
+  const int iters = 20000, blocks = 256 * 2;
+  hipEvent_t e0, e1;
+  GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, d, 100);
+  GH_HIP(hipDeviceSynchronize());
+  GH_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, d, iters);
+  GH_HIP(hipEventRecord(e1, 0));
+  GH_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * 2048.0;
+  *tflops_out = flops / (ms * 1e-3) * 1e-12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+  return GH_OK;
+}
+__global__ void copy16_kernel(const double2* __restrict__ in, double2* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i];
+}
+extern "C" int gh_microbench_hbm_copy(double* gbps_out) {
+  if (gh_device_count() <= 0) { gh_set_error("no HIP device"); return GH_ERR_HIP; }
+  const long n = 1L << 27;   // 2 GiB in + 2 GiB out
+  double2 *a = nullptr, *b = nullptr;
+  GH_HIP(hipMalloc((void**)&a, n * sizeof(double2)));
+  GH_HIP(hipMalloc((void**)&b, n * sizeof(double2)));
+  GH_HIP(hipMemset(a, 0, n * sizeof(double2)));
+  hipEvent_t e0, e1;
+  GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, 0, a, b, n);
+  GH_HIP(hipDeviceSynchronize());
+  GH_HIP(hipEventRecord(e0, 0));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, 0, a, b, n);
+  GH_HIP(hipEventRecord(e1, 0));
+  GH_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *gbps_out = 5.0 * 2.0 * n * sizeof(double2) / (ms * 1e-3) * 1e-9;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+  return GH_OK;
+}

@@ -1,0 +1,184 @@
+"""``BasicSolver`` -- dense Cholesky on one MI355X.
+
+Drop-in for the reference's ``BasicSolver`` (``src/george/solvers/basic.py``):
+same constructor, methods, shapes and error behaviour, but ``compute`` builds
+the covariance matrix on the device from ``(kernel, x)`` and factorises it there
+(blocked fp64-MFMA Cholesky, george_amd/csrc/gh_chol.hip); the N x N matrix
+never visits the host.  Extra, optional entry points (``predict``, ``grad``)
+keep the GP glue of ``gp.py:482-545`` / ``:429-466`` device-resident;
+:class:`george_amd.GP` uses them when present, the reference GP simply ignores
+them.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _native as N
+from ..program import DeviceKernel
+
+__all__ = ["BasicSolver"]
+
+
+class BasicSolver(object):
+
+    def __init__(self, kernel, device=0, nb=0, profile=False, lookahead=True):
+        self.kernel = kernel
+        self._computed = False
+        self._log_det = None
+        self._opts = dict(device=int(device), nb=int(nb), profile=bool(profile), lookahead=bool(lookahead))
+        self._handle = None
+        self._dk = None
+
+    # -- properties (basic.py:25-49)
+    @property
+    def computed(self):
+        return self._computed
+
+    @computed.setter
+    def computed(self, v):
+        self._computed = v
+
+    @property
+    def log_determinant(self):
+        return self._log_det
+
+    @log_determinant.setter
+    def log_determinant(self, v):
+        self._log_det = v
+
+    # -- lifetime
+    def _ensure_handle(self):
+        if self._handle is None:
+            o = N.gh_chol_opts()
+            o.device, o.nb = self._opts["device"], self._opts["nb"]
+            o.profile, o.lookahead = int(self._opts["profile"]), int(self._opts["lookahead"])
+            h = N._vp()
+            N.check(N.lib.gh_chol_create(C.byref(o), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                N.lib.gh_chol_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # pickling drops the device factor and flags the solver uncomputed, the precedent the
+    # reference sets for its own native solver (solvers/hodlr.py:69-76)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handle"] = None
+        state["_dk"] = None
+        state["_computed"] = False
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    # -- the solver protocol
+    def compute(self, x, yerr):
+        """basic.py:51-70.  ``yerr`` already contains the white noise (gp.py:330)."""
+        x = N.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError("x must be (nsamples, ndim)")
+        yerr = N.as_f64(np.zeros(len(x)) + yerr)
+        self._computed = False
+        self._dk = DeviceKernel(self.kernel)
+        if x.shape[1] != self._dk.ndim:
+            raise RuntimeError("dimension mismatch")
+        h = self._ensure_handle()
+        logdet = C.c_double(0.0)
+        N.check(N.lib.gh_chol_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        self._n = len(x)
+        self.log_determinant = logdet.value
+        self.computed = True
+
+    def _need(self):
+        if not self._computed or self._handle is None:
+            raise RuntimeError("you must call 'compute' first")
+        return self._handle
+
+    def apply_inverse(self, y, in_place=False):
+        """basic.py:72-87 (``cho_solve``): ``y`` is (n,) or (n, nrhs)."""
+        h = self._need()
+        yin = y
+        y = np.asarray(y, dtype=np.float64)
+        if y.shape[0] != self._n or y.ndim > 2:
+            raise ValueError("dimension mismatch")
+        yc = np.ascontiguousarray(y)
+        nrhs = 1 if yc.ndim == 1 else yc.shape[1]
+        writable_inplace = (in_place and isinstance(yin, np.ndarray) and yin.dtype == np.float64
+                            and yin.flags.c_contiguous and yin.flags.writeable)
+        out = yin if writable_inplace else np.empty_like(yc)
+        if nrhs > 0:
+            N.check(N.lib.gh_chol_solve(h, N.ptr(yc), nrhs, N.ptr(out)))
+        if in_place and not writable_inplace and isinstance(yin, np.ndarray):
+            try:
+                yin[...] = out                     # honour overwrite_b for non-contiguous callers (gp.py:296-301)
+                return yin
+            except (ValueError, TypeError):
+                pass
+        return out
+
+    def dot_solve(self, y):
+        """basic.py:89-102."""
+        h = self._need()
+        y = N.as_f64(y).reshape(-1)
+        if len(y) != self._n:
+            raise ValueError("dimension mismatch")
+        out = C.c_double(0.0)
+        N.check(N.lib.gh_chol_dot_solve(h, N.ptr(y), C.byref(out)))
+        return out.value
+
+    def apply_sqrt(self, r):
+        """basic.py:104-114: ``r @ U`` with ``U^T U = K``."""
+        h = self._need()
+        r = N.as_f64(r)
+        one_d = r.ndim == 1
+        r2 = r.reshape(1, -1) if one_d else r
+        if r2.shape[1] != self._n:
+            raise ValueError("dimension mismatch")
+        out = np.empty_like(r2)
+        N.check(N.lib.gh_chol_apply_sqrt(h, N.ptr(r2), r2.shape[0], N.ptr(out)))
+        return out[0] if one_d else out
+
+    def get_inverse(self):
+        """basic.py:116-121."""
+        h = self._need()
+        out = np.empty((self._n, self._n), dtype=np.float64)
+        N.check(N.lib.gh_chol_get_inverse(h, N.ptr(out)))
+        return out
+
+    # -- fused, device-resident GP glue (optional protocol extensions)
+    def predict(self, kernel, r, xs, return_var=False, return_cov=False):
+        """mean / variance / covariance terms of gp.py:532-545 for residual ``r = y - mean``:
+        returns ``K* K^-1 r`` and (optionally) ``diag`` or full ``K** - K* K^-1 K*^T``."""
+        h = self._need()
+        dk = DeviceKernel(kernel) if kernel is not self.kernel else self._dk
+        r, xs = N.as_f64(r).reshape(-1), N.as_f64(xs)
+        m = len(xs)
+        mu = np.empty(m)
+        var = np.empty(m) if return_var else None
+        cov = np.empty((m, m)) if return_cov else None
+        N.check(N.lib.gh_chol_predict(h, dk.handle, N.ptr(r), N.ptr(xs), m, N.ptr(mu), N.ptr(var), N.ptr(cov)))
+        return mu, var, cov
+
+    def grad(self, r, which):
+        """kernel part of gp.py:429-466: returns (grad over ALL kernel params (masked ones 0),
+        alpha = K^-1 r, diag(alpha alpha^T - K^-1))."""
+        h = self._need()
+        r = N.as_f64(r).reshape(-1)
+        which = np.ascontiguousarray(which, dtype=np.uint32)
+        g = np.zeros(max(self._dk.size, 1))
+        alpha, diagA = np.empty(self._n), np.empty(self._n)
+        N.check(N.lib.gh_chol_grad(h, self._dk.handle, N.ptr(which), N.ptr(r), N.ptr(g), N.ptr(alpha), N.ptr(diagA)))
+        return g[:self._dk.size], alpha, diagA
+
+    def profile(self):
+        p = N.gh_chol_profile()
+        N.check(N.lib.gh_chol_get_profile(self._need(), C.byref(p)))
+        return dict(ms_total=p.ms_total, ms_build=p.ms_build, ms_panel=p.ms_panel, ms_trailing=p.ms_trailing,
+                    trailing_flops=p.trailing_flops, n_trailing=p.n_trailing, ms_solve=p.ms_solve)

@@ -1,0 +1,106 @@
+"""``HODLRSolver`` -- level-batched HODLR factorisation on one MI355X.
+
+Drop-in for the reference's ``HODLRSolver`` (``src/george/solvers/hodlr.py:13-76``
+over ``_hodlr.cpp`` / ``include/george/hodlr.h``): same constructor keywords
+(``min_size=100, tol=0.1, seed=42``), same methods, ``apply_sqrt`` raises
+``NotImplementedError`` (hodlr.py:62-64), pickling drops the factor (:69-76).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _native as N
+from ..program import DeviceKernel
+from .basic import BasicSolver
+
+__all__ = ["HODLRSolver"]
+
+
+class HODLRSolver(BasicSolver):
+
+    def __init__(self, kernel, min_size=100, tol=0.1, seed=42, device=0, max_rank=0):
+        self.min_size = min_size
+        self.tol = tol
+        self.seed = seed
+        self._hopts = dict(device=int(device), max_rank=int(max_rank))
+        super(HODLRSolver, self).__init__(kernel, device=device)
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            o = N.gh_hodlr_opts()
+            o.device, o.min_size, o.seed = self._hopts["device"], int(self.min_size), int(self.seed)
+            o.max_rank, o.tol = self._hopts["max_rank"], float(self.tol)
+            h = N._vp()
+            N.check(N.lib.gh_hodlr_create(C.byref(o), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                N.lib.gh_hodlr_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def compute(self, x, yerr):
+        x = N.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError("x must be (nsamples, ndim)")
+        yerr = N.as_f64(np.zeros(len(x)) + yerr)
+        self._computed = False
+        self._dk = DeviceKernel(self.kernel)
+        if x.shape[1] != self._dk.ndim:
+            raise RuntimeError("dimension mismatch")
+        if self._handle is not None:          # options may have been changed on the instance
+            N.lib.gh_hodlr_destroy(self._handle)
+            self._handle = None
+        h = self._ensure_handle()
+        logdet = C.c_double(0.0)
+        N.check(N.lib.gh_hodlr_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        self._n = len(x)
+        self._log_det = logdet.value
+        self.computed = True
+
+    def apply_inverse(self, y, in_place=False):
+        # the reference's pybind/Eigen binding always returns a fresh array
+        h = self._need()
+        y = np.asarray(y, dtype=np.float64)
+        if y.shape[0] != self._n or y.ndim > 2:
+            raise ValueError("dimension mismatch")
+        yc = np.ascontiguousarray(y)
+        nrhs = 1 if yc.ndim == 1 else yc.shape[1]
+        out = np.empty_like(yc)
+        if nrhs > 0:
+            N.check(N.lib.gh_hodlr_solve(h, N.ptr(yc), nrhs, N.ptr(out)))
+        return out
+
+    def dot_solve(self, y):
+        h = self._need()
+        y = N.as_f64(y).reshape(-1)
+        if len(y) != self._n:
+            raise ValueError("dimension mismatch")
+        out = C.c_double(0.0)
+        N.check(N.lib.gh_hodlr_dot_solve(h, N.ptr(y), C.byref(out)))
+        return out.value
+
+    def apply_sqrt(self, r):
+        raise NotImplementedError("apply_sqrt is not implemented for the HODLRSolver")
+
+    def get_inverse(self):
+        h = self._need()
+        out = np.empty((self._n, self._n), dtype=np.float64)
+        N.check(N.lib.gh_hodlr_get_inverse(h, N.ptr(out)))
+        return out
+
+    def ranks(self):
+        buf = (C.c_int32 * 65536)()
+        cnt = C.c_int32(0)
+        N.check(N.lib.gh_hodlr_ranks(self._need(), buf, 65536, C.byref(cnt)))
+        return list(buf[:cnt.value])
+
+    # the fused dense-only extensions do not apply
+    predict = None
+    grad = None
+    profile = None

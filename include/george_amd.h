@@ -1,0 +1,255 @@
+/*
+ * george_amd.h -- C ABI of the MI355X-native GP solver backend for dfm/george.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point cites the reference interface it replaces (paths relative
+ * to the dfm/george source tree).  The Python host layer (george_amd/ *.py)
+ * binds these with ctypes; INTEGRATION.md shows the stub a george maintainer
+ * would add.
+ *
+ * Conventions
+ *   - all matrices are C-contiguous (row-major) fp64, exactly as the reference
+ *     passes them through pybind11 / NumPy;
+ *   - every data pointer may be a HOST pointer or a DEVICE (HBM) pointer; the
+ *     library detects which (hipPointerGetAttributes) and stages host buffers
+ *     itself.  Results are written to the memory space of the `out` pointer;
+ *   - every function returns a status code (GH_OK == 0); gh_last_error() gives
+ *     a thread-local message.  No exception crosses the boundary;
+ *   - handles are opaque, owned by the library, freed by *_destroy, and not
+ *     re-entrant (one call at a time per handle);
+ *   - calls are synchronous: on return the result is complete.
+ */
+#ifndef GEORGE_AMD_H_
+#define GEORGE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GH_MAX_AXES    8           /* max active axes of one leaf kernel */
+#define GH_MAX_NDIM    16          /* max input dimension */
+#define GH_MAX_PARAMS  4
+#define GH_MAX_METRIC  36          /* GH_MAX_AXES*(GH_MAX_AXES+1)/2 */
+#define GH_MAX_NODES   64
+#define GH_MAX_GRAD    64          /* max full_size of a kernel expression */
+#define GH_MAX_STACK   8           /* max postfix evaluation depth */
+
+/* status codes.  The Python layer maps NOT_PD -> numpy.linalg.LinAlgError,
+ * BAD_ARG -> ValueError, DIM -> RuntimeError("dimension mismatch")
+ * (reference include/george/exceptions.h:8-12), NOT_COMPUTED ->
+ * RuntimeError("you must call 'compute' first") (exceptions.h:14-18). */
+enum {
+  GH_OK = 0,
+  GH_ERR_NOT_PD = 1,
+  GH_ERR_BAD_ARG = 2,
+  GH_ERR_HIP = 3,
+  GH_ERR_NOT_COMPUTED = 4,
+  GH_ERR_DIM = 5,
+  GH_ERR_NOMEM = 6
+};
+
+/* node operators */
+enum { GH_OP_LEAF = 0, GH_OP_SUM = 1, GH_OP_PRODUCT = 2 };
+
+/* leaf kernel ids == the reference's `kernel_type` class attributes
+ * (src/george/kernels.py:273,322,391,464,500,546,588,666,712,753,822,897,944) */
+enum {
+  GH_K_LINEAR = 0, GH_K_RATQUAD = 1, GH_K_EXP = 2, GH_K_LOCALGAUSS = 3,
+  GH_K_EMPTY = 4, GH_K_COSINE = 5, GH_K_MATERN52 = 6, GH_K_EXPSINE2 = 7,
+  GH_K_CONSTANT = 8, GH_K_EXPSQUARED = 9, GH_K_MATERN32 = 10,
+  GH_K_POLYNOMIAL = 11, GH_K_DOTPRODUCT = 12
+};
+
+/*
+ * One node of a kernel expression, flattened in POSTFIX order (children
+ * before their operator).  This POD replaces the heap-allocated C++ object
+ * tree that `george::parse_kernel_spec` builds from the Python spec
+ * (include/george/parser.h:14-35 operators, :344-403 stationary leaves);
+ * the fields are exactly the attributes that parser reads.
+ */
+typedef struct gh_knode {
+  int32_t op;                       /* GH_OP_*                                        */
+  int32_t kernel_type;              /* GH_K_* (leaf only)                              */
+  int32_t metric_type;              /* 0 isotropic, 1 axis-aligned, 2 general; -1 = non-stationary leaf */
+  int32_t ndim;                     /* input dimension                                 */
+  int32_t naxes;                    /* number of active axes                           */
+  int32_t blocked;                  /* stationary leaves: `blocked` flag               */
+  int32_t n_params;                 /* own parameters (e.g. log_alpha)                 */
+  int32_t n_metric;                 /* metric parameters                               */
+  int32_t axes[GH_MAX_AXES];
+  double  params[GH_MAX_PARAMS];    /* own parameters, in parameter_names order        */
+  double  constant;                 /* `order` for Linear/Polynomial                   */
+  double  metric[GH_MAX_METRIC];    /* metric.get_parameter_vector(include_frozen=True) */
+  double  min_block[GH_MAX_AXES];
+  double  max_block[GH_MAX_AXES];
+} gh_knode;
+
+typedef struct gh_kernel gh_kernel;
+typedef struct gh_chol   gh_chol;
+typedef struct gh_hodlr  gh_hodlr;
+
+/* ------------------------------------------------------------------ misc */
+int         gh_device_count(void);
+const char* gh_last_error(void);
+const char* gh_version(void);
+/* fp64 MFMA / HBM micro-benchmarks used to pin the roofline denominators
+ * (SURVEY.md 8d): returns TFLOP/s of a v_mfma_f64_16x16x4_f64-only kernel and
+ * GB/s of a 16-B/lane copy. */
+int gh_microbench_mfma_f64(double* tflops_out);
+/* validation switch: 0 routes every GEMM through the plain-VALU kernel (same semantics) so the
+ * MFMA lane maps can be cross-checked on the device; returns the previous setting. */
+int gh_debug_set_mfma(int enabled);
+int gh_microbench_hbm_copy(double* gbps_out);
+
+/* ---------------------------------------------- kernel-function evaluator
+ * Replaces the pybind11 class KernelInterface, src/george/kernel_interface.cpp:
+ *   ctor + parse_kernel_spec  :12-14   -> gh_kernel_create
+ *   value_general             :47-60   -> gh_kernel_value_general
+ *   value_symmetric           :62-77   -> gh_kernel_value_symmetric
+ *   value_diagonal            :79-90   -> gh_kernel_value_diagonal
+ *   gradient_general          :92-107  -> gh_kernel_gradient_general
+ *   gradient_symmetric        :109-125 -> gh_kernel_gradient_symmetric
+ *   x1_gradient_general       :127-141 -> gh_kernel_x1_gradient_general
+ *   x2_gradient_general       :143-157 -> gh_kernel_x2_gradient_general
+ * `which` is the uint32 mask of kernels.py:120; masked-out slots (left
+ * uninitialised by the reference, kernels.h:85-91) are written as 0. */
+int  gh_kernel_create(const gh_knode* nodes, int n_nodes, gh_kernel** out);
+void gh_kernel_destroy(gh_kernel* k);
+int  gh_kernel_ndim(const gh_kernel* k);
+int  gh_kernel_size(const gh_kernel* k);          /* full_size */
+int  gh_kernel_value_general(gh_kernel* k, const double* x1, int64_t n1,
+                             const double* x2, int64_t n2, double* out /* n1*n2 */);
+int  gh_kernel_value_symmetric(gh_kernel* k, const double* x, int64_t n, double* out /* n*n */);
+int  gh_kernel_value_diagonal(gh_kernel* k, const double* x1, const double* x2,
+                              int64_t n, double* out /* n */);
+int  gh_kernel_gradient_general(gh_kernel* k, const uint32_t* which,
+                                const double* x1, int64_t n1, const double* x2, int64_t n2,
+                                double* out /* n1*n2*size */);
+int  gh_kernel_gradient_symmetric(gh_kernel* k, const uint32_t* which,
+                                  const double* x, int64_t n, double* out /* n*n*size */);
+int  gh_kernel_x1_gradient_general(gh_kernel* k, const double* x1, int64_t n1,
+                                   const double* x2, int64_t n2, double* out /* n1*n2*ndim */);
+int  gh_kernel_x2_gradient_general(gh_kernel* k, const double* x1, int64_t n1,
+                                   const double* x2, int64_t n2, double* out /* n1*n2*ndim */);
+
+/* ------------------------------------------------------- dense Cholesky solver
+ * Replaces BasicSolver (src/george/solvers/basic.py) and the SciPy/LAPACK
+ * dpotrf/dpotrs it calls:
+ *   compute        :51-70   (K = kernel(x); K_ii += yerr_i^2; cholesky; log_det)
+ *   apply_inverse  :72-87   (cho_solve)            -> gh_chol_solve
+ *   dot_solve      :89-102  (y . cho_solve(y))     -> gh_chol_dot_solve
+ *   apply_sqrt     :104-114 (r @ U)                -> gh_chol_apply_sqrt
+ *   get_inverse    :116-121                        -> gh_chol_get_inverse
+ * plus fused device-resident forms of the GP glue around it
+ *   GP.predict            src/george/gp.py:482-545 -> gh_chol_predict
+ *   GP.grad_log_likelihood (kernel part) gp.py:429-466 -> gh_chol_grad
+ * K is built on the device from (kernel, x) and never visits the host. */
+typedef struct gh_chol_opts {
+  int32_t device;        /* HIP device ordinal                                   */
+  int32_t nb;            /* outer panel width (multiple of 128); 0 = default      */
+  int32_t profile;       /* 1: record per-kernel-class hipEvent timings           */
+  int32_t lookahead;     /* 1: overlap panel factorisation with trailing update   */
+  int32_t reserved[4];
+} gh_chol_opts;
+
+int  gh_chol_create(const gh_chol_opts* opts, gh_chol** out);
+void gh_chol_destroy(gh_chol* s);
+/* yerr: (n,) standard deviations ALREADY including white noise (gp.py:330). */
+int  gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                     const double* yerr, double* logdet_out);
+int64_t gh_chol_info(const gh_chol* s);     /* 1-based index of the failing pivot after GH_ERR_NOT_PD, else 0 */
+int64_t gh_chol_size(const gh_chol* s);
+int  gh_chol_solve(gh_chol* s, const double* b, int64_t nrhs, double* out);   /* b, out: (n, nrhs) row-major; may alias */
+int  gh_chol_dot_solve(gh_chol* s, const double* y, double* out);
+int  gh_chol_apply_sqrt(gh_chol* s, const double* r, int64_t nrows, double* out); /* r, out: (nrows, n) */
+int  gh_chol_get_inverse(gh_chol* s, double* out /* n*n */);
+/* mu = K(xs,x) K^-1 r ; var = diag(K(xs,xs)) - diag(K(xs,x) K^-1 K(x,xs)) ;
+ * cov = K(xs,xs) - K(xs,x) K^-1 K(x,xs).   var / cov may be NULL. */
+int  gh_chol_predict(gh_chol* s, gh_kernel* k, const double* r /* n: y - mean */,
+                     const double* xs, int64_t m, double* mu /* m */,
+                     double* var /* m or NULL */, double* cov /* m*m or NULL */);
+/* alpha = K^-1 r; A = alpha alpha^T - K^-1; grad[p] = 1/2 sum_ij A_ij dK_ij/dtheta_p
+ * for the parameters selected by `which` (others 0); diagA (n) = diag(A). */
+int  gh_chol_grad(gh_chol* s, gh_kernel* k, const uint32_t* which, const double* r,
+                  double* grad /* size */, double* alpha /* n or NULL */, double* diagA /* n or NULL */);
+/* profile counters of the last compute(): see george_amd/csrc/gh_chol.hip */
+typedef struct gh_chol_profile {
+  double ms_total;          /* build + factor, device time                     */
+  double ms_build;          /* kernel-matrix build                             */
+  double ms_panel;          /* potf2 + trsm + inner updates                    */
+  double ms_trailing;       /* sum of trailing-update (SYRK) launches          */
+  double trailing_flops;    /* algorithmic flops of those launches             */
+  int64_t n_trailing;       /* number of trailing-update launches              */
+  double ms_solve;          /* last dot_solve / solve                          */
+  double reserved[4];
+} gh_chol_profile;
+int  gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out);
+
+/* ------------------------------------------------------------ HODLR solver
+ * Replaces HODLRSolver (src/george/solvers/hodlr.py:13-76), the pybind11
+ * `Solver` (src/george/solvers/_hodlr.cpp:38-110) and hodlr::Node
+ * (include/george/hodlr.h:13-258). */
+typedef struct gh_hodlr_opts {
+  int32_t device;
+  int32_t min_size;      /* hodlr.py:43 default 100 */
+  int32_t seed;          /* hodlr.py:43 default 42  */
+  int32_t max_rank;      /* cap on the ACA rank per block; 0 = default (256) */
+  double  tol;           /* hodlr.py:43 default 0.1 */
+  int32_t reserved[4];
+} gh_hodlr_opts;
+
+int  gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out);
+void gh_hodlr_destroy(gh_hodlr* h);
+int  gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                      const double* yerr, double* logdet_out);
+int  gh_hodlr_solve(gh_hodlr* h, const double* b, int64_t nrhs, double* out);  /* (n, nrhs) row-major */
+int  gh_hodlr_dot_solve(gh_hodlr* h, const double* y, double* out);
+int  gh_hodlr_get_inverse(gh_hodlr* h, double* out /* n*n */);
+int  gh_hodlr_ranks(const gh_hodlr* h, int32_t* ranks_out, int32_t max_out, int32_t* n_out);
+
+/* ------------------------------------------- device-level tile operations
+ * Building blocks of the blocked factorisation on DEVICE pointers and an
+ * explicit hipStream_t (passed as void*; NULL = default stream).  Used by the
+ * multi-GPU 2-D block-cyclic driver (george_amd/distributed.py), which moves
+ * panels between ranks with torch.distributed (RCCL) in between.  Leading
+ * dimensions are in elements; all sizes must be multiples of 128. */
+/* out[r, c] = k(x[row0+r], x[col0+c]) (+ yerr[row0+r]^2 where row0+r == col0+c) */
+int gh_dev_kmat_block(gh_kernel* k, const double* x, int32_t ndim, const double* yerr,
+                      int64_t row0, int64_t nrows, int64_t col0, int64_t ncols,
+                      double* out, int64_t ldo, void* stream);
+/* in-place lower Cholesky of the n x n block `a`; dinv receives the inverses of
+ * its 128x128 diagonal blocks, (n/128) x 128 x 128; *info_dev (device int64) is
+ * set to base_index + failing pivot (1-based) when not positive definite. */
+int gh_dev_potrf_block(double* a, int64_t lda, int64_t n, double* dinv,
+                       int64_t* info_dev, int64_t base_index, void* stream);
+/* a21 (m x n) <- a21 * L11^-T using L11 (n x n, lower) and its diagonal-block inverses */
+int gh_dev_trsm_right(const double* l11, int64_t ld11, const double* dinv,
+                      double* a21, int64_t lda, int64_t m, int64_t n, void* stream);
+/* c (m x n) -= a (m x k) * b (n x k)^T ; lower != 0: only tiles on/below the diagonal of the
+ * square c are updated (SYRK-shaped, a and b rows aligned with c rows/cols). */
+int gh_dev_gemm_nt(double* c, int64_t ldc, const double* a, int64_t lda,
+                   const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k,
+                   int32_t lower, void* stream);
+/* general form: c = beta*c + alpha * sum_k A(m,k) B(n,k); by default A(m,k) = a[m*lda + k] and
+ * B(n,k) = b[n*ldb + k] ("k-major"); flags select the transposed layouts, SYRK-style lower-only
+ * tile sets and k-range clipping for triangular operands. */
+enum {
+  GH_GEMM_A_MMAJOR = 1,   /* A(m,k) = a[k*lda + m]                                   */
+  GH_GEMM_B_NMAJOR = 2,   /* B(n,k) = b[k*ldb + n]                                   */
+  GH_GEMM_LOWER    = 4,   /* square c: only tiles on/below the diagonal              */
+  GH_GEMM_KLO_MAX  = 8,   /* k starts at max(tile row0, tile col0)                   */
+  GH_GEMM_KHI_COL  = 16,  /* k ends at tile col0 + 128                               */
+  GH_GEMM_KHI_ROW  = 32   /* k ends at tile row0 + 128                               */
+};
+int gh_dev_gemm(double* c, int64_t ldc, const double* a, int64_t lda,
+                const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k,
+                double alpha, double beta, int32_t flags, void* stream);
+/* sum_i 2*log(a[i*lda+i]) over the n diagonal entries, accumulated into *out_dev */
+int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, double* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* GEORGE_AMD_H_ */

@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/george_amd.h declares (CPU only:
+no compute call is made)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "george_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    from george_amd import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "libgeorge_amd.so does not export %s" % n
+    # and the ctypes signature table covers exactly the header
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_struct_layout_matches_header():
+    from george_amd import _native as N
+    # gh_knode: 8 int32 + 8 int32 axes + (4 + 1 + 36 + 8 + 8) doubles
+    assert ctypes.sizeof(N.gh_knode) == 16 * 4 + 57 * 8
+    assert ctypes.sizeof(N.gh_chol_opts) == 8 * 4
+    assert ctypes.sizeof(N.gh_chol_profile) == 11 * 8
+    assert ctypes.sizeof(N.gh_hodlr_opts) == 4 * 4 + 8 + 4 * 4
+
+
+def test_program_validation_runs_without_gpu():
+    """gh_kernel_create is host code: flattening + validation + error mapping work on CPU."""
+    import george_amd.kernels as K
+    from george_amd import program
+    k = 12. * K.ExpSquaredKernel(0.4, ndim=3) + 0.1
+    dk = program.DeviceKernel(k)
+    assert (dk.ndim, dk.size) == (3, 3)
+    arr = program.flatten(k)
+    assert [n.op for n in arr] == [0, 0, 0, 2, 1]          # postfix: c, c, expsq, *, +
+    with pytest.raises(ValueError):
+        program.flatten(object())                          # "invalid kernel", parser.h:16
+    with pytest.raises(ValueError):
+        K.ExpSquaredKernel(1.0, ndim=2) + K.ExpSquaredKernel(1.0, ndim=3)   # dimension mismatch at build time
+
+
+def test_fails_loudly_without_gpu():
+    import george_amd
+    if george_amd.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    k = george_amd.kernels.ExpSquaredKernel(1.0)
+    with pytest.raises(RuntimeError):
+        k.get_value(np.zeros((4, 1)))
+    gp = george_amd.GP(k)
+    with pytest.raises(RuntimeError):
+        gp.compute(np.arange(4.0), 0.1)

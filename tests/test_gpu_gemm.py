@@ -1,0 +1,145 @@
+"""Device unit tests of the building blocks behind the C ABI (need an MI355X): fp64 MFMA GEMM in
+every operand layout vs NumPy and vs the plain-VALU arm, diagonal-block Cholesky + inverse,
+TRSM, and the roofline micro-benchmarks.  Operands are ASYMMETRIC random matrices so a
+transposed fragment map cannot pass."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = dict(A_MMAJOR=1, B_NMAJOR=2, LOWER=4, KLO_MAX=8, KHI_COL=16, KHI_ROW=32)
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _gemm(c, a, b, m, n, k, alpha, beta, flags, lda, ldb, ldc):
+    from george_amd import _native as N
+    import torch
+    N.check(N.lib.gh_dev_gemm(c.data_ptr(), ldc, a.data_ptr(), lda, b.data_ptr(), ldb, m, n, k,
+                              alpha, beta, flags, None))
+    torch.cuda.synchronize()
+
+
+def test_microbench_peaks():
+    from george_amd import _native as N
+    tf, gb = C.c_double(0), C.c_double(0)
+    N.check(N.lib.gh_microbench_mfma_f64(C.byref(tf)))
+    N.check(N.lib.gh_microbench_hbm_copy(C.byref(gb)))
+    print("\n[microbench] v_mfma_f64_16x16x4_f64 peak: %.2f TFLOP/s ; 16B copy: %.0f GB/s" % (tf.value, gb.value))
+    assert 20.0 < tf.value < 200.0
+    assert 1000.0 < gb.value < 9000.0
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("a_mm,b_nm", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_layouts(mfma, a_mm, b_nm):
+    from george_amd import _native as N
+    rng = np.random.RandomState(7 + a_mm * 2 + b_nm)
+    M, Nn, K = 256, 384, 272
+    A = rng.randn(M, K)
+    B = rng.randn(Nn, K)
+    C0 = rng.randn(M, Nn + 64)                       # ldc > n: strided C
+    a = _dev(A.T if a_mm else A)
+    b = _dev(B.T if b_nm else B)
+    c = _dev(C0)
+    prev = N.lib.gh_debug_set_mfma(mfma)
+    try:
+        flags = (FLAGS["A_MMAJOR"] if a_mm else 0) | (FLAGS["B_NMAJOR"] if b_nm else 0)
+        _gemm(c, a, b, M, Nn, K, -1.5, 0.75, flags, M if a_mm else K, Nn if b_nm else K, Nn + 64)
+    finally:
+        N.lib.gh_debug_set_mfma(prev)
+    got = c.cpu().numpy()
+    want = C0.copy()
+    want[:, :Nn] = 0.75 * C0[:, :Nn] - 1.5 * A @ B.T
+    err = np.abs(got - want).max()
+    assert err < 1e-11, "max err %g (mfma=%d a_mm=%d b_nm=%d); first bad %s" % (
+        err, mfma, a_mm, b_nm, np.argwhere(np.abs(got - want) > 1e-11)[:4].tolist())
+    # beta == 0 must not read C (NaN garbage allowed)
+    c2 = _dev(np.full((M, Nn), np.nan))
+    prev = N.lib.gh_debug_set_mfma(mfma)
+    try:
+        _gemm(c2, a, b, M, Nn, K, 1.0, 0.0, flags, M if a_mm else K, Nn if b_nm else K, Nn)
+    finally:
+        N.lib.gh_debug_set_mfma(prev)
+    assert np.abs(c2.cpu().numpy() - A @ B.T).max() < 1e-11
+
+
+def test_gemm_lower_and_k_clipping():
+    rng = np.random.RandomState(3)
+    n = 512
+    P = rng.randn(n, 256)
+    C0 = rng.randn(n, n)
+    c = _dev(C0)
+    p = _dev(P)
+    _gemm(c, p, p, n, n, 256, -1.0, 1.0, FLAGS["LOWER"], 256, 256, n)        # SYRK, lower tiles only
+    got = c.cpu().numpy()
+    want = C0 - P @ P.T
+    for ti in range(4):
+        for tj in range(4):
+            blk = (slice(128 * ti, 128 * ti + 128), slice(128 * tj, 128 * tj + 128))
+            if tj <= ti:
+                assert np.abs(got[blk] - want[blk]).max() < 1e-11
+            else:
+                assert np.array_equal(got[blk], C0[blk])                      # upper tiles untouched
+    # triangular operands: W = Linv^T Linv with k >= max(row0, col0); out = r L^T with k <= col0+128
+    L = np.tril(rng.randn(n, n))
+    l = _dev(L)
+    w = _dev(np.zeros((n, n)))
+    _gemm(w, l, l, n, n, n, 1.0, 0.0, FLAGS["A_MMAJOR"] | FLAGS["B_NMAJOR"] | FLAGS["LOWER"] | FLAGS["KLO_MAX"], n, n, n)
+    assert np.abs(np.tril(w.cpu().numpy()) - np.tril(L.T @ L)).max() < 1e-10
+    R = rng.randn(128, n)
+    o = _dev(np.zeros((128, n)))
+    _gemm(o, _dev(R), l, 128, n, n, 1.0, 0.0, FLAGS["KHI_COL"], n, n, n)
+    assert np.abs(o.cpu().numpy() - R @ L.T).max() < 1e-10
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_potrf_block_and_trsm(mfma):
+    import torch
+    from george_amd import _native as N
+    rng = np.random.RandomState(11)
+    n, m = 384, 256
+    G = rng.randn(n, n)
+    A = G @ G.T + n * np.eye(n)
+    a = _dev(np.tril(A) + np.triu(rng.randn(n, n), 1) * 0)      # only the lower triangle matters
+    dinv = _dev(np.zeros((n // 128, 128, 128)))
+    info = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prev = N.lib.gh_debug_set_mfma(mfma)
+    try:
+        N.check(N.lib.gh_dev_potrf_block(a.data_ptr(), n, n, dinv.data_ptr(), info.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        L = np.linalg.cholesky(A)
+        got = np.tril(a.cpu().numpy())
+        assert int(info.item()) == 0
+        assert np.abs(got - L).max() < 1e-10 * np.abs(L).max()
+        d = dinv.cpu().numpy()
+        for j in range(n // 128):
+            Ljj = L[128 * j:128 * j + 128, 128 * j:128 * j + 128]
+            assert np.abs(d[j] @ Ljj - np.eye(128)).max() < 1e-10
+        B = rng.randn(m, n)
+        b = _dev(B)
+        N.check(N.lib.gh_dev_trsm_right(a.data_ptr(), n, dinv.data_ptr(), b.data_ptr(), n, m, n, None))
+        torch.cuda.synchronize()
+        want = np.linalg.solve(L, B.T).T                                      # B L^-T
+        assert np.abs(b.cpu().numpy() - want).max() < 1e-10 * max(1.0, np.abs(want).max())
+    finally:
+        N.lib.gh_debug_set_mfma(prev)
+
+
+def test_potrf_reports_failing_pivot():
+    import torch
+    from george_amd import _native as N
+    n = 256
+    A = np.eye(n)
+    A[200, 200] = -1.0
+    a = _dev(A)
+    dinv = _dev(np.zeros((2, 128, 128)))
+    info = torch.zeros(1, dtype=torch.int64, device="cuda")
+    N.check(N.lib.gh_dev_potrf_block(a.data_ptr(), n, n, dinv.data_ptr(), info.data_ptr(), 1000, None))
+    torch.cuda.synchronize()
+    assert int(info.item()) == 1000 + 201          # LAPACK dpotrf-style 1-based index

@@ -1,0 +1,122 @@
+"""Parity of the HIP kernel-function evaluator (through the C ABI) with the reference: committed
+golden vectors from the real reference, the oracle on larger / ragged / empty inputs, and the
+reference's own finite-difference tests (tests/test_kernels.py:65-128)."""
+import numpy as np
+import pytest
+
+import zoo
+from oracle import kernels_np
+import george_amd
+import george_amd.kernels as AK
+
+pytestmark = pytest.mark.gpu
+
+# fp64; device libm (ocml) vs glibc differ by <= 1-2 ulp in exp/sin/cos/pow, amplified by the
+# argument magnitude (|r2| up to ~1e2 in the zoo): stated tolerance
+RTOL, ATOL = 2e-12, 1e-14
+ZOO = zoo.kernel_zoo(AK)
+
+
+@pytest.mark.parametrize("name,kernel", ZOO, ids=[n for n, _ in ZOO])
+def test_golden_vectors(name, kernel, golden_kernels):
+    g = golden_kernels
+    t1, t2 = g[name + "/t1"], g[name + "/t2"]
+    ki = kernel.kernel
+    which = np.ones(kernel.full_size, dtype=np.uint32)
+    np.testing.assert_allclose(ki.value_symmetric(t1), g[name + "/vsym"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ki.value_general(t1, t2), g[name + "/vgen"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ki.value_diagonal(t1, t1[::-1].copy()), g[name + "/vdiag"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ki.gradient_general(which, t1, t2), g[name + "/ggen"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ki.gradient_symmetric(which, t1), g[name + "/gsym"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ki.x1_gradient_general(t1, t2), g[name + "/x1"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ki.x2_gradient_general(t1, t2), g[name + "/x2"], rtol=1e-10, atol=1e-12)
+    # exact symmetry of the symmetric build (kernel_interface.cpp:68-74 mirrors one evaluation)
+    v = ki.value_symmetric(t1)
+    assert np.array_equal(v, v.T)
+
+
+@pytest.mark.parametrize("name,kernel", ZOO[::3], ids=[n for n, _ in ZOO[::3]])
+def test_ragged_sizes_vs_oracle(name, kernel):
+    rng = np.random.RandomState(99)
+    for n1, n2 in [(1, 1), (130, 67), (257, 3), (64, 64)]:
+        a, b = rng.randn(n1, kernel.ndim), rng.randn(n2, kernel.ndim)
+        np.testing.assert_allclose(kernel.get_value(a, b), kernels_np.value_general(kernel, a, b), rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(kernel.get_value(a), kernels_np.value_symmetric(kernel, a), rtol=RTOL, atol=ATOL)
+    # masked gradients: masked slots are dropped exactly as kernels.py:127 does
+    if kernel.full_size >= 2:
+        kernel.freeze_parameter(kernel.get_parameter_names()[0])
+        a = rng.randn(33, kernel.ndim)
+        g = kernel.get_gradient(a)
+        full = kernels_np.gradient_symmetric(kernel, a)
+        np.testing.assert_allclose(g, full[:, :, kernel.unfrozen_mask], rtol=1e-10, atol=1e-12)
+        kernel.thaw_all_parameters()
+
+
+def test_empty_and_bad_inputs():
+    k = AK.ExpSquaredKernel(1.0, ndim=2)
+    assert k.get_value(np.zeros((0, 2)), np.zeros((5, 2))).shape == (0, 5)
+    assert k.get_value(np.zeros((0, 2))).shape == (0, 0)
+    with pytest.raises(RuntimeError):
+        k.kernel.value_symmetric(np.zeros((4, 3)))            # "dimension mismatch", kernel_interface.cpp:65
+
+
+def test_large_tile_coverage_vs_oracle():
+    """A size that is not a tile multiple and spans many workgroups (1-D and 3-D)."""
+    rng = np.random.RandomState(5)
+    k1 = 0.7 * AK.ExpSquaredKernel(1.3)
+    x = np.sort(rng.uniform(0, 10, 1500))[:, None]
+    np.testing.assert_allclose(k1.get_value(x), kernels_np.value_symmetric(k1, x), rtol=RTOL, atol=ATOL)
+    k3 = AK.Matern52Kernel(0.5, ndim=3) + AK.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)
+    x3 = rng.uniform(0, 1, (700, 3))
+    t3 = rng.uniform(0, 1, (333, 3))
+    np.testing.assert_allclose(k3.get_value(t3, x3), kernels_np.value_general(k3, t3, x3), rtol=RTOL, atol=ATOL)
+
+
+STATIONARY = [
+    (AK.ExpKernel, {}), (AK.ExpSquaredKernel, {}), (AK.Matern32Kernel, {}), (AK.Matern52Kernel, {}),
+    (AK.RationalQuadraticKernel, dict(log_alpha=np.log(1.0))),
+    (AK.RationalQuadraticKernel, dict(log_alpha=np.log(0.1))),
+    (AK.RationalQuadraticKernel, dict(log_alpha=np.log(10.0))),
+]
+
+
+def _fd_checks(kernel, N=20, seed=123, eps=1.32e-6):
+    np.random.seed(seed)
+    t1 = np.random.randn(N, kernel.ndim)
+    kernel.test_gradient(t1, eps=eps)
+    kernel.test_gradient(t1, t1[:1], eps=eps)
+    kernel.test_x1_gradient(t1, eps=eps)
+    kernel.test_x1_gradient(t1, np.array(t1[:1]), eps=eps)
+    kernel.test_x2_gradient(t1, eps=eps)
+    kernel.test_x2_gradient(np.array(t1[:1]), t1, eps=eps)
+
+
+@pytest.mark.parametrize("cls,kw", STATIONARY)
+def test_stationary_finite_differences(cls, kw):
+    """tests/test_kernels.py:83-128"""
+    for metric, more in [(0.1, {}), (1.0, {}), (10.0, {}), ([1.0, 0.1, 10.0], dict(ndim=3)), (1.0, dict(ndim=3)),
+                         (1.0, dict(ndim=3, axes=2)), (1.0, dict(ndim=3, axes=2, block=(-0.1, 0.1)))]:
+        _fd_checks(cls(metric=metric, **dict(kw, **more)))
+
+
+@pytest.mark.parametrize("name,kernel", ZOO[:21], ids=[n for n, _ in ZOO[:21]])
+def test_kernel_finite_differences(name, kernel):
+    """tests/test_kernels.py:65-80"""
+    _fd_checks(kernel)
+
+
+def test_general_metric_closed_form():
+    """tests/test_metrics.py:40-88"""
+    rng = np.random.RandomState(1234)
+    ndim = 3
+    L = rng.randn(ndim, ndim)
+    L[np.diag_indices(ndim)] = np.exp(L[np.diag_indices(ndim)])
+    L[np.triu_indices(ndim, 1)] = 0.0
+    for metric in (np.eye(ndim), L @ L.T):
+        kernel = 0.1 * AK.ExpSquaredKernel(metric, ndim=ndim)
+        x = rng.rand(50, ndim)
+        M0 = kernel.get_value(x)
+        d = x[:, None, :] - x[None, :, :]
+        r2 = np.einsum("ijk,kl,ijl->ij", d, np.linalg.inv(metric), d)
+        assert np.allclose(M0, 0.1 * np.exp(-0.5 * r2))
+        assert np.allclose(george_amd.GP(kernel).get_matrix(x), M0)
