@@ -54,6 +54,28 @@ if not os.path.exists(LIB_PATH):
         "george_amd: %s not found -- build the HIP extension first "
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C george_amd/csrc)" % LIB_PATH)
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process each
+    claim the device and the second one to initialise sees "No HIP GPUs".  Because our library
+    must interoperate with torch (device tensors, torch.distributed/RCCL), make both resolve to
+    ONE runtime: if torch ships a bundled runtime, load it (RTLD_GLOBAL) before libgeorge_amd.so
+    so the dynamic loader binds our DT_NEEDED libamdhip64 to it.  GEORGE_AMD_HIP_RUNTIME=system
+    skips this (stand-alone use against /opt/rocm)."""
+    if os.environ.get("GEORGE_AMD_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+_share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 _vp, _dp, _i64, _i32 = C.c_void_p, C.c_void_p, C.c_int64, C.c_int32   # data pointers are passed as raw addresses
@@ -66,6 +88,7 @@ SIGNATURES = {
     "gh_microbench_mfma_f64": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_microbench_hbm_copy": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
+    "gh_microbench_suite": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "gh_kernel_create": (C.c_int, [C.POINTER(gh_knode), C.c_int, C.POINTER(_vp)]),
     "gh_kernel_destroy": (None, [_vp]),
     "gh_kernel_ndim": (C.c_int, [_vp]),

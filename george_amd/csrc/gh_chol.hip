@@ -307,12 +307,25 @@ static int gemm_nt(hipStream_t st, double* C, int64_t ldc, const double* A, int6
   return gh_launch_gemm(g, st);
 }
 
+// gh_potf2.hip: MFMA-blocked 128x128 Cholesky + inverse (the default); GEORGE_AMD_POTF2=simple
+// selects the first scalar version above for A/B validation
+int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, long long base, hipStream_t st);
+static bool use_simple_potf2() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GEORGE_AMD_POTF2"); v = (e && e[0] == 's') ? 1 : 0; }
+  return v == 1;
+}
+
 // in-place lower Cholesky of the n x n block at A (n multiple of 128) + diagonal-block inverses
 static int potrf_block(hipStream_t st, double* A, int64_t ld, int64_t n, double* dinv, long long* d_info, long long base) {
   for (int64_t j0 = 0; j0 < n; j0 += T) {
     double* dj = dinv + (j0 / T) * T * T;
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, blk(A, ld, j0, j0), (long)ld, dj, d_info, base + j0);
-    GH_HIP(hipGetLastError());
+    if (use_simple_potf2()) {
+      hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, blk(A, ld, j0, j0), (long)ld, dj, d_info, base + j0);
+      GH_HIP(hipGetLastError());
+    } else {
+      GH_CHECK(gh_launch_potf2_mfma(blk(A, ld, j0, j0), ld, dj, d_info, base + j0, st));
+    }
     const int64_t rem = n - (j0 + T);
     if (rem > 0) {
       double* P = blk(A, ld, j0 + T, j0);

@@ -99,7 +99,16 @@ __device__ __forceinline__ void k_range(const GemmDev& g, long row0, long col0, 
   if (g.khi_row && row0 + BM < kend) kend = row0 + BM;
 }
 
-template <bool A_KM, bool B_KM>
+// MM selects the matrix instruction (measured on MI355X, tests/test_gpu_gemm.py microbench suite):
+//   MM == 1: v_mfma_f64_16x16x4_f64       -- saturates at ~47 TFLOP/s chip-wide (~100 cycles/SIMD)
+//   MM == 2: v_mfma_f64_4x4x4_4b_f64      -- >= 66 TFLOP/s: four 4x4x4 blocks per instruction.
+// The 4-block form builds the same 16x16x4 product from four instructions that share the B
+// fragment: lane 16k+4b+i of the A operand holds A[4n+i][k] for EVERY block b (a broadcast LDS
+// read), lane 16k+c of B holds B[k][c]; instruction n then yields rows 4n..4n+3 of the tile in
+// exactly the (row = 4n + lane>>4, col = lane&15) slot that element n of the 16x16x4 result
+// vector occupies, so accumulators and epilogue are shared.  (Lane maps probed on hardware:
+// scripts/probes/mfma444_probe.hip.)
+template <bool A_KM, bool B_KM, int MM>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
   __shared__ double sA[2][BM * LS];
   __shared__ double sB[2][BN * LS];
@@ -129,30 +138,61 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
   __syncthreads();
   for (long kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      stage_load<A_KM>(g.A, g.lda, row0, kbeg + (kt + 1) * BK, tid, ra);
-      stage_load<B_KM>(g.B, g.ldb, col0, kbeg + (kt + 1) * BK, tid, rb);
-    }
-    const double* pa = sA[cur] + (wm * 64 + fr) * LS + fk;
+    // unconditional prefetch (the last iteration re-reads its own slab into the idle buffer):
+    // a branch here makes the compiler keep the staging registers in scratch memory
+    const long knext = kbeg + ((kt + 1 < nk) ? kt + 1 : kt) * BK;
+    stage_load<A_KM>(g.A, g.lda, row0, knext, tid, ra);
+    stage_load<B_KM>(g.B, g.ldb, col0, knext, tid, rb);
     const double* pb = sB[cur] + (wn * 64 + fr) * LS + fk;
+    if (MM == 1) {
+      const double* pa = sA[cur] + (wm * 64 + fr) * LS + fk;
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[4], b[4];
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = pa[i * 16 * LS + kk * 4];
+        for (int i = 0; i < 4; ++i) a[i] = pa[i * 16 * LS + kk * 4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = pb[j * 16 * LS + kk * 4];
+        for (int j = 0; j < 4; ++j) b[j] = pb[j * 16 * LS + kk * 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const double* pa = sA[cur] + (wm * 64 + (lane & 3)) * LS + fk;     // row 4n + (lane&3), replicated over blocks
+      // 16 steps of (one 16-row A group x 4 k): fragments of step s+1 are fetched while the 16
+      // MFMAs of step s issue; sched_barrier keeps the compiler from hoisting every fragment of
+      // the slab at once (which spills: 64 live A doubles on top of the 128-VGPR accumulator).
+      // (two fragment sets selected by compile-time parity after full unrolling: no copies)
+      double fa[2][4], fb[2][4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fa[0][n] = pa[(n * 4) * LS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[0][j] = pb[j * 16 * LS];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int kk = s >> 2, i = s & 3;
+        if (s + 1 < 16) {
+          const int kk1 = (s + 1) >> 2, i1 = (s + 1) & 3;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) fa[(s + 1) & 1][n] = pa[(i1 * 16 + n * 4) * LS + kk1 * 4];
+          if (i1 == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[kk1 & 1][j] = pb[j * 16 * LS + kk1 * 4];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[i][j][n] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s & 1][n], fb[kk & 1][j], acc[i][j][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (more) {
-      stage_store<A_KM>(sA[cur ^ 1], tid, ra);
-      stage_store<B_KM>(sB[cur ^ 1], tid, rb);
-    }
+    stage_store<A_KM>(sA[cur ^ 1], tid, ra);
+    stage_store<B_KM>(sB[cur ^ 1], tid, rb);
     __syncthreads();
   }
   // epilogue.  f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
@@ -218,14 +258,20 @@ __global__ __launch_bounds__(256) void gemm_f64_valu(GemmDev g) {
     }
 }
 
+// 0 = plain VALU (validation arm), 1 = v_mfma_f64_16x16x4 (default: 52-58 TFLOP/s on the SYRK
+// shape), 2 = v_mfma_f64_4x4x4_4b (correct, but 36 TFLOP/s in this kernel: kept as an A/B arm)
 static int g_mfma = -1;
-bool gh_use_mfma() {
-  if (g_mfma < 0) { const char* e = getenv("GEORGE_AMD_NO_MFMA"); g_mfma = (e && e[0] == '1') ? 0 : 1; }
-  return g_mfma == 1;
+static int mfma_mode() {
+  if (g_mfma < 0) {
+    const char* e = getenv("GEORGE_AMD_MFMA_MODE");
+    g_mfma = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 1;
+  }
+  return g_mfma;
 }
-extern "C" int gh_debug_set_mfma(int enabled) {
-  const int prev = gh_use_mfma() ? 1 : 0;
-  g_mfma = enabled ? 1 : 0;
+bool gh_use_mfma() { return mfma_mode() != 0; }
+extern "C" int gh_debug_set_mfma(int mode) {
+  const int prev = mfma_mode();
+  g_mfma = (mode < 0 || mode > 2) ? 1 : mode;
   return prev;
 }
 
@@ -241,11 +287,12 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   g.nblk = h.lower ? (long)g.tiles_m * (g.tiles_m + 1) / 2 : (long)g.tiles_m * g.tiles_n;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);
-  const bool mfma = gh_use_mfma();
-#define GH_GEMM_LAUNCH(AK, BKM)                                                             \
-  do {                                                                                      \
-    if (mfma) hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM>), grid, block, 0, st, g);          \
-    else      hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g);          \
+  const int mode = mfma_mode();
+#define GH_GEMM_LAUNCH(AK, BKM)                                                                  \
+  do {                                                                                           \
+    if (mode == 2)      hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM, 2>), grid, block, 0, st, g);  \
+    else if (mode == 1) hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM, 1>), grid, block, 0, st, g);  \
+    else                hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g);     \
   } while (0)
   if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
   else if (h.a_km && !h.b_km) GH_GEMM_LAUNCH(true, false);
@@ -312,6 +359,86 @@ extern "C" int gh_microbench_mfma_f64(double* tflops_out) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
   return GH_OK;
 }
+// ---- instruction-level suite: pins the fp64 ceilings the roofline is priced against ----
+// MODE 0: v_mfma_f64_16x16x4_f64, 4 independent accumulators; MODE 1: v_fma_f64, 8 independent
+// chains per lane; MODE 2: v_mfma_f64_4x4x4_4b_f64.  stats[0]=shader cycles (s_memtime),
+// stats[1]=100 MHz wall ticks, both for workgroup 0 / wavefront 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void fp64_rate_kernel(double* out, long long* stats, int iters) {
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  v4d m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0, m6 = m0, m7 = m0;
+  const double a2 = a + 0.5, b2 = b - 0.5;
+  double f0 = a, f1 = b, f2 = a + 1, f3 = b + 1, f4 = a + 2, f5 = b + 2, f6 = a + 3, f7 = b + 3;
+  double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 0) {     // 8 independent accumulators, 2x2 distinct operand registers (as in a GEMM tile)
+      m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, m0, 0, 0, 0);
+      m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, m1, 0, 0, 0);
+      m2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, m2, 0, 0, 0);
+      m3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, m3, 0, 0, 0);
+      m4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, m4, 0, 0, 0);
+      m5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, m5, 0, 0, 0);
+      m6 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, m6, 0, 0, 0);
+      m7 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, m7, 0, 0, 0);
+    } else if (MODE == 1) {
+      f0 = fma(f0, a, b); f1 = fma(f1, a, b); f2 = fma(f2, a, b); f3 = fma(f3, a, b);
+      f4 = fma(f4, a, b); f5 = fma(f5, a, b); f6 = fma(f6, a, b); f7 = fma(f7, a, b);
+    } else {
+      q0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, q0, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, q1, 0, 0, 0);
+      q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, q2, 0, 0, 0);
+      q3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, q3, 0, 0, 0);
+    }
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = c1 - c0; stats[1] = w1 - w0; }
+  const v4d s = m0 + m1 + m2 + m3 + m4 + m5 + m6 + m7;
+  const double t = s[0] + s[1] + s[2] + s[3] + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + q0 + q1 + q2 + q3;
+  if (t == 12345.678) out[0] = t;
+}
+template <int MODE>
+static int run_rate(int blocks, int iters, double flop_per_wave_iter, double* tf, double* cyc_per_instr, double* ghz,
+                    double instr_per_iter) {
+  double* d = nullptr; long long* st = nullptr;
+  GH_HIP(hipMalloc((void**)&d, 64));
+  GH_HIP(hipMalloc((void**)&st, 64));
+  hipEvent_t e0, e1;
+  GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(fp64_rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, d, st, 200);
+  GH_HIP(hipDeviceSynchronize());
+  GH_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(fp64_rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, d, st, iters);
+  GH_HIP(hipEventRecord(e1, 0));
+  GH_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  GH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  long long h[2] = {0, 0};
+  GH_HIP(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+  *tf = (double)blocks * 4.0 * iters * flop_per_wave_iter / (ms * 1e-3) * 1e-12;
+  *cyc_per_instr = (double)h[0] / ((double)iters * instr_per_iter);
+  *ghz = h[1] > 0 ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;    // cycles per ns (wall tick = 10 ns)
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); (void)hipFree(st);
+  return GH_OK;
+}
+extern "C" int gh_microbench_suite(double* out, int n) {
+  if (gh_device_count() <= 0) { gh_set_error("no HIP device"); return GH_ERR_HIP; }
+  if (!out || n < 16) { gh_set_error("need room for 16 doubles"); return GH_ERR_BAD_ARG; }
+  for (int i = 0; i < n; ++i) out[i] = 0.0;
+  double tf, cyc, ghz;
+  const int iters = 20000;
+  // f64 MFMA 16x16x4 at 1, 2, 4 wavefronts per SIMD (256 / 512 / 1024 workgroups of 4 waves on 256 CUs)
+  GH_CHECK(run_rate<0>(256, iters, 8 * 2048.0, &tf, &cyc, &ghz, 8)); out[0] = tf; out[1] = cyc; out[2] = ghz;
+  GH_CHECK(run_rate<0>(512, iters, 8 * 2048.0, &tf, &cyc, &ghz, 8)); out[3] = tf; out[4] = cyc; out[5] = ghz;
+  GH_CHECK(run_rate<0>(1024, iters, 8 * 2048.0, &tf, &cyc, &ghz, 8)); out[6] = tf;
+  // v_fma_f64 at 4 and 8 wavefronts per SIMD
+  GH_CHECK(run_rate<1>(1024, iters * 4, 8 * 128.0, &tf, &cyc, &ghz, 8)); out[7] = tf; out[8] = cyc; out[9] = ghz;
+  GH_CHECK(run_rate<1>(2048, iters * 4, 8 * 128.0, &tf, &cyc, &ghz, 8)); out[10] = tf;
+  // f64 MFMA 4x4x4 (4 blocks): 4*4*4*4*2 = 512 flop per instruction
+  GH_CHECK(run_rate<2>(512, iters, 4 * 512.0, &tf, &cyc, &ghz, 4)); out[11] = tf; out[12] = cyc;
+  return GH_OK;
+}
+
 __global__ void copy16_kernel(const double2* __restrict__ in, double2* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i];
 }

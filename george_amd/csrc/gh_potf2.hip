@@ -1,0 +1,218 @@
+// gh_potf2.hip -- the critical-path kernel of the blocked factorisation: one workgroup takes a
+// 128x128 diagonal block to its Cholesky factor L AND to L^-1 (which turns every TRSM of the
+// solver into an MFMA GEMM).
+//
+// The whole block lives in LDS (128 x 129 doubles = 129 KiB of the CU's 160 KiB).
+//   phase 1  blocked right-looking Cholesky, 16-column steps:
+//            (a) 16x16 diagonal block, unblocked, by ONE wavefront (no workgroup barriers),
+//            (b) rows below: x D^T = a by per-row substitution, one thread per row, registers,
+//            (c) trailing update on the matrix pipe: 16x16 tiles, v_mfma_f64_16x16x4_f64.
+//   phase 2  L^-1 by recursive doubling: the eight 16x16 diagonal inverses (wave-parallel
+//            substitution), then blocks of 16 -> 32 -> 64:  X = -B^-1 (C A^-1), every product a
+//            set of 16x16 MFMA tile jobs spread over the four wavefronts.  L^-1 is assembled in
+//            its final place in HBM (`dinv`); its unused upper-right quadrant is the scratch for
+//            C A^-1 and is zeroed at the end.
+//
+// The first version of this kernel (scalar rank-1 updates, 3 barriers per column, column-wise
+// inverse) took 553 us per block and was half of compute() at N = 16384; it is kept in
+// gh_chol.hip (`potf2_inv_kernel`) as the A/B validation arm (GEORGE_AMD_POTF2=simple).
+#include <stdlib.h>
+#include "gh_common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define T 128
+#define LP 129
+#define IP 17                    // pitch of the 16x16 diagonal-inverse scratch
+
+// ---------------------------------------------------------------- MFMA tile helpers
+// one 16x16 tile:  acc += sign * A(16 x 4*nkk) * B(4*nkk x 16), operands fetched by functors
+// A(i, k) and B(k, j);  lane map: A operand lane l <- A(l & 15, 4kk + (l >> 4)),
+//                                 B operand lane l <- B(4kk + (l >> 4), l & 15),
+//                                 acc[r] <-> C((l >> 4) + 4r, l & 15).
+template <typename FA, typename FB>
+__device__ __forceinline__ v4d tile_mma(v4d acc, int kk0, int kk1, FA fa, FB fb, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int kk = kk0; kk < kk1; ++kk) {
+    const double a = fa(fr, 4 * kk + fk);
+    const double b = fb(4 * kk + fk, fr);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda, double* dinv,
+                                                        long long* info, long long base) {
+  __shared__ double s[T * LP];
+  __shared__ double inv16[8 * 16 * IP];
+  __shared__ int fail_at;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (*info != 0) return;                       // uniform: an earlier block already failed
+  if (tid == 0) fail_at = -1;
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;
+    s[i * LP + j] = A[(long)i * lda + j];
+  }
+  __syncthreads();
+
+  // ================================================================ phase 1: Cholesky
+  for (int jb = 0; jb < 8; ++jb) {
+    const int c0 = 16 * jb;
+    // (a) diagonal block: wavefront 0 only; LDS operations of one wavefront execute in program
+    //     order, `volatile` keeps the compiler from caching or reordering them
+    if (wave == 0) {
+      volatile double* vs = s;
+      const int i = lane & 15, q = lane >> 4;
+      for (int j = 0; j < 16; ++j) {
+        double d = vs[(c0 + j) * LP + c0 + j];
+        if (!(d > 0.0)) {                       // also catches NaN
+          if (lane == 0 && fail_at < 0) fail_at = c0 + j;
+          d = 1.0;
+        }
+        const double ajj = sqrt(d);
+        if (q == 0) {
+          if (i > j) vs[(c0 + i) * LP + c0 + j] = vs[(c0 + i) * LP + c0 + j] / ajj;
+          else if (i == j) vs[(c0 + j) * LP + c0 + j] = ajj;
+        }
+        const double lij = vs[(c0 + i) * LP + c0 + j];
+        for (int k = j + 1 + q; k <= i; k += 4)
+          vs[(c0 + i) * LP + c0 + k] -= lij * vs[(c0 + k) * LP + c0 + j];
+      }
+    }
+    __syncthreads();
+    if (jb == 7) break;
+    // (b) panel rows below the diagonal block: solve x D^T = a, one row per thread
+    {
+      const int r = c0 + 16 + tid;
+      if (r < T) {
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = s[r * LP + c0 + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          double v = x[k];
+#pragma unroll
+          for (int m = 0; m < k; ++m) v -= x[m] * s[(c0 + k) * LP + c0 + m];
+          x[k] = v / s[(c0 + k) * LP + c0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[r * LP + c0 + k] = x[k];
+      }
+    }
+    __syncthreads();
+    // (c) trailing update of the lower 16x16 tiles: C(ti,tj) -= P_ti P_tj^T, K = 16
+    {
+      const int m = 7 - jb;                       // tile rows/cols remaining
+      const int ntiles = m * (m + 1) / 2;
+      for (int e = wave; e < ntiles; e += 4) {
+        int ti = 0, acc_t = 0;
+        while (acc_t + ti + 1 <= e) { acc_t += ti + 1; ++ti; }
+        const int tj = e - acc_t;
+        const int R0 = 16 * (jb + 1 + ti), C0 = 16 * (jb + 1 + tj);
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = s[(R0 + (lane >> 4) + 4 * r) * LP + C0 + (lane & 15)];
+        acc = tile_mma(acc, 0, 4,
+                       [&](int i, int k) { return -s[(R0 + i) * LP + c0 + k]; },
+                       [&](int k, int j) { return s[(C0 + j) * LP + c0 + k]; }, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[(R0 + (lane >> 4) + 4 * r) * LP + C0 + (lane & 15)] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  if (fail_at >= 0) {                             // (all threads see it: barrier above)
+    if (tid == 0) *info = base + fail_at + 1;
+    return;
+  }
+  // factor back to HBM, strict upper triangle of the tile zeroed
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;
+    A[(long)i * lda + j] = (j <= i) ? s[i * LP + j] : 0.0;
+  }
+
+  // ================================================================ phase 2: L^-1 -> dinv
+  // (a) the eight 16x16 diagonal inverses; wavefront w takes blocks 2w and 2w+1.
+  //     lane (c = lane & 15, q = lane >> 4): column c of the inverse, dot products split 4 ways.
+  for (int bb = 0; bb < 2; ++bb) {
+    const int bI = 2 * wave + bb, d0 = 16 * bI;
+    volatile double* xs = inv16 + bI * 16 * IP;
+    const int c = lane & 15, q = lane >> 4;
+    if (q == 0) {
+      for (int i = 0; i < 16; ++i) xs[i * IP + c] = 0.0;
+      xs[c * IP + c] = 1.0 / s[(d0 + c) * LP + d0 + c];
+    }
+    for (int i = 1; i < 16; ++i) {
+      double acc = 0.0;
+      if (i > c)
+        for (int k = c + q; k < i; k += 4) acc += s[(d0 + i) * LP + d0 + k] * xs[k * IP + c];
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      if (q == 0 && i > c) xs[i * IP + c] = -acc / s[(d0 + i) * LP + d0 + i];
+    }
+    for (int e = lane; e < 256; e += 64) {
+      const int i = e >> 4, j = e & 15;
+      dinv[(d0 + i) * T + d0 + j] = (j <= i) ? xs[i * IP + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  // (b) doubling: blocks of size sz = 16, 32, 64.  Pair p: P0 = 2 p sz,
+  //     A^-1 = Linv[P0 : P0+sz, P0 : P0+sz], B^-1 = Linv[P0+sz : P0+2sz, same cols shifted],
+  //     C = L[P0+sz : P0+2sz, P0 : P0+sz]  ->  Linv[P0+sz.., P0..] = -B^-1 (C A^-1).
+  for (int sz = 16; sz <= 64; sz *= 2) {
+    const int tps = sz / 16;                      // tiles per side
+    const int njobs = (64 / sz) * tps * tps;
+    double* scr = dinv + 64;                      // scratch: rows [0,64) x cols [64,128) of dinv
+    // T = C A^-1   (K = sz; A^-1 lower triangular: k >= 16 tj)
+    for (int e = wave; e < njobs; e += 4) {
+      const int p = e / (tps * tps), rem = e % (tps * tps), ti = rem / tps, tj = rem % tps;
+      const int P0 = 2 * p * sz;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      if (sz == 16) {
+        const double* ai = inv16 + (2 * p) * 16 * IP;
+        acc = tile_mma(acc, 0, 4,
+                       [&](int i, int k) { return s[(P0 + 16 + i) * LP + P0 + k]; },
+                       [&](int k, int j) { return ai[k * IP + j]; }, lane);
+      } else {
+        acc = tile_mma(acc, 4 * tj, sz / 4,
+                       [&](int i, int k) { return s[(P0 + sz + 16 * ti + i) * LP + P0 + k]; },
+                       [&](int k, int j) { return dinv[(P0 + k) * T + P0 + 16 * tj + j]; }, lane);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        scr[(p * sz + 16 * ti + (lane >> 4) + 4 * r) * T + 16 * tj + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+    // X = -B^-1 T   (B^-1 lower triangular: k <= 16 ti + 15)
+    for (int e = wave; e < njobs; e += 4) {
+      const int p = e / (tps * tps), rem = e % (tps * tps), ti = rem / tps, tj = rem % tps;
+      const int P0 = 2 * p * sz;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      if (sz == 16) {
+        const double* bi = inv16 + (2 * p + 1) * 16 * IP;
+        acc = tile_mma(acc, 0, 4,
+                       [&](int i, int k) { return -bi[i * IP + k]; },
+                       [&](int k, int j) { return scr[(p * sz + k) * T + j]; }, lane);
+      } else {
+        acc = tile_mma(acc, 0, 4 * (ti + 1),
+                       [&](int i, int k) { return -dinv[(P0 + sz + 16 * ti + i) * T + P0 + sz + k]; },
+                       [&](int k, int j) { return scr[(p * sz + k) * T + 16 * tj + j]; }, lane);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dinv[(P0 + sz + 16 * ti + (lane >> 4) + 4 * r) * T + P0 + 16 * tj + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+  }
+  // (c) everything above the diagonal (including the scratch quadrant) is zero
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int i = idx >> 7, j = idx & 127;
+    if (j > i) dinv[idx] = 0.0;
+  }
+}
+
+int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, long long base, hipStream_t st) {
+  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info, base);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}

@@ -98,10 +98,16 @@ const char* gh_version(void);
  * (SURVEY.md 8d): returns TFLOP/s of a v_mfma_f64_16x16x4_f64-only kernel and
  * GB/s of a 16-B/lane copy. */
 int gh_microbench_mfma_f64(double* tflops_out);
-/* validation switch: 0 routes every GEMM through the plain-VALU kernel (same semantics) so the
- * MFMA lane maps can be cross-checked on the device; returns the previous setting. */
-int gh_debug_set_mfma(int enabled);
+/* validation / A-B switch for every GEMM: 0 = plain-VALU kernel (same semantics, cross-checks the
+ * MFMA lane maps on the device), 1 = v_mfma_f64_16x16x4, 2 = v_mfma_f64_4x4x4_4b (default);
+ * returns the previous setting. */
+int gh_debug_set_mfma(int mode);
 int gh_microbench_hbm_copy(double* gbps_out);
+/* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
+ * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
+ * TFLOP/s, cycles/instr, GHz at 4 waves/SIMD; out[10] TFLOP/s at 8 waves/SIMD; out[11..12]
+ * v_mfma_f64_4x4x4 TFLOP/s and cycles/instr. */
+int gh_microbench_suite(double* out, int n);
 
 /* ---------------------------------------------- kernel-function evaluator
  * Replaces the pybind11 class KernelInterface, src/george/kernel_interface.cpp:

@@ -33,9 +33,15 @@ def test_microbench_peaks():
     print("\n[microbench] v_mfma_f64_16x16x4_f64 peak: %.2f TFLOP/s ; 16B copy: %.0f GB/s" % (tf.value, gb.value))
     assert 20.0 < tf.value < 200.0
     assert 1000.0 < gb.value < 9000.0
+    out = (C.c_double * 16)()
+    N.check(N.lib.gh_microbench_suite(out, 16))
+    o = list(out)
+    print("[suite] mfma_f64_16x16x4: 1w/SIMD %.1f TF (%.1f cyc/instr @ %.2f GHz), 2w/SIMD %.1f TF (%.1f cyc @ %.2f GHz), "
+          "4w/SIMD %.1f TF | v_fma_f64: 4w/SIMD %.1f TF (%.2f cyc/instr @ %.2f GHz), 8w/SIMD %.1f TF | "
+          "mfma_f64_4x4x4: %.1f TF (%.1f cyc/instr)" % (o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12]))
 
 
-@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("mfma", [2, 1, 0])
 @pytest.mark.parametrize("a_mm,b_nm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_layouts(mfma, a_mm, b_nm):
     from george_amd import _native as N
@@ -98,7 +104,7 @@ def test_gemm_lower_and_k_clipping():
     assert np.abs(o.cpu().numpy() - R @ L.T).max() < 1e-10
 
 
-@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("mfma", [2, 1, 0])
 def test_potrf_block_and_trsm(mfma):
     import torch
     from george_amd import _native as N
