@@ -1,11 +1,777 @@
-// gh_hodlr.hip -- placeholder while the HODLR path is being written (replaced in the next commit)
+// gh_hodlr.hip -- level-batched HODLR solver on one MI355X.
+//
+// Replaces the reference's recursive, single-threaded HODLR factorisation
+// (include/george/hodlr.h: Node ctor :29-66, low_rank_approx :136-221, compute :75-103,
+// factorize :223-235, apply_inverse :237-254, solve :107-114; driver src/george/solvers/_hodlr.cpp
+// :55-94).  The algebra is the same -- off-diagonal blocks compressed by partially-pivoted ACA with
+// randomly chosen rows, leaves factored exactly, one Woodbury step per internal node -- but the
+// recursion is turned inside out so that every kernel launch works on ALL nodes of a tree level:
+//
+//   * the binary tree (hodlr.h:48: internal iff size/2 >= min_size) is built on the host;
+//   * ACA for all nodes of a level runs as one launch, one workgroup per node, evaluating kernel
+//     rows/columns on the fly (gh_eval.h) -- the N x N matrix is never formed;
+//   * U and V of every level live in two N x Rtot row-major arrays (UA, VA): column block l holds
+//     level l, row i the point i (rows [start, start+half) of a node hold its U_[0] / V_[0], the
+//     rest U_[1] / V_[1], zero-padded to the level's max rank).  "Apply the inverse of level l to
+//     the U's of all its ancestors" (hodlr.h:95-102) is then ONE multi-column solve on the
+//     contiguous column range [0, off_l) of UA;
+//   * leaves and the 2r x 2r Woodbury cores S are inverted explicitly once (batched Gauss-Jordan
+//     with partial pivoting; log|det| = sum log|pivot| as hodlr.h:87-93), so that every apply is a
+//     batched small dense product: reduce (V^T x per 128-row chunk) -> sum -> S^-1 -> update.
+//
+// Differences from the reference that stay inside its own tolerance criterion (tests compare to
+// the dense answer with allclose): one RNG stream per node (the reference threads ONE mt19937
+// through the pre-order construction, so the row choices differ); partial-pivot LU / Gauss-Jordan
+// instead of Eigen FullPivLU / LDLT; ranks capped at opts.max_rank.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
 #include "gh_common.h"
-struct gh_hodlr { int dummy; };
-static int ni() { gh_set_error("HODLR solver not implemented yet"); return GH_ERR_BAD_ARG; }
-extern "C" int gh_hodlr_create(const gh_hodlr_opts*, gh_hodlr**) { return ni(); }
-extern "C" void gh_hodlr_destroy(gh_hodlr*) {}
-extern "C" int gh_hodlr_compute(gh_hodlr*, gh_kernel*, const double*, int64_t, int32_t, const double*, double*) { return ni(); }
-extern "C" int gh_hodlr_solve(gh_hodlr*, const double*, int64_t, double*) { return ni(); }
-extern "C" int gh_hodlr_dot_solve(gh_hodlr*, const double*, double*) { return ni(); }
-extern "C" int gh_hodlr_get_inverse(gh_hodlr*, double*) { return ni(); }
-extern "C" int gh_hodlr_ranks(const gh_hodlr*, int32_t*, int32_t, int32_t*) { return ni(); }
+
+#define HCH 128          // rows per reduce/update chunk
+#define CPASS 256        // columns handled per pass of an apply (also the cap on a level's rank)
+
+// ------------------------------------------------------------------ device structs
+struct LvlNode { int start, half, size, pad; };
+struct Chunk { int node, half, row0, nrows; };
+struct MMJob { long a_off; int b_row, o_row, m, kd; };
+struct LeafDesc { int start, size; long off; };
+
+__device__ __forceinline__ double hw_wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// block-wide sum broadcast to all threads; `sh` needs blockDim/64 doubles
+__device__ __forceinline__ double hw_block_sum(double v, double* sh) {
+  v = hw_wave_sum(v);
+  const int nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nw; ++w) t += sh[w];
+  return t;
+}
+// block-wide argmax of (val, idx): largest val, smallest idx on ties (Eigen maxCoeff order)
+__device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* shv, int* shi) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_down(val, off, 64);
+    const int oi = __shfl_down(idx, off, 64);
+    if (ov > val || (ov == val && oi >= 0 && (idx < 0 || oi < idx))) { val = ov; idx = oi; }
+  }
+  const int nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = val; shi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  double bv = shv[0];
+  int bi = shi[0];
+  for (int w = 1; w < nw; ++w)
+    if (shv[w] > bv || (shv[w] == bv && shi[w] >= 0 && (bi < 0 || shi[w] < bi))) { bv = shv[w]; bi = shi[w]; }
+  val = bv; idx = bi;
+}
+
+// =========================================================================== ACA
+// hodlr.h:136-221 for every internal node of one level.  Tcm is column-major scratch
+// (Tcm[k*N + i]): for a node, entries at its first-half rows hold V(:,k) (the block's columns),
+// at its second-half rows U(:,k).
+#define ACA_THREADS 512
+#define ACA_MAXR 512
+__global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
+    const GhNode* prog, int n_prog, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
+    int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level) {
+  __shared__ double shd[8];
+  __shared__ int shi[8];
+  __shared__ double coef[ACA_MAXR];
+  __shared__ int s_i;
+  const LvlNode nodev = nodes[blockIdx.x];
+  const int col0 = nodev.start, n_cols = nodev.half;
+  const int row0 = nodev.start + nodev.half, n_rows = nodev.size - nodev.half;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int max_rank = n_rows < n_cols ? n_rows : n_cols;
+  if (max_rank > rcap) max_rank = rcap;
+  for (int t = tid; t < n_rows; t += nt) idx[row0 + t] = t;
+  int remaining = n_rows, rank = 0;
+  double norm = 0.0;
+  const double tol2 = tol * tol;
+  unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)blockIdx.x * 0x9E3779B97F4A7C15ull);
+  __syncthreads();
+  while (rank < max_rank) {
+    // ---- choose a random unused row with a non-negligible residual (hodlr.h:159-191)
+    bool got = false;
+    int j = -1;
+    while (remaining > 0) {
+      if (tid == 0) {
+        st += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = st;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const int k = (int)(z % (unsigned long long)remaining);
+        s_i = idx[row0 + k];
+        idx[row0 + k] = idx[row0 + remaining - 1];
+      }
+      --remaining;
+      __syncthreads();
+      const int i = s_i;
+      for (int k = tid; k < rank; k += nt) coef[k] = Tcm[(long)k * N + row0 + i];     // U(i, 0:rank)
+      __syncthreads();
+      double best = -1.0;
+      int bestn = -1;
+      const double* xi = x + (long)(row0 + i) * nd;
+      for (int n = tid; n < n_cols; n += nt) {
+        double v = gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
+        for (int k = 0; k < rank; ++k) v -= coef[k] * Tcm[(long)k * N + col0 + n];
+        Tcm[(long)rank * N + col0 + n] = v;
+        const double a = fabs(v);
+        if (a > best) { best = a; bestn = n; }
+      }
+      hw_block_argmax(best, bestn, shd, shi);
+      if (best >= 1e-14) { got = true; j = bestn; break; }                             // hodlr.h:191
+    }
+    if (!got) break;       // rows exhausted: keep what we have (residual rows all < 1e-14)
+    // ---- normalise the row by its pivot, build the column (hodlr.h:194-199)
+    const double pivot = Tcm[(long)rank * N + col0 + j];
+    __syncthreads();
+    double vn2 = 0.0;
+    for (int n = tid; n < n_cols; n += nt) {
+      const double v = Tcm[(long)rank * N + col0 + n] / pivot;
+      Tcm[(long)rank * N + col0 + n] = v;
+      vn2 += v * v;
+    }
+    for (int k = tid; k < rank; k += nt) coef[k] = Tcm[(long)k * N + col0 + j];        // V(j, 0:rank)
+    __syncthreads();
+    double un2 = 0.0;
+    const double* xj = x + (long)(col0 + j) * nd;
+    for (int m = tid; m < n_rows; m += nt) {
+      double u = gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
+      for (int k = 0; k < rank; ++k) u -= coef[k] * Tcm[(long)k * N + row0 + m];
+      Tcm[(long)rank * N + row0 + m] = u;
+      un2 += u * u;
+    }
+    ++rank;
+    if (rank >= max_rank) break;                                                       // hodlr.h:203
+    un2 = hw_block_sum(un2, shd);
+    vn2 = hw_block_sum(vn2, shd);
+    const double rowcol = un2 * vn2;
+    if (rowcol < tol2 * norm) break;                                                   // hodlr.h:206-207
+    norm += rowcol;                                                                    // hodlr.h:210-214
+    if (rank > 1) {
+      double maxu = 0.0, maxv = 0.0;
+      const double* ul = Tcm + (long)(rank - 1) * N + row0;
+      const double* vl = Tcm + (long)(rank - 1) * N + col0;
+      for (int k0 = 0; k0 < rank - 1; k0 += 4) {
+        double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
+        for (int m = tid; m < n_rows; m += nt) {
+          const double u = ul[m];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) du[q] += Tcm[(long)(k0 + q) * N + row0 + m] * u;
+        }
+        for (int n = tid; n < n_cols; n += nt) {
+          const double v = vl[n];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) dv[q] += Tcm[(long)(k0 + q) * N + col0 + n] * v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double a = fabs(hw_block_sum(du[q], shd));
+          const double b = fabs(hw_block_sum(dv[q], shd));
+          if (a > maxu) maxu = a;
+          if (b > maxv) maxv = b;
+        }
+      }
+      norm += 2.0 * maxu + 2.0 * maxv;
+    }
+  }
+  if (tid == 0) ranks[blockIdx.x] = rank;
+}
+
+// B (rows of this level's nodes x R, row-major, ld = R) <- first rank columns of Tcm, zero padded
+__global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* nodes, const int* ranks,
+                                     int R, double* UA, double* VA, long ld, int off) {
+  const LvlNode nd = nodes[blockIdx.x];
+  const int rk = ranks[blockIdx.x];
+  const long tot = (long)nd.size * R;
+  for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.y * blockDim.x) {
+    const int r = (int)(e / R), k = (int)(e % R);
+    const long i = nd.start + r;
+    const double v = (k < rk) ? Tcm[(long)k * N + i] : 0.0;
+    UA[i * ld + off + k] = v;
+    VA[i * ld + off + k] = v;
+  }
+}
+
+// ======================================================================== leaves
+__global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, int nd, const double* x,
+                                        const double* yerr, const LeafDesc* leaves, double* Lf) {
+  const LeafDesc lf = leaves[blockIdx.x];
+  const long tot = (long)lf.size * lf.size;
+  for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.y * blockDim.x) {
+    const int r = (int)(e / lf.size), c = (int)(e % lf.size);
+    const int lo = r < c ? r : c, hi = r < c ? c : r;        // ordered arguments: exactly symmetric
+    double v = gh_eval_value(prog, n_prog, x + (long)(lf.start + lo) * nd, x + (long)(lf.start + hi) * nd);
+    if (r == c) { const double e2 = yerr[lf.start + r]; v += e2 * e2; }              // hodlr.h:125, _hodlr.cpp:76
+    Lf[lf.off + e] = v;
+  }
+}
+
+// Batched in-place inverse by Gauss-Jordan with partial (row) pivoting; one workgroup per matrix
+// (row-major n x n at base + offs[b]).  logdet[b] = sum log|pivot|.  scratch: n doubles + n ints
+// per matrix at sc_off[b].
+__global__ __launch_bounds__(256) void gj_inverse_kernel(double* base, const long* offs, const int* sizes,
+                                                         double* scratch_d, int* scratch_i, const long* sc_off,
+                                                         double* logdet, int* fail) {
+  __shared__ double shd[4];
+  __shared__ int shi[4];
+  const int b = blockIdx.x, n = sizes[b], tid = threadIdx.x;
+  double* M = base + offs[b];
+  double* fcol = scratch_d + sc_off[b];
+  int* piv = scratch_i + sc_off[b];
+  double ld = 0.0;
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    double best = -1.0;
+    int bi = -1;
+    for (int i = k + tid; i < n; i += 256) {
+      const double a = fabs(M[(long)i * n + k]);
+      if (a > best) { best = a; bi = i; }
+    }
+    hw_block_argmax(best, bi, shd, shi);
+    const int p = bi;
+    if (!(best > 0.0) || p < 0) { bad = true; break; }     // singular or NaN (uniform)
+    if (tid == 0) piv[k] = p;
+    if (p != k)
+      for (int c = tid; c < n; c += 256) {
+        const double t = M[(long)k * n + c];
+        M[(long)k * n + c] = M[(long)p * n + c];
+        M[(long)p * n + c] = t;
+      }
+    __syncthreads();
+    const double pv = M[(long)k * n + k];
+    ld += log(fabs(pv));
+    for (int i = tid; i < n; i += 256) fcol[i] = M[(long)i * n + k];
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) M[(long)k * n + c] = ((c == k) ? 1.0 : M[(long)k * n + c]) / pv;
+    for (int i = tid; i < n; i += 256) if (i != k) M[(long)i * n + k] = 0.0;
+    __syncthreads();
+    const long tot = (long)n * n;
+    for (long e = tid; e < tot; e += 256) {
+      const int i = (int)(e / n), c = (int)(e % n);
+      if (i != k) M[e] -= fcol[i] * M[(long)k * n + c];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (tid == 0) { atomicExch(fail, b + 1); logdet[b] = 0.0; }
+    return;
+  }
+  for (int k = n - 1; k >= 0; --k) {                        // undo the row swaps on the columns
+    const int p = piv[k];
+    if (p != k)
+      for (int r = tid; r < n; r += 256) {
+        const double t = M[(long)r * n + k];
+        M[(long)r * n + k] = M[(long)r * n + p];
+        M[(long)r * n + p] = t;
+      }
+    __syncthreads();
+  }
+  if (tid == 0) logdet[b] = ld;
+}
+
+// =============================================================== batched small dense products
+// O(job rows, 0:C) (=|-=) A_job (m x kd) * B(job rows, 0:C); A element (r, k) at
+// A[a_off + r*a_rs + k*a_cs]; B row b_row+k at B[(b_row+k)*ldb + b_col0 + c].
+struct MMArgs {
+  const MMJob* jobs;
+  const double* A; long a_rs, a_cs;
+  const double* B; long ldb, b_col0;
+  double* O; long ldo, o_col0;
+  int C, subtract;
+};
+__global__ __launch_bounds__(256) void hodlr_mm_kernel(MMArgs a) {
+  __shared__ double As[32 * 33];
+  __shared__ double Bs[32 * 64];
+  const MMJob job = a.jobs[blockIdx.x];
+  const int m0 = blockIdx.y * 32;
+  if (m0 >= job.m) return;
+  const int c0 = blockIdx.z * 64, tid = threadIdx.x;
+  const int c = tid & 63, rq = tid >> 6;
+  double acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+  const bool rfast = (a.a_rs == 1);
+  for (int k0 = 0; k0 < job.kd; k0 += 32) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int r = rfast ? (e & 31) : (e >> 5), k = rfast ? (e >> 5) : (e & 31);
+      double v = 0.0;
+      if (m0 + r < job.m && k0 + k < job.kd) v = a.A[job.a_off + (long)(m0 + r) * a.a_rs + (long)(k0 + k) * a.a_cs];
+      As[r * 33 + k] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 256 * q;
+      const int k = e >> 6, cc = e & 63;
+      double v = 0.0;
+      if (k0 + k < job.kd && c0 + cc < a.C) v = a.B[(long)(job.b_row + k0 + k) * a.ldb + a.b_col0 + c0 + cc];
+      Bs[k * 64 + cc] = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double bv = Bs[k * 64 + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += As[(rq + 4 * j) * 33 + k] * bv;
+    }
+    __syncthreads();
+  }
+  if (c0 + c < a.C) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = m0 + rq + 4 * j;
+      if (r < job.m) {
+        double* o = a.O + (long)(job.o_row + r) * a.ldo + a.o_col0 + c0 + c;
+        *o = a.subtract ? (*o - acc[j]) : acc[j];
+      }
+    }
+  }
+}
+// Tsum[node][0:R] = sum of the partials of its half-1 chunks, [R:2R] = half-0 chunks (hodlr.h:247-249)
+__global__ void hodlr_sum_kernel(const double* P, const int* crange /* [node][half][2] */, int R, long Cp, int C, double* Tsum) {
+  const int node = blockIdx.x, row = blockIdx.y;          // row in [0, 2R)
+  const int half = row < R ? 1 : 0, k = row < R ? row : row - R;
+  const int cb = crange[(node * 2 + half) * 2], ce = crange[(node * 2 + half) * 2 + 1];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double v = 0.0;
+    for (int ch = cb; ch < ce; ++ch) v += P[((long)ch * R + k) * Cp + c];
+    Tsum[((long)node * 2 * R + row) * Cp + c] = v;
+  }
+}
+// S = [[I, V1^T U1], [V0^T U0, I]]  (hodlr.h:229-232) from Tsum (C == R)
+__global__ void hodlr_sbuild_kernel(const double* Tsum, long Cp, int R, double* S) {
+  const int node = blockIdx.x, n2 = 2 * R;
+  double* s = S + (long)node * n2 * n2;
+  for (int e = threadIdx.x; e < n2 * n2; e += blockDim.x) {
+    const int r = e / n2, c = e % n2;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < R && c >= R) v = Tsum[((long)node * n2 + r) * Cp + (c - R)];
+    else if (r >= R && c < R) v = Tsum[((long)node * n2 + r) * Cp + c];
+    s[e] = v;
+  }
+}
+__global__ void hodlr_copyrows_kernel(const double* Y, long ldy, double* X, long ldx, long x_col0, long n, int C) {
+  const long tot = n * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const long i = e / C;
+    const int c = (int)(e % C);
+    X[i * ldx + x_col0 + c] = Y[i * ldy + c];
+  }
+}
+__global__ __launch_bounds__(256) void hodlr_dot_kernel(const double* a, const double* b, long n, double* out) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) v += a[i] * b[i];
+  v = hw_block_sum(v, sh);
+  if (threadIdx.x == 0) out[0] = v;
+}
+__global__ void hodlr_eye_kernel(double* p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i * n + i] = 1.0;
+}
+
+// ================================================================================ host side
+struct HNode { int start, size, half, level, is_leaf; };
+struct HLevel {
+  std::vector<int> node_ids;
+  int R = 0, off = 0, nchunks = 0;
+  GhBuf d_nodes, d_chunks, d_crange, d_red_jobs, d_upd_jobs, d_smul_jobs, d_ranks, sinv;
+  std::vector<int> ranks;
+};
+
+struct gh_hodlr {
+  gh_hodlr_opts opts;
+  hipStream_t st = nullptr;
+  int64_t n = 0;
+  int ndim = 0;
+  bool computed = false;
+  double logdet = 0.0;
+  std::vector<HNode> nodes;
+  std::vector<HLevel*> levels;
+  std::vector<LeafDesc> leaves;
+  int Rtot = 0, max_leaf = 0, max_chunks = 0, maxR = 0;
+  GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work;
+  ~gh_hodlr() {
+    for (auto* l : levels) delete l;
+    if (st) (void)hipStreamDestroy(st);
+  }
+  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); }
+};
+
+extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
+  if (!out) { gh_set_error("null output"); return GH_ERR_BAD_ARG; }
+  if (gh_device_count() <= 0) { gh_set_error("no HIP device available: the george_amd HODLR solver needs an MI355X"); return GH_ERR_HIP; }
+  gh_hodlr* h = new gh_hodlr();
+  memset(&h->opts, 0, sizeof(h->opts));
+  if (opts) h->opts = *opts;
+  else { h->opts.min_size = 100; h->opts.tol = 0.1; h->opts.seed = 42; }
+  if (h->opts.min_size < 1) h->opts.min_size = 1;
+  if (h->opts.max_rank <= 0) h->opts.max_rank = 256;
+  if (h->opts.max_rank > CPASS) h->opts.max_rank = CPASS;      // one column pass holds a level's R columns
+  if (hipSetDevice(h->opts.device) != hipSuccess || hipStreamCreate(&h->st) != hipSuccess) {
+    delete h; gh_set_error("cannot initialise HIP device %d", opts ? opts->device : 0); return GH_ERR_HIP;
+  }
+  *out = h;
+  return GH_OK;
+}
+extern "C" void gh_hodlr_destroy(gh_hodlr* h) { if (h) { (void)hipSetDevice(h->opts.device); delete h; } }
+
+template <typename Tv>
+static int upload(GhBuf& buf, const std::vector<Tv>& v, hipStream_t st) {
+  GH_CHECK(buf.ensure(std::max<size_t>(v.size(), 1) * sizeof(Tv)));
+  if (!v.empty()) GH_HIP(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice, st));
+  return GH_OK;
+}
+
+static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
+                     const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract) {
+  if (njobs <= 0 || C <= 0 || max_m <= 0) return GH_OK;
+  MMArgs a;
+  a.jobs = jobs; a.A = A; a.a_rs = a_rs; a.a_cs = a_cs; a.B = B; a.ldb = ldb; a.b_col0 = b_col0;
+  a.O = O; a.ldo = ldo; a.o_col0 = o_col0; a.C = C; a.subtract = subtract ? 1 : 0;
+  hipLaunchKernelGGL(hodlr_mm_kernel, dim3(njobs, (max_m + 31) / 32, (C + 63) / 64), dim3(256), 0, h->st, a);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+// X[:, xcol0 : xcol0+C] <- (level lv)^-1 applied (hodlr.h:244-253 for every node of the level)
+static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, int C, const double* U, long ldu) {
+  if (L->R == 0 || C <= 0) return GH_OK;
+  const int R = L->R, nn = (int)L->node_ids.size();
+  for (int cp = 0; cp < C; cp += CPASS) {
+    const int cw = std::min(CPASS, C - cp);
+    const long Cp = CPASS;
+    // reduce: P[chunk] = V_chunk^T X_chunk
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + L->off, 1, h->Rtot,
+                       X, ldx, xcol0 + cp, h->P.d(), Cp, 0, cw, false));
+    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, cw, h->Tsum.d());
+    GH_HIP(hipGetLastError());
+    // core: Tout = S^-1 Tsum
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
+                       h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, cw, false));
+    // update: X_chunk -= U_chunk * Tout[half]
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, HCH, U + L->off, ldu, 1,
+                       h->Tout.d(), Cp, 0, X, ldx, xcol0 + cp, cw, true));
+  }
+  return GH_OK;
+}
+// X rows of every leaf <- K_leaf^-1 X
+static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
+  if (C <= 0) return GH_OK;
+  for (int cp = 0; cp < C; cp += CPASS) {
+    const int cw = std::min(CPASS, C - cp);
+    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_jobs.p, (int)h->leaves.size(), h->max_leaf, h->leaf_inv.d(), h->max_leaf, 1,
+                       X, ldx, xcol0 + cp, h->Y.d(), CPASS, 0, cw, false));
+    const long tot = h->n * cw;
+    hipLaunchKernelGGL(hodlr_copyrows_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65535)), dim3(256), 0, h->st,
+                       h->Y.d(), (long)CPASS, X, ldx, xcol0 + cp, (long)h->n, cw);
+    GH_HIP(hipGetLastError());
+  }
+  return GH_OK;
+}
+// full solve on X (n x C): leaves, then levels bottom-up (hodlr.h:107-114)
+static int solve_all(gh_hodlr* h, double* X, long ldx, int C) {
+  GH_CHECK(apply_leaves(h, X, ldx, 0, C));
+  for (int l = (int)h->levels.size() - 1; l >= 0; --l)
+    GH_CHECK(apply_level(h, h->levels[l], X, ldx, 0, C, h->UA.d(), h->Rtot));
+  return GH_OK;
+}
+
+static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& offs, const std::vector<int>& sizes,
+                           std::vector<double>& logdets) {
+  const int nb = (int)sizes.size();
+  if (nb == 0) return GH_OK;
+  std::vector<long> sc(nb);
+  long tot = 0;
+  for (int i = 0; i < nb; ++i) { sc[i] = tot; tot += sizes[i]; }
+  GhBuf d_offs, d_sizes, d_sc, d_sd, d_si, d_ld, d_fail;
+  GH_CHECK(upload(d_offs, offs, h->st));
+  GH_CHECK(upload(d_sizes, sizes, h->st));
+  GH_CHECK(upload(d_sc, sc, h->st));
+  GH_CHECK(d_sd.ensure(tot * sizeof(double)));
+  GH_CHECK(d_si.ensure(tot * sizeof(int)));
+  GH_CHECK(d_ld.ensure(nb * sizeof(double)));
+  GH_CHECK(d_fail.ensure(sizeof(int)));
+  GH_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), h->st));
+  hipLaunchKernelGGL(gj_inverse_kernel, dim3(nb), dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p,
+                     d_sd.d(), (int*)d_si.p, (const long*)d_sc.p, d_ld.d(), (int*)d_fail.p);
+  GH_HIP(hipGetLastError());
+  logdets.resize(nb);
+  int fail = 0;
+  GH_HIP(hipMemcpyAsync(logdets.data(), d_ld.p, nb * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GH_HIP(hipMemcpyAsync(&fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  GH_HIP(hipStreamSynchronize(h->st));
+  if (fail != 0) { gh_set_error("HODLR: singular block encountered (matrix %d)", fail - 1); return GH_ERR_NOT_PD; }
+  return GH_OK;
+}
+
+extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                                const double* yerr, double* logdet_out) {
+  if (!h || !k || !x || !yerr || n <= 0) { gh_set_error("bad argument to compute"); return GH_ERR_BAD_ARG; }
+  if (ndim != k->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
+  if (n > 0x3fffffffL) { gh_set_error("HODLR: n too large"); return GH_ERR_BAD_ARG; }
+  GH_HIP(hipSetDevice(h->opts.device));
+  GH_CHECK(k->upload());
+  hipStream_t st = h->st;
+  h->computed = false;
+  h->reset_tree();
+  h->n = n; h->ndim = ndim;
+  GH_CHECK(h->x.ensure((size_t)n * ndim * sizeof(double)));
+  GH_CHECK(h->yerr.ensure((size_t)n * sizeof(double)));
+  GH_CHECK(gh_to_device(h->x.d(), x, (size_t)n * ndim, st));
+  GH_CHECK(gh_to_device(h->yerr.d(), yerr, (size_t)n, st));
+  GH_CHECK(h->scal.ensure(64));
+
+  // ---- tree (hodlr.h:47-64), breadth first
+  const int min_size = h->opts.min_size;
+  h->nodes.push_back({0, (int)n, (int)n / 2, 0, 0});
+  for (size_t q = 0; q < h->nodes.size(); ++q) {
+    HNode nd = h->nodes[q];
+    if (nd.half >= min_size) {
+      h->nodes.push_back({nd.start, nd.half, nd.half / 2, nd.level + 1, 0});
+      h->nodes.push_back({nd.start + nd.half, nd.size - nd.half, (nd.size - nd.half) / 2, nd.level + 1, 0});
+      if ((int)h->levels.size() <= nd.level) h->levels.resize(nd.level + 1, nullptr);
+      if (!h->levels[nd.level]) h->levels[nd.level] = new HLevel();
+      h->levels[nd.level]->node_ids.push_back((int)q);
+    } else {
+      h->nodes[q].is_leaf = 1;
+      long off = h->leaves.empty() ? 0 : h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
+      h->leaves.push_back({nd.start, nd.size, off});
+    }
+  }
+  h->max_leaf = 0;
+  for (auto& lf : h->leaves) h->max_leaf = std::max(h->max_leaf, lf.size);
+
+  // ---- ACA level by level into column-major scratch, ranks back to the host
+  const int rcap = h->opts.max_rank;
+  const int nlev = (int)h->levels.size();
+  GhBuf Tcm, idx;
+  if (nlev > 0) {
+    GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
+    GH_CHECK(idx.ensure((size_t)n * sizeof(int)));
+  }
+  std::vector<GhBuf*> levelB(nlev, nullptr);
+  struct Cleanup { std::vector<GhBuf*>& v; ~Cleanup() { for (auto* b : v) delete b; } } cleanup{levelB};
+  h->Rtot = 0; h->maxR = 0; h->max_chunks = 0;
+  for (int l = 0; l < nlev; ++l) {
+    HLevel* L = h->levels[l];
+    const int nn = (int)L->node_ids.size();
+    std::vector<LvlNode> ln(nn);
+    for (int q = 0; q < nn; ++q) { const HNode& nd = h->nodes[L->node_ids[q]]; ln[q] = {nd.start, nd.half, nd.size, 0}; }
+    GH_CHECK(upload(L->d_nodes, ln, st));
+    GH_CHECK(L->d_ranks.ensure(nn * sizeof(int)));
+    hipLaunchKernelGGL(hodlr_aca_kernel, dim3(nn), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), ndim,
+                       h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p, (int*)L->d_ranks.p,
+                       h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l);
+    GH_HIP(hipGetLastError());
+    L->ranks.resize(nn);
+    GH_HIP(hipMemcpyAsync(L->ranks.data(), L->d_ranks.p, nn * sizeof(int), hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    L->R = 0;
+    for (int r : L->ranks) L->R = std::max(L->R, r);
+    L->off = h->Rtot;
+    h->Rtot += L->R;
+    h->maxR = std::max(h->maxR, L->R);
+    // keep this level's factors in a compact buffer (rows of the whole range x R) until Rtot is known
+    if (L->R > 0) {
+      levelB[l] = new GhBuf();
+      GH_CHECK(levelB[l]->ensure((size_t)n * L->R * sizeof(double)));
+      GH_HIP(hipMemsetAsync(levelB[l]->p, 0, (size_t)n * L->R * sizeof(double), st));
+      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, 8), dim3(256), 0, st, Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
+                         (const int*)L->d_ranks.p, L->R, levelB[l]->d(), levelB[l]->d(), (long)L->R, 0);
+      GH_HIP(hipGetLastError());
+    }
+  }
+  Tcm.release();
+  idx.release();
+
+  // ---- UA / VA (n x Rtot) and the per-level chunk / job tables
+  const long Rtot = std::max(h->Rtot, 1);
+  GH_CHECK(h->UA.ensure((size_t)n * Rtot * sizeof(double)));
+  GH_CHECK(h->VA.ensure((size_t)n * Rtot * sizeof(double)));
+  GH_HIP(hipMemsetAsync(h->UA.p, 0, (size_t)n * Rtot * sizeof(double), st));
+  GH_HIP(hipMemsetAsync(h->VA.p, 0, (size_t)n * Rtot * sizeof(double), st));
+  for (int l = 0; l < nlev; ++l) {
+    HLevel* L = h->levels[l];
+    if (L->R == 0) continue;
+    const int R = L->R, nn = (int)L->node_ids.size();
+    // scatter the compact level buffer into column block [off, off+R) of UA and VA
+    GH_HIP(hipMemcpy2DAsync(h->UA.d() + L->off, Rtot * sizeof(double), levelB[l]->p, R * sizeof(double), R * sizeof(double), n, hipMemcpyDeviceToDevice, st));
+    GH_HIP(hipMemcpy2DAsync(h->VA.d() + L->off, Rtot * sizeof(double), levelB[l]->p, R * sizeof(double), R * sizeof(double), n, hipMemcpyDeviceToDevice, st));
+    std::vector<Chunk> chunks;
+    std::vector<int> crange(nn * 4);
+    std::vector<MMJob> red, upd, smul(nn);
+    for (int q = 0; q < nn; ++q) {
+      const HNode& nd = h->nodes[L->node_ids[q]];
+      for (int half = 0; half < 2; ++half) {
+        const int r0 = half == 0 ? nd.start : nd.start + nd.half;
+        const int cnt = half == 0 ? nd.half : nd.size - nd.half;
+        crange[(q * 2 + half) * 2] = (int)chunks.size();
+        for (int s = 0; s < cnt; s += HCH) {
+          const int nr = std::min(HCH, cnt - s);
+          const int ch = (int)chunks.size();
+          chunks.push_back({q, half, r0 + s, nr});
+          red.push_back({(long)(r0 + s) * Rtot, r0 + s, ch * R, R, nr});                 // A = VA rows (transposed access)
+          upd.push_back({(long)(r0 + s) * Rtot, q * 2 * R + (half == 0 ? 0 : R), r0 + s, nr, R});
+        }
+        crange[(q * 2 + half) * 2 + 1] = (int)chunks.size();
+      }
+      smul[q] = {(long)q * 4 * R * R, q * 2 * R, q * 2 * R, 2 * R, 2 * R};
+    }
+    L->nchunks = (int)chunks.size();
+    h->max_chunks = std::max(h->max_chunks, L->nchunks);
+    GH_CHECK(upload(L->d_chunks, chunks, st));
+    GH_CHECK(upload(L->d_crange, crange, st));
+    GH_CHECK(upload(L->d_red_jobs, red, st));
+    GH_CHECK(upload(L->d_upd_jobs, upd, st));
+    GH_CHECK(upload(L->d_smul_jobs, smul, st));
+    GH_CHECK(L->sinv.ensure((size_t)nn * 4 * R * R * sizeof(double)));
+  }
+  GH_HIP(hipStreamSynchronize(st));          // levelB buffers are freed when `cleanup` goes out of scope
+  {
+    size_t maxnodes = 1;
+    for (auto* L : h->levels) maxnodes = std::max(maxnodes, L->node_ids.size() * (size_t)std::max(L->R, 1));
+    GH_CHECK(h->P.ensure((size_t)std::max(h->max_chunks, 1) * std::max(h->maxR, 1) * CPASS * sizeof(double)));
+    GH_CHECK(h->Tsum.ensure(maxnodes * 2 * CPASS * sizeof(double)));
+    GH_CHECK(h->Tout.ensure(maxnodes * 2 * CPASS * sizeof(double)));
+    GH_CHECK(h->Y.ensure((size_t)n * CPASS * sizeof(double)));
+  }
+
+  // ---- leaves: exact blocks -> explicit inverses + log-dets (hodlr.h:223-227, 87-89)
+  double logdet = 0.0;
+  {
+    const int nl = (int)h->leaves.size();
+    const long tot = h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
+    GH_CHECK(h->leaf_inv.ensure(tot * sizeof(double)));
+    GH_CHECK(upload(h->d_leaves, h->leaves, st));
+    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), ndim,
+                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d());
+    GH_HIP(hipGetLastError());
+    std::vector<long> offs(nl);
+    std::vector<int> sizes(nl);
+    std::vector<MMJob> jobs(nl);
+    for (int i = 0; i < nl; ++i) {
+      offs[i] = h->leaves[i].off; sizes[i] = h->leaves[i].size;
+      jobs[i] = {h->leaves[i].off, h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
+    }
+    GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+    std::vector<double> lds;
+    GH_CHECK(batched_inverse(h, h->leaf_inv.d(), offs, sizes, lds));
+    for (double v : lds) logdet += v;
+  }
+  // leaf job rows use a per-job A stride = its own size: encode through a_rs = 0 -> handled below
+  // (hodlr_mm_kernel takes one a_rs per launch, so leaves are launched with a_rs = max_leaf after
+  //  re-packing: simpler -- store every leaf inverse with row pitch max_leaf)
+  // NOTE: leaf inverses were produced with pitch == size; repack to pitch max_leaf when sizes differ.
+  {
+    bool uniform = true;
+    for (auto& lf : h->leaves) if (lf.size != h->max_leaf) uniform = false;
+    if (!uniform) {
+      const int nl = (int)h->leaves.size(), ml = h->max_leaf;
+      GhBuf packed;
+      GH_CHECK(packed.ensure((size_t)nl * ml * ml * sizeof(double)));
+      GH_HIP(hipMemsetAsync(packed.p, 0, (size_t)nl * ml * ml * sizeof(double), st));
+      std::vector<MMJob> jobs(nl);
+      for (int i = 0; i < nl; ++i) {
+        const LeafDesc& lf = h->leaves[i];
+        GH_HIP(hipMemcpy2DAsync(packed.d() + (size_t)i * ml * ml, ml * sizeof(double), h->leaf_inv.d() + lf.off,
+                                lf.size * sizeof(double), lf.size * sizeof(double), lf.size, hipMemcpyDeviceToDevice, st));
+        jobs[i] = {(long)i * ml * ml, lf.start, lf.start, lf.size, lf.size};
+      }
+      GH_HIP(hipStreamSynchronize(st));
+      std::swap(h->leaf_inv.p, packed.p);
+      std::swap(h->leaf_inv.bytes, packed.bytes);
+      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+    }
+  }
+
+  // ---- factorisation sweep (hodlr.h:75-103, level-batched): leaves into every U, then levels bottom-up
+  if (h->Rtot > 0) GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot));
+  for (int l = nlev - 1; l >= 0; --l) {
+    HLevel* L = h->levels[l];
+    if (L->R == 0) continue;
+    const int R = L->R, nn = (int)L->node_ids.size();
+    // S = I + [0, V1^T U1; V0^T U0, 0] with the CURRENT U of this level
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + L->off, 1, Rtot,
+                       h->UA.d(), Rtot, L->off, h->P.d(), CPASS, 0, R, false));
+    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)CPASS, R, h->Tsum.d());
+    GH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)CPASS, R, L->sinv.d());
+    GH_HIP(hipGetLastError());
+    std::vector<long> offs(nn);
+    std::vector<int> sizes(nn, 2 * R);
+    for (int q = 0; q < nn; ++q) offs[q] = (long)q * 4 * R * R;
+    std::vector<double> lds;
+    GH_CHECK(batched_inverse(h, L->sinv.d(), offs, sizes, lds));
+    for (double v : lds) logdet += v;
+    // apply this level's inverse to the U's of all shallower levels: columns [0, off)
+    GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
+  }
+  GH_HIP(hipStreamSynchronize(st));
+  h->logdet = logdet;
+  h->computed = true;
+  if (logdet_out) *logdet_out = logdet;
+  return GH_OK;
+}
+
+static int need(gh_hodlr* h) {
+  if (!h) { gh_set_error("null solver"); return GH_ERR_BAD_ARG; }
+  if (!h->computed) { gh_set_error("you must call 'compute' first"); return GH_ERR_NOT_COMPUTED; }
+  GH_HIP(hipSetDevice(h->opts.device));
+  return GH_OK;
+}
+
+extern "C" int gh_hodlr_solve(gh_hodlr* h, const double* b, int64_t nrhs, double* out) {
+  GH_CHECK(need(h));
+  if (!b || !out || nrhs <= 0) { gh_set_error("bad argument to solve"); return GH_ERR_BAD_ARG; }
+  const size_t tot = (size_t)h->n * nrhs;
+  GH_CHECK(h->rhs.ensure(tot * sizeof(double)));
+  GH_CHECK(gh_to_device(h->rhs.d(), b, tot, h->st));
+  GH_CHECK(solve_all(h, h->rhs.d(), nrhs, (int)nrhs));
+  return gh_from_device(out, h->rhs.d(), tot, h->st);
+}
+extern "C" int gh_hodlr_dot_solve(gh_hodlr* h, const double* y, double* out) {
+  GH_CHECK(need(h));
+  if (!y || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  GH_CHECK(h->rhs.ensure((size_t)h->n * sizeof(double)));
+  GH_CHECK(h->work.ensure((size_t)h->n * sizeof(double)));
+  GH_CHECK(gh_to_device(h->rhs.d(), y, (size_t)h->n, h->st));
+  GH_CHECK(gh_to_device(h->work.d(), y, (size_t)h->n, h->st));
+  GH_CHECK(solve_all(h, h->rhs.d(), 1, 1));
+  hipLaunchKernelGGL(hodlr_dot_kernel, dim3(1), dim3(256), 0, h->st, h->work.d(), h->rhs.d(), (long)h->n, h->scal.d());
+  GH_HIP(hipGetLastError());
+  double v = 0.0;
+  GH_HIP(hipMemcpyAsync(&v, h->scal.d(), sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GH_HIP(hipStreamSynchronize(h->st));
+  *out = v;
+  return GH_OK;
+}
+extern "C" int gh_hodlr_get_inverse(gh_hodlr* h, double* out) {
+  GH_CHECK(need(h));
+  if (!out) { gh_set_error("null output"); return GH_ERR_BAD_ARG; }
+  const long n = h->n;
+  GH_CHECK(h->rhs.ensure((size_t)n * n * sizeof(double)));
+  GH_HIP(hipMemsetAsync(h->rhs.p, 0, (size_t)n * n * sizeof(double), h->st));
+  hipLaunchKernelGGL(hodlr_eye_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, h->rhs.d(), n);
+  GH_HIP(hipGetLastError());
+  GH_CHECK(solve_all(h, h->rhs.d(), n, (int)n));
+  return gh_from_device(out, h->rhs.d(), (size_t)n * n, h->st);
+}
+extern "C" int gh_hodlr_ranks(const gh_hodlr* h, int32_t* ranks_out, int32_t max_out, int32_t* n_out) {
+  if (!h || !n_out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  int cnt = 0;
+  for (auto* L : h->levels)
+    for (int r : L->ranks) { if (ranks_out && cnt < max_out) ranks_out[cnt] = r; ++cnt; }
+  *n_out = cnt < max_out ? cnt : max_out;
+  return GH_OK;
+}
