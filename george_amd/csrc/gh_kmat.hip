@@ -11,6 +11,7 @@
 // the fp64 VALU rate; see DESIGN.md.
 #include <stdarg.h>
 #include <string.h>
+#include <algorithm>
 #include <math.h>
 #include "gh_common.h"
 
@@ -536,12 +537,46 @@ extern "C" int gh_kernel_x2_gradient_general(gh_kernel* k, const double* x1, int
   return xgrad_common(k, 2, x1, n1, x2, n2, out);
 }
 
-extern "C" int gh_dev_kmat_block(gh_kernel* k, const double* x, int32_t ndim, const double* yerr,
+extern "C" int gh_dev_kmat_block(gh_kernel* k, const double* x, int64_t n, int32_t ndim, const double* yerr,
                                  int64_t row0, int64_t nrows, int64_t col0, int64_t ncols,
                                  double* out, int64_t ldo, void* stream) {
   GH_CHECK(check_kernel(k));
   if (ndim != k->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
-  // x / yerr are the FULL device arrays; the block's points start at row0 / col0
-  return gh_launch_kmat(k, x + row0 * ndim, nrows, x + col0 * ndim, ncols, yerr ? yerr + row0 : nullptr,
+  // x / yerr are the FULL device arrays of n points; the block's points start at row0 / col0.
+  // Rows/columns past n are identity padding (1 on the global diagonal, 0 elsewhere).
+  const int64_t vr = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row0));
+  const int64_t vc = std::max<int64_t>(0, std::min<int64_t>(ncols, n - col0));
+  const int64_t r0 = std::min(row0, n > 0 ? n - 1 : 0), c0 = std::min(col0, n > 0 ? n - 1 : 0);
+  return gh_launch_kmat(k, x + r0 * ndim, vr, x + c0 * ndim, vc, yerr ? yerr + r0 : nullptr,
                         out, ldo, nrows, ncols, row0, col0, true, false, (hipStream_t)stream);
+}
+
+// y = beta*y + alpha * A x  (trans == 0, A is m x n row-major)  or  alpha * A^T x (trans != 0):
+// the O(N^2) steps of the distributed triangular solves.  One wavefront per row (coalesced row
+// reads + shuffle reduction) or one lane per column (coalesced across lanes) respectively.
+__global__ __launch_bounds__(256) void gemv_n_kernel(const double* A, long lda, long m, long n, const double* x,
+                                                     double* y, double alpha, double beta) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  double acc = 0.0;
+  for (long c = lane; c < n; c += 64) acc += A[row * lda + c] * x[c];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+}
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* A, long lda, long m, long n, const double* x,
+                                                     double* y, double alpha, double beta) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  double acc = 0.0;
+  for (long r = 0; r < m; ++r) acc += A[r * lda + c] * x[r];
+  y[c] = (beta == 0.0 ? 0.0 : beta * y[c]) + alpha * acc;
+}
+extern "C" int gh_dev_gemv(const double* a, int64_t lda, int64_t m, int64_t n, int32_t trans,
+                           const double* x, double* y, double alpha, double beta, void* stream) {
+  if (m <= 0 || n <= 0) return GH_OK;
+  if (!trans) hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, (long)m, (long)n, x, y, alpha, beta);
+  else hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, (long)m, (long)n, x, y, alpha, beta);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
 }

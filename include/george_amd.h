@@ -221,10 +221,14 @@ int  gh_hodlr_ranks(const gh_hodlr* h, int32_t* ranks_out, int32_t max_out, int3
  * multi-GPU 2-D block-cyclic driver (george_amd/distributed.py), which moves
  * panels between ranks with torch.distributed (RCCL) in between.  Leading
  * dimensions are in elements; all sizes must be multiples of 128. */
-/* out[r, c] = k(x[row0+r], x[col0+c]) (+ yerr[row0+r]^2 where row0+r == col0+c) */
-int gh_dev_kmat_block(gh_kernel* k, const double* x, int32_t ndim, const double* yerr,
+/* out[r, c] = k(x[row0+r], x[col0+c]) (+ yerr[row0+r]^2 where row0+r == col0+c); x / yerr are the
+ * full n-point device arrays, rows / columns past n are identity padding */
+int gh_dev_kmat_block(gh_kernel* k, const double* x, int64_t n, int32_t ndim, const double* yerr,
                       int64_t row0, int64_t nrows, int64_t col0, int64_t ncols,
                       double* out, int64_t ldo, void* stream);
+/* y = beta*y + alpha * A x (trans == 0; A is m x n row-major) or alpha * A^T x (trans != 0) */
+int gh_dev_gemv(const double* a, int64_t lda, int64_t m, int64_t n, int32_t trans,
+                const double* x, double* y, double alpha, double beta, void* stream);
 /* in-place lower Cholesky of the n x n block `a`; dinv receives the inverses of
  * its 128x128 diagonal blocks, (n/128) x 128 x 128; *info_dev (device int64) is
  * set to base_index + failing pivot (1-based) when not positive definite. */
