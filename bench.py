@@ -65,7 +65,7 @@ def cpu_baseline(n_cpu):
 class DenseJob(object):
     """compute()+log_likelihood() straight through the C ABI with device-resident inputs."""
 
-    def __init__(self, n, nb, device, profile=True):
+    def __init__(self, n, nb, device, profile=True, lookahead=True):
         import torch
         import george_amd.kernels as K
         from george_amd import _native as N
@@ -80,7 +80,7 @@ class DenseJob(object):
         self.y = torch.from_numpy(y).to(dev)
         torch.cuda.synchronize(dev)
         o = N.gh_chol_opts()
-        o.device, o.nb, o.profile, o.lookahead = device, nb, int(profile), 1
+        o.device, o.nb, o.profile, o.lookahead = device, nb, int(profile), int(lookahead)
         self.h = N._vp()
         N.check(N.lib.gh_chol_create(C.byref(o), C.byref(self.h)))
 
@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--nb", type=int, default=0, help="outer panel width (0 = library default)")
     ap.add_argument("--cpu-n", type=int, default=12288, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true", help="single-stream factorisation (profiling aid)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary N=16384 (configs[1]) measurement")
     args = ap.parse_args()
 
@@ -141,7 +142,7 @@ def main():
         job = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs)
         barrier = dist.barrier
     else:
-        job = DenseJob(args.n, args.nb, local_rank, profile=True)
+        job = DenseJob(args.n, args.nb, local_rank, profile=True, lookahead=not args.no_lookahead)
         barrier = lambda: None
 
     elapsed, ll = run_timed(job, args.steps, args.warmup, barrier)

@@ -141,10 +141,17 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* L, long ld, c
   __shared__ double zj[T];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double2 wv = *reinterpret_cast<const double2*>(w + j0 + 2 * lane);
-  for (int r = wave; r < T; r += 4) {
-    const double2 a = *reinterpret_cast<const double2*>(dinv_j + r * T + 2 * lane);
-    const double v = wave_sum(a.x * wv.x + a.y * wv.y);
-    if (lane == 0) zj[r] = v;
+  // 8 rows per trip: all eight 1-KiB row loads are in flight before the first reduction
+  // (one load per trip left this kernel latency-bound: 52 us per step at N = 16384)
+  for (int r0 = wave * 8; r0 < T; r0 += 32) {
+    double2 a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const double2*>(dinv_j + (r0 + q) * T + 2 * lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double v = wave_sum(a[q].x * wv.x + a[q].y * wv.y);
+      if (lane == 0) zj[r0 + q] = v;
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -153,10 +160,15 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* L, long ld, c
   }
   const long row0 = j0 + (long)blockIdx.x * T;
   const double zx = zj[2 * lane], zy = zj[2 * lane + 1];
-  for (int r = wave; r < T; r += 4) {
-    const double2 a = *reinterpret_cast<const double2*>(L + (row0 + r) * ld + j0 + 2 * lane);
-    const double v = wave_sum(a.x * zx + a.y * zy);
-    if (lane == 0) w[row0 + r] -= v;
+  for (int r0 = wave * 8; r0 < T; r0 += 32) {
+    double2 a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const double2*>(L + (row0 + r0 + q) * ld + j0 + 2 * lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double v = wave_sum(a[q].x * zx + a[q].y * zy);
+      if (lane == 0) w[row0 + r0 + q] -= v;
+    }
   }
 }
 // Backward step j of L^T x = z.  x_j = L_jj^-T w_j; columns c < j0: w[c] -= sum_r L[j0+r][c] x_j[r].
@@ -167,6 +179,7 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* L, long ld, c
   __shared__ double part[2][T];
   const int tid = threadIdx.x, c = tid & 127, h = tid >> 7;
   double acc = 0.0;
+#pragma unroll 16
   for (int r = h * 64; r < h * 64 + 64; ++r) acc += dinv_j[r * T + c] * w[j0 + r];
   part[h][c] = acc;
   __syncthreads();
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* L, long ld, c
   }
   const long col0 = (long)blockIdx.x * T;
   acc = 0.0;
+#pragma unroll 16
   for (int r = h * 64; r < h * 64 + 64; ++r) acc += L[(j0 + r) * ld + col0 + c] * xj[r];
   __syncthreads();
   part[h][c] = acc;
@@ -239,6 +253,8 @@ struct EvPair { hipEvent_t a, b; };
 struct gh_chol {
   gh_chol_opts opts;
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;             // high-priority panel stream (look-ahead)
+  hipEvent_t ev_sync[3] = {nullptr, nullptr, nullptr};
   int64_t n = 0, np = 0;
   int ndim = 0;
   bool computed = false;
@@ -262,6 +278,8 @@ struct gh_chol {
   ~gh_chol() {
     for (auto& p : ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (d_info) (void)hipFree(d_info);
+    for (auto& e : ev_sync) if (e) (void)hipEventDestroy(e);
+    if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
 };
@@ -282,7 +300,34 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   if (s->opts.nb % T) { delete s; gh_set_error("nb must be a multiple of 128"); return GH_ERR_BAD_ARG; }
   int rc = set_device(s);
   if (rc != GH_OK) { delete s; return rc; }
-  if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  // Look-ahead needs the panel stream's small latency-bound kernels (one 149-KiB-LDS workgroup
+  // for potf2) to find a free CU at once; behind a saturating SYRK grid they would wait for a
+  // whole CU to drain.  So the MAIN stream is created with a CU mask that leaves a few CUs out
+  // (GEORGE_AMD_RESERVE_CUS, default 8 of 256), and the panel stream may run anywhere.
+  // Measured (MI355X, ROCm 7.2): the masked stream costs ~1 s to create and slows the SYRK by 12 %
+  // even for 8 reserved CUs, a net loss at N = 65536 (1775 -> 1925 ms) and a gain only when the
+  // panel dominates (N = 16384: 70 -> 63 ms); so it is OFF unless the variable asks for it.
+  int reserve = 0;
+  if (const char* e = getenv("GEORGE_AMD_RESERVE_CUS")) reserve = atoi(e);
+  bool made = false;
+  if (reserve > 0 && reserve < 128) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, s->opts.device) == hipSuccess && prop.multiProcessorCount > reserve) {
+      const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+      std::vector<uint32_t> mask(words, 0u);
+      for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+      if (hipExtStreamCreateWithCUMask(&s->st, words, mask.data()) == hipSuccess) made = true;
+      else { s->st = nullptr; (void)hipGetLastError(); }
+    }
+  }
+  if (!made && hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  if (s->opts.lookahead) {
+    int lo = 0, hi = 0;                    // numerically lowest value = highest priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi) != hipSuccess) { s->st2 = nullptr; (void)hipGetLastError(); }
+    for (auto& e : s->ev_sync)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete s; gh_set_error("hipEventCreate failed"); return GH_ERR_HIP; }
+  }
   if (hipMalloc((void**)&s->d_info, sizeof(long long)) != hipSuccess) { delete s; gh_set_error("hipMalloc failed"); return GH_ERR_HIP; }
   *out = s;
   return GH_OK;
@@ -360,7 +405,84 @@ extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, doub
   return GH_OK;
 }
 
+// One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
+static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
+  double* A = s->A.d();
+  const int64_t np = s->np, ld = np;
+  double* dinv = s->dinv.d() + (k0 / T) * T * T;
+  GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
+  const int64_t m = np - (k0 + nb);
+  if (m > 0) GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
+  return GH_OK;
+}
+
+// Right-looking factorisation with one-panel look-ahead on two HIP streams:
+//   main stream  : trailing updates (the MFMA-bound >90 % of the work);
+//   panel stream : (high priority) potf2/TRSM chain of the NEXT panel, which is latency-bound
+//                  and would otherwise sit on the critical path between two trailing updates.
+// Step k: the main stream first updates only block column k+1 (the next panel), signals the panel
+// stream, then updates the rest of the trailing matrix while the panel stream factors panel k+1.
+// The two touch disjoint regions: panel k+1 = columns [k1, k1+nb1), the remainder = rows and
+// columns >= k1+nb1; both only READ panel k.
+static int factor_lookahead(gh_chol* s) {
+  hipStream_t sm = s->st, sp = s->st2;
+  double* A = s->A.d();
+  const int64_t np = s->np, ld = np, NB = s->opts.nb;
+  const bool prof = s->opts.profile != 0;
+  auto rec = [&](hipEvent_t e, hipStream_t st) -> int { GH_HIP(hipEventRecord(e, st)); return GH_OK; };
+  // panel 0
+  {
+    const int64_t nb0 = std::min<int64_t>(NB, np);
+    GH_HIP(hipEventRecord(s->ev_sync[0], sm));
+    GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));            // the matrix build (on sm) is complete
+    const long ep = prof ? s->next_ev() : -1;
+    if (ep >= 0) { GH_CHECK(rec(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
+    GH_CHECK(panel_step(s, sp, 0, nb0));
+    if (ep >= 0) GH_CHECK(rec(s->ev_pool[ep].b, sp));
+    GH_HIP(hipEventRecord(s->ev_sync[1], sp));
+  }
+  int flip = 1;                                                   // ev_sync[flip] = "panel k is factored"
+  for (int64_t k0 = 0; k0 < np; k0 += NB) {
+    const int64_t nb = std::min<int64_t>(NB, np - k0);
+    const int64_t k1 = k0 + nb;
+    GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[flip], 0));          // panel k done
+    if (k1 >= np) break;
+    const int64_t nb1 = std::min<int64_t>(NB, np - k1);
+    const int64_t k2 = k1 + nb1;
+    const double* P1 = blk(A, ld, k1, k0);                        // panel k rows [k1, np)
+    // (a) bring block column k+1 up to date: its diagonal block (lower) and the rows below
+    GH_CHECK(gemm_nt(sm, blk(A, ld, k1, k1), ld, P1, ld, P1, ld, nb1, nb1, nb, -1.0, 1.0, true));
+    if (np - k2 > 0)
+      GH_CHECK(gemm_nt(sm, blk(A, ld, k2, k1), ld, blk(A, ld, k2, k0), ld, P1, ld, np - k2, nb1, nb, -1.0, 1.0, false));
+    const int nxt = 3 - flip;                                     // alternate ev_sync[1] / ev_sync[2]
+    GH_HIP(hipEventRecord(s->ev_sync[0], sm));
+    GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
+    {
+      const long ep = prof ? s->next_ev() : -1;
+      if (ep >= 0) { GH_CHECK(rec(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
+      GH_CHECK(panel_step(s, sp, k1, nb1));
+      if (ep >= 0) GH_CHECK(rec(s->ev_pool[ep].b, sp));
+      GH_HIP(hipEventRecord(s->ev_sync[nxt], sp));
+    }
+    // (b) the rest of the trailing matrix, concurrently with panel k+1
+    const int64_t m2 = np - k2;
+    if (m2 > 0) {
+      const long et = prof ? s->next_ev() : -1;
+      if (et >= 0) { GH_CHECK(rec(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); }
+      const double* P2 = blk(A, ld, k2, k0);
+      GH_CHECK(gemm_nt(sm, blk(A, ld, k2, k2), ld, P2, ld, P2, ld, m2, m2, nb, -1.0, 1.0, true));
+      if (et >= 0) GH_CHECK(rec(s->ev_pool[et].b, sm));
+      const double tiles = (double)(m2 / T) * (m2 / T + 1) / 2.0;
+      s->prof.trailing_flops += tiles * 2.0 * T * T * (double)nb;
+      s->prof.n_trailing += 1;
+    }
+    flip = nxt;
+  }
+  return GH_OK;
+}
+
 static int factor(gh_chol* s) {
+  if (s->opts.lookahead && s->st2) return factor_lookahead(s);
   hipStream_t st = s->st;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = s->opts.nb;

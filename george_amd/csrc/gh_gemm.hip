@@ -47,7 +47,12 @@ __device__ __forceinline__ long xcd_remap(long bid, long nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-__device__ __forceinline__ void tile_of(const GemmDev& g, int& tm, int& tn) {
+// Workgroup -> C tile: row-major over the (lower-triangular) tile grid inside each XCD's chunk.
+// (Tried and measured: grouping tiles into 8x8 super-tiles per XCD, which would cut the L2-miss
+// traffic of the operand slabs -- FETCH_SIZE is 4.8x the algorithmic read bytes, profiles/r01 --
+// left the SYRK at the same 51-57 TFLOP/s and cost 8 % end to end through 8x larger grids on the
+// skinny panel GEMMs.  The kernel is MFMA-issue bound, not fabric bound.)
+__device__ __forceinline__ bool tile_of(const GemmDev& g, int& tm, int& tn) {
   const long l = xcd_remap(blockIdx.x, g.nblk);
   if (g.lower) {
     long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
@@ -59,6 +64,7 @@ __device__ __forceinline__ void tile_of(const GemmDev& g, int& tm, int& tn) {
     tm = (int)(l / g.tiles_n);
     tn = (int)(l % g.tiles_n);
   }
+  return true;
 }
 
 template <bool KM>
@@ -99,9 +105,12 @@ __device__ __forceinline__ void k_range(const GemmDev& g, long row0, long col0, 
   if (g.khi_row && row0 + BM < kend) kend = row0 + BM;
 }
 
-// MM selects the matrix instruction (measured on MI355X, tests/test_gpu_gemm.py microbench suite):
-//   MM == 1: v_mfma_f64_16x16x4_f64       -- saturates at ~47 TFLOP/s chip-wide (~100 cycles/SIMD)
-//   MM == 2: v_mfma_f64_4x4x4_4b_f64      -- >= 66 TFLOP/s: four 4x4x4 blocks per instruction.
+// MM selects the matrix instruction (A/B measured on MI355X, scripts/gemm_ab.py):
+//   MM == 1: v_mfma_f64_16x16x4_f64   -- 52 TFLOP/s (K = 512) to 58 TFLOP/s (K = 1024) on the
+//            trailing-update shape in this kernel; the default.
+//   MM == 2: v_mfma_f64_4x4x4_4b_f64  -- a bare issue loop of it runs faster than a bare loop of
+//            the 16x16x4 form (66 vs 47 TFLOP/s with 8 accumulators), but inside this kernel its
+//            4x larger instruction count and the extra fragment reads leave it at 36 TFLOP/s.
 // The 4-block form builds the same 16x16x4 product from four instructions that share the B
 // fragment: lane 16k+4b+i of the A operand holds A[4n+i][k] for EVERY block b (a broadcast LDS
 // read), lane 16k+c of B holds B[k][c]; instruction n then yields rows 4n..4n+3 of the tile in
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
   __shared__ double sA[2][BM * LS];
   __shared__ double sB[2][BN * LS];
   int tm, tn;
-  tile_of(g, tm, tn);
+  if (!tile_of(g, tm, tn)) return;       // (uniform per workgroup, before any barrier)
   const long row0 = (long)tm * BM, col0 = (long)tn * BN;
   long kbeg, kend;
   k_range(g, row0, col0, kbeg, kend);
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_f64_valu(GemmDev g) {
   __shared__ double sA[BM * LS];
   __shared__ double sB[BN * LS];
   int tm, tn;
-  tile_of(g, tm, tn);
+  if (!tile_of(g, tm, tn)) return;       // (uniform per workgroup, before any barrier)
   const long row0 = (long)tm * BM, col0 = (long)tn * BN;
   long kbeg, kend;
   k_range(g, row0, col0, kbeg, kend);

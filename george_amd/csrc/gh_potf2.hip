@@ -2,7 +2,11 @@
 // 128x128 diagonal block to its Cholesky factor L AND to L^-1 (which turns every TRSM of the
 // solver into an MFMA GEMM).
 //
-// The whole block lives in LDS (128 x 129 doubles = 129 KiB of the CU's 160 KiB).
+// The lower triangle of the block lives in LDS in PACKED row-major form (128*129/2 doubles =
+// 64.5 KiB; 81.5 KiB with the scratch below).  Packing is what lets this kernel run beside the
+// trailing SYRK during look-ahead: a SYRK workgroup holds 72 KiB of LDS and 254 VGPRs, so a CU
+// with one SYRK workgroup still has room for this one, whereas the unpacked 129-KiB tile had to
+// wait for a whole CU to drain (rocprof, profiles/r01: 180 us alone, 1.7 ms average under SYRK).
 //   phase 1  blocked right-looking Cholesky, 16-column steps:
 //            (a) 16x16 diagonal block, unblocked, by ONE wavefront (no workgroup barriers),
 //            (b) rows below: x D^T = a by per-row substitution, one thread per row, registers,
@@ -22,28 +26,38 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define T 128
-#define LP 129
-#define IP 17                    // pitch of the 16x16 diagonal-inverse scratch
+#define IP 17                                   // pitch of the 16x16 diagonal-inverse scratch
+#define PK(i, j) ((((i) * ((i) + 1)) >> 1) + (j))   // packed lower-triangular index, j <= i
 
-// ---------------------------------------------------------------- MFMA tile helpers
-// one 16x16 tile:  acc += sign * A(16 x 4*nkk) * B(4*nkk x 16), operands fetched by functors
-// A(i, k) and B(k, j);  lane map: A operand lane l <- A(l & 15, 4kk + (l >> 4)),
-//                                 B operand lane l <- B(4kk + (l >> 4), l & 15),
-//                                 acc[r] <-> C((l >> 4) + 4r, l & 15).
-template <typename FA, typename FB>
+// ---------------------------------------------------------------- MFMA tile helper
+// one 16x16 tile:  acc += A(16 x 4*nkk) * B(4*nkk x 16), operands fetched by functors A(i, k) and
+// B(k, j);  lane map: A operand lane l <- A(l & 15, 4kk + (l >> 4)),
+//                     B operand lane l <- B(4kk + (l >> 4), l & 15),
+//                     acc[r] <-> C((l >> 4) + 4r, l & 15).
+// All operand fetches of a tile (at most NK k-steps) are issued BEFORE the dependent MFMA chain:
+// the phase-2 operands come from HBM/L2 (`dinv`), and one exposed load latency per k-step is what
+// made the first MFMA version 180 us.  Loads are unconditional (the k index is clamped, surplus
+// MFMAs are skipped by a wave-uniform test): a per-element load predicate makes hipcc wait per
+// element.
+template <int NK, typename FA, typename FB>
 __device__ __forceinline__ v4d tile_mma(v4d acc, int kk0, int kk1, FA fa, FB fb, int lane) {
   const int fr = lane & 15, fk = lane >> 4;
-  for (int kk = kk0; kk < kk1; ++kk) {
-    const double a = fa(fr, 4 * kk + fk);
-    const double b = fb(4 * kk + fk, fr);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  double a[NK], b[NK];
+#pragma unroll
+  for (int q = 0; q < NK; ++q) {
+    const int kk = (kk0 + q < kk1) ? kk0 + q : kk1 - 1;
+    a[q] = fa(fr, 4 * kk + fk);
+    b[q] = fb(4 * kk + fk, fr);
   }
+#pragma unroll
+  for (int q = 0; q < NK; ++q)
+    if (kk0 + q < kk1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
   return acc;
 }
 
 __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda, double* dinv,
-                                                        long long* info, long long base) {
-  __shared__ double s[T * LP];
+                                                             long long* info, long long base) {
+  __shared__ double s[T * (T + 1) / 2];
   __shared__ double inv16[8 * 16 * IP];
   __shared__ int fail_at;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,7 +65,7 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   if (tid == 0) fail_at = -1;
   for (int idx = tid; idx < T * T; idx += 256) {
     const int i = idx >> 7, j = idx & 127;
-    s[i * LP + j] = A[(long)i * lda + j];
+    if (j <= i) s[PK(i, j)] = A[(long)i * lda + j];
   }
   __syncthreads();
 
@@ -64,19 +78,21 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
       volatile double* vs = s;
       const int i = lane & 15, q = lane >> 4;
       for (int j = 0; j < 16; ++j) {
-        double d = vs[(c0 + j) * LP + c0 + j];
+        double d = vs[PK(c0 + j, c0 + j)];
         if (!(d > 0.0)) {                       // also catches NaN
           if (lane == 0 && fail_at < 0) fail_at = c0 + j;
           d = 1.0;
         }
         const double ajj = sqrt(d);
         if (q == 0) {
-          if (i > j) vs[(c0 + i) * LP + c0 + j] = vs[(c0 + i) * LP + c0 + j] / ajj;
-          else if (i == j) vs[(c0 + j) * LP + c0 + j] = ajj;
+          if (i > j) vs[PK(c0 + i, c0 + j)] = vs[PK(c0 + i, c0 + j)] / ajj;
+          else if (i == j) vs[PK(c0 + j, c0 + j)] = ajj;
         }
-        const double lij = vs[(c0 + i) * LP + c0 + j];
-        for (int k = j + 1 + q; k <= i; k += 4)
-          vs[(c0 + i) * LP + c0 + k] -= lij * vs[(c0 + k) * LP + c0 + j];
+        if (i > j) {
+          const double lij = vs[PK(c0 + i, c0 + j)];
+          for (int k = j + 1 + q; k <= i; k += 4)
+            vs[PK(c0 + i, c0 + k)] -= lij * vs[PK(c0 + k, c0 + j)];
+        }
       }
     }
     __syncthreads();
@@ -87,16 +103,16 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
       if (r < T) {
         double x[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = s[r * LP + c0 + k];
+        for (int k = 0; k < 16; ++k) x[k] = s[PK(r, c0 + k)];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           double v = x[k];
 #pragma unroll
-          for (int m = 0; m < k; ++m) v -= x[m] * s[(c0 + k) * LP + c0 + m];
-          x[k] = v / s[(c0 + k) * LP + c0 + k];
+          for (int m = 0; m < k; ++m) v -= x[m] * s[PK(c0 + k, c0 + m)];
+          x[k] = v / s[PK(c0 + k, c0 + k)];
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s[r * LP + c0 + k] = x[k];
+        for (int k = 0; k < 16; ++k) s[PK(r, c0 + k)] = x[k];
       }
     }
     __syncthreads();
@@ -109,14 +125,21 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
         while (acc_t + ti + 1 <= e) { acc_t += ti + 1; ++ti; }
         const int tj = e - acc_t;
         const int R0 = 16 * (jb + 1 + ti), C0 = 16 * (jb + 1 + tj);
+        const int cc = C0 + (lane & 15);
         v4d acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = s[(R0 + (lane >> 4) + 4 * r) * LP + C0 + (lane & 15)];
-        acc = tile_mma(acc, 0, 4,
-                       [&](int i, int k) { return -s[(R0 + i) * LP + c0 + k]; },
-                       [&](int k, int j) { return s[(C0 + j) * LP + c0 + k]; }, lane);
+        for (int r = 0; r < 4; ++r) {
+          const int rr = R0 + (lane >> 4) + 4 * r;
+          acc[r] = (cc <= rr) ? s[PK(rr, cc)] : 0.0;
+        }
+        acc = tile_mma<4>(acc, 0, 4,
+                          [&](int i, int k) { return -s[PK(R0 + i, c0 + k)]; },
+                          [&](int k, int j) { return s[PK(C0 + j, c0 + k)]; }, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[(R0 + (lane >> 4) + 4 * r) * LP + C0 + (lane & 15)] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+          const int rr = R0 + (lane >> 4) + 4 * r;
+          if (cc <= rr) s[PK(rr, cc)] = acc[r];
+        }
       }
     }
     __syncthreads();
@@ -128,7 +151,7 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   // factor back to HBM, strict upper triangle of the tile zeroed
   for (int idx = tid; idx < T * T; idx += 256) {
     const int i = idx >> 7, j = idx & 127;
-    A[(long)i * lda + j] = (j <= i) ? s[i * LP + j] : 0.0;
+    A[(long)i * lda + j] = (j <= i) ? s[PK(i, j)] : 0.0;
   }
 
   // ================================================================ phase 2: L^-1 -> dinv
@@ -140,15 +163,15 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
     const int c = lane & 15, q = lane >> 4;
     if (q == 0) {
       for (int i = 0; i < 16; ++i) xs[i * IP + c] = 0.0;
-      xs[c * IP + c] = 1.0 / s[(d0 + c) * LP + d0 + c];
+      xs[c * IP + c] = 1.0 / s[PK(d0 + c, d0 + c)];
     }
     for (int i = 1; i < 16; ++i) {
       double acc = 0.0;
       if (i > c)
-        for (int k = c + q; k < i; k += 4) acc += s[(d0 + i) * LP + d0 + k] * xs[k * IP + c];
+        for (int k = c + q; k < i; k += 4) acc += s[PK(d0 + i, d0 + k)] * xs[k * IP + c];
       acc += __shfl_xor(acc, 16, 64);
       acc += __shfl_xor(acc, 32, 64);
-      if (q == 0 && i > c) xs[i * IP + c] = -acc / s[(d0 + i) * LP + d0 + i];
+      if (q == 0 && i > c) xs[i * IP + c] = -acc / s[PK(d0 + i, d0 + i)];
     }
     for (int e = lane; e < 256; e += 64) {
       const int i = e >> 4, j = e & 15;
@@ -170,13 +193,13 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
       v4d acc = {0.0, 0.0, 0.0, 0.0};
       if (sz == 16) {
         const double* ai = inv16 + (2 * p) * 16 * IP;
-        acc = tile_mma(acc, 0, 4,
-                       [&](int i, int k) { return s[(P0 + 16 + i) * LP + P0 + k]; },
-                       [&](int k, int j) { return ai[k * IP + j]; }, lane);
+        acc = tile_mma<4>(acc, 0, 4,
+                          [&](int i, int k) { return s[PK(P0 + 16 + i, P0 + k)]; },
+                          [&](int k, int j) { return ai[k * IP + j]; }, lane);
       } else {
-        acc = tile_mma(acc, 4 * tj, sz / 4,
-                       [&](int i, int k) { return s[(P0 + sz + 16 * ti + i) * LP + P0 + k]; },
-                       [&](int k, int j) { return dinv[(P0 + k) * T + P0 + 16 * tj + j]; }, lane);
+        acc = tile_mma<16>(acc, 4 * tj, sz / 4,
+                           [&](int i, int k) { return s[PK(P0 + sz + 16 * ti + i, P0 + k)]; },
+                           [&](int k, int j) { return dinv[(P0 + k) * T + P0 + 16 * tj + j]; }, lane);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -190,13 +213,13 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
       v4d acc = {0.0, 0.0, 0.0, 0.0};
       if (sz == 16) {
         const double* bi = inv16 + (2 * p + 1) * 16 * IP;
-        acc = tile_mma(acc, 0, 4,
-                       [&](int i, int k) { return -bi[i * IP + k]; },
-                       [&](int k, int j) { return scr[(p * sz + k) * T + j]; }, lane);
+        acc = tile_mma<4>(acc, 0, 4,
+                          [&](int i, int k) { return -bi[i * IP + k]; },
+                          [&](int k, int j) { return scr[(p * sz + k) * T + j]; }, lane);
       } else {
-        acc = tile_mma(acc, 0, 4 * (ti + 1),
-                       [&](int i, int k) { return -dinv[(P0 + sz + 16 * ti + i) * T + P0 + sz + k]; },
-                       [&](int k, int j) { return scr[(p * sz + k) * T + 16 * tj + j]; }, lane);
+        acc = tile_mma<16>(acc, 0, 4 * (ti + 1),
+                           [&](int i, int k) { return -dinv[(P0 + sz + 16 * ti + i) * T + P0 + sz + k]; },
+                           [&](int k, int j) { return scr[(p * sz + k) * T + 16 * tj + j]; }, lane);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
