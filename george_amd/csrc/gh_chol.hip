@@ -296,7 +296,7 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   memset(&s->opts, 0, sizeof(s->opts));
   memset(&s->prof, 0, sizeof(s->prof));
   if (opts) s->opts = *opts;
-  if (s->opts.nb <= 0) s->opts.nb = 512;
+  if (s->opts.nb < 0) s->opts.nb = 0;       // 0 = choose per problem size (panel_width())
   if (s->opts.nb % T) { delete s; gh_set_error("nb must be a multiple of 128"); return GH_ERR_BAD_ARG; }
   int rc = set_device(s);
   if (rc != GH_OK) { delete s; return rc; }
@@ -405,6 +405,14 @@ extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, doub
   return GH_OK;
 }
 
+// Outer panel width.  Wider panels raise the SYRK's arithmetic intensity and K-loop length
+// (52 -> 58 TFLOP/s from K = 512 to 1024, scripts/gemm_ab.py) but put more work into the
+// latency-bound panel chain; measured crossover (bench.py): N = 16384 -> 512, N = 65536 -> 1024.
+static int64_t panel_width(const gh_chol* s) {
+  if (s->opts.nb > 0) return s->opts.nb;
+  return s->np >= 24576 ? 1024 : 512;
+}
+
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
 static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   double* A = s->A.d();
@@ -427,7 +435,7 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
 static int factor_lookahead(gh_chol* s) {
   hipStream_t sm = s->st, sp = s->st2;
   double* A = s->A.d();
-  const int64_t np = s->np, ld = np, NB = s->opts.nb;
+  const int64_t np = s->np, ld = np, NB = panel_width(s);
   const bool prof = s->opts.profile != 0;
   auto rec = [&](hipEvent_t e, hipStream_t st) -> int { GH_HIP(hipEventRecord(e, st)); return GH_OK; };
   // panel 0
@@ -485,7 +493,7 @@ static int factor(gh_chol* s) {
   if (s->opts.lookahead && s->st2) return factor_lookahead(s);
   hipStream_t st = s->st;
   double* A = s->A.d();
-  const int64_t np = s->np, ld = np, NB = s->opts.nb;
+  const int64_t np = s->np, ld = np, NB = panel_width(s);
   const bool prof = s->opts.profile != 0;
   for (int64_t k0 = 0; k0 < np; k0 += NB) {
     const int64_t nb = std::min<int64_t>(NB, np - k0);

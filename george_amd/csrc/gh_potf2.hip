@@ -29,6 +29,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define IP 17                                   // pitch of the 16x16 diagonal-inverse scratch
 #define PK(i, j) ((((i) * ((i) + 1)) >> 1) + (j))   // packed lower-triangular index, j <= i
 
+// value of `v` in lane `src` (a compile-time constant after unrolling), delivered through SGPRs
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------- MFMA tile helper
 // one 16x16 tile:  acc += A(16 x 4*nkk) * B(4*nkk x 16), operands fetched by functors A(i, k) and
 // B(k, j);  lane map: A operand lane l <- A(l & 15, 4kk + (l >> 4)),
@@ -74,25 +81,35 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
     const int c0 = 16 * jb;
     // (a) diagonal block: wavefront 0 only; LDS operations of one wavefront execute in program
     //     order, `volatile` keeps the compiler from caching or reordering them
+    //     Register-resident: lane i (mod 16) holds row i of the block in 16 VGPR pairs, a column's
+    //     pivot and multipliers travel by v_readlane (SGPR broadcast), the j/k loops are fully
+    //     unrolled so every register index is static.  (The first MFMA version did this through
+    //     volatile LDS round trips: ~1100 cycles per column, a third of the kernel.)
     if (wave == 0) {
-      volatile double* vs = s;
-      const int i = lane & 15, q = lane >> 4;
+      const int i = lane & 15;
+      double a[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = (k <= i) ? s[PK(c0 + i, c0 + k)] : 0.0;
+#pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double d = vs[PK(c0 + j, c0 + j)];
-        if (!(d > 0.0)) {                       // also catches NaN
+        double d = bcast_lane(a[j], j);
+        if (!(d > 0.0)) {                       // also catches NaN (uniform: d is a broadcast)
           if (lane == 0 && fail_at < 0) fail_at = c0 + j;
           d = 1.0;
         }
         const double ajj = sqrt(d);
-        if (q == 0) {
-          if (i > j) vs[PK(c0 + i, c0 + j)] = vs[PK(c0 + i, c0 + j)] / ajj;
-          else if (i == j) vs[PK(c0 + j, c0 + j)] = ajj;
+        const double inv = 1.0 / ajj;
+        a[j] = (i == j) ? ajj : a[j] * inv;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = bcast_lane(a[j], k);
+          a[k] -= a[j] * lkj;                   // meaningful for i >= k; other lanes' values are never stored
         }
-        if (i > j) {
-          const double lij = vs[PK(c0 + i, c0 + j)];
-          for (int k = j + 1 + q; k <= i; k += 4)
-            vs[PK(c0 + i, c0 + k)] -= lij * vs[PK(c0 + k, c0 + j)];
-        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k <= i) s[PK(c0 + i, c0 + k)] = a[k];
       }
     }
     __syncthreads();
@@ -157,25 +174,29 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   // ================================================================ phase 2: L^-1 -> dinv
   // (a) the eight 16x16 diagonal inverses; wavefront w takes blocks 2w and 2w+1.
   //     lane (c = lane & 15, q = lane >> 4): column c of the inverse, dot products split 4 ways.
+  //     Registers again: lane r (mod 16) holds ROW r of the block (a[]) and COLUMN r of its
+  //     inverse (x[]); x_i = -(sum_{k<i} L_ik x_k) / L_ii with L_ik broadcast from lane i.
   for (int bb = 0; bb < 2; ++bb) {
     const int bI = 2 * wave + bb, d0 = 16 * bI;
-    volatile double* xs = inv16 + bI * 16 * IP;
-    const int c = lane & 15, q = lane >> 4;
-    if (q == 0) {
-      for (int i = 0; i < 16; ++i) xs[i * IP + c] = 0.0;
-      xs[c * IP + c] = 1.0 / s[PK(d0 + c, d0 + c)];
-    }
-    for (int i = 1; i < 16; ++i) {
+    double* xs = inv16 + bI * 16 * IP;
+    const int c = lane & 15;
+    double a[16], x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = (k <= c) ? s[PK(d0 + c, d0 + k)] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double rdiag = 1.0 / bcast_lane(a[i], i);
       double acc = 0.0;
-      if (i > c)
-        for (int k = c + q; k < i; k += 4) acc += s[PK(d0 + i, d0 + k)] * xs[k * IP + c];
-      acc += __shfl_xor(acc, 16, 64);
-      acc += __shfl_xor(acc, 32, 64);
-      if (q == 0 && i > c) xs[i * IP + c] = -acc / s[PK(d0 + i, d0 + i)];
+#pragma unroll
+      for (int k = 0; k < i; ++k) acc += bcast_lane(a[k], i) * x[k];      // x[k] = 0 for k < c
+      x[i] = (i < c) ? 0.0 : ((i == c) ? rdiag : -acc * rdiag);
     }
-    for (int e = lane; e < 256; e += 64) {
-      const int i = e >> 4, j = e & 15;
-      dinv[(d0 + i) * T + d0 + j] = (j <= i) ? xs[i * IP + j] : 0.0;
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        xs[i * IP + c] = x[i];
+        dinv[(d0 + i) * T + d0 + c] = x[i];
+      }
     }
   }
   __syncthreads();

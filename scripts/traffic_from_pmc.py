@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""HBM/fabric traffic of the trailing-update (SYRK) launches from two rocprofv3 --pmc passes.
+
+usage: traffic_from_pmc.py <fetch.db> <write.db> <N> <nb> [<out.json>]
+
+Method (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
+passes (they do not fit one TCC pass); both are in KiB; on gfx950 FETCH_SIZE reports exactly half
+of the bytes of a wide coalesced read stream -- confirmed here on a 16-B/lane copy of known size
+(profiles/r01/pmc_calibration_*: 2 GiB read -> FETCH_SIZE 1 048 590 KiB, 2 GiB written ->
+WRITE_SIZE 2 097 150 KiB) -- so  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+The trailing launches are picked out of all gemm_f64_mfma dispatches by their grid size
+(a triangular number of 128x128 tiles).  Infinity-Cache hits are counted by these counters, so
+this is traffic leaving the L2s, an upper bound on HBM traffic.
+"""
+import json
+import sqlite3
+import sys
+
+
+def trailing_grids(n, nb):
+    np_ = (n + 127) // 128 * 128
+    grids = {}
+    k0 = 0
+    while k0 < np_:
+        b = min(nb, np_ - k0)
+        k1 = k0 + b
+        if k1 >= np_:
+            break
+        b1 = min(nb, np_ - k1)
+        m2 = (np_ - (k1 + b1)) // 128
+        if m2 > 0:
+            grids[m2 * (m2 + 1) // 2] = (m2, b)
+        k0 = k1
+    return grids
+
+
+def collect(db, counter, grids):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    q = ("select d.dispatch_id, d.grid_size_x/256, d.end-d.start, e.value from rocpd_pmc_event e "
+         "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
+         "join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+         "where s.kernel_name like '%gemm_f64_mfma%' and p.name = ?")
+    per = {}
+    for did, g, dt, v in cur.execute(q, (counter,)):
+        if g in grids and g > 36:
+            e = per.setdefault(did, [g, dt, 0.0])
+            e[2] += v
+    return per
+
+
+def main():
+    fdb, wdb, n, nb = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    grids = trailing_grids(n, nb)
+    f = collect(fdb, "FETCH_SIZE", grids)
+    w = collect(wdb, "WRITE_SIZE", grids)
+    nf, nw = len(f), len(w)
+    fetch_kib = sum(v[2] for v in f.values())
+    write_kib = sum(v[2] for v in w.values())
+    alg = 0.0
+    for did, (g, dt, _) in f.items():
+        m2, b = grids[g]
+        alg += g * 2.0 * 128 * 128 * 8 + m2 * 128.0 * b * 8      # C read + write, panel read once
+    out = {
+        "N": n, "nb": nb, "launches_fetch_pass": nf, "launches_write_pass": nw,
+        "FETCH_SIZE_KiB_sum": fetch_kib, "WRITE_SIZE_KiB_sum": write_kib,
+        "bytes_per_launch": ((2.0 * fetch_kib / max(nf, 1)) + write_kib / max(nw, 1)) * 1024.0,
+        "read_bytes_per_launch": 2.0 * fetch_kib / max(nf, 1) * 1024.0,
+        "write_bytes_per_launch": write_kib / max(nw, 1) * 1024.0,
+        "algorithmic_bytes_per_launch": alg / max(nf, 1),
+        "avg_launch_ms_under_pmc": sum(v[1] for v in f.values()) / max(nf, 1) / 1e6,
+        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 of every 128 B)",
+    }
+    txt = json.dumps(out, indent=1)
+    print(txt)
+    if len(sys.argv) > 5:
+        open(sys.argv[5], "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
