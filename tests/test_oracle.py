@@ -93,6 +93,25 @@ def test_mt19937_matches_std():
     assert [r(), r()] == [1608637542, 3421126067]     # std::mt19937 seeded with 42
 
 
+def test_flattener_accepts_reference_kernel_objects():
+    """Drop-in claim of INTEGRATION.md section 1: our spec flattener reads the reference's own
+    `george.kernels` objects (same attribute protocol as parser.h) into the same POD program."""
+    george = ref_loader.load_reference()
+    if george is None:
+        pytest.skip("/root/reference not present (GPU box)")
+    from george_amd import program
+    ours = zoo.kernel_zoo(AK)
+    theirs = zoo.kernel_zoo(george.kernels)
+    for (name, ka), (_, kr) in zip(ours, theirs):
+        assert bytes(program.flatten(ka)) == bytes(program.flatten(kr)), name
+        dk = program.DeviceKernel(kr)
+        assert (dk.ndim, dk.size) == (kr.ndim, kr.full_size)
+    # and the reference GP accepts our solver classes as its `solver=` plug-in (construction only here)
+    import george_amd
+    gp = george.GP(1.0 * george.kernels.ExpSquaredKernel(1.0), solver=george_amd.BasicSolver)
+    assert gp.solver_type is george_amd.BasicSolver
+
+
 def test_against_live_reference_when_available():
     george = ref_loader.load_reference()
     if george is None:
