@@ -5,24 +5,30 @@ The N x N covariance matrix is cut into NB x NB tiles; tile (I, J) lives on the 
 BUILDS its own tiles on its own GPU from (kernel, x) -- nothing is scattered -- and the factorisation
 proceeds right-looking, one tile column per step:
 
-  1. the owner of the diagonal tile factors it (gh_dev_potrf_block) and broadcasts L_kk and its
-     diagonal-block inverses down its process column;
-  2. the ranks of that process column TRSM their panel tiles (gh_dev_trsm_right);
-  3. the panel travels: a broadcast along every process row (the "row panel"), then an all-gather
-     inside every process column of the tiles that column needs transposed (the "column panel");
-  4. every rank updates its own trailing tiles with fp64-MFMA GEMMs (gh_dev_gemm).
+  P(k) "panel"   1. the owner of the diagonal tile factors it (gh_dev_potrf_block) and broadcasts
+                    L_kk and its diagonal-block inverses down its process column;
+                 2. the ranks of that process column TRSM their panel tiles (gh_dev_trsm_right);
+                 3. the panel travels: a broadcast along every process row (the "row panel"), then
+                    an all-gather inside every process column of the tiles that column needs
+                    transposed (the "column panel");
+  U(k) "update"  4. every rank updates its own trailing tiles with fp64-MFMA GEMMs (gh_dev_gemm).
 
-Collectives are torch.distributed (backend "nccl" == RCCL over xGMI on the GPUs; "gloo" in the
-CPU tests): a broadcast to the 1-3 peers of a row/column is a direct-link transfer on the xGMI
-mesh.  log|K| and r^T K^-1 r need one all-reduce of a scalar each; the forward substitution for
-r^T K^-1 r = ||L^-1 r||^2 is a left-looking tile sweep (one small reduce + broadcast per tile row).
+With look-ahead (default on GPUs) U(k) is split: the tiles of block column k+1 first, then P(k+1)
+is issued on a second HIP stream -- its kernels AND its collectives -- while the rest of U(k) runs
+on the main stream; panel workspaces are double-buffered.  Collectives are torch.distributed
+(backend "nccl" == RCCL over xGMI on the GPUs; "gloo" in the CPU tests): a broadcast to the 1-3
+peers of a row/column is a direct-link transfer on the xGMI mesh.  log|K| and the failure flag need
+one all-reduce of a scalar each; r^T K^-1 r = ||L^-1 r||^2 is a left-looking tile sweep (one small
+reduce + broadcast per tile row).
 
 The tile arithmetic is delegated to an `ops` object: `HipTileOps` (the product path: device
-pointers into the C ABI of include/george_amd.h) -- the CPU tests substitute a NumPy stand-in
-to exercise the ownership / communication logic with world_size 2 and 4 under gloo.
+pointers into the C ABI of include/george_amd.h, launched on torch's CURRENT stream) -- the CPU
+tests substitute a NumPy stand-in to exercise the ownership / communication logic with world_size
+2, 4 and 8 under gloo.
 """
-import ctypes as C
+import contextlib
 import math
+import os
 
 import numpy as np
 
@@ -38,7 +44,10 @@ def grid_shape(world):
 
 
 class HipTileOps(object):
-    """Tile kernels on the local GPU through the C ABI (device pointers, current HIP stream)."""
+    """Tile kernels on the local GPU through the C ABI (device pointers).  Every launch goes to
+    torch's CURRENT stream, so `with torch.cuda.stream(s):` routes kernels and collectives alike."""
+
+    has_streams = True
 
     def __init__(self, device, kernel_spec):
         import torch
@@ -50,6 +59,9 @@ class HipTileOps(object):
         self.dk = DeviceKernel(kernel_spec)
         self.ndim = self.dk.ndim
 
+    def _st(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream or None
+
     def zeros(self, *shape, dtype=None):
         return self.torch.zeros(*shape, dtype=dtype or self.torch.float64, device=self.device)
 
@@ -58,36 +70,55 @@ class HipTileOps(object):
 
     def kmat(self, x, n, yerr, row0, nrows, col0, ncols, out):
         self.N.check(self.N.lib.gh_dev_kmat_block(self.dk.handle, x.data_ptr(), n, self.ndim, yerr.data_ptr(),
-                                                  row0, nrows, col0, ncols, out.data_ptr(), out.stride(0), None))
+                                                  row0, nrows, col0, ncols, out.data_ptr(), out.stride(0), self._st()))
 
     def potrf(self, a, dinv, info, base):
         self.N.check(self.N.lib.gh_dev_potrf_block(a.data_ptr(), a.stride(0), a.shape[0], dinv.data_ptr(),
-                                                   info.data_ptr(), base, None))
+                                                   info.data_ptr(), base, self._st()))
 
     def trsm(self, l11, dinv, a21):
         self.N.check(self.N.lib.gh_dev_trsm_right(l11.data_ptr(), l11.stride(0), dinv.data_ptr(), a21.data_ptr(),
-                                                  a21.stride(0), a21.shape[0], a21.shape[1], None))
+                                                  a21.stride(0), a21.shape[0], a21.shape[1], self._st()))
 
     def gemm_nt(self, c, a, b):
         """c -= a @ b.T"""
         self.N.check(self.N.lib.gh_dev_gemm(c.data_ptr(), c.stride(0), a.data_ptr(), a.stride(0), b.data_ptr(),
-                                            b.stride(0), c.shape[0], c.shape[1], a.shape[1], -1.0, 1.0, 0, None))
+                                            b.stride(0), c.shape[0], c.shape[1], a.shape[1], -1.0, 1.0, 0, self._st()))
 
     def gemv(self, a, x, y, alpha, beta):
         """y = beta*y + alpha * a @ x"""
         self.N.check(self.N.lib.gh_dev_gemv(a.data_ptr(), a.stride(0), a.shape[0], a.shape[1], 0,
-                                            x.data_ptr(), y.data_ptr(), alpha, beta, None))
+                                            x.data_ptr(), y.data_ptr(), alpha, beta, self._st()))
 
     def logdet_accum(self, a, out):
-        self.N.check(self.N.lib.gh_dev_logdet_accum(a.data_ptr(), a.stride(0), a.shape[0], out.data_ptr(), None))
+        self.N.check(self.N.lib.gh_dev_logdet_accum(a.data_ptr(), a.stride(0), a.shape[0], out.data_ptr(), self._st()))
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
+    # stream plumbing for the look-ahead pipeline
+    def make_side_stream(self):
+        lo, hi = self.torch.cuda.Stream.priority_range()
+        return self.torch.cuda.Stream(device=self.device, priority=hi)
+
+    def main_stream(self):
+        return self.torch.cuda.current_stream(self.device)
+
+    def on(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def event(self, stream):
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def wait(self, stream, event):
+        stream.wait_event(event)
+
 
 class BlockCyclicCholesky(object):
 
-    def __init__(self, ops, n, nb=512, rank=None, world=None):
+    def __init__(self, ops, n, nb=512, rank=None, world=None, lookahead=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.ops = torch, dist, ops
@@ -104,11 +135,19 @@ class BlockCyclicCholesky(object):
         self.cols = [j for j in range(self.nt) if j % self.Pc == self.pc]
         self.lrow = {i: li for li, i in enumerate(self.rows)}
         self.lcol = {j: lj for lj, j in enumerate(self.cols)}
-        nbk = self.nb
-        self.A = ops.zeros(max(len(self.rows), 1) * nbk, max(len(self.cols), 1) * nbk)
+        if lookahead is None:
+            lookahead = os.environ.get("GEORGE_AMD_DIST_LOOKAHEAD", "1") != "0"
+        self.lookahead = bool(lookahead) and getattr(ops, "has_streams", False)
+        nbk, nlr = self.nb, max(len(self.rows), 1)
+        self.A = ops.zeros(nlr * nbk, max(len(self.cols), 1) * nbk)
         self.dinv = ops.zeros(self.nt, nbk // 128, 128, 128)        # inverses of the 128-blocks of every L_kk I see
         self.Lkk = ops.zeros(nbk, nbk)
-        self.ws_row = ops.zeros(max(len(self.rows), 1) * nbk, nbk)
+        # panel workspaces, double-buffered for the look-ahead pipeline
+        cmax0 = max([len([j for j in range(1, self.nt) if j % self.Pc == self.pc and j % self.Pr == mm])
+                     for mm in range(self.Pr)] + [1])
+        self.ws_row = [ops.zeros(nlr * nbk, nbk) for _ in range(2)]
+        self.ws_send = [ops.zeros(cmax0, nbk, nbk) for _ in range(2)]
+        self.ws_gath = [[ops.zeros(cmax0, nbk, nbk) for _ in range(self.Pr)] for _ in range(2)] if self.Pr > 1 else None
         self.info = ops.zeros(1, dtype=torch.int64)
         self.logdet_dev = ops.zeros(1)
         self.log_determinant = None
@@ -151,68 +190,94 @@ class BlockCyclicCholesky(object):
                 if j <= i:
                     self.ops.kmat(x, self.n, yerr, i * nb, nb, j * nb, nb, self.tile(i, j))
 
+    # -- P(k): factor panel k and distribute it; returns (li0, wrow, {j: P_j}) -----------------------
+    def _panel(self, k, buf):
+        nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
+        ops = self.ops
+        nloc_r = len(self.rows)
+        kr, kc = k % Pr, k % Pc
+        in_col = (pc == kc)
+        if pr == kr and in_col:
+            akk = self.tile(k, k)
+            ops.potrf(akk, self.dinv[k], self.info, k * nb)
+            ops.logdet_accum(akk, self.logdet_dev)
+            self.Lkk.copy_(akk)
+        if k == nt - 1:
+            return None
+        if in_col and Pr > 1:
+            self._bcast(self.Lkk, self.grank(kr, kc), self.col_groups[kc])
+            self._bcast(self.dinv[k], self.grank(kr, kc), self.col_groups[kc])
+        li0 = self._first_local_row_at_least(k + 1)
+        m = (nloc_r - li0) * nb
+        wrow = self.ws_row[buf][:m]
+        if in_col and m > 0:
+            lk = self.lcol[k]
+            panel = self.A[li0 * nb:, lk * nb:(lk + 1) * nb]
+            ops.trsm(self.Lkk, self.dinv[k], panel)
+            wrow.copy_(panel)
+        if Pc > 1 and m > 0:
+            self._bcast(wrow, self.grank(pr, kc), self.row_groups[pr])
+        # column panel: tiles P_j, j > k, j % Pc == pc, gathered inside my process column
+        mine = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == pr]
+        cnt = [len([j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]) for mm in range(Pr)]
+        cmax = max(cnt) if cnt else 0
+        pj = {}
+        if cmax > 0:
+            send = self.ws_send[buf][:cmax]
+            for t, j in enumerate(mine):
+                s = (self.lrow[j] - li0) * nb
+                send[t].copy_(wrow[s:s + nb])
+            if Pr > 1 and self.live:
+                gathered = [g[:cmax] for g in self.ws_gath[buf]]
+                self.dist.all_gather(gathered, send, group=self.col_groups[pc])
+            else:
+                gathered = [send]
+            for mm in range(Pr):
+                js = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]
+                for t, j in enumerate(js):
+                    pj[j] = gathered[mm][t]
+        return li0, wrow, pj
+
+    # -- U(k) restricted to the given global tile columns ---------------------------------------------
+    def _update(self, panel, cols):
+        if panel is None:
+            return
+        li0, wrow, pj = panel
+        nb, nloc_r = self.nb, len(self.rows)
+        for j in cols:
+            ls = self._first_local_row_at_least(j)
+            if ls >= nloc_r:
+                continue
+            lj = self.lcol[j]
+            self.ops.gemm_nt(self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj[j])
+
     # -- factorisation -----------------------------------------------------------------------------
     def factor(self):
-        nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
+        nt = self.nt
         ops = self.ops
         self.info.zero_()
         self.logdet_dev.zero_()
-        nloc_r = len(self.rows)
-        for k in range(nt):
-            kr, kc = k % Pr, k % Pc
-            in_col = (pc == kc)
-            # 1. diagonal tile
-            if pr == kr and in_col:
-                akk = self.tile(k, k)
-                ops.potrf(akk, self.dinv[k], self.info, k * nb)
-                ops.logdet_accum(akk, self.logdet_dev)
-                self.Lkk.copy_(akk)
-            if k == nt - 1:
-                break
-            # 2. L_kk and its diagonal-block inverses go down the process column that owns the panel
-            if in_col and Pr > 1:
-                self._bcast(self.Lkk, self.grank(kr, kc), self.col_groups[kc])
-                self._bcast(self.dinv[k], self.grank(kr, kc), self.col_groups[kc])
-            li0 = self._first_local_row_at_least(k + 1)
-            m = (nloc_r - li0) * nb
-            # 3. TRSM on my rows of the panel
-            if in_col and m > 0:
-                lk = self.lcol[k]
-                panel = self.A[li0 * nb:, lk * nb:(lk + 1) * nb]
-                ops.trsm(self.Lkk, self.dinv[k], panel)
-                self.ws_row[:m].copy_(panel)
-            # 4a. row panel: along every process row, from the rank sitting in process column kc
-            if Pc > 1 and m > 0:
-                self._bcast(self.ws_row[:m], self.grank(pr, kc), self.row_groups[pr])
-            wrow = self.ws_row[:m]
-            # 4b. column panel: tiles P_j, j > k, j % Pc == pc, gathered inside my process column
-            mine = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == pr]
-            cnt = [len([j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]) for mm in range(Pr)]
-            cmax = max(cnt) if cnt else 0
-            pj = {}
-            if cmax > 0:
-                send = ops.zeros(cmax, nb, nb)
-                for t, j in enumerate(mine):
-                    s = (self.lrow[j] - li0) * nb
-                    send[t].copy_(wrow[s:s + nb])
-                if Pr > 1 and self.live:
-                    gathered = [ops.zeros(cmax, nb, nb) for _ in range(Pr)]
-                    self.dist.all_gather(gathered, send, group=self.col_groups[pc])
-                else:
-                    gathered = [send]
-                for mm in range(Pr):
-                    js = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]
-                    for t, j in enumerate(js):
-                        pj[j] = gathered[mm][t]
-            # 5. trailing update of my tiles (i, j), k < j <= i
-            for j in self.cols:
-                if j <= k:
-                    continue
-                ls = self._first_local_row_at_least(j)
-                if ls >= nloc_r:
-                    continue
-                lj = self.lcol[j]
-                ops.gemm_nt(self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj[j])
+        if not self.lookahead:
+            for k in range(nt):
+                panel = self._panel(k, 0)
+                self._update(panel, [j for j in self.cols if j > k])
+        else:
+            s_main, s_side = ops.main_stream(), ops.make_side_stream()
+            ops.wait(s_side, ops.event(s_main))                    # the build is complete
+            with ops.on(s_side):
+                panel = self._panel(0, 0)
+                done = ops.event(s_side)
+            for k in range(nt):
+                ops.wait(s_main, done)                             # panel k is here
+                if k == nt - 1:
+                    break
+                self._update(panel, [j for j in self.cols if j == k + 1])       # block column k+1 first
+                ops.wait(s_side, ops.event(s_main))
+                with ops.on(s_side):
+                    nxt = self._panel(k + 1, (k + 1) % 2)
+                    done = ops.event(s_side)
+                self._update(panel, [j for j in self.cols if j > k + 1])       # the rest, under P(k+1)
+                panel = nxt
         # scalars: log-det and failure flag
         tot = self.logdet_dev.clone()
         info = self.info.clone()
@@ -273,10 +338,11 @@ class DistributedBasicSolver(object):
     (``compute`` / ``log_determinant`` / ``dot_solve`` / ``computed``), sharded over the process
     group.  ``GP(kernel, solver=DistributedBasicSolver, nb=512)`` works unchanged on every rank."""
 
-    def __init__(self, kernel, nb=512, device=None, ops=None):
+    def __init__(self, kernel, nb=512, device=None, ops=None, lookahead=None):
         self.kernel, self.nb = kernel, nb
         self._ops = ops
         self._device = device
+        self._lookahead = lookahead
         self.computed = False
         self.log_determinant = None
 
@@ -291,7 +357,7 @@ class DistributedBasicSolver(object):
         ops = self._make_ops()
         x = np.ascontiguousarray(x, dtype=np.float64)
         yerr = np.ascontiguousarray(np.zeros(len(x)) + yerr, dtype=np.float64)
-        self._chol = BlockCyclicCholesky(ops, len(x), self.nb)
+        self._chol = BlockCyclicCholesky(ops, len(x), self.nb, lookahead=self._lookahead)
         self._n = len(x)
         xd, ed = ops.to_device(x), ops.to_device(yerr)
         self._chol.build(xd, ed)
@@ -317,7 +383,7 @@ class DistributedDenseJob(object):
         x, yerr, y = make_inputs(n)
         kernel = float(np.var(y)) * K.ExpSquaredKernel(1.0)
         self.ops = HipTileOps(local_rank, kernel)
-        self.n, self.nb = n, (nb or 512)
+        self.n, self.nb = n, (nb or (1024 if n >= 24576 else 512))
         self.chol = BlockCyclicCholesky(self.ops, n, self.nb)
         self.x = self.ops.to_device(x[:, None])
         self.yerr = self.ops.to_device(np.sqrt(yerr ** 2 + 1.25e-12))

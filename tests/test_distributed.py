@@ -114,7 +114,7 @@ def _worker(rank, world, port, n, nb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nb", [(2, 700, 128), (4, 1100, 128), (2, 900, 256), (4, 513, 128)])
+@pytest.mark.parametrize("world,n,nb", [(2, 700, 128), (4, 1100, 128), (2, 900, 256), (4, 513, 128), (8, 1300, 128)])
 def test_block_cyclic_cholesky_gloo(world, n, nb):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -126,7 +126,7 @@ def test_block_cyclic_cholesky_gloo(world, n, nb):
         p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     logdet, quad, grid = q.get(timeout=10)
-    assert grid == {2: (1, 2), 4: (2, 2)}[world]
+    assert grid == {2: (1, 2), 4: (2, 2), 8: (2, 4)}[world]
     # dense reference
     sys.path.insert(0, ROOT)
     import george_amd.kernels as K
