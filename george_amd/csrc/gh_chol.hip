@@ -627,38 +627,47 @@ extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
 }
 
 // B (np x rp, row-major, zero padded) <- L^-1 B  (forward) and optionally L^-T (backward)
-static int trsm_multi(gh_chol* s, double* B, int64_t rp, bool forward, bool backward) {
+// Two-level blocking: 128-row steps (multiplication by the stored diagonal inverse + a small
+// update) inside super-blocks of SB tiles, then ONE K = 128*SB update of everything below (above)
+// the super-block -- the right-hand side is swept N/(128*SB) times instead of N/128 times.
+// `tri`: B is the identity being overwritten by L^-1 (forward only): block row j is non-zero in
+// columns [0, (j+1)*128) only, so every product is clipped to those columns.
+#define SB 4
+static int trsm_multi(gh_chol* s, double* B, int64_t rp, bool forward, bool backward, bool tri = false) {
   const int64_t np = s->np, nt = np / T;
   const double* L = s->A.d();
+  auto mm = [&](double* Cp, const double* Ap, int64_t lda, bool a_km, const double* Bp, int64_t M, int64_t N, int64_t K,
+                double alpha, double beta) -> int {
+    if (M <= 0 || N <= 0) return GH_OK;
+    GhGemm g{};
+    g.C = Cp; g.ldc = rp; g.A = Ap; g.lda = lda; g.B = Bp; g.ldb = rp;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.a_km = a_km; g.b_km = false;
+    return gh_launch_gemm(g, s->st);
+  };
   if (forward) {
-    for (int64_t j = 0; j < nt; ++j) {
-      double* Bj = B + j * T * rp;
-      GhGemm g{};
-      g.C = Bj; g.ldc = rp; g.A = s->dinv.d() + j * T * T; g.lda = T; g.B = Bj; g.ldb = rp;
-      g.M = T; g.N = rp; g.K = T; g.alpha = 1.0; g.beta = 0.0; g.a_km = true; g.b_km = false;
-      GH_CHECK(gh_launch_gemm(g, s->st));
-      const int64_t rem = np - (j + 1) * T;
-      if (rem > 0) {
-        GhGemm u{};
-        u.C = B + (j + 1) * T * rp; u.ldc = rp; u.A = L + (j + 1) * T * np + j * T; u.lda = np; u.B = Bj; u.ldb = rp;
-        u.M = rem; u.N = rp; u.K = T; u.alpha = -1.0; u.beta = 1.0; u.a_km = true; u.b_km = false;
-        GH_CHECK(gh_launch_gemm(u, s->st));
+    for (int64_t J = 0; J < nt; J += SB) {
+      const int64_t Je = std::min<int64_t>(J + SB, nt);
+      for (int64_t j = J; j < Je; ++j) {
+        double* Bj = B + j * T * rp;
+        const int64_t nc = tri ? (j + 1) * T : rp;
+        GH_CHECK(mm(Bj, s->dinv.d() + j * T * T, T, true, Bj, T, nc, T, 1.0, 0.0));               // B_j <- L_jj^-1 B_j
+        GH_CHECK(mm(B + (j + 1) * T * rp, L + (j + 1) * T * np + j * T, np, true, Bj,
+                    (Je - j - 1) * T, nc, T, -1.0, 1.0));                                           // rows of the super-block
       }
+      const int64_t nc = tri ? Je * T : rp;
+      GH_CHECK(mm(B + Je * T * rp, L + Je * T * np + J * T, np, true, B + J * T * rp,
+                  (nt - Je) * T, nc, (Je - J) * T, -1.0, 1.0));                                     // everything below
     }
   }
   if (backward) {
-    for (int64_t j = nt - 1; j >= 0; --j) {
-      double* Bj = B + j * T * rp;
-      GhGemm g{};
-      g.C = Bj; g.ldc = rp; g.A = s->dinv.d() + j * T * T; g.lda = T; g.B = Bj; g.ldb = rp;
-      g.M = T; g.N = rp; g.K = T; g.alpha = 1.0; g.beta = 0.0; g.a_km = false; g.b_km = false;
-      GH_CHECK(gh_launch_gemm(g, s->st));
-      if (j > 0) {
-        GhGemm u{};
-        u.C = B; u.ldc = rp; u.A = L + j * T * np; u.lda = np; u.B = Bj; u.ldb = rp;
-        u.M = j * T; u.N = rp; u.K = T; u.alpha = -1.0; u.beta = 1.0; u.a_km = false; u.b_km = false;
-        GH_CHECK(gh_launch_gemm(u, s->st));
+    for (int64_t Je = nt; Je > 0; Je -= SB) {
+      const int64_t J = std::max<int64_t>(Je - SB, 0);
+      for (int64_t j = Je - 1; j >= J; --j) {
+        double* Bj = B + j * T * rp;
+        GH_CHECK(mm(Bj, s->dinv.d() + j * T * T, T, false, Bj, T, rp, T, 1.0, 0.0));              // B_j <- L_jj^-T B_j
+        GH_CHECK(mm(B + J * T * rp, L + j * T * np + J * T, np, false, Bj, (j - J) * T, rp, T, -1.0, 1.0));
       }
+      GH_CHECK(mm(B, L + J * T * np, np, false, B + J * T * rp, J * T, rp, (Je - J) * T, -1.0, 1.0));   // everything above
     }
   }
   return GH_OK;
@@ -716,23 +725,8 @@ static int inverse_lower(gh_chol* s, double* W /* np*np */, double* Linv /* np*n
   GH_HIP(hipMemsetAsync(Linv, 0, (size_t)np * np * sizeof(double), s->st));
   hipLaunchKernelGGL(eye_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s->st, Linv, (long)np, (long)np);
   GH_HIP(hipGetLastError());
-  // forward substitution exploiting the lower-triangular right-hand side: at step j only
-  // columns [0, (j+1)*128) of block row j are non-zero
-  for (int64_t j = 0; j < nt; ++j) {
-    double* Bj = Linv + j * T * np;
-    const int64_t ncols = (j + 1) * T;
-    GhGemm g{};
-    g.C = Bj; g.ldc = np; g.A = s->dinv.d() + j * T * T; g.lda = T; g.B = Bj; g.ldb = np;
-    g.M = T; g.N = ncols; g.K = T; g.alpha = 1.0; g.beta = 0.0; g.a_km = true; g.b_km = false;
-    GH_CHECK(gh_launch_gemm(g, s->st));
-    const int64_t rem = np - (j + 1) * T;
-    if (rem > 0) {
-      GhGemm u{};
-      u.C = Linv + (j + 1) * T * np; u.ldc = np; u.A = L + (j + 1) * T * np + j * T; u.lda = np; u.B = Bj; u.ldb = np;
-      u.M = rem; u.N = ncols; u.K = T; u.alpha = -1.0; u.beta = 1.0; u.a_km = true; u.b_km = false;
-      GH_CHECK(gh_launch_gemm(u, s->st));
-    }
-  }
+  // forward substitution exploiting the lower-triangular right-hand side (tri = true)
+  GH_CHECK(trsm_multi(s, Linv, np, true, false, true));
   GhGemm q{};
   q.C = W; q.ldc = np; q.A = Linv; q.lda = np; q.B = Linv; q.ldb = np;
   q.M = np; q.N = np; q.K = np; q.alpha = 1.0; q.beta = 0.0; q.a_km = false; q.b_km = false;

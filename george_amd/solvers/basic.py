@@ -46,9 +46,21 @@ class BasicSolver(object):
     def log_determinant(self, v):
         self._log_det = v
 
-    # -- lifetime
+    # -- lifetime.  `GP.compute` instantiates a NEW solver on every call (gp.py:327) -- thousands of
+    # times inside an optimiser loop -- so native handles (and the N x N device buffers they own)
+    # are recycled through a small per-configuration pool instead of being hipMalloc'ed each time.
+    _POOL = {}
+    _POOL_MAX = 2
+
+    def _pool_key(self):
+        return tuple(sorted(self._opts.items()))
+
     def _ensure_handle(self):
         if self._handle is None:
+            free = BasicSolver._POOL.get(self._pool_key())
+            if free:
+                self._handle = free.pop()
+                return self._handle
             o = N.gh_chol_opts()
             o.device, o.nb = self._opts["device"], self._opts["nb"]
             o.profile, o.lookahead = int(self._opts["profile"]), int(self._opts["lookahead"])
@@ -61,7 +73,11 @@ class BasicSolver(object):
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
             try:
-                N.lib.gh_chol_destroy(h)
+                free = BasicSolver._POOL.setdefault(self._pool_key(), [])
+                if len(free) < BasicSolver._POOL_MAX:
+                    free.append(h)
+                else:
+                    N.lib.gh_chol_destroy(h)
             except Exception:
                 pass
             self._handle = None
