@@ -115,6 +115,13 @@ class HipTileOps(object):
     def wait(self, stream, event):
         stream.wait_event(event)
 
+    def pool(self):
+        """A few extra streams: independent tile launches (one GEMM per tile column, one build per
+        tile) are spread over them so that the tail of one launch overlaps the head of the next."""
+        if getattr(self, "_pool", None) is None:
+            self._pool = [self.torch.cuda.Stream(device=self.device) for _ in range(3)]
+        return self._pool
+
 
 class BlockCyclicCholesky(object):
 
@@ -182,13 +189,34 @@ class BlockCyclicCholesky(object):
         if self.live and group is not None:
             self.dist.broadcast(t, src=src, group=group)
 
+    def _fanout(self, thunks):
+        """Run independent tile launches; on the GPU they are spread over a small stream pool,
+        fenced against the current stream on both sides."""
+        ops = self.ops
+        if not getattr(ops, "has_streams", False) or len(thunks) < 2:
+            for f in thunks:
+                f()
+            return
+        cur = ops.main_stream()
+        pool = ops.pool()[:len(thunks)]
+        ev0 = ops.event(cur)
+        for st in pool:
+            ops.wait(st, ev0)
+        for idx, f in enumerate(thunks):
+            with ops.on(pool[idx % len(pool)]):
+                f()
+        for st in pool:
+            ops.wait(cur, ops.event(st))
+
     # -- build: every rank evaluates its own tiles on its own GPU ------------------------------------
     def build(self, x, yerr):
         nb = self.nb
+        todo = []
         for i in self.rows:
             for j in self.cols:
                 if j <= i:
-                    self.ops.kmat(x, self.n, yerr, i * nb, nb, j * nb, nb, self.tile(i, j))
+                    todo.append(lambda i=i, j=j: self.ops.kmat(x, self.n, yerr, i * nb, nb, j * nb, nb, self.tile(i, j)))
+        self._fanout(todo)
 
     # -- P(k): factor panel k and distribute it; returns (li0, wrow, {j: P_j}) -----------------------
     def _panel(self, k, buf):
@@ -244,12 +272,15 @@ class BlockCyclicCholesky(object):
             return
         li0, wrow, pj = panel
         nb, nloc_r = self.nb, len(self.rows)
+        todo = []
         for j in cols:
             ls = self._first_local_row_at_least(j)
             if ls >= nloc_r:
                 continue
             lj = self.lcol[j]
-            self.ops.gemm_nt(self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj[j])
+            todo.append(lambda ls=ls, lj=lj, j=j: self.ops.gemm_nt(
+                self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj[j]))
+        self._fanout(todo)
 
     # -- factorisation -----------------------------------------------------------------------------
     def factor(self):
