@@ -62,6 +62,7 @@ struct gh_kernel {
   int size = 0;                // full parameter count
   int device = -1;
   GhNode* d_nodes = nullptr;   // device copy (lazily uploaded per device)
+  GhFast fast;                 // affine single-leaf form a + b*F(r2), fast.ok != 0 when it exists
   ~gh_kernel() { if (d_nodes) (void)hipFree(d_nodes); }
   int upload();                // ensure d_nodes valid on the current device
 };

@@ -318,6 +318,44 @@ struct GhStack {
   GH_HD void drop() { s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; }
 };
 
+// ---------------------------------------------------------------- fast affine form
+// Most kernels people fit -- `c * Stationary(metric) [+ c']`, every BASELINE config -- reduce to
+//     k(x1, x2) = a + b * F(r2(x1, x2))
+// with ONE unblocked stationary leaf F over an isotropic / axis-aligned metric.  The host
+// recognises that shape when the program is created (gh_kernel_create) and the value kernels then
+// take this struct BY VALUE as a launch argument (SGPRs): no node reads from memory, no operand
+// stack, one uniform switch.  Same formulas and evaluation order as the interpreter below.
+struct GhFast {
+  int ok, ktype, mtype, naxes;
+  int axes[GH_MAX_AXES];
+  double m[GH_MAX_AXES];     // exp(-log_M) per axis (isotropic: m[0])
+  double a, b, q0;           // q0: alpha of RationalQuadratic
+};
+
+GH_HD double gh_fast_value(const GhFast& f, const double* x1, const double* x2) {
+  double r2 = 0.0;
+  if (f.mtype == 0) {
+    double s = 0.0;
+    for (int i = 0; i < f.naxes; ++i) { const double d = x1[f.axes[i]] - x2[f.axes[i]]; s += d * d; }
+    r2 = s * f.m[0];
+  } else {
+    for (int i = 0; i < f.naxes; ++i) { const double d = x1[f.axes[i]] - x2[f.axes[i]]; r2 += d * d * f.m[i]; }
+  }
+  double v;
+  switch (f.ktype) {
+    case GH_K_EXPSQUARED: v = exp(-0.5 * r2); break;
+    case GH_K_MATERN32: { const double r = sqrt(3.0 * r2); v = (1.0 + r) * exp(-r); break; }
+    case GH_K_MATERN52: { const double r = sqrt(5.0 * r2); v = (1 + r + 5.0 * r2 / 3.0) * exp(-r); break; }
+    case GH_K_EXP: v = exp(-sqrt(r2)); break;
+    default: v = pow(1.0 + 0.5 * r2 / f.q0, -f.q0); break;        // GH_K_RATQUAD
+  }
+  {
+#pragma clang fp contract(off)          // two roundings, like the interpreter's separate * and + nodes
+    const double t = f.b * v;
+    return f.a + t;
+  }
+}
+
 // Sum / Product: kernels.h:75-80, 111-116
 GH_HD double gh_eval_value(const GhNode* prog, int n_nodes, const double* x1, const double* x2) {
   GhStack st;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* s
 #define ACA_THREADS 512
 #define ACA_MAXR 512
 __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
-    const GhNode* prog, int n_prog, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
+    const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level) {
   __shared__ double shd[8];
   __shared__ int shi[8];
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       int bestn = -1;
       const double* xi = x + (long)(row0 + i) * nd;
       for (int n = tid; n < n_cols; n += nt) {
-        double v = gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
+        double v = fast.ok ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
+                           : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
         for (int k = 0; k < rank; ++k) v -= coef[k] * Tcm[(long)k * N + col0 + n];
         Tcm[(long)rank * N + col0 + n] = v;
         const double a = fabs(v);
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     double un2 = 0.0;
     const double* xj = x + (long)(col0 + j) * nd;
     for (int m = tid; m < n_rows; m += nt) {
-      double u = gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
+      double u = fast.ok ? gh_fast_value(fast, x + (long)(row0 + m) * nd, xj)
+                         : gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
       for (int k = 0; k < rank; ++k) u -= coef[k] * Tcm[(long)k * N + row0 + m];
       Tcm[(long)rank * N + row0 + m] = u;
       un2 += u * u;
@@ -202,14 +204,16 @@ __global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* n
 }
 
 // ======================================================================== leaves
-__global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, int nd, const double* x,
+__global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x,
                                         const double* yerr, const LeafDesc* leaves, double* Lf) {
   const LeafDesc lf = leaves[blockIdx.x];
   const long tot = (long)lf.size * lf.size;
   for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.y * blockDim.x) {
     const int r = (int)(e / lf.size), c = (int)(e % lf.size);
     const int lo = r < c ? r : c, hi = r < c ? c : r;        // ordered arguments: exactly symmetric
-    double v = gh_eval_value(prog, n_prog, x + (long)(lf.start + lo) * nd, x + (long)(lf.start + hi) * nd);
+    const double* pa = x + (long)(lf.start + lo) * nd;
+    const double* pb = x + (long)(lf.start + hi) * nd;
+    double v = fast.ok ? gh_fast_value(fast, pa, pb) : gh_eval_value(prog, n_prog, pa, pb);
     if (r == c) { const double e2 = yerr[lf.start + r]; v += e2 * e2; }              // hodlr.h:125, _hodlr.cpp:76
     Lf[lf.off + e] = v;
   }
@@ -570,7 +574,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     for (int q = 0; q < nn; ++q) { const HNode& nd = h->nodes[L->node_ids[q]]; ln[q] = {nd.start, nd.half, nd.size, 0}; }
     GH_CHECK(upload(L->d_nodes, ln, st));
     GH_CHECK(L->d_ranks.ensure(nn * sizeof(int)));
-    hipLaunchKernelGGL(hodlr_aca_kernel, dim3(nn), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), ndim,
+    hipLaunchKernelGGL(hodlr_aca_kernel, dim3(nn), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
                        h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p, (int*)L->d_ranks.p,
                        h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l);
     GH_HIP(hipGetLastError());
@@ -654,7 +658,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     const long tot = h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
     GH_CHECK(h->leaf_inv.ensure(tot * sizeof(double)));
     GH_CHECK(upload(h->d_leaves, h->leaves, st));
-    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), ndim,
+    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
                        h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d());
     GH_HIP(hipGetLastError());
     std::vector<long> offs(nl);

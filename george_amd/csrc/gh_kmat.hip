@@ -10,6 +10,7 @@
 // one fp64 exp() per element costs ~40 fp64 VALU ops, so the measured bound is
 // the fp64 VALU rate; see DESIGN.md.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <math.h>
@@ -68,6 +69,49 @@ static int n_own_params(int kt) {
 }
 static bool is_stationary(int kt) {
   return kt == GH_K_RATQUAD || kt == GH_K_EXP || kt == GH_K_MATERN52 || kt == GH_K_EXPSQUARED || kt == GH_K_MATERN32;
+}
+
+// Reduce the postfix program to  a + b * F(r2)  with one unblocked stationary leaf F over an
+// isotropic / axis-aligned metric, if it has that shape (constants fold: Constant = naxes * c).
+static void detect_fast_form(gh_kernel* k) {
+  memset(&k->fast, 0, sizeof(k->fast));
+  if (getenv("GEORGE_AMD_NO_FAST_KERNEL")) return;
+  struct Aff { bool ok; double a, b; int leaf; };
+  std::vector<Aff> st;
+  for (size_t i = 0; i < k->nodes.size(); ++i) {
+    const GhNode& nd = k->nodes[i];
+    if (nd.op == GH_OP_LEAF) {
+      if (nd.ktype == GH_K_CONSTANT) st.push_back({true, nd.naxes * nd.q[0], 0.0, -1});
+      else if (nd.mtype >= 0 && nd.mtype <= 1 && !nd.blocked) st.push_back({true, 0.0, 1.0, (int)i});
+      else st.push_back({false, 0.0, 0.0, -1});
+    } else {
+      const Aff r = st.back(); st.pop_back();
+      const Aff l = st.back(); st.pop_back();
+      Aff o{false, 0.0, 0.0, -1};
+      if (l.ok && r.ok) {
+        if (nd.op == GH_OP_SUM) {
+          if (l.leaf < 0 || r.leaf < 0 || l.leaf == r.leaf) o = {true, l.a + r.a, l.b + r.b, l.leaf >= 0 ? l.leaf : r.leaf};
+        } else if (l.leaf < 0) {
+          o = {true, l.a * r.a, l.a * r.b, r.leaf};
+        } else if (r.leaf < 0) {
+          o = {true, l.a * r.a, l.b * r.a, l.leaf};
+        }
+      }
+      st.push_back(o);
+    }
+  }
+  if (st.size() != 1 || !st[0].ok || st[0].leaf < 0) return;
+  // only the shapes whose rounding the interpreter reproduces exactly: a single scaling and/or
+  // a single offset (two leaves of the same kernel summed would fold b = b1 + b2 differently)
+  int nstat = 0;
+  for (const GhNode& nd : k->nodes) if (nd.op == GH_OP_LEAF && nd.mtype >= 0) ++nstat;
+  if (nstat != 1) return;
+  const GhNode& lf = k->nodes[st[0].leaf];
+  GhFast& f = k->fast;
+  f.ktype = lf.ktype; f.mtype = lf.mtype; f.naxes = lf.naxes;
+  for (int i = 0; i < lf.naxes; ++i) { f.axes[i] = lf.axes[i]; f.m[i] = lf.m[lf.mtype == 0 ? 0 : i]; }
+  f.a = st[0].a; f.b = st[0].b; f.q0 = lf.q[0];
+  f.ok = 1;
 }
 
 extern "C" int gh_kernel_create(const gh_knode* in, int n_nodes, gh_kernel** out) {
@@ -146,6 +190,7 @@ extern "C" int gh_kernel_create(const gh_knode* in, int n_nodes, gh_kernel** out
   k->ndim = st[0].ndim;
   k->size = st[0].psize;
   if (k->size > GH_MAX_GRAD) { delete k; gh_set_error("too many kernel parameters (max %d)", GH_MAX_GRAD); return GH_ERR_BAD_ARG; }
+  detect_fast_form(k);
   *out = k;
   return GH_OK;
 }
@@ -185,6 +230,7 @@ struct KmatArgs {
   long row0, col0;         // global offset of out[0][0] (for the diagonal / ordering tests)
   int sym, lower_only;
   int tiles_n;             // tiles per row of the (padded) output
+  GhFast fast;             // affine single-leaf form (fast.ok) -> no interpreter, no node loads
 };
 
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
@@ -226,7 +272,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
         const double* p2 = &xc[(lc + e) * nd];
         // symmetric build: evaluate k(x_min, x_max) as kernel_interface.cpp:68-74 does
         const bool swap = a.sym && (gr > gc);
-        double val = gh_eval_value(a.prog, a.n_nodes, swap ? p2 : p1, swap ? p1 : p2);
+        double val = a.fast.ok ? gh_fast_value(a.fast, swap ? p2 : p1, swap ? p1 : p2)
+                               : gh_eval_value(a.prog, a.n_nodes, swap ? p2 : p1, swap ? p1 : p2);
         if (a.sym && a.yerr && gr == gc) { const double e2 = a.yerr[r]; val += e2 * e2; }   // basic.py:65
         v[e] = val;
       } else {
@@ -252,6 +299,7 @@ int gh_launch_kmat(const gh_kernel* k, const double* x1, int64_t n1, const doubl
   a.x1 = x1; a.n1 = n1; a.x2 = x2; a.n2 = n2; a.yerr = yerr;
   a.out = out; a.ldo = ldo; a.rows_p = rows_p; a.cols_p = cols_p; a.row0 = row0; a.col0 = col0;
   a.sym = sym; a.lower_only = lower_only;
+  a.fast = k->fast;
   const long tm = (rows_p + KT - 1) / KT, tn = (cols_p + KT - 1) / KT;
   a.tiles_n = (int)tn;
   const long tm128 = (rows_p + 2 * KT - 1) / (2 * KT);

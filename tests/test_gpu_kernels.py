@@ -120,3 +120,35 @@ def test_general_metric_closed_form():
         r2 = np.einsum("ijk,kl,ijl->ij", d, np.linalg.inv(metric), d)
         assert np.allclose(M0, 0.1 * np.exp(-0.5 * r2))
         assert np.allclose(george_amd.GP(kernel).get_matrix(x), M0)
+
+
+FAST_FORMS = [
+    ("scaled_expsq", lambda: 10.0 * AK.ExpSquaredKernel(1.3)),
+    ("bare_matern32", lambda: AK.Matern32Kernel(0.7)),
+    ("offset_matern52", lambda: 2.0 * AK.Matern52Kernel(0.4) + 0.3),
+    ("ratquad_axis", lambda: 0.5 * AK.RationalQuadraticKernel(log_alpha=0.1, metric=[0.5, 2.0], ndim=2)),
+    ("exp_subspace", lambda: 1.7 * AK.ExpKernel(2.0, ndim=3, axes=[0, 2])),
+    ("nested", lambda: 3.0 * (2.0 * AK.ExpSquaredKernel(0.9) + 1.0)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", FAST_FORMS, ids=[f[0] for f in FAST_FORMS])
+def test_fast_affine_form_matches_interpreter(name, make, monkeypatch):
+    """Kernels of the shape a + b*F(r^2) take the interpreter-free evaluator (gh_eval.h GhFast);
+    it must agree with the postfix interpreter to rounding (<= 4 ulp of the largest entry)."""
+    from george_amd.kernel_interface import KernelInterface
+    kernel = make()
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-3, 3, size=(301, kernel.ndim))
+    x2 = rng.uniform(-3, 3, size=(77, kernel.ndim))
+    fast = KernelInterface(kernel)
+    monkeypatch.setenv("GEORGE_AMD_NO_FAST_KERNEL", "1")
+    slow = KernelInterface(kernel)
+    monkeypatch.delenv("GEORGE_AMD_NO_FAST_KERNEL")
+    for a, b in ((fast.value_symmetric(x), slow.value_symmetric(x)),
+                 (fast.value_general(x, x2), slow.value_general(x, x2))):
+        assert np.max(np.abs(a - b)) <= 1e-15 * np.max(np.abs(b))
+    ks = fast.value_symmetric(x)
+    assert np.array_equal(ks, ks.T)
+    assert np.allclose(ks, kernels_np.value_symmetric(kernel, x), rtol=1e-13, atol=1e-14)
