@@ -149,11 +149,12 @@ class GP(ModelSet):
     def compute(self, x, yerr=0.0, **kwargs):
         """Build and factorise K(x, x) + diag(yerr^2 + exp(white_noise))  (gp.py:303-337)."""
         self._x = np.ascontiguousarray(self.parse_samples(x), dtype=np.float64)
-        try:
-            self._yerr2 = float(yerr) ** 2 * np.ones(len(x))
-        except TypeError:
-            self._yerr2 = self._check_dimensions(yerr) ** 2
-        self._yerr2 = np.ascontiguousarray(self._yerr2, dtype=np.float64)
+        # scalar yerr broadcasts over the points, anything else must have one entry per point
+        if np.ndim(yerr) == 0 or (np.size(yerr) == 1 and len(self._x) != 1):
+            sig = np.full(len(self._x), float(np.reshape(yerr, ())))
+        else:
+            sig = self._check_dimensions(yerr)
+        self._yerr2 = np.ascontiguousarray(sig ** 2, dtype=np.float64)
 
         self.solver = self.solver_type(self.kernel, **(self.solver_kwargs))
         sigma = np.sqrt(self._yerr2 + np.exp(self._call_white_noise(self._x)))
