@@ -188,6 +188,8 @@ def run_timed(job, steps, warmup, barrier):
     ll = None
     for _ in range(warmup):
         ll = job.step()
+    if hasattr(job, "reset_profile"):
+        job.reset_profile()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -211,12 +213,15 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary N=16384 (configs[1]) measurement")
     ap.add_argument("--workload", default="dense", choices=["dense", "hodlr"],
                     help="dense = the headline metric; hodlr = secondary report for BASELINE config C4")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl == RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="debug: every rank uses device 0 (with --backend gloo: exercises the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if args.workload == "hodlr":
         if rank == 0:
@@ -225,7 +230,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.backend)
         from george_amd.distributed import DistributedDenseJob
         job = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs)
         barrier = dist.barrier
@@ -258,6 +263,17 @@ def main():
             "log_likelihood": ll,
             "frac_of_fp64_mfma_peak": value / (PEAK_FP64_MFMA_TFLOPS * world),
         }
+        if world > 1:
+            ms, fl, calls = job.chol.update_profile()          # rank 0's trailing updates, HIP events on its main stream
+            if ms > 0:
+                ach = fl / (ms * 1e-3) * 1e-12
+                out["roofline"] = {
+                    "kernel": "gemm_f64_mfma<k-major,k-major> (rank 0's trailing tile updates; one event pair per "
+                              "update sweep, its tile-column GEMMs fanned over 3 streams)",
+                    "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "launches": calls,
+                    "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": fl / max(calls, 1),
+                    "scope": "per GPU (rank 0)"}
         if world == 1:
             p = job.profile()
             if p.n_trailing > 0 and p.ms_trailing > 0:

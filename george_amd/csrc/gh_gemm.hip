@@ -221,6 +221,117 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant of the k-major x k-major case (the trailing SYRK, the biggest consumer):
+// slabs go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wavefront instruction), so
+// there are no staging VGPRs and no ds_write pass, and the loads of slab t+1 have the whole
+// 64-MFMA block of slab t (~4000 cycles) to land before the vmcnt(0) in front of the barrier.
+// The DMA writes LDS lane-linearly (base + lane*16), so the LDS image cannot be padded; it is
+// XOR-swizzled instead, through the SOURCE address: 16-byte piece p of row r holds k-pair
+// p ^ ((r >> 1) & 7).  A fragment read (16 rows x 2 k-pairs per 32 lanes) then touches 32
+// distinct 8-byte slots of the 256-byte bank row: conflict-free, like the padded layout.
+typedef __attribute__((address_space(3))) void gh_lds_void;
+typedef const __attribute__((address_space(1))) void gh_glb_void;
+
+template <int MM>
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
+  __shared__ __attribute__((aligned(1024))) double sA[2][BM * BK];
+  __shared__ __attribute__((aligned(1024))) double sB[2][BN * BK];
+  int tm, tn;
+  if (!tile_of(g, tm, tn)) return;
+  const long row0 = (long)tm * BM, col0 = (long)tn * BN;
+  long kbeg, kend;
+  k_range(g, row0, col0, kbeg, kend);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  const long nk = (kend - kbeg) / BK;
+  // DMA sources: instruction i of this wavefront moves rows wave*32 + 8i + (lane>>3), piece lane&7
+  const double* ga[4];
+  const double* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + (lane >> 3);
+    const int kp = (lane & 7) ^ ((r >> 1) & 7);
+    ga[i] = g.A + (row0 + r) * g.lda + kbeg + kp * 2;
+    gb[i] = g.B + (col0 + r) * g.ldb + kbeg + kp * 2;
+  }
+  // fragment offsets (doubles) inside a row, per 4-wide k step
+  const int sw = (fr >> 1) & 7;
+  int offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+  const int rowA = (wm * 64 + fr) * BK, rowB = (wn * 64 + fr) * BK;
+  const int dst = wave * 4 * 128;                  // this wavefront's first 1 KiB (= 128 doubles) piece
+
+#define GH_DMA_ISSUE(buf)                                                                              \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+      __builtin_amdgcn_global_load_lds((gh_glb_void*)ga[i], (gh_lds_void*)(sA[buf] + dst + i * 128), 16, 0, 0); \
+      ga[i] += BK;                                                                                     \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+      __builtin_amdgcn_global_load_lds((gh_glb_void*)gb[i], (gh_lds_void*)(sB[buf] + dst + i * 128), 16, 0, 0); \
+      gb[i] += BK;                                                                                     \
+    }                                                                                                  \
+  } while (0)
+
+  if (nk > 0) GH_DMA_ISSUE(0);
+  __syncthreads();                                  // (hipcc puts the vmcnt(0) of the DMA in front of the barrier)
+  for (long kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const double* pa = sA[cur] + rowA;
+    const double* pb = sB[cur] + rowB;
+    double a[4][4], b[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[kk][i] = pa[i * 16 * BK + offk[kk]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
+    }
+    // fragment reads first, THEN the DMA of the next slab into the other buffer (last read one
+    // barrier ago), then the MFMAs: a DMA issued ahead of the reads would make the compiler wait
+    // for it (vmcnt(0)) in front of every later ds_read
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (cur) GH_DMA_ISSUE(0); else GH_DMA_ISSUE(1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);              // (else 63 of the 64 MFMAs sink below the barrier)
+    __syncthreads();
+  }
+#undef GH_DMA_ISSUE
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = row0 + wm * 64 + i * 16 + fk + 4 * r;
+      double* crow = g.C + row * g.ldc + col0 + wn * 64 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = alpha * acc[i][j][r];
+        crow[j * 16] = (beta == 0.0) ? v : beta * crow[j * 16] + v;
+      }
+    }
+  }
+}
+
 // Plain-VALU kernel with identical semantics: validation arm for the MFMA lane maps
 // (GEORGE_AMD_NO_MFMA=1) -- each thread owns an 8x8 micro-tile of the 128x128 C tile.
 template <bool A_KM, bool B_KM>
@@ -267,20 +378,23 @@ __global__ __launch_bounds__(256) void gemm_f64_valu(GemmDev g) {
     }
 }
 
-// 0 = plain VALU (validation arm), 1 = v_mfma_f64_16x16x4 (default: 52-58 TFLOP/s on the SYRK
-// shape), 2 = v_mfma_f64_4x4x4_4b (correct, but 36 TFLOP/s in this kernel: kept as an A/B arm)
+// 0 = plain VALU (validation arm), 1 = v_mfma_f64_16x16x4 (default; the k-major x k-major case
+// takes the LDS-DMA kernel), 2 = v_mfma_f64_4x4x4_4b (correct, but 36 TFLOP/s in this kernel:
+// kept as an A/B arm), 3 = v_mfma_f64_16x16x4 with register staging everywhere (A/B arm)
 static int g_mfma = -1;
-static int mfma_mode() {
+static int mfma_raw_mode() {
   if (g_mfma < 0) {
     const char* e = getenv("GEORGE_AMD_MFMA_MODE");
-    g_mfma = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 1;
+    g_mfma = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : 1;
   }
   return g_mfma;
 }
+static int mfma_mode() { return mfma_raw_mode() == 3 ? 1 : mfma_raw_mode(); }
+static bool dma_mode() { return mfma_raw_mode() == 1; }
 bool gh_use_mfma() { return mfma_mode() != 0; }
 extern "C" int gh_debug_set_mfma(int mode) {
-  const int prev = mfma_mode();
-  g_mfma = (mode < 0 || mode > 2) ? 1 : mode;
+  const int prev = mfma_raw_mode();
+  g_mfma = (mode < 0 || mode > 3) ? 1 : mode;
   return prev;
 }
 
@@ -303,7 +417,10 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     else if (mode == 1) hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM, 1>), grid, block, 0, st, g);  \
     else                hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g);     \
   } while (0)
-  if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
+  if (h.a_km && h.b_km && mode == 1 && dma_mode() && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
+      ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0)
+    hipLaunchKernelGGL((gemm_f64_mfma_dma<1>), grid, block, 0, st, g);
+  else if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
   else if (h.a_km && !h.b_km) GH_GEMM_LAUNCH(true, false);
   else if (!h.a_km && !h.b_km) GH_GEMM_LAUNCH(false, false);
   else GH_GEMM_LAUNCH(false, true);

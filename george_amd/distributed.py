@@ -107,8 +107,8 @@ class HipTileOps(object):
     def on(self, stream):
         return self.torch.cuda.stream(stream)
 
-    def event(self, stream):
-        ev = self.torch.cuda.Event()
+    def event(self, stream, timing=False):
+        ev = self.torch.cuda.Event(enable_timing=timing)
         ev.record(stream)
         return ev
 
@@ -159,6 +159,8 @@ class BlockCyclicCholesky(object):
         self.logdet_dev = ops.zeros(1)
         self.log_determinant = None
         self.computed = False
+        self.profile = False          # record HIP events around every trailing update (bench.py roofline)
+        self._upd = []                # (event before, event after, flops launched) per _update call
         # sub-communicators: every rank creates every group, in the same order
         self.row_groups, self.col_groups = [None] * self.Pr, [None] * self.Pc
         if self.live and self.world > 1:
@@ -280,7 +282,23 @@ class BlockCyclicCholesky(object):
             lj = self.lcol[j]
             todo.append(lambda ls=ls, lj=lj, j=j: self.ops.gemm_nt(
                 self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj[j]))
+        timed = self.profile and todo and getattr(self.ops, "has_streams", False)
+        if timed:
+            e0 = self.ops.event(self.ops.main_stream(), timing=True)
         self._fanout(todo)
+        if timed:
+            flops = sum(2.0 * (nloc_r - self._first_local_row_at_least(j)) * nb * nb * nb
+                        for j in cols if self._first_local_row_at_least(j) < nloc_r)
+            self._upd.append((e0, self.ops.event(self.ops.main_stream(), timing=True), flops))
+
+    def update_profile(self):
+        """(milliseconds, flops, calls) of the trailing updates recorded since the last call."""
+        self.ops.sync()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self._upd)
+        fl = sum(f for _, _, f in self._upd)
+        n = len(self._upd)
+        self._upd = []
+        return ms, fl, n
 
     # -- factorisation -----------------------------------------------------------------------------
     def factor(self):
@@ -416,6 +434,7 @@ class DistributedDenseJob(object):
         self.ops = HipTileOps(local_rank, kernel)
         self.n, self.nb = n, (nb or (1024 if n >= 24576 else 512))
         self.chol = BlockCyclicCholesky(self.ops, n, self.nb)
+        self.chol.profile = True
         self.x = self.ops.to_device(x[:, None])
         self.yerr = self.ops.to_device(np.sqrt(yerr ** 2 + 1.25e-12))
         ypad = np.zeros(self.chol.nt * self.chol.nb)
@@ -428,6 +447,9 @@ class DistributedDenseJob(object):
         self.chol.factor()
         q = self.chol.dot_solve(self.y)
         return -0.5 * (self.n * np.log(2 * np.pi) + self.chol.log_determinant) - 0.5 * q
+
+    def reset_profile(self):
+        self.chol.update_profile()
 
     def close(self):
         pass
