@@ -37,6 +37,7 @@ struct GemmDev {
   int tiles_m, tiles_n;
   int lower, klo_max, khi_col, khi_row;
   long nblk;
+  int preload;      // beta == +-alpha != 0: accumulators start from (beta/alpha) * C, write-back is store-only
 };
 
 // XCD-aware remap (bijective for any nblk): workgroup b runs on XCD b % 8; give each XCD
@@ -105,6 +106,63 @@ __device__ __forceinline__ void k_range(const GemmDev& g, long row0, long col0, 
   if (g.khi_row && row0 + BM < kend) kend = row0 + BM;
 }
 
+// C tile write-back of one wavefront's 64x64 sub-tile at (r0, c0).  f64 MFMA C/D map:
+// col = lane & 15, row = (lane >> 4) + 4 * reg.  The beta test is hoisted and the 16 C loads of a
+// 16-row group are issued together: written as `beta == 0 ? v : beta * c + v` per element the
+// compiler emits 64 serial load -> vmcnt(0) -> store round trips per lane.
+//
+// When beta == +-alpha (every accumulate call of the solver is C -= A B^T) the read moves to the
+// FRONT instead: the accumulators start from (beta/alpha) * C -- exact, the ratio is +-1 -- while
+// the first operand slab is still in flight, and the write-back is alpha * acc, store-only
+// (measured on the SYRK shape at K = 1024: the trailing read costs 8-10 %).
+__device__ __forceinline__ void gemm_init_acc(const GemmDev& g, v4d (&acc)[4][4], long r0, long c0, int fr, int fk) {
+  if (g.preload) {
+    const double rho = (g.beta == g.alpha) ? 1.0 : -1.0;
+    const double* cbase = g.C + (r0 + fk) * g.ldc + c0 + fr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = rho * cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+}
+
+__device__ __forceinline__ void gemm_epilogue(const GemmDev& g, const v4d (&acc)[4][4], long r0, long c0,
+                                              int fr, int fk) {
+  const double alpha = g.alpha, beta = g.preload ? 0.0 : g.beta;
+  double* cbase = g.C + (r0 + fk) * g.ldc + c0 + fr;
+  if (beta == 0.0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* crow = cbase + (long)(i * 16 + 4 * r) * g.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][r];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double c[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[r][j] = cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16] = fma(beta, c[r][j], alpha * acc[i][j][r]);
+    }
+  }
+}
+
 // MM selects the matrix instruction (A/B measured on MI355X, scripts/gemm_ab.py):
 //   MM == 1: v_mfma_f64_16x16x4_f64   -- 52 TFLOP/s (K = 512) to 58 TFLOP/s (K = 1024) on the
 //            trailing-update shape in this kernel; the default.
@@ -131,10 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
   const int fr = lane & 15, fk = lane >> 4;
 
   v4d acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  gemm_init_acc(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
 
   const long nk = (kend - kbeg) / BK;
   double2 ra[4], rb[4];
@@ -204,21 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
     stage_store<B_KM>(sB[cur ^ 1], tid, rb);
     __syncthreads();
   }
-  // epilogue.  f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
-  const double alpha = g.alpha, beta = g.beta;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long row = row0 + wm * 64 + i * 16 + fk + 4 * r;
-      double* crow = g.C + row * g.ldc + col0 + wn * 64 + fr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double v = alpha * acc[i][j][r];
-        crow[j * 16] = (beta == 0.0) ? v : beta * crow[j * 16] + v;
-      }
-    }
-  }
+  gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
 typedef __attribute__((address_space(3))) void gh_lds_void;
 typedef const __attribute__((address_space(1))) void gh_glb_void;
 
-template <int MM>
+template <int DPOS>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   __shared__ __attribute__((aligned(1024))) double sA[2][BM * BK];
   __shared__ __attribute__((aligned(1024))) double sB[2][BN * BK];
@@ -247,11 +288,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   const int fr = lane & 15, fk = lane >> 4;
 
   v4d acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
   const long nk = (kend - kbeg) / BK;
   // DMA sources: instruction i of this wavefront moves rows wave*32 + 8i + (lane>>3), piece lane&7
   const double* ga[4];
@@ -284,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   } while (0)
 
   if (nk > 0) GH_DMA_ISSUE(0);
+  gemm_init_acc(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);      // C loads ride on the first slab's latency
   __syncthreads();                                  // (hipcc puts the vmcnt(0) of the DMA in front of the barrier)
   for (long kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
@@ -298,15 +335,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
       for (int j = 0; j < 4; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
     }
     // fragment reads first, THEN the DMA of the next slab into the other buffer (last read one
-    // barrier ago), then the MFMAs: a DMA issued ahead of the reads would make the compiler wait
-    // for it (vmcnt(0)) in front of every later ds_read
+    // barrier ago): a DMA issued ahead of the reads would make the compiler wait for it
+    // (vmcnt(0)) in front of every later ds_read.  The first DPOS k-groups of MFMAs go ahead of
+    // the DMA issue: hipcc drains lgkmcnt to 0 after a global_load_lds, so MFMAs placed before
+    // it can start on counted waits as soon as their own fragments have landed.
+#pragma unroll
+    for (int kk = 0; kk < DPOS; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       if (cur) GH_DMA_ISSUE(0); else GH_DMA_ISSUE(1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = DPOS; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -316,20 +362,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
     __syncthreads();
   }
 #undef GH_DMA_ISSUE
-  const double alpha = g.alpha, beta = g.beta;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long row = row0 + wm * 64 + i * 16 + fk + 4 * r;
-      double* crow = g.C + row * g.ldc + col0 + wn * 64 + fr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double v = alpha * acc[i][j][r];
-        crow[j * 16] = (beta == 0.0) ? v : beta * crow[j * 16] + v;
-      }
-    }
-  }
+  gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
 }
 
 // Plain-VALU kernel with identical semantics: validation arm for the MFMA lane maps
@@ -408,6 +441,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   g.tiles_m = (int)(h.M / BM); g.tiles_n = (int)(h.N / BN);
   g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
   g.nblk = h.lower ? (long)g.tiles_m * (g.tiles_m + 1) / 2 : (long)g.tiles_m * g.tiles_n;
+  g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha) && !getenv("GEORGE_AMD_GEMM_NO_PRELOAD")) ? 1 : 0;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);
   const int mode = mfma_mode();
@@ -419,7 +453,13 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   } while (0)
   if (h.a_km && h.b_km && mode == 1 && dma_mode() && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
       ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0)
-    hipLaunchKernelGGL((gemm_f64_mfma_dma<1>), grid, block, 0, st, g);
+  {
+    static int dpos = -1;
+    if (dpos < 0) { const char* e = getenv("GEORGE_AMD_DMA_POS"); dpos = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+    if (dpos == 0)      hipLaunchKernelGGL((gemm_f64_mfma_dma<0>), grid, block, 0, st, g);
+    else if (dpos == 1) hipLaunchKernelGGL((gemm_f64_mfma_dma<1>), grid, block, 0, st, g);
+    else                hipLaunchKernelGGL((gemm_f64_mfma_dma<2>), grid, block, 0, st, g);
+  }
   else if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
   else if (h.a_km && !h.b_km) GH_GEMM_LAUNCH(true, false);
   else if (!h.a_km && !h.b_km) GH_GEMM_LAUNCH(false, false);
