@@ -458,10 +458,10 @@ static int factor_lookahead(gh_chol* s) {
     const int64_t nb1 = std::min<int64_t>(NB, np - k1);
     const int64_t k2 = k1 + nb1;
     const double* P1 = blk(A, ld, k1, k0);                        // panel k rows [k1, np)
-    // (a) bring block column k+1 up to date: its diagonal block (lower) and the rows below
-    GH_CHECK(gemm_nt(sm, blk(A, ld, k1, k1), ld, P1, ld, P1, ld, nb1, nb1, nb, -1.0, 1.0, true));
-    if (np - k2 > 0)
-      GH_CHECK(gemm_nt(sm, blk(A, ld, k2, k1), ld, blk(A, ld, k2, k0), ld, P1, ld, np - k2, nb1, nb, -1.0, 1.0, false));
+    // (a) bring block column k+1 up to date, diagonal block and the rows below in ONE launch (the
+    //     strictly-upper tiles of the diagonal block are computed too: nobody reads them, and a
+    //     separate 10-36 tile `lower` launch costs more than those few tiles)
+    GH_CHECK(gemm_nt(sm, blk(A, ld, k1, k1), ld, P1, ld, P1, ld, np - k1, nb1, nb, -1.0, 1.0, false));
     const int nxt = 3 - flip;                                     // alternate ev_sync[1] / ev_sync[2]
     GH_HIP(hipEventRecord(s->ev_sync[0], sm));
     GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));

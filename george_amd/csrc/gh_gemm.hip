@@ -38,6 +38,7 @@ struct GemmDev {
   int lower, klo_max, khi_col, khi_row;
   long nblk;
   int preload;      // beta == +-alpha != 0: accumulators start from (beta/alpha) * C, write-back is store-only
+  int prio;         // launch cannot fill the chip (panel-chain GEMMs): run at top wavefront priority
 };
 
 // XCD-aware remap (bijective for any nblk): workgroup b runs on XCD b % 8; give each XCD
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
   __shared__ double sB[2][BN * LS];
   int tm, tn;
   if (!tile_of(g, tm, tn)) return;       // (uniform per workgroup, before any barrier)
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   const long row0 = (long)tm * BM, col0 = (long)tn * BN;
   long kbeg, kend;
   k_range(g, row0, col0, kbeg, kend);
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   __shared__ __attribute__((aligned(1024))) double sB[2][BN * BK];
   int tm, tn;
   if (!tile_of(g, tm, tn)) return;
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   const long row0 = (long)tm * BM, col0 = (long)tn * BN;
   long kbeg, kend;
   k_range(g, row0, col0, kbeg, kend);
@@ -441,6 +444,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   g.tiles_m = (int)(h.M / BM); g.tiles_n = (int)(h.N / BN);
   g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
   g.nblk = h.lower ? (long)g.tiles_m * (g.tiles_m + 1) / 2 : (long)g.tiles_m * g.tiles_n;
+  g.prio = g.nblk <= 512 ? 1 : 0;
   g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha) && !getenv("GEORGE_AMD_GEMM_NO_PRELOAD")) ? 1 : 0;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   __shared__ double inv16[8 * 16 * IP];
   __shared__ int fail_at;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // latency-bound chain of dependent steps that, under look-ahead, shares its CU with wavefronts
+  // of the trailing SYRK issuing 64 MFMAs back to back: take the instruction arbiter's top priority
+  __builtin_amdgcn_s_setprio(3);
   if (*info != 0) return;                       // uniform: an earlier block already failed
   if (tid == 0) fail_at = -1;
   for (int idx = tid; idx < T * T; idx += 256) {
