@@ -254,6 +254,12 @@ struct gh_chol {
   gh_chol_opts opts;
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;             // high-priority panel stream (look-ahead)
+  hipStream_t st3 = nullptr;             // second panel stream: rows-below TRSM beside the potf2 chain
+  hipEvent_t ev_diag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_aux = nullptr;
+  hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
+  int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
+  hipEvent_t ev_xfer = nullptr;
   hipEvent_t ev_sync[3] = {nullptr, nullptr, nullptr};
   int64_t n = 0, np = 0;
   int ndim = 0;
@@ -279,6 +285,11 @@ struct gh_chol {
     for (auto& p : ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (d_info) (void)hipFree(d_info);
     for (auto& e : ev_sync) if (e) (void)hipEventDestroy(e);
+    if (ev_xfer) (void)hipEventDestroy(ev_xfer);
+    if (ev_aux) (void)hipEventDestroy(ev_aux);
+    for (auto& e : ev_diag) if (e) (void)hipEventDestroy(e);
+    if (st3) (void)hipStreamDestroy(st3);
+    if (st_mask) (void)hipStreamDestroy(st_mask);
     if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -300,33 +311,19 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   if (s->opts.nb % T) { delete s; gh_set_error("nb must be a multiple of 128"); return GH_ERR_BAD_ARG; }
   int rc = set_device(s);
   if (rc != GH_OK) { delete s; return rc; }
-  // Look-ahead needs the panel stream's small latency-bound kernels (one 149-KiB-LDS workgroup
-  // for potf2) to find a free CU at once; behind a saturating SYRK grid they would wait for a
-  // whole CU to drain.  So the MAIN stream is created with a CU mask that leaves a few CUs out
-  // (GEORGE_AMD_RESERVE_CUS, default 8 of 256), and the panel stream may run anywhere.
-  // Measured (MI355X, ROCm 7.2): the masked stream costs ~1 s to create and slows the SYRK by 12 %
-  // even for 8 reserved CUs, a net loss at N = 65536 (1775 -> 1925 ms) and a gain only when the
-  // panel dominates (N = 16384: 70 -> 63 ms); so it is OFF unless the variable asks for it.
-  int reserve = 0;
-  if (const char* e = getenv("GEORGE_AMD_RESERVE_CUS")) reserve = atoi(e);
-  bool made = false;
-  if (reserve > 0 && reserve < 128) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, s->opts.device) == hipSuccess && prop.multiProcessorCount > reserve) {
-      const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-      std::vector<uint32_t> mask(words, 0u);
-      for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-      if (hipExtStreamCreateWithCUMask(&s->st, words, mask.data()) == hipSuccess) made = true;
-      else { s->st = nullptr; (void)hipGetLastError(); }
-    }
-  }
-  if (!made && hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
   if (s->opts.lookahead) {
     int lo = 0, hi = 0;                    // numerically lowest value = highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi) != hipSuccess) { s->st2 = nullptr; (void)hipGetLastError(); }
     for (auto& e : s->ev_sync)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete s; gh_set_error("hipEventCreate failed"); return GH_ERR_HIP; }
+    if (s->st2) {
+      bool ok = hipStreamCreateWithPriority(&s->st3, hipStreamNonBlocking, hi) == hipSuccess &&
+                hipEventCreateWithFlags(&s->ev_aux, hipEventDisableTiming) == hipSuccess;
+      for (auto& e : s->ev_diag) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); if (s->st3) (void)hipStreamDestroy(s->st3); s->st3 = nullptr; }
+    }
   }
   if (hipMalloc((void**)&s->d_info, sizeof(long long)) != hipSuccess) { delete s; gh_set_error("hipMalloc failed"); return GH_ERR_HIP; }
   *out = s;
@@ -418,9 +415,38 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   double* A = s->A.d();
   const int64_t np = s->np, ld = np;
   double* dinv = s->dinv.d() + (k0 / T) * T * T;
-  GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
   const int64_t m = np - (k0 + nb);
-  if (m > 0) GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
+  static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
+  if (!s->st3 || st != s->st2 || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
+    GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
+    if (m > 0) GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
+    return GH_OK;
+  }
+  // Look-ahead panels: the potf2 chain of the diagonal block stays on `st`; the TRSM of the rows
+  // below runs on a second panel stream, column block j as soon as L_jj^-1 exists, so that only
+  // the last block's TRSM is left when the chain ends (instead of all nb/128 of them).
+  hipStream_t sa = s->st3;
+  double* Ak = blk(A, ld, k0, k0);
+  double* B = blk(A, ld, k0 + nb, k0);
+  GH_HIP(hipEventRecord(s->ev_aux, st));
+  GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
+  for (int64_t j0 = 0; j0 < nb; j0 += T) {
+    double* dj = dinv + (j0 / T) * T * T;
+    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
+    GH_HIP(hipEventRecord(s->ev_diag[j0 / T], st));
+    GH_HIP(hipStreamWaitEvent(sa, s->ev_diag[j0 / T], 0));
+    double* Xj = B + j0;
+    if (j0 > 0) GH_CHECK(gemm_nt(sa, Xj, ld, B, ld, Ak + j0 * ld, ld, m, T, j0, -1.0, 1.0, false));
+    GH_CHECK(gemm_nt(sa, Xj, ld, Xj, ld, dj, T, m, T, T, 1.0, 0.0, false));
+    const int64_t rem = nb - (j0 + T);
+    if (rem > 0) {
+      double* P = blk(Ak, ld, j0 + T, j0);
+      GH_CHECK(gemm_nt(st, P, ld, P, ld, dj, T, rem, T, T, 1.0, 0.0, false));
+      GH_CHECK(gemm_nt(st, blk(Ak, ld, j0 + T, j0 + T), ld, P, ld, P, ld, rem, rem, T, -1.0, 1.0, true));
+    }
+  }
+  GH_HIP(hipEventRecord(s->ev_aux, sa));
+  GH_HIP(hipStreamWaitEvent(st, s->ev_aux, 0));
   return GH_OK;
 }
 
@@ -432,8 +458,44 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
 // stream, then updates the rest of the trailing matrix while the panel stream factors panel k+1.
 // The two touch disjoint regions: panel k+1 = columns [k1, k1+nb1), the remainder = rows and
 // columns >= k1+nb1; both only READ panel k.
+// Small matrices are bound by the panel chain (128 potf2 workgroups in a row at N = 16384), and
+// that chain runs 4x slower when its workgroups share a CU with wavefronts of the trailing SYRK
+// (in-kernel timers: potf2 114 us alone, 420-480 us beside SYRK -- LDS-queue contention, wavefront
+// priority does not help).  For those sizes the trailing updates go to a stream whose CU mask
+// leaves 32 CUs free for the panel stream.  The count is not arbitrary: the mask bits are dealt
+// round-robin over the 8 XCDs and then over the 4 shader engines of each, and the workgroup
+// dispatcher feeds shader engines evenly -- leaving out 8 CUs (one engine of every XCD one CU
+// short) costs the SYRK 12 %, the same as leaving out 32 (every engine one short), so 32 it is:
+// 12.5 % of the chip, about the panel's share of the flops at N = 16384 (9 %).  Larger matrices
+// hide the chain behind the SYRK anyway and keep all 256 CUs.  The masked stream takes ~1 s to
+// create (ROCm 7.2), once per handle.  GEORGE_AMD_RESERVE_CUS=0 disables, =<n> forces n CUs.
+static hipStream_t trailing_stream(gh_chol* s) {
+  int want = s->np < 24576 ? 32 : 0;
+  if (const char* e = getenv("GEORGE_AMD_RESERVE_CUS")) want = atoi(e);
+  if (want <= 0 || want >= 128) return s->st;
+  if (s->mask_reserved != want) {
+    if (s->st_mask) { (void)hipStreamSynchronize(s->st_mask); (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr; }
+    s->mask_reserved = want;                                       // (a failed creation is not retried)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, s->opts.device) == hipSuccess && prop.multiProcessorCount > 2 * want) {
+      const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+      std::vector<uint32_t> mask(words, 0u);
+      for (int c = want; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+      if (hipExtStreamCreateWithCUMask(&s->st_mask, words, mask.data()) != hipSuccess) { s->st_mask = nullptr; (void)hipGetLastError(); }
+    }
+    if (s->st_mask && !s->ev_xfer && hipEventCreateWithFlags(&s->ev_xfer, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError(); (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr;
+    }
+  }
+  return s->st_mask ? s->st_mask : s->st;
+}
+
 static int factor_lookahead(gh_chol* s) {
-  hipStream_t sm = s->st, sp = s->st2;
+  hipStream_t sm = trailing_stream(s), sp = s->st2;
+  if (sm != s->st) {                                               // everything queued so far (the build) first
+    GH_HIP(hipEventRecord(s->ev_xfer, s->st));
+    GH_HIP(hipStreamWaitEvent(sm, s->ev_xfer, 0));
+  }
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);
   const bool prof = s->opts.profile != 0;
@@ -485,6 +547,10 @@ static int factor_lookahead(gh_chol* s) {
       s->prof.n_trailing += 1;
     }
     flip = nxt;
+  }
+  if (sm != s->st) {                                               // hand back to the handle's stream
+    GH_HIP(hipEventRecord(s->ev_xfer, sm));
+    GH_HIP(hipStreamWaitEvent(s->st, s->ev_xfer, 0));
   }
   return GH_OK;
 }
