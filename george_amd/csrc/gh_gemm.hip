@@ -265,18 +265,70 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant of the k-major x k-major case (the trailing SYRK, the biggest consumer):
-// slabs go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wavefront instruction), so
-// there are no staging VGPRs and no ds_write pass, and the loads of slab t+1 have the whole
-// 64-MFMA block of slab t (~4000 cycles) to land before the vmcnt(0) in front of the barrier.
-// The DMA writes LDS lane-linearly (base + lane*16), so the LDS image cannot be padded; it is
-// XOR-swizzled instead, through the SOURCE address: 16-byte piece p of row r holds k-pair
-// p ^ ((r >> 1) & 7).  A fragment read (16 rows x 2 k-pairs per 32 lanes) then touches 32
-// distinct 8-byte slots of the 256-byte bank row: conflict-free, like the padded layout.
+// LDS-DMA kernel (the default for every layout): slabs go global -> LDS directly
+// (global_load_lds_dwordx4, 1 KiB per wavefront instruction), so there are no staging VGPRs and
+// no ds_write pass, and the loads of slab t+1 have the 64-MFMA block of slab t (~4000 cycles) to
+// land before the vmcnt(0) in front of the barrier.  The DMA writes LDS lane-linearly
+// (base + lane*16), so the LDS image cannot be padded; it is XOR-swizzled instead, through the
+// SOURCE address, so that a fragment read (16 rows x 2 k per 32 lanes) touches 32 distinct 8-byte
+// slots of the 256-byte bank row, like the padded layout of the register-staged kernel:
+//   k-major operand (row r, k contiguous): LDS image [row][16 k], one instruction = 8 rows;
+//       16-byte piece p of row r holds k-pair p ^ ((r >> 1) & 7);
+//   m-major operand (k strided, rows contiguous): LDS image [k][128 rows], one instruction = one
+//       k (1 KiB of rows); piece p of k-row k holds row-pair p ^ ((k & 1) << 3), i.e. odd k swap
+//       the two 128-byte halves of every 256 bytes -- for the reader that is "16-row group i^1".
 typedef __attribute__((address_space(3))) void gh_lds_void;
 typedef const __attribute__((address_space(1))) void gh_glb_void;
 
-template <int DPOS>
+template <bool KM>
+struct DmaOperand {
+  const double* src[4];     // this lane's source of the wavefront's 4 DMA instructions per slab
+  long step;                // doubles to advance per slab
+  int f0, f1;               // fragment read offsets (doubles), see frag()
+  int offk[4];
+
+  __device__ __forceinline__ void init(const double* base, long ld, long r0, long kbeg, int wave, int lane, int wsub) {
+    const int fr = lane & 15, fk = lane >> 4;
+    if (KM) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        src[i] = base + (r0 + r) * ld + kbeg + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+      }
+      step = BK;
+      const int sw = (fr >> 1) & 7;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+      f0 = (wsub * 64 + fr) * BK;
+      f1 = 0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = wave * 4 + i;
+        src[i] = base + (kbeg + k) * ld + r0 + ((lane ^ ((k & 1) << 3)) * 2);
+      }
+      step = BK * ld;
+      const int ix = fk & 1;
+      f0 = fk * 128 + wsub * 64 + fr + 16 * ix;      // even 16-row groups
+      f1 = fk * 128 + wsub * 64 + fr - 16 * ix;      // odd 16-row groups
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) offk[kk] = kk * 512;
+    }
+  }
+  // fragment (k-step kk, 16-row group i) of the slab image at `s`
+  __device__ __forceinline__ double frag(const double* s, int kk, int i) const {
+    if (KM) return s[f0 + i * 16 * BK + offk[kk]];
+    return s[((i & 1) ? f1 : f0) + i * 16 + offk[kk]];
+  }
+};
+
+#define GH_DMA_ISSUE(op, sbuf)                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
+    __builtin_amdgcn_global_load_lds((gh_glb_void*)op.src[i_], (gh_lds_void*)((sbuf) + dst + i_ * 128), 16, 0, 0); \
+    op.src[i_] += op.step;                                                                            \
+  }
+
+template <bool A_KM, bool B_KM>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   __shared__ __attribute__((aligned(1024))) double sA[2][BM * BK];
   __shared__ __attribute__((aligned(1024))) double sB[2][BN * BK];
@@ -292,70 +344,43 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
 
   v4d acc[4][4];
   const long nk = (kend - kbeg) / BK;
-  // DMA sources: instruction i of this wavefront moves rows wave*32 + 8i + (lane>>3), piece lane&7
-  const double* ga[4];
-  const double* gb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + (lane >> 3);
-    const int kp = (lane & 7) ^ ((r >> 1) & 7);
-    ga[i] = g.A + (row0 + r) * g.lda + kbeg + kp * 2;
-    gb[i] = g.B + (col0 + r) * g.ldb + kbeg + kp * 2;
-  }
-  // fragment offsets (doubles) inside a row, per 4-wide k step
-  const int sw = (fr >> 1) & 7;
-  int offk[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
-  const int rowA = (wm * 64 + fr) * BK, rowB = (wn * 64 + fr) * BK;
+  DmaOperand<A_KM> oa;
+  DmaOperand<B_KM> ob;
+  oa.init(g.A, g.lda, row0, kbeg, wave, lane, wm);
+  ob.init(g.B, g.ldb, col0, kbeg, wave, lane, wn);
   const int dst = wave * 4 * 128;                  // this wavefront's first 1 KiB (= 128 doubles) piece
 
-#define GH_DMA_ISSUE(buf)                                                                              \
-  do {                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-      __builtin_amdgcn_global_load_lds((gh_glb_void*)ga[i], (gh_lds_void*)(sA[buf] + dst + i * 128), 16, 0, 0); \
-      ga[i] += BK;                                                                                     \
-    }                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-      __builtin_amdgcn_global_load_lds((gh_glb_void*)gb[i], (gh_lds_void*)(sB[buf] + dst + i * 128), 16, 0, 0); \
-      gb[i] += BK;                                                                                     \
-    }                                                                                                  \
-  } while (0)
-
-  if (nk > 0) GH_DMA_ISSUE(0);
+  if (nk > 0) { GH_DMA_ISSUE(oa, sA[0]) GH_DMA_ISSUE(ob, sB[0]) }
   gemm_init_acc(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);      // C loads ride on the first slab's latency
   __syncthreads();                                  // (hipcc puts the vmcnt(0) of the DMA in front of the barrier)
   for (long kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
-    const double* pa = sA[cur] + rowA;
-    const double* pb = sB[cur] + rowB;
     double a[4][4], b[4][4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[kk][i] = pa[i * 16 * BK + offk[kk]];
+      for (int i = 0; i < 4; ++i) a[kk][i] = oa.frag(sA[cur], kk, i);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
+      for (int j = 0; j < 4; ++j) b[kk][j] = ob.frag(sB[cur], kk, j);
     }
     // fragment reads first, THEN the DMA of the next slab into the other buffer (last read one
     // barrier ago): a DMA issued ahead of the reads would make the compiler wait for it
-    // (vmcnt(0)) in front of every later ds_read.  The first DPOS k-groups of MFMAs go ahead of
-    // the DMA issue: hipcc drains lgkmcnt to 0 after a global_load_lds, so MFMAs placed before
-    // it can start on counted waits as soon as their own fragments have landed.
+    // (vmcnt(0)) in front of every later ds_read.  The first k-group of MFMAs goes ahead of the
+    // DMA issue: hipcc drains lgkmcnt to 0 after a global_load_lds, so MFMAs placed before it
+    // start on counted waits as soon as their own fragments have landed.
 #pragma unroll
-    for (int kk = 0; kk < DPOS; ++kk)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
-      if (cur) GH_DMA_ISSUE(0); else GH_DMA_ISSUE(1);
+      if (cur) { GH_DMA_ISSUE(oa, sA[0]) GH_DMA_ISSUE(ob, sB[0]) }
+      else     { GH_DMA_ISSUE(oa, sA[1]) GH_DMA_ISSUE(ob, sB[1]) }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = DPOS; kk < 4; ++kk)
+    for (int kk = 1; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -364,9 +389,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
     __builtin_amdgcn_sched_barrier(0);              // (else 63 of the 64 MFMAs sink below the barrier)
     __syncthreads();
   }
-#undef GH_DMA_ISSUE
   gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
 }
+#undef GH_DMA_ISSUE
 
 // Plain-VALU kernel with identical semantics: validation arm for the MFMA lane maps
 // (GEORGE_AMD_NO_MFMA=1) -- each thread owns an 8x8 micro-tile of the 128x128 C tile.
@@ -455,15 +480,12 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     else if (mode == 1) hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM, 1>), grid, block, 0, st, g);  \
     else                hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g);     \
   } while (0)
-  if (h.a_km && h.b_km && mode == 1 && dma_mode() && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
-      ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0)
-  {
-    static int dpos = -1;
-    if (dpos < 0) { const char* e = getenv("GEORGE_AMD_DMA_POS"); dpos = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
-    if (dpos == 0)      hipLaunchKernelGGL((gemm_f64_mfma_dma<0>), grid, block, 0, st, g);
-    else if (dpos == 1) hipLaunchKernelGGL((gemm_f64_mfma_dma<1>), grid, block, 0, st, g);
-    else                hipLaunchKernelGGL((gemm_f64_mfma_dma<2>), grid, block, 0, st, g);
-  }
+  const bool dma = mode == 1 && dma_mode() && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
+                   ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0;
+  if (dma && h.a_km && h.b_km)        hipLaunchKernelGGL((gemm_f64_mfma_dma<true, true>), grid, block, 0, st, g);
+  else if (dma && h.a_km && !h.b_km)  hipLaunchKernelGGL((gemm_f64_mfma_dma<true, false>), grid, block, 0, st, g);
+  else if (dma && !h.a_km && !h.b_km) hipLaunchKernelGGL((gemm_f64_mfma_dma<false, false>), grid, block, 0, st, g);
+  else if (dma)                       hipLaunchKernelGGL((gemm_f64_mfma_dma<false, true>), grid, block, 0, st, g);
   else if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
   else if (h.a_km && !h.b_km) GH_GEMM_LAUNCH(true, false);
   else if (!h.a_km && !h.b_km) GH_GEMM_LAUNCH(false, false);
