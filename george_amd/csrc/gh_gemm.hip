@@ -55,7 +55,9 @@ __device__ __forceinline__ long xcd_remap(long bid, long nblk) {
 // left the SYRK at the same 51-57 TFLOP/s and cost 8 % end to end through 8x larger grids on the
 // skinny panel GEMMs.  The kernel is MFMA-issue bound, not fabric bound.)
 __device__ __forceinline__ bool tile_of(const GemmDev& g, int& tm, int& tn) {
-  const long l = xcd_remap(blockIdx.x, g.nblk);
+  // (triangular operands: the K extent shrinks along the tile order, so contiguous per-XCD chunks
+  //  would hand one XCD all the long tiles -- deal those round-robin instead)
+  const long l = (g.klo_max | g.khi_col | g.khi_row) ? (long)blockIdx.x : xcd_remap(blockIdx.x, g.nblk);
   if (g.lower) {
     long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
     while (t * (t + 1) / 2 > l) --t;
