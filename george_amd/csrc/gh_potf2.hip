@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
                                                              long long* info, long long base) {
   __shared__ double s[T * (T + 1) / 2];
   __shared__ double inv16[8 * 16 * IP];
+  __shared__ double rdiag[T];                   // 1 / L_jj, written as the pivots are taken
   __shared__ int fail_at;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // latency-bound chain of dependent steps that, under look-ahead, shares its CU with wavefronts
@@ -73,9 +74,21 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   __builtin_amdgcn_s_setprio(3);
   if (*info != 0) return;                       // uniform: an earlier block already failed
   if (tid == 0) fail_at = -1;
-  for (int idx = tid; idx < T * T; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    if (j <= i) s[PK(i, j)] = A[(long)i * lda + j];
+  // block -> packed LDS image; 16 unconditional loads in flight per thread (a load under the
+  // `j <= i` predicate is waited for one at a time: 22 % of the kernel in the first version)
+  {
+    const int j = tid & 127, ih = tid >> 7;
+#pragma unroll
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = A[(long)(ih + 2 * (q0 + q)) * lda + j];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = ih + 2 * (q0 + q);
+        if (j <= i) s[PK(i, j)] = v[q];
+      }
+    }
   }
   __syncthreads();
 
@@ -100,8 +113,16 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
           if (lane == 0 && fail_at < 0) fail_at = c0 + j;
           d = 1.0;
         }
-        const double ajj = sqrt(d);
-        const double inv = 1.0 / ajj;
+        // sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 seed (~2^-23) + two Newton steps and a final
+        // correction each: half the dependent chain of sqrt() followed by a division
+        double y = __builtin_amdgcn_rsq(d);
+        const double hd = 0.5 * d;
+        y = fma(y, fma(-hd * y, y, 0.5), y);
+        y = fma(y, fma(-hd * y, y, 0.5), y);
+        double ajj = d * y;
+        ajj = fma(0.5 * y, fma(-ajj, ajj, d), ajj);
+        const double inv = fma(fma(-ajj, y, 1.0), y, y);
+        if (lane == 0) rdiag[c0 + j] = inv;
         a[j] = (i == j) ? ajj : a[j] * inv;
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
@@ -126,10 +147,14 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
         for (int k = 0; k < 16; ++k) x[k] = s[PK(r, c0 + k)];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          double v = x[k];
+          double v0 = x[k], v1 = 0.0;             // two partial sums: half the dependent FMA chain
 #pragma unroll
-          for (int m = 0; m < k; ++m) v -= x[m] * s[PK(c0 + k, c0 + m)];
-          x[k] = v / s[PK(c0 + k, c0 + k)];
+          for (int m = 0; m + 1 < k; m += 2) {
+            v0 -= x[m] * s[PK(c0 + k, c0 + m)];
+            v1 -= x[m + 1] * s[PK(c0 + k, c0 + m + 1)];
+          }
+          if (k & 1) v0 -= x[k - 1] * s[PK(c0 + k, c0 + k - 1)];
+          x[k] = (v0 + v1) * rdiag[c0 + k];
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) s[PK(r, c0 + k)] = x[k];
@@ -188,11 +213,11 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
     for (int k = 0; k < 16; ++k) a[k] = (k <= c) ? s[PK(d0 + c, d0 + k)] : 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const double rdiag = 1.0 / bcast_lane(a[i], i);
+      const double rd = rdiag[d0 + i];
       double acc = 0.0;
 #pragma unroll
       for (int k = 0; k < i; ++k) acc += bcast_lane(a[k], i) * x[k];      // x[k] = 0 for k < c
-      x[i] = (i < c) ? 0.0 : ((i == c) ? rdiag : -acc * rdiag);
+      x[i] = (i < c) ? 0.0 : ((i == c) ? rd : -acc * rd);
     }
     if (lane < 16) {
 #pragma unroll
