@@ -268,7 +268,7 @@ def main():
             if ms > 0:
                 ach = fl / (ms * 1e-3) * 1e-12
                 out["roofline"] = {
-                    "kernel": "gemm_f64_mfma<k-major,k-major> (rank 0's trailing tile updates; one event pair per "
+                    "kernel": "gemm_f64_mfma_dma<k-major, k-major, full> (rank 0's trailing tile updates; one event pair per "
                               "update sweep, its tile-column GEMMs fanned over 3 streams)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "launches": calls,
@@ -279,7 +279,7 @@ def main():
             if p.n_trailing > 0 and p.ms_trailing > 0:
                 ach = p.trailing_flops / (p.ms_trailing * 1e-3) * 1e-12
                 out["roofline"] = {
-                    "kernel": "gemm_f64_mfma<k-major,k-major> (trailing SYRK update, lower tiles)",
+                    "kernel": "gemm_f64_mfma_dma<k-major, k-major, lower> (trailing SYRK update)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                     "launches": int(p.n_trailing), "avg_launch_ms": p.ms_trailing / p.n_trailing,

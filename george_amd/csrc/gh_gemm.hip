@@ -330,7 +330,9 @@ struct DmaOperand {
     op.src[i_] += op.step;                                                                            \
   }
 
-template <bool A_KM, bool B_KM>
+// LOWER (== g.lower) only names the symbol: rocprof then tells the triangular-grid launches (the
+// trailing SYRK updates, the roofline kernel of bench.py) from the rectangular panel GEMMs.
+template <bool A_KM, bool B_KM, bool LOWER>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   __shared__ __attribute__((aligned(1024))) double sA[2][BM * BK];
   __shared__ __attribute__((aligned(1024))) double sB[2][BN * BK];
@@ -484,10 +486,16 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   } while (0)
   const bool dma = mode == 1 && dma_mode() && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
                    ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0;
-  if (dma && h.a_km && h.b_km)        hipLaunchKernelGGL((gemm_f64_mfma_dma<true, true>), grid, block, 0, st, g);
-  else if (dma && h.a_km && !h.b_km)  hipLaunchKernelGGL((gemm_f64_mfma_dma<true, false>), grid, block, 0, st, g);
-  else if (dma && !h.a_km && !h.b_km) hipLaunchKernelGGL((gemm_f64_mfma_dma<false, false>), grid, block, 0, st, g);
-  else if (dma)                       hipLaunchKernelGGL((gemm_f64_mfma_dma<false, true>), grid, block, 0, st, g);
+#define GH_DMA_LAUNCH(AK, BKM)                                                                            \
+  do {                                                                                                   \
+    if (h.lower) hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, true>), grid, block, 0, st, g);          \
+    else         hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, false>), grid, block, 0, st, g);         \
+  } while (0)
+  if (dma && h.a_km && h.b_km)        GH_DMA_LAUNCH(true, true);
+  else if (dma && h.a_km && !h.b_km)  GH_DMA_LAUNCH(true, false);
+  else if (dma && !h.a_km && !h.b_km) GH_DMA_LAUNCH(false, false);
+  else if (dma)                       GH_DMA_LAUNCH(false, true);
+#undef GH_DMA_LAUNCH
   else if (h.a_km && h.b_km) GH_GEMM_LAUNCH(true, true);
   else if (h.a_km && !h.b_km) GH_GEMM_LAUNCH(true, false);
   else if (!h.a_km && !h.b_km) GH_GEMM_LAUNCH(false, false);

@@ -5,7 +5,7 @@
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT="$R/gpurun_out/prof_$TAG"
-mkdir -p "$OUT"
+mkdir -p "$OUT"; rm -f "$OUT/bench_lines_under_rocprof.jsonl"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu --no-extra"
 # 1. kernel traces of the headline config (N = 65536) with and without look-ahead, and of configs[1]
@@ -25,9 +25,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel
 cd "$R"
 for d in trace64k trace64k_nola trace16k pmc_fetch pmc_write cal_fetch cal_write pmc_mfma; do
   f=$(find "$OUT/$d" -name "*.db" | head -1)
-  if [ -n "$f" ]; then python scripts/summarize_prof.py "$f" "$OUT/$d.md"; fi
+  case $d in trace16k) TMIN=4;; trace64k*|pmc_fetch|pmc_write) TMIN=8;; *) TMIN="";; esac
+  if [ -n "$f" ]; then python scripts/summarize_prof.py "$f" "$OUT/$d.md" $TMIN; fi
 done
 python scripts/traffic_from_pmc.py "$(find $OUT/pmc_fetch -name '*.db' | head -1)" "$(find $OUT/pmc_write -name '*.db' | head -1)" 65536 1024 "$OUT/traffic_N65536.json"
-for f in trace64k trace64k_nola trace16k; do tail -c 1500 "$OUT/$f.log" | grep '^{' | cut -c1-400; done
+for f in trace64k trace64k_nola trace16k; do grep '^{"metric' "$OUT/$f.log" | tail -1 >> "$OUT/bench_lines_under_rocprof.jsonl"; done
+cut -c1-300 "$OUT/bench_lines_under_rocprof.jsonl"
 ls "$OUT"
 find "$OUT" -name "*.db" -size +8M -delete

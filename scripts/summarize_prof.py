@@ -22,6 +22,24 @@ def main():
     for r in rows:
         out.write("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.1f |\n" % (r[0][:110], r[1], r[2], 100 * r[2] / tot, r[3], r[4], r[5]))
     out.write("\ntotal kernel time: %.3f ms\n" % tot)
+    # The trailing SYRK updates (bench.py's roofline kernel) are the launches of the LOWER
+    # instantiation gemm_f64_mfma_dma<true, true, true> (triangular grid of t(t+1)/2 workgroups)
+    # with t >= tmin = panel width / 128: the in-panel updates are triangular too, but smaller.
+    if len(sys.argv) > 3:
+        tmin = int(sys.argv[3])
+        g = list(cur.execute(
+            "select d.grid_size_x / d.workgroup_size_x, d.end - d.start, s.kernel_name "
+            "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+            "where s.kernel_name like '%gemm_f64_mfma%'"))
+        is_tr = lambda grid, name: "dmaILb1ELb1ELb1EE" in name and grid >= tmin * (tmin + 1) // 2
+        tr = [dur for grid, dur, name in g if is_tr(grid, name)]
+        ot = [dur for grid, dur, name in g if not is_tr(grid, name)]
+        out.write("\n`gemm_f64_mfma*` dispatches by role (trailing update <=> the LOWER instantiation with a grid of "
+                  "t(t+1)/2 workgroups, t >= %d):\n\n" % tmin)
+        out.write("| role | launches | total ms | avg ms |\n|---|---|---|---|\n")
+        for name, v in (("trailing SYRK update", tr), ("panel / block-column GEMMs", ot)):
+            if v:
+                out.write("| %s | %d | %.3f | %.3f |\n" % (name, len(v), sum(v) / 1e6, sum(v) / 1e6 / len(v)))
     # PMC counters (if this was a --pmc run)
     try:
         pm = list(cur.execute(

@@ -8,8 +8,8 @@ passes (they do not fit one TCC pass); both are in KiB; on gfx950 FETCH_SIZE rep
 of the bytes of a wide coalesced read stream -- confirmed here on a 16-B/lane copy of known size
 (profiles/r01/pmc_calibration_*: 2 GiB read -> FETCH_SIZE 1 048 590 KiB, 2 GiB written ->
 WRITE_SIZE 2 097 150 KiB) -- so  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-The trailing launches are picked out of all gemm_f64_mfma dispatches by their grid size
-(a triangular number of 128x128 tiles).  Infinity-Cache hits are counted by these counters, so
+The trailing launches are the dispatches of the LOWER instantiation gemm_f64_mfma_dma<1,1,1> whose
+grid is one of the factorisation's trailing sizes (a triangular number of 128x128 tiles).  Infinity-Cache hits are counted by these counters, so
 this is traffic leaving the L2s, an upper bound on HBM traffic.
 """
 import json
@@ -40,7 +40,7 @@ def collect(db, counter, grids):
     q = ("select d.dispatch_id, d.grid_size_x/256, d.end-d.start, e.value from rocpd_pmc_event e "
          "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
          "join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
-         "where s.kernel_name like '%gemm_f64_mfma%' and p.name = ?")
+         "where s.kernel_name like '%gemm_f64_mfma_dmaILb1ELb1ELb1EE%' and p.name = ?")
     per = {}
     for did, g, dt, v in cur.execute(q, (counter,)):
         if g in grids and g > 36:
