@@ -205,7 +205,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536, help="N (north-star target config: 65536, 1-D ExpSquared)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=65536,
+                    help="N (north-star target config: 65536, 1-D ExpSquared); spell it --size under "
+                         "torch.distributed.run, whose own parser trips over the abbreviation --n")
     ap.add_argument("--nb", type=int, default=0, help="outer panel width (0 = library default)")
     ap.add_argument("--cpu-n", type=int, default=12288, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
