@@ -1,23 +1,23 @@
 // gh_gemm.hip -- fp64 GEMM / SYRK family on the CDNA4 matrix pipe.
 //
-// One kernel template serves every O(N^3) step of the solver (trailing SYRK
+// One kernel family serves every O(N^3) step of the solver (trailing SYRK
 // update, panel updates, TRSM-by-inverse multiplies, multi-RHS solves, K^-1):
 //     C[m][n] = beta * C[m][n] + alpha * sum_k A(m,k) * B(n,k)
 // with each operand either "k-major" (row-major, k contiguous) or "m-major"
-// (k strided); both are staged into LDS in the same [row][k] image so the MFMA
-// fragment reads are identical.
+// (k strided).
 //
 // Tiling (gfx950): 128x128 C tile per 256-thread workgroup = 2x2 wavefronts,
 // each wavefront a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators
 // (64 f64 = 128 VGPRs/lane).  K is consumed in slabs of 16 through a
-// double-buffered LDS image (2 x 2 x 128 x 18 doubles = 72 KiB -> 2 workgroups
-// per CU); global loads for slab t+1 are issued before the 64 MFMAs of slab t
-// and written to the other buffer after them, one barrier per slab.  LDS rows
-// are padded to 18 doubles so the fragment read (16 rows x 4 k per wavefront,
-// ds_read_b64) hits 32 distinct even banks per 32-lane half: conflict-free.
+// double-buffered LDS image, one barrier per slab, 2 workgroups per CU.  Per 16
+// MFMAs (1024 matrix-pipe cycles) a wavefront needs 8 fragment reads, so the
+// kernel is MFMA-issue bound, not LDS bound.
 //
-// fp64 MFMA issue is 2048 flop / 64 cycles / SIMD: per 16 MFMAs a wavefront needs
-// only 8 fragment reads, so the kernel is MFMA-issue bound, not LDS bound.
+// Two implementations of the operand path:
+//   gemm_f64_mfma_dma  (default)  global -> LDS by global_load_lds_dwordx4, XOR-swizzled image;
+//   gemm_f64_mfma      (A/B arm)  global -> VGPR -> LDS, rows padded to 18 doubles;
+// plus gemm_f64_valu, a plain-VALU kernel with the same semantics that cross-checks the MFMA
+// lane maps on the device.  GEORGE_AMD_MFMA_MODE / gh_debug_set_mfma select among them.
 #include <stdlib.h>
 #include "gh_common.h"
 

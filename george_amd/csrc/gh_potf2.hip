@@ -3,10 +3,12 @@
 // solver into an MFMA GEMM).
 //
 // The lower triangle of the block lives in LDS in PACKED row-major form (128*129/2 doubles =
-// 64.5 KiB; 81.5 KiB with the scratch below).  Packing is what lets this kernel run beside the
-// trailing SYRK during look-ahead: a SYRK workgroup holds 72 KiB of LDS and 254 VGPRs, so a CU
-// with one SYRK workgroup still has room for this one, whereas the unpacked 129-KiB tile had to
-// wait for a whole CU to drain (rocprof, profiles/r01: 180 us alone, 1.7 ms average under SYRK).
+// 64.5 KiB; 82.5 KiB with the scratch below).  Packing is what lets this kernel be PLACED beside
+// the trailing SYRK during look-ahead: a SYRK workgroup holds 64 KiB of LDS, so a CU with one SYRK
+// workgroup still has room for this one, whereas the first, unpacked 129-KiB tile had to wait for
+// a whole CU to drain (1.7 ms average under SYRK).  Placed is not the same as fast: beside SYRK
+// wavefronts the kernel runs 4x slower (LDS queue contention), which is why small matrices keep
+// 32 CUs free of SYRK work (gh_chol.hip, trailing_stream).
 //   phase 1  blocked right-looking Cholesky, 16-column steps:
 //            (a) 16x16 diagonal block, unblocked, by ONE wavefront (no workgroup barriers),
 //            (b) rows below: x D^T = a by per-row substitution, one thread per row, registers,

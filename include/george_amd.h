@@ -99,8 +99,9 @@ const char* gh_version(void);
  * GB/s of a 16-B/lane copy. */
 int gh_microbench_mfma_f64(double* tflops_out);
 /* validation / A-B switch for every GEMM: 0 = plain-VALU kernel (same semantics, cross-checks the
- * MFMA lane maps on the device), 1 = v_mfma_f64_16x16x4, 2 = v_mfma_f64_4x4x4_4b (default);
- * returns the previous setting. */
+ * MFMA lane maps on the device), 1 = v_mfma_f64_16x16x4 with LDS-DMA operand staging (default),
+ * 2 = v_mfma_f64_4x4x4_4b, 3 = v_mfma_f64_16x16x4 with register staging; returns the previous
+ * setting. */
 int gh_debug_set_mfma(int mode);
 int gh_microbench_hbm_copy(double* gbps_out);
 /* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
