@@ -77,115 +77,208 @@ __device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* s
 // at its second-half rows U(:,k).
 #define ACA_THREADS 512
 #define ACA_MAXR 512
+// One node is worked on by a CLUSTER of G workgroups (blockIdx.x = node * G + g): the top levels
+// have 1, 2, 4, ... nodes with blocks of N/2, N/4, ... rows, and one workgroup per node left the
+// single workgroup of level 0 with 70 % of the whole HODLR compute() at N = 262144.  Workgroup g
+// owns the columns and rows  t = g * 512 + tid (+ G * 512 ...)  of the block; the cluster meets
+// at three barriers per ACA step (row chosen / pivot search / norms), each a monotonic counter in
+// HBM, and exchanges its partial results (arg-max candidates, partial sums) through `part`.
+// Every workgroup reduces the SAME partials in the SAME order, so all of them take identical
+// decisions without a broadcast.  Data written by another workgroup of the cluster is read with
+// agent-scope atomic loads (a plain load may hit a stale line of this CU's L1).  G = 1 is the
+// old one-workgroup-per-node kernel (no counters touched).  The launch keeps nodes * G <= 256 so
+// that the whole grid is resident (a spinning cluster member never waits for an unscheduled one);
+// a spin that outlasts ~2 s raises `*fail` and bails out instead of hanging the GPU.
+struct AcaShared {
+  double shd[8];
+  int shi[8];
+  double coef[ACA_MAXR];
+  int s_i;
+};
+__device__ __forceinline__ double aca_ld(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int aca_ldi(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// cluster barrier number `epoch` (0, 1, 2, ...) on counter `bar`; returns false on time-out
+__device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoch, int* fail) {
+  if (G == 1) { __syncthreads(); return true; }
+  __shared__ int ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(bar, 1u);
+    const unsigned target = (unsigned)G * (epoch + 1u);
+    const long long t0 = wall_clock64();
+    int good = 1;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 200000000LL || aca_ldi(fail)) { good = 0; break; }     // 100 MHz ticks: 2 s
+    }
+    if (!good) atomicExch(fail, 1);
+    __threadfence();
+    ok = good;
+  }
+  __syncthreads();
+  ++epoch;
+  return ok != 0;
+}
+
 __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
-    int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level) {
-  __shared__ double shd[8];
-  __shared__ int shi[8];
-  __shared__ double coef[ACA_MAXR];
-  __shared__ int s_i;
-  const LvlNode nodev = nodes[blockIdx.x];
+    int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
+    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail) {
+  __shared__ AcaShared sh;
+  const int node = blockIdx.x / G, g = blockIdx.x % G;
+  const LvlNode nodev = nodes[node];
   const int col0 = nodev.start, n_cols = nodev.half;
   const int row0 = nodev.start + nodev.half, n_rows = nodev.size - nodev.half;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int t0 = g * nt + tid, ts = G * nt;            // this thread's first column/row and its stride
+  unsigned* bar = bars + node;
+  double* mypart = part + ((long)node * G + g) * pstride;
+  const double* allpart = part + (long)node * G * pstride;
+  unsigned epoch = 0;
   int max_rank = n_rows < n_cols ? n_rows : n_cols;
   if (max_rank > rcap) max_rank = rcap;
-  for (int t = tid; t < n_rows; t += nt) idx[row0 + t] = t;
+  if (g == 0) for (int t = tid; t < n_rows; t += nt) idx[row0 + t] = t;
   int remaining = n_rows, rank = 0;
   double norm = 0.0;
   const double tol2 = tol * tol;
-  unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)blockIdx.x * 0x9E3779B97F4A7C15ull);
+  unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)node * 0x9E3779B97F4A7C15ull);
   __syncthreads();
   while (rank < max_rank) {
     // ---- choose a random unused row with a non-negligible residual (hodlr.h:159-191)
     bool got = false;
     int j = -1;
+    double pivot = 0.0;
     while (remaining > 0) {
-      if (tid == 0) {
+      if (g == 0 && tid == 0) {
         st += 0x9E3779B97F4A7C15ull;
         unsigned long long z = st;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z ^= z >> 31;
         const int k = (int)(z % (unsigned long long)remaining);
-        s_i = idx[row0 + k];
+        const int pick = idx[row0 + k];
         idx[row0 + k] = idx[row0 + remaining - 1];
+        sel[node] = pick;
       }
       --remaining;
+      if (!aca_barrier(bar, G, epoch, fail)) return;                                  // B1: row chosen
+      const int i = (G == 1) ? sel[node] : aca_ldi(sel + node);
+      for (int k = tid; k < rank; k += nt) sh.coef[k] = aca_ld(Tcm + (long)k * N + row0 + i);   // U(i, 0:rank)
       __syncthreads();
-      const int i = s_i;
-      for (int k = tid; k < rank; k += nt) coef[k] = Tcm[(long)k * N + row0 + i];     // U(i, 0:rank)
-      __syncthreads();
-      double best = -1.0;
+      double best = -1.0, bestv = 0.0;
       int bestn = -1;
       const double* xi = x + (long)(row0 + i) * nd;
-      for (int n = tid; n < n_cols; n += nt) {
+      for (int n = t0; n < n_cols; n += ts) {
         double v = fast.ok ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
                            : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
-        for (int k = 0; k < rank; ++k) v -= coef[k] * Tcm[(long)k * N + col0 + n];
+        for (int k = 0; k < rank; ++k) v -= sh.coef[k] * Tcm[(long)k * N + col0 + n];
         Tcm[(long)rank * N + col0 + n] = v;
         const double a = fabs(v);
         if (a > best) { best = a; bestn = n; }
       }
-      hw_block_argmax(best, bestn, shd, shi);
-      if (best >= 1e-14) { got = true; j = bestn; break; }                             // hodlr.h:191
+      hw_block_argmax(best, bestn, sh.shd, sh.shi);
+      if (G > 1) {
+        if (tid == 0) {
+          mypart[0] = best;
+          mypart[1] = (double)bestn;
+          mypart[2] = bestn >= 0 ? Tcm[(long)rank * N + col0 + bestn] : 0.0;         // (this workgroup wrote it)
+        }
+        if (!aca_barrier(bar, G, epoch, fail)) return;                                // B2: pivot search
+        best = -1.0; bestn = -1;
+        for (int q = 0; q < G; ++q) {                                                 // largest value, smallest column on ties
+          const double bv = aca_ld(allpart + (long)q * pstride);
+          const int bn = (int)aca_ld(allpart + (long)q * pstride + 1);
+          if (bn >= 0 && (bv > best || (bv == best && (bestn < 0 || bn < bestn)))) {
+            best = bv; bestn = bn; bestv = aca_ld(allpart + (long)q * pstride + 2);
+          }
+        }
+      } else {
+        bestv = bestn >= 0 ? Tcm[(long)rank * N + col0 + bestn] : 0.0;
+      }
+      if (best >= 1e-14) { got = true; j = bestn; pivot = bestv; break; }              // hodlr.h:191
     }
     if (!got) break;       // rows exhausted: keep what we have (residual rows all < 1e-14)
     // ---- normalise the row by its pivot, build the column (hodlr.h:194-199)
-    const double pivot = Tcm[(long)rank * N + col0 + j];
     __syncthreads();
     double vn2 = 0.0;
-    for (int n = tid; n < n_cols; n += nt) {
+    for (int n = t0; n < n_cols; n += ts) {
       const double v = Tcm[(long)rank * N + col0 + n] / pivot;
       Tcm[(long)rank * N + col0 + n] = v;
       vn2 += v * v;
     }
-    for (int k = tid; k < rank; k += nt) coef[k] = Tcm[(long)k * N + col0 + j];        // V(j, 0:rank)
+    for (int k = tid; k < rank; k += nt) sh.coef[k] = aca_ld(Tcm + (long)k * N + col0 + j);    // V(j, 0:rank)
     __syncthreads();
     double un2 = 0.0;
     const double* xj = x + (long)(col0 + j) * nd;
-    for (int m = tid; m < n_rows; m += nt) {
+    for (int m = t0; m < n_rows; m += ts) {
       double u = fast.ok ? gh_fast_value(fast, x + (long)(row0 + m) * nd, xj)
                          : gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
-      for (int k = 0; k < rank; ++k) u -= coef[k] * Tcm[(long)k * N + row0 + m];
+      for (int k = 0; k < rank; ++k) u -= sh.coef[k] * Tcm[(long)k * N + row0 + m];
       Tcm[(long)rank * N + row0 + m] = u;
       un2 += u * u;
     }
     ++rank;
     if (rank >= max_rank) break;                                                       // hodlr.h:203
-    un2 = hw_block_sum(un2, shd);
-    vn2 = hw_block_sum(vn2, shd);
-    const double rowcol = un2 * vn2;
-    if (rowcol < tol2 * norm) break;                                                   // hodlr.h:206-207
-    norm += rowcol;                                                                    // hodlr.h:210-214
-    if (rank > 1) {
-      double maxu = 0.0, maxv = 0.0;
-      const double* ul = Tcm + (long)(rank - 1) * N + row0;
-      const double* vl = Tcm + (long)(rank - 1) * N + col0;
-      for (int k0 = 0; k0 < rank - 1; k0 += 4) {
-        double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
-        for (int m = tid; m < n_rows; m += nt) {
-          const double u = ul[m];
+    un2 = hw_block_sum(un2, sh.shd);
+    vn2 = hw_block_sum(vn2, sh.shd);
+    // cross terms |u_new . u_k|, |v_new . v_k|, k < rank-1, of the norm estimate (hodlr.h:210-214):
+    // this workgroup's share of each dot product, four at a time
+    const double* ul = Tcm + (long)(rank - 1) * N + row0;
+    const double* vl = Tcm + (long)(rank - 1) * N + col0;
+    double maxu = 0.0, maxv = 0.0;
+    for (int k0 = 0; k0 < rank - 1; k0 += 4) {
+      double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
+      for (int m = t0; m < n_rows; m += ts) {
+        const double u = ul[m];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) du[q] += Tcm[(long)(k0 + q) * N + row0 + m] * u;
-        }
-        for (int n = tid; n < n_cols; n += nt) {
-          const double v = vl[n];
+        for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) du[q] += Tcm[(long)(k0 + q) * N + row0 + m] * u;
+      }
+      for (int n = t0; n < n_cols; n += ts) {
+        const double v = vl[n];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) dv[q] += Tcm[(long)(k0 + q) * N + col0 + n] * v;
-        }
+        for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) dv[q] += Tcm[(long)(k0 + q) * N + col0 + n] * v;
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double a = fabs(hw_block_sum(du[q], shd));
-          const double b = fabs(hw_block_sum(dv[q], shd));
-          if (a > maxu) maxu = a;
-          if (b > maxv) maxv = b;
+      for (int q = 0; q < 4; ++q) {
+        const double a = hw_block_sum(du[q], sh.shd);
+        const double b = hw_block_sum(dv[q], sh.shd);
+        if (G > 1) {
+          if (tid == 0 && k0 + q < rank - 1) { mypart[6 + 2 * (k0 + q)] = a; mypart[7 + 2 * (k0 + q)] = b; }
+        } else {
+          if (fabs(a) > maxu) maxu = fabs(a);
+          if (fabs(b) > maxv) maxv = fabs(b);
         }
       }
-      norm += 2.0 * maxu + 2.0 * maxv;
     }
+    if (G > 1) {
+      if (tid == 0) { mypart[3] = un2; mypart[4] = vn2; }     // (slots 0-2 may still be read by a slow member)
+      if (!aca_barrier(bar, G, epoch, fail)) return;                                  // B3: norms
+      un2 = 0.0; vn2 = 0.0;
+      for (int q = 0; q < G; ++q) { un2 += aca_ld(allpart + (long)q * pstride + 3); vn2 += aca_ld(allpart + (long)q * pstride + 4); }
+      for (int k = tid; k < rank - 1; k += nt) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < G; ++q) { a += aca_ld(allpart + (long)q * pstride + 6 + 2 * k); b += aca_ld(allpart + (long)q * pstride + 7 + 2 * k); }
+        sh.coef[k] = fabs(a);                 // (coef is free here: reloaded at the next step)
+        sh.coef[ACA_MAXR / 2 + k] = fabs(b);
+      }
+      __syncthreads();
+      for (int k = 0; k < rank - 1; ++k) {
+        if (sh.coef[k] > maxu) maxu = sh.coef[k];
+        if (sh.coef[ACA_MAXR / 2 + k] > maxv) maxv = sh.coef[ACA_MAXR / 2 + k];
+      }
+      __syncthreads();
+    }
+    const double rowcol = un2 * vn2;
+    if (rowcol < tol2 * norm) break;                                                   // hodlr.h:206-207
+    norm += rowcol;
+    if (rank > 1) norm += 2.0 * maxu + 2.0 * maxv;
   }
-  if (tid == 0) ranks[blockIdx.x] = rank;
+  if (g == 0 && tid == 0) ranks[node] = rank;
 }
 
 // B (rows of this level's nodes x R, row-major, ld = R) <- first rank columns of Tcm, zero padded
@@ -559,7 +652,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // ---- ACA level by level into column-major scratch, ranks back to the host
   const int rcap = h->opts.max_rank;
   const int nlev = (int)h->levels.size();
-  GhBuf Tcm, idx;
+  GhBuf Tcm, idx, aca_sync, aca_part;
   if (nlev > 0) {
     GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
     GH_CHECK(idx.ensure((size_t)n * sizeof(int)));
@@ -574,13 +667,32 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     for (int q = 0; q < nn; ++q) { const HNode& nd = h->nodes[L->node_ids[q]]; ln[q] = {nd.start, nd.half, nd.size, 0}; }
     GH_CHECK(upload(L->d_nodes, ln, st));
     GH_CHECK(L->d_ranks.ensure(nn * sizeof(int)));
-    hipLaunchKernelGGL(hodlr_aca_kernel, dim3(nn), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
+    // cluster size: as many workgroups per node as keep the whole grid resident (nodes * G <= 256)
+    // and leave every workgroup at least two columns per thread
+    int G = 1;
+    if (!getenv("GEORGE_AMD_HODLR_NO_CLUSTER")) {
+      int min_half = INT32_MAX;
+      for (int q = 0; q < nn; ++q) min_half = std::min(min_half, ln[q].half);
+      while (G * 2 * nn <= 256 && (long)(G * 2) * ACA_THREADS * 2 <= min_half) G *= 2;
+    }
+    const int pstride = 8 + 2 * ACA_MAXR;
+    GH_CHECK(aca_sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + sizeof(int)));
+    GH_CHECK(aca_part.ensure((size_t)nn * G * pstride * sizeof(double)));
+    GH_HIP(hipMemsetAsync(aca_sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + sizeof(int), st));
+    unsigned* d_bars = (unsigned*)aca_sync.p;
+    int* d_sel = (int*)(d_bars + nn);
+    int* d_fail = d_sel + nn;
+    hipLaunchKernelGGL(hodlr_aca_kernel, dim3(nn * G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
                        h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p, (int*)L->d_ranks.p,
-                       h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l);
+                       h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,
+                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail);
     GH_HIP(hipGetLastError());
+    int aca_failed = 0;
+    GH_HIP(hipMemcpyAsync(&aca_failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
     L->ranks.resize(nn);
     GH_HIP(hipMemcpyAsync(L->ranks.data(), L->d_ranks.p, nn * sizeof(int), hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));
+    if (aca_failed) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", l); return GH_ERR_HIP; }
     L->R = 0;
     for (int r : L->ranks) L->R = std::max(L->R, r);
     L->off = h->Rtot;
