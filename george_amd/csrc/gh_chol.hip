@@ -171,6 +171,89 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* L, long ld, c
     }
   }
 }
+// The whole forward sweep L z = y as ONE launch: workgroup b owns block row b.  It walks the blocks
+// L[b, 0..b-1] left to right, folding each z_j into per-lane partial sums as soon as workgroup j
+// has published it (a flag per block row in HBM), then solves its own diagonal block with the
+// stored inverse and publishes z_b.  The step-per-launch version above costs a launch gap plus
+// two dependent 128x128 mat-vecs per block row (25-27 us, 14.3 ms at N = 65536 against 3.8 ms of
+// HBM time for the triangle); here a link of the chain is flag -> 128 FMAs per lane -> reduce ->
+// one mat-vec, and the L blocks of a row stream in ahead of the flags (the next block is loaded
+// into registers before the wait).  512 threads: wavefront w takes rows 16w..16w+15, a lane two
+// columns.  Deadlock freedom: workgroup b only waits for workgroups j < b, and a 1-D grid is
+// dispatched in blockIdx order, so whatever it waits for is resident or finished (the grid need
+// not fit the chip).  A wait that outlasts ~2 s raises *fail instead of hanging.
+#define CHAIN_THREADS 512
+__device__ __forceinline__ double2 ld_coherent2(const double* p) {
+  double2 v;
+  v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+__global__ __launch_bounds__(CHAIN_THREADS) void trsv_fwd_chain(const double* L, long ld, const double* dinv,
+                                                                const double* y, double* z, unsigned* flags, int* fail) {
+  __shared__ double ws[T];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)b * T + wave * 16;
+  double acc[16];
+  double2 dv[16], blk[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    acc[q] = 0.0;
+    dv[q] = *reinterpret_cast<const double2*>(dinv + (long)b * T * T + (wave * 16 + q) * T + 2 * lane);
+  }
+  if (b > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) blk[q] = *reinterpret_cast<const double2*>(L + (row0 + q) * ld + 2 * lane);
+  }
+  for (int j = 0; j < b; ++j) {
+    if (tid == 0) {
+      // ONE poller per workgroup, and the further a workgroup is from the front of the chain the
+      // more patiently it polls: with every wavefront of every waiting workgroup spinning on the
+      // same flag the L2 atomics queue was the critical path (29 ms at N = 65536)
+      const int dist = b - j;
+      const long long t0 = wall_clock64();
+      unsigned spins = 0;
+      while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);   // 0 .. 8k cycles
+        if ((++spins & 63u) == 0u) {
+          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // somebody gave up
+          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); break; }       // 100 MHz ticks: 2 s
+        }
+      }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");                         // (compiler only: nothing below moves above the wait)
+    const double2 zj = ld_coherent2(z + (long)j * T + 2 * lane);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] += blk[q].x * zj.x + blk[q].y * zj.y;
+    if (j + 1 < b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        blk[q] = *reinterpret_cast<const double2*>(L + (row0 + q) * ld + (long)(j + 1) * T + 2 * lane);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double v = wave_sum(acc[q]);
+    if (lane == 0) ws[wave * 16 + q] = y[row0 + q] - v;
+  }
+  __syncthreads();
+  const double wx = ws[2 * lane], wy = ws[2 * lane + 1];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double v = wave_sum(dv[q].x * wx + dv[q].y * wy);
+    if (lane == 0) __hip_atomic_store(z + row0 + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // No fences: z and the flag travel as agent-scope atomics (write-through past this XCD's L2,
+  // read past the reader's), and s_waitcnt makes every z store complete before the flag is
+  // issued.  A release/acquire pair instead costs an L2 write-back on this side and an L2
+  // invalidate on the other at every link of the chain (chain neighbours sit on different XCDs):
+  // 16-29 us per link measured, against the ~5 us of the work itself.
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Backward step j of L^T x = z.  x_j = L_jj^-T w_j; columns c < j0: w[c] -= sum_r L[j0+r][c] x_j[r].
 // Workgroup j0/128 (the last one) publishes x_j; workgroup b < j0/128 updates columns [128b, 128b+128).
 __global__ __launch_bounds__(256) void trsv_bwd_step(const double* L, long ld, const double* dinv_j,
@@ -266,7 +349,7 @@ struct gh_chol {
   bool computed = false;
   int64_t info = 0;
   double logdet = 0.0;
-  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch;
+  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
   long long* d_info = nullptr;
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
@@ -654,6 +737,20 @@ static int load_vec(gh_chol* s, GhBuf& buf, const double* src) {
 // z = L^-1 w  (w is destroyed)
 static int trsv_forward(gh_chol* s, double* w, double* z) {
   const int64_t nt = s->np / T;
+  static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;       // A/B arm: one launch per block row
+  if (!stepwise) {
+    GH_CHECK(s->chain.ensure((size_t)(nt + 1) * sizeof(unsigned)));
+    GH_HIP(hipMemsetAsync(s->chain.p, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
+    unsigned* flags = (unsigned*)s->chain.p;
+    hipLaunchKernelGGL(trsv_fwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, s->st,
+                       s->A.d(), (long)s->np, s->dinv.d(), w, z, flags, (int*)(flags + nt));
+    GH_HIP(hipGetLastError());
+    int failed = 0;
+    GH_HIP(hipMemcpyAsync(&failed, flags + nt, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GH_HIP(hipStreamSynchronize(s->st));
+    if (failed) { gh_set_error("forward solve: a workgroup waited more than 2 s for its predecessor"); return GH_ERR_HIP; }
+    return GH_OK;
+  }
   for (int64_t j = 0; j < nt; ++j) {
     hipLaunchKernelGGL(trsv_fwd_step, dim3((unsigned)(nt - j)), dim3(256), 0, s->st,
                        s->A.d(), (long)s->np, s->dinv.d() + j * T * T, (long)(j * T), w, z);
