@@ -292,3 +292,20 @@ def test_full_size_c2_properties():
     gp3 = GP(kernel)
     gp3.compute(x, yerr)
     assert gp3.log_likelihood(y) == ll                                   # deterministic
+
+
+@pytest.mark.parametrize("n", [130, 1000, 5000, 20000])
+def test_chained_forward_solve_repeatable(n):
+    """The forward sweep is ONE launch whose workgroups hand z blocks to each other through flags
+    (gh_chol.hip, trsv_fwd_chain): hammer it -- 25 sweeps per size must give the same bits, and
+    r^T K^-1 r must agree with the full solve r . apply_inverse(r) (forward + backward sweeps)."""
+    x, yerr, y = zoo.bench_data(n)
+    s = BasicSolver(np.var(y) * kernels.Matern32Kernel(1.0))
+    s.compute(x[:, None] if x.ndim == 1 else x, yerr)
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal(n)
+    first = s.dot_solve(r)
+    for _ in range(24):
+        assert s.dot_solve(r) == first
+    full = float(r @ s.apply_inverse(r))
+    assert abs(first - full) <= 1e-10 * abs(full)
