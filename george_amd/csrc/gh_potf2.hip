@@ -15,9 +15,9 @@
 //            (c) trailing update on the matrix pipe: 16x16 tiles, v_mfma_f64_16x16x4_f64.
 //   phase 2  L^-1 by recursive doubling: the eight 16x16 diagonal inverses (wave-parallel
 //            substitution), then blocks of 16 -> 32 -> 64:  X = -B^-1 (C A^-1), every product a
-//            set of 16x16 MFMA tile jobs spread over the four wavefronts.  L^-1 is assembled in
-//            its final place in HBM (`dinv`); its unused upper-right quadrant is the scratch for
-//            C A^-1 and is zeroed at the end.
+//            set of 16x16 MFMA tile jobs spread over the four wavefronts.  L^-1 overwrites the
+//            factor in LDS block by block (the factor itself has gone to HBM by then) and is
+//            written to `dinv` once at the end.
 //
 // The first version of this kernel (scalar rank-1 updates, 3 barriers per column, column-wise
 // inverse) took 553 us per block and was half of compute() at N = 16384; it is kept in
@@ -201,14 +201,14 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
     A[(long)i * lda + j] = (j <= i) ? s[PK(i, j)] : 0.0;
   }
 
-  // ================================================================ phase 2: L^-1 -> dinv
+  // ================================================================ phase 2: L^-1, in place in LDS
+  // (the factor is already in HBM; `s` is free to become L^-1, `inv16` is the scratch for C A^-1)
   // (a) the eight 16x16 diagonal inverses; wavefront w takes blocks 2w and 2w+1.
-  //     lane (c = lane & 15, q = lane >> 4): column c of the inverse, dot products split 4 ways.
   //     Registers again: lane r (mod 16) holds ROW r of the block (a[]) and COLUMN r of its
   //     inverse (x[]); x_i = -(sum_{k<i} L_ik x_k) / L_ii with L_ik broadcast from lane i.
+  __syncthreads();                                // (the write-back above still reads s)
   for (int bb = 0; bb < 2; ++bb) {
     const int bI = 2 * wave + bb, d0 = 16 * bI;
-    double* xs = inv16 + bI * 16 * IP;
     const int c = lane & 15;
     double a[16], x[16];
 #pragma unroll
@@ -223,65 +223,58 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
     }
     if (lane < 16) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        xs[i * IP + c] = x[i];
-        dinv[(d0 + i) * T + d0 + c] = x[i];
-      }
+      for (int i = 0; i < 16; ++i)
+        if (i >= c) s[PK(d0 + i, d0 + c)] = x[i];
     }
   }
   __syncthreads();
   // (b) doubling: blocks of size sz = 16, 32, 64.  Pair p: P0 = 2 p sz,
-  //     A^-1 = Linv[P0 : P0+sz, P0 : P0+sz], B^-1 = Linv[P0+sz : P0+2sz, same cols shifted],
-  //     C = L[P0+sz : P0+2sz, P0 : P0+sz]  ->  Linv[P0+sz.., P0..] = -B^-1 (C A^-1).
+  //     A^-1 = s[P0 : P0+sz, P0 : P0+sz], B^-1 = s[P0+sz : P0+2sz, P0+sz : P0+2sz] (both lower
+  //     triangular, already inverted), C = L[P0+sz : P0+2sz, P0 : P0+sz] (still the factor)
+  //     ->  C is overwritten by  X = -B^-1 (C A^-1).  Columns go in chunks of <= 32 (the scratch
+  //     holds 64 x 32 doubles), left to right: chunk c of T = C A^-1 needs the columns >= c of C
+  //     only (A^-1 is lower triangular), so overwriting the chunks already done is safe.
+  //     Operands of the first version came from HBM (`dinv`): 20 % of the kernel.
+  auto tri = [&](int r, int c) { return s[PK(r > c ? r : c, r > c ? c : r)]; };   // (valid address for any r, c)
+  double* scr = inv16;
   for (int sz = 16; sz <= 64; sz *= 2) {
-    const int tps = sz / 16;                      // tiles per side
-    const int njobs = (64 / sz) * tps * tps;
-    double* scr = dinv + 64;                      // scratch: rows [0,64) x cols [64,128) of dinv
-    // T = C A^-1   (K = sz; A^-1 lower triangular: k >= 16 tj)
-    for (int e = wave; e < njobs; e += 4) {
-      const int p = e / (tps * tps), rem = e % (tps * tps), ti = rem / tps, tj = rem % tps;
-      const int P0 = 2 * p * sz;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-      if (sz == 16) {
-        const double* ai = inv16 + (2 * p) * 16 * IP;
-        acc = tile_mma<4>(acc, 0, 4,
-                          [&](int i, int k) { return s[PK(P0 + 16 + i, P0 + k)]; },
-                          [&](int k, int j) { return ai[k * IP + j]; }, lane);
-      } else {
-        acc = tile_mma<16>(acc, 4 * tj, sz / 4,
+    const int tps = sz / 16;                      // tiles per side of a block
+    const int cw = sz < 32 ? sz : 32, tpc = cw / 16;   // chunk width, tile columns per chunk
+    const int npair = 64 / sz;
+    for (int c0 = 0; c0 < sz; c0 += cw) {
+      const int njobs = npair * tps * tpc;
+      // T[:, chunk] = C A^-1[:, chunk]   (k >= column: A^-1 lower triangular)
+      for (int e = wave; e < njobs; e += 4) {
+        const int p = e / (tps * tpc), rem = e % (tps * tpc), ti = rem / tpc, tj = rem % tpc;
+        const int P0 = 2 * p * sz, col = c0 + 16 * tj;          // column offset inside the block
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = tile_mma<16>(acc, col / 4, sz / 4,
                            [&](int i, int k) { return s[PK(P0 + sz + 16 * ti + i, P0 + k)]; },
-                           [&](int k, int j) { return dinv[(P0 + k) * T + P0 + 16 * tj + j]; }, lane);
-      }
+                           [&](int k, int j) { const double v = tri(P0 + k, P0 + col + j); return k >= col + j ? v : 0.0; }, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        scr[(p * sz + 16 * ti + (lane >> 4) + 4 * r) * T + 16 * tj + (lane & 15)] = acc[r];
-    }
-    __syncthreads();
-    // X = -B^-1 T   (B^-1 lower triangular: k <= 16 ti + 15)
-    for (int e = wave; e < njobs; e += 4) {
-      const int p = e / (tps * tps), rem = e % (tps * tps), ti = rem / tps, tj = rem % tps;
-      const int P0 = 2 * p * sz;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-      if (sz == 16) {
-        const double* bi = inv16 + (2 * p + 1) * 16 * IP;
-        acc = tile_mma<4>(acc, 0, 4,
-                          [&](int i, int k) { return -bi[i * IP + k]; },
-                          [&](int k, int j) { return scr[(p * sz + k) * T + j]; }, lane);
-      } else {
+        for (int r = 0; r < 4; ++r)
+          scr[(p * sz + 16 * ti + (lane >> 4) + 4 * r) * cw + 16 * tj + (lane & 15)] = acc[r];
+      }
+      __syncthreads();
+      // X[:, chunk] = -B^-1 T[:, chunk]   (k <= row: B^-1 lower triangular)
+      for (int e = wave; e < njobs; e += 4) {
+        const int p = e / (tps * tpc), rem = e % (tps * tpc), ti = rem / tpc, tj = rem % tpc;
+        const int P0 = 2 * p * sz;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
         acc = tile_mma<16>(acc, 0, 4 * (ti + 1),
-                           [&](int i, int k) { return -dinv[(P0 + sz + 16 * ti + i) * T + P0 + sz + k]; },
-                           [&](int k, int j) { return scr[(p * sz + k) * T + 16 * tj + j]; }, lane);
-      }
+                           [&](int i, int k) { const double v = tri(P0 + sz + 16 * ti + i, P0 + sz + k); return k <= 16 * ti + i ? -v : 0.0; },
+                           [&](int k, int j) { return scr[(p * sz + k) * cw + 16 * tj + j]; }, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dinv[(P0 + sz + 16 * ti + (lane >> 4) + 4 * r) * T + P0 + 16 * tj + (lane & 15)] = acc[r];
+        for (int r = 0; r < 4; ++r)
+          s[PK(P0 + sz + 16 * ti + (lane >> 4) + 4 * r, P0 + c0 + 16 * tj + (lane & 15))] = acc[r];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  // (c) everything above the diagonal (including the scratch quadrant) is zero
+  // (c) L^-1 to HBM, zeros above the diagonal
   for (int idx = tid; idx < T * T; idx += 256) {
     const int i = idx >> 7, j = idx & 127;
-    if (j > i) dinv[idx] = 0.0;
+    dinv[idx] = (j <= i) ? s[PK(i, j)] : 0.0;
   }
 }
 
