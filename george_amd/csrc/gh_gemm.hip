@@ -397,6 +397,138 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
 }
 #undef GH_DMA_ISSUE
 
+// ---------------------------------------------------------------------------------------------
+// 64x64-tile variant for launches that cannot fill the chip anyway (the GEMMs inside the panel
+// chain: <= 128 tiles of 128x128, K = 128..1024).  A 128x128x128 tile is 512 MFMAs per wavefront
+// = 15 us on its one CU no matter how idle the other 255 are; four times as many workgroups of a
+// quarter of the work bring such a launch from ~23 us to ~10.  k-major operands only (all panel
+// GEMMs are); same DMA + swizzle scheme, 2x2 wavefronts of 32 x 16*NBJ.  NBJ = 2: 64x64 tiles;
+// NBJ = 4: 64x128 tiles, for the in-place calls  P <- P L_jj^-T  (C == A, N = 128): a workgroup
+// must own whole rows there, or it would overwrite columns a neighbour is still reading.
+template <int NBJ>
+__global__ __launch_bounds__(256) void gemm_f64_mfma_dma64(GemmDev g) {
+  constexpr int BNT = 32 * NBJ;
+  __shared__ __attribute__((aligned(1024))) double sA[2][64 * BK];
+  __shared__ __attribute__((aligned(1024))) double sB[2][BNT * BK];
+  const long l = blockIdx.x;
+  int tm, tn;
+  if (g.lower) {        // the four 64x64 quarters of every lower 128x128 tile (the documented granularity)
+    const long l4 = l >> 2;
+    long t = (long)((sqrt(8.0 * (double)l4 + 1.0) - 1.0) * 0.5);
+    while (t * (t + 1) / 2 > l4) --t;
+    while ((t + 1) * (t + 2) / 2 <= l4) ++t;
+    tm = 2 * (int)t + (int)((l >> 1) & 1);
+    tn = 2 * (int)(l4 - t * (t + 1) / 2) + (int)(l & 1);
+  } else {
+    tm = (int)(l / g.tiles_n); tn = (int)(l % g.tiles_n);
+  }
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  const long row0 = (long)tm * 64, col0 = (long)tn * BNT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const long nk = g.K / BK;
+  // DMA: instruction i (of 2) of this wavefront moves rows wave*16 + 8i + (lane>>3), piece lane&7
+  const double* ga[2];
+  const double* gb[NBJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wave * 16 + i * 8 + (lane >> 3);
+    ga[i] = g.A + (row0 + r) * g.lda + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < NBJ; ++i) {
+    const int r = wave * 8 * NBJ + i * 8 + (lane >> 3);
+    gb[i] = g.B + (col0 + r) * g.ldb + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+  }
+  const int sw = (fr >> 1) & 7;
+  int offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+  const int rowA = (wm * 32 + fr) * BK, rowB = (wn * 16 * NBJ + fr) * BK;
+  const int dstA = wave * 2 * 128, dstB = wave * NBJ * 128;
+#define GH_DMA64_ISSUE(buf)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+    __builtin_amdgcn_global_load_lds((gh_glb_void*)ga[i], (gh_lds_void*)(sA[buf] + dstA + i * 128), 16, 0, 0); \
+    ga[i] += BK;                                                                                       \
+  }                                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < NBJ; ++i) {                                                    \
+    __builtin_amdgcn_global_load_lds((gh_glb_void*)gb[i], (gh_lds_void*)(sB[buf] + dstB + i * 128), 16, 0, 0); \
+    gb[i] += BK;                                                                                       \
+  }
+  v4d acc[2][NBJ];
+  const double alpha = g.alpha;
+  double* cbase = g.C + (row0 + wm * 32 + fk) * g.ldc + col0 + wn * 16 * NBJ + fr;
+  if (nk > 0) { GH_DMA64_ISSUE(0) }
+  if (g.preload) {
+    const double rho = (g.beta == g.alpha) ? 1.0 : -1.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) acc[i][j][r] = rho * cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+  for (long kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const double* pa = sA[cur] + rowA;
+    const double* pb = sB[cur] + rowB;
+    double a[4][2], b[4][NBJ];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[kk][i] = pa[i * 16 * BK + offk[kk]];
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (cur) { GH_DMA64_ISSUE(0) } else { GH_DMA64_ISSUE(1) }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+#undef GH_DMA64_ISSUE
+  const double beta = g.preload ? 0.0 : g.beta;
+  if (beta == 0.0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16] = alpha * acc[i][j][r];
+  } else {
+    double c[2][4][NBJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) c[i][r][j] = cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j)
+          cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16] = fma(beta, c[i][r][j], alpha * acc[i][j][r]);
+  }
+}
+
 // Plain-VALU kernel with identical semantics: validation arm for the MFMA lane maps
 // (GEORGE_AMD_NO_MFMA=1) -- each thread owns an 8x8 micro-tile of the 128x128 C tile.
 template <bool A_KM, bool B_KM>
@@ -491,7 +623,23 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     if (h.lower) hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, true>), grid, block, 0, st, g);          \
     else         hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, false>), grid, block, 0, st, g);         \
   } while (0)
-  if (dma && h.a_km && h.b_km)        GH_DMA_LAUNCH(true, true);
+  static const bool no_small = getenv("GEORGE_AMD_GEMM_NO_SMALL") != nullptr;
+  const bool inplace = (const double*)h.C == h.A || (const double*)h.C == h.B;
+  if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small &&
+      (!inplace || (h.N == 128 && !h.lower))) {
+    // sub-chip launch: 64-row tiles, 2-4x the workgroups (see gemm_f64_mfma_dma64)
+    GemmDev q = g;
+    if (inplace) {                      // whole rows per workgroup: 64 x 128 tiles
+      q.tiles_m = (int)(h.M / 64); q.tiles_n = 1;
+      q.nblk = q.tiles_m;
+      hipLaunchKernelGGL(gemm_f64_mfma_dma64<4>, dim3((unsigned)q.nblk), block, 0, st, q);
+    } else {
+      q.tiles_m = (int)(h.M / 64); q.tiles_n = (int)(h.N / 64);
+      q.nblk = h.lower ? 4 * g.nblk : (long)q.tiles_m * q.tiles_n;
+      hipLaunchKernelGGL(gemm_f64_mfma_dma64<2>, dim3((unsigned)q.nblk), block, 0, st, q);
+    }
+  }
+  else if (dma && h.a_km && h.b_km)   GH_DMA_LAUNCH(true, true);
   else if (dma && h.a_km && !h.b_km)  GH_DMA_LAUNCH(true, false);
   else if (dma && !h.a_km && !h.b_km) GH_DMA_LAUNCH(false, false);
   else if (dma)                       GH_DMA_LAUNCH(false, true);
