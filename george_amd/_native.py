@@ -126,6 +126,7 @@ SIGNATURES = {
     "gh_dev_gemm_nt": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "gh_dev_gemm": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _i32, _vp]),
     "gh_dev_logdet_accum": (C.c_int, [_dp, _i64, _i64, _dp, _vp]),
+    "gh_dev_trsv_lower": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _dp, _vp, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

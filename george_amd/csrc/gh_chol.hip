@@ -479,6 +479,18 @@ extern "C" int gh_dev_trsm_right(const double* l11, int64_t ld11, const double* 
   if (n % T || m % T) { gh_set_error("trsm_right: sizes must be multiples of 128"); return GH_ERR_BAD_ARG; }
   return trsm_right((hipStream_t)stream, l11, ld11, dinv, a21, lda, m, n);
 }
+extern "C" int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* dinv, int64_t n,
+                                 const double* w, double* z, void* scratch, void* stream) {
+  if (n % T || n <= 0 || !scratch) { gh_set_error("trsv_lower: n must be a positive multiple of 128"); return GH_ERR_BAD_ARG; }
+  const int64_t nt = n / T;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* flags = (unsigned*)scratch;
+  GH_HIP(hipMemsetAsync(flags, 0, (size_t)(nt + 1) * sizeof(unsigned), st));
+  hipLaunchKernelGGL(trsv_fwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, st, l, (long)ldl, dinv, w, z,
+                     flags, (int*)(flags + nt));
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
 extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, double* out_dev, void* stream) {
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (long)lda, (long)n, out_dev, 1);
   GH_HIP(hipGetLastError());

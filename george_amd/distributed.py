@@ -93,6 +93,14 @@ class HipTileOps(object):
     def logdet_accum(self, a, out):
         self.N.check(self.N.lib.gh_dev_logdet_accum(a.data_ptr(), a.stride(0), a.shape[0], out.data_ptr(), self._st()))
 
+    def trsv(self, l, dinv, w, z):
+        """z = L^-1 w for a factored diagonal tile (one chained launch)."""
+        n = l.shape[0]
+        if getattr(self, "_trsv_scratch", None) is None or self._trsv_scratch.numel() < n // 128 + 1:
+            self._trsv_scratch = self.torch.zeros(n // 128 + 1, dtype=self.torch.int32, device=self.device)
+        self.N.check(self.N.lib.gh_dev_trsv_lower(l.data_ptr(), l.stride(0), dinv.data_ptr(), n, w.data_ptr(), z.data_ptr(),
+                                                  self._trsv_scratch.data_ptr(), self._st()))
+
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -351,7 +359,6 @@ class BlockCyclicCholesky(object):
         w = ops.zeros(nb)
         zk = ops.zeros(nb)
         acc = ops.zeros(1)
-        nblk = nb // 128
         for k in range(nt):
             kr, kc = k % Pr, k % Pc
             if pr == kr:
@@ -366,11 +373,7 @@ class BlockCyclicCholesky(object):
             if pr == kr and pc == kc:
                 w.copy_(y[k * nb:(k + 1) * nb])
                 w -= part
-                akk = self.tile(k, k)
-                for b in range(nblk):                              # z_b = L_bb^-1 (w_b - sum_{c<b} L_bc z_c)
-                    if b > 0:
-                        ops.gemv(akk[b * 128:(b + 1) * 128, :b * 128], zk[:b * 128], w[b * 128:(b + 1) * 128], -1.0, 1.0)
-                    ops.gemv(self.dinv[k][b], w[b * 128:(b + 1) * 128], zk[b * 128:(b + 1) * 128], 1.0, 0.0)
+                ops.trsv(self.tile(k, k), self.dinv[k], w, zk)    # z_k = L_kk^-1 w, one chained launch
                 acc += (zk * zk).sum()
             if pc == kc:
                 if Pr > 1 and self.live:

@@ -230,6 +230,11 @@ int gh_dev_kmat_block(gh_kernel* k, const double* x, int64_t n, int32_t ndim, co
 /* y = beta*y + alpha * A x (trans == 0; A is m x n row-major) or alpha * A^T x (trans != 0) */
 int gh_dev_gemv(const double* a, int64_t lda, int64_t m, int64_t n, int32_t trans,
                 const double* x, double* y, double alpha, double beta, void* stream);
+/* z = L^-1 w for the n x n lower-triangular block `l` factored by gh_dev_potrf_block (`dinv` = its
+ * diagonal-block inverses): one chained launch (gh_chol.hip, trsv_fwd_chain).  `scratch` needs
+ * (n/128 + 1) * 4 bytes of device memory, zeroed here.  w is read only. */
+int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* dinv, int64_t n,
+                      const double* w, double* z, void* scratch, void* stream);
 /* in-place lower Cholesky of the n x n block `a`; dinv receives the inverses of
  * its 128x128 diagonal blocks, (n/128) x 128 x 128; *info_dev (device int64) is
  * set to base_index + failing pivot (1-based) when not positive definite. */

@@ -66,6 +66,10 @@ class NumpyTileOps(object):
     def logdet_accum(self, a, out):
         out += 2.0 * torch.log(torch.diagonal(a)).sum()
 
+    def trsv(self, l, dinv, w, z):
+        import scipy.linalg
+        z.copy_(torch.from_numpy(scipy.linalg.solve_triangular(np.tril(l.numpy()), w.numpy(), lower=True)))
+
     def sync(self):
         pass
 
