@@ -232,7 +232,11 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(args.backend)
+        if args.backend == "nccl":
+            from george_amd.distributed import nccl_options
+            dist.init_process_group("nccl", pg_options=nccl_options())
+        else:
+            dist.init_process_group(args.backend)
         from george_amd.distributed import DistributedDenseJob
         job = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs)
         barrier = dist.barrier

@@ -32,7 +32,21 @@ import os
 
 import numpy as np
 
-__all__ = ["grid_shape", "HipTileOps", "BlockCyclicCholesky", "DistributedBasicSolver", "DistributedDenseJob"]
+__all__ = ["grid_shape", "nccl_options", "HipTileOps", "BlockCyclicCholesky", "DistributedBasicSolver", "DistributedDenseJob"]
+
+
+def nccl_options():
+    """ProcessGroupNCCL options that put RCCL's kernels on a high-priority stream (they share the
+    GPU with trailing-update GEMMs that fill every CU), or None when the backend is not nccl."""
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_backend() != "nccl":
+            return None
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:
+        return None
 
 
 def grid_shape(world):
@@ -173,10 +187,10 @@ class BlockCyclicCholesky(object):
         self.row_groups, self.col_groups = [None] * self.Pr, [None] * self.Pc
         if self.live and self.world > 1:
             for r in range(self.Pr):
-                g = dist.new_group([r * self.Pc + c for c in range(self.Pc)])
+                g = dist.new_group([r * self.Pc + c for c in range(self.Pc)], pg_options=nccl_options())
                 self.row_groups[r] = g
             for c in range(self.Pc):
-                g = dist.new_group([r * self.Pc + c for r in range(self.Pr)])
+                g = dist.new_group([r * self.Pc + c for r in range(self.Pr)], pg_options=nccl_options())
                 self.col_groups[c] = g
 
     # -- helpers ---------------------------------------------------------------------------------
