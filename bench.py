@@ -238,7 +238,10 @@ def main():
         import torch.distributed as dist
         if args.backend == "nccl":
             from george_amd.distributed import nccl_options
-            dist.init_process_group("nccl", pg_options=nccl_options())
+            try:
+                dist.init_process_group("nccl", pg_options=nccl_options())
+            except TypeError:
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.backend)
         from george_amd.distributed import DistributedDenseJob

@@ -49,6 +49,16 @@ def nccl_options():
         return None
 
 
+def _new_group(dist, ranks):
+    opts = nccl_options()
+    if opts is not None:
+        try:
+            return dist.new_group(ranks, pg_options=opts)
+        except (TypeError, RuntimeError):        # older signature / options rejected: plain group
+            pass
+    return dist.new_group(ranks)
+
+
 def grid_shape(world):
     """Pr x Pc with Pr <= Pc, as square as the world size allows."""
     pr = int(math.isqrt(world))
@@ -187,10 +197,10 @@ class BlockCyclicCholesky(object):
         self.row_groups, self.col_groups = [None] * self.Pr, [None] * self.Pc
         if self.live and self.world > 1:
             for r in range(self.Pr):
-                g = dist.new_group([r * self.Pc + c for c in range(self.Pc)], pg_options=nccl_options())
+                g = _new_group(dist, [r * self.Pc + c for c in range(self.Pc)])
                 self.row_groups[r] = g
             for c in range(self.Pc):
-                g = dist.new_group([r * self.Pc + c for r in range(self.Pr)], pg_options=nccl_options())
+                g = _new_group(dist, [r * self.Pc + c for r in range(self.Pr)])
                 self.col_groups[c] = g
 
     # -- helpers ---------------------------------------------------------------------------------
