@@ -283,6 +283,86 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* L, long ld, c
   if (tid < T) w[col0 + tid] -= part[0][tid] + part[1][tid];
 }
 
+// The backward sweep L^T x = z as one chained launch, the mirror image of trsv_fwd_chain: the
+// chain runs from the LAST block to the first, so workgroup w owns block column b = nt-1-w (its
+// predecessors in the chain then have smaller workgroup indices and are dispatched first).
+//   x_b = L_bb^-T ( z_b - sum_{j>b} L_jb^T x_j )
+// Wavefront v takes rows 16v..16v+15 of every block L_jb (row segments of 1 KiB, a lane two
+// columns), accumulates its lane's two columns of L_jb^T x_j over all j, and the eight wavefront
+// partials meet in LDS once, before the diagonal solve (same scheme again with L_bb^-1).
+__global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain(const double* L, long ld, const double* dinv, int nt,
+                                                                const double* zin, double* x, unsigned* flags, int* fail) {
+  __shared__ double red[8][T];
+  __shared__ double wv[T];
+  const int w = blockIdx.x, b = nt - 1 - w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long col0 = (long)b * T + 2 * lane;
+  double2 acc = make_double2(0.0, 0.0);
+  double2 dv[16], blk[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    dv[q] = *reinterpret_cast<const double2*>(dinv + (long)b * T * T + (wave * 16 + q) * T + 2 * lane);
+  if (b + 1 < nt) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      blk[q] = *reinterpret_cast<const double2*>(L + ((long)(nt - 1) * T + wave * 16 + q) * ld + col0);
+  }
+  for (int j = nt - 1; j > b; --j) {
+    if (tid == 0) {
+      const int dist = j - b;
+      const long long t0 = wall_clock64();
+      unsigned spins = 0;
+      while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 63u) == 0u) {
+          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); break; }
+        }
+      }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    // x_j[16 wave + q]: the same address for every lane of the wavefront (one broadcast load each)
+    double xr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      xr[q] = __hip_atomic_load(x + (long)j * T + wave * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc.x += blk[q].x * xr[q]; acc.y += blk[q].y * xr[q]; }
+    if (j - 1 > b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        blk[q] = *reinterpret_cast<const double2*>(L + ((long)(j - 1) * T + wave * 16 + q) * ld + col0);
+    }
+  }
+  red[wave][2 * lane] = acc.x;
+  red[wave][2 * lane + 1] = acc.y;
+  __syncthreads();
+  if (tid < T) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += red[q][tid];
+    wv[tid] = zin[(long)b * T + tid] - v;
+  }
+  __syncthreads();
+  acc = make_double2(0.0, 0.0);                         // x_b[c] = sum_r dinv_b[r][c] w[r]
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const double wr = wv[wave * 16 + q]; acc.x += dv[q].x * wr; acc.y += dv[q].y * wr; }
+  __syncthreads();
+  red[wave][2 * lane] = acc.x;
+  red[wave][2 * lane + 1] = acc.y;
+  __syncthreads();
+  if (tid < T) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += red[q][tid];
+    __hip_atomic_store(x + (long)b * T + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ========================================================= predict reductions
 // partial[s][c] = sum over the s-th row chunk of V[r][c] * z[r]  and of V[r][c]^2
 __global__ __launch_bounds__(256) void colreduce_kernel(const double* V, long ldv, long nrows, long rows_per,
@@ -773,6 +853,20 @@ static int trsv_forward(gh_chol* s, double* w, double* z) {
 // x = L^-T w  (w is destroyed)
 static int trsv_backward(gh_chol* s, double* w, double* x) {
   const int64_t nt = s->np / T;
+  static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;
+  if (!stepwise) {
+    GH_CHECK(s->chain.ensure((size_t)(nt + 1) * sizeof(unsigned)));
+    GH_HIP(hipMemsetAsync(s->chain.p, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
+    unsigned* flags = (unsigned*)s->chain.p;
+    hipLaunchKernelGGL(trsv_bwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, s->st,
+                       s->A.d(), (long)s->np, s->dinv.d(), (int)nt, w, x, flags, (int*)(flags + nt));
+    GH_HIP(hipGetLastError());
+    int failed = 0;
+    GH_HIP(hipMemcpyAsync(&failed, flags + nt, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    GH_HIP(hipStreamSynchronize(s->st));
+    if (failed) { gh_set_error("backward solve: a workgroup waited more than 2 s for its predecessor"); return GH_ERR_HIP; }
+    return GH_OK;
+  }
   for (int64_t j = nt - 1; j >= 0; --j) {
     hipLaunchKernelGGL(trsv_bwd_step, dim3((unsigned)(j + 1)), dim3(256), 0, s->st,
                        s->A.d(), (long)s->np, s->dinv.d() + j * T * T, (long)(j * T), w, x);
