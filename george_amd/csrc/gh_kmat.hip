@@ -233,6 +233,9 @@ struct KmatArgs {
   GhFast fast;             // affine single-leaf form (fast.ok) -> no interpreter, no node loads
 };
 
+// FAST: the kernel has the affine single-leaf form (a.fast): no interpreter in the instantiation
+// (half the registers), passes unrolled so that several exp() chains are in flight per lane.
+template <bool FAST>
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
   __shared__ double xr[KT * GH_MAX_NDIM];
   __shared__ double xc[KT * GH_MAX_NDIM];
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
   __syncthreads();
   const int lc = (threadIdx.x & 31) * 2;          // two adjacent columns per lane -> 16-B stores
   const int lr = threadIdx.x >> 5;                // 8 rows per pass
-#pragma unroll 1
+#pragma unroll FAST ? 4 : 1
   for (int pass = 0; pass < KT / 8; ++pass) {
     const int rr = lr + pass * 8;
     const long r = r0 + rr, c = c0 + lc;
@@ -272,8 +275,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
         const double* p2 = &xc[(lc + e) * nd];
         // symmetric build: evaluate k(x_min, x_max) as kernel_interface.cpp:68-74 does
         const bool swap = a.sym && (gr > gc);
-        double val = a.fast.ok ? gh_fast_value(a.fast, swap ? p2 : p1, swap ? p1 : p2)
-                               : gh_eval_value(a.prog, a.n_nodes, swap ? p2 : p1, swap ? p1 : p2);
+        double val = FAST ? gh_fast_value(a.fast, swap ? p2 : p1, swap ? p1 : p2)
+                          : gh_eval_value(a.prog, a.n_nodes, swap ? p2 : p1, swap ? p1 : p2);
         if (a.sym && a.yerr && gr == gc) { const double e2 = a.yerr[r]; val += e2 * e2; }   // basic.py:65
         v[e] = val;
       } else {
@@ -305,7 +308,8 @@ int gh_launch_kmat(const gh_kernel* k, const double* x1, int64_t n1, const doubl
   const long tm128 = (rows_p + 2 * KT - 1) / (2 * KT);
   long nblk = lower_only ? tm128 * (tm128 + 1) / 2 : tm * tn;
   if (nblk > 0x7fffffffL) { gh_set_error("kernel matrix too large"); return GH_ERR_BAD_ARG; }
-  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)nblk, lower_only ? 4 : 1), dim3(256), 0, st, a);
+  if (a.fast.ok) hipLaunchKernelGGL(kmat_kernel<true>, dim3((unsigned)nblk, lower_only ? 4 : 1), dim3(256), 0, st, a);
+  else           hipLaunchKernelGGL(kmat_kernel<false>, dim3((unsigned)nblk, lower_only ? 4 : 1), dim3(256), 0, st, a);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
