@@ -125,6 +125,7 @@ __device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoc
   return ok != 0;
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       int bestn = -1;
       const double* xi = x + (long)(row0 + i) * nd;
       for (int n = t0; n < n_cols; n += ts) {
-        double v = fast.ok ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
-                           : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
+        double v = FAST ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
+                        : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
         for (int k = 0; k < rank; ++k) v -= sh.coef[k] * Tcm[(long)k * N + col0 + n];
         Tcm[(long)rank * N + col0 + n] = v;
         const double a = fabs(v);
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     double un2 = 0.0;
     const double* xj = x + (long)(col0 + j) * nd;
     for (int m = t0; m < n_rows; m += ts) {
-      double u = fast.ok ? gh_fast_value(fast, x + (long)(row0 + m) * nd, xj)
-                         : gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
+      double u = FAST ? gh_fast_value(fast, x + (long)(row0 + m) * nd, xj)
+                      : gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
       for (int k = 0; k < rank; ++k) u -= sh.coef[k] * Tcm[(long)k * N + row0 + m];
       Tcm[(long)rank * N + row0 + m] = u;
       un2 += u * u;
@@ -721,10 +722,13 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     unsigned* d_bars = (unsigned*)aca_sync.p;
     int* d_sel = (int*)(d_bars + nn);
     int* d_fail = d_sel + nn;
-    hipLaunchKernelGGL(hodlr_aca_kernel, dim3(nn * G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
-                       h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p, (int*)L->d_ranks.p,
-                       h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,
-                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail);
+#define GH_ACA_LAUNCH(F)                                                                                          \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(),  \
+                       k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p,   \
+                       (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
+                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail)
+    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+#undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
     int aca_failed = 0;
     GH_HIP(hipMemcpyAsync(&aca_failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
