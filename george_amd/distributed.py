@@ -184,7 +184,15 @@ class BlockCyclicCholesky(object):
         # panel workspaces, double-buffered for the look-ahead pipeline
         cmax0 = max([len([j for j in range(1, self.nt) if j % self.Pc == self.pc and j % self.Pr == mm])
                      for mm in range(self.Pr)] + [1])
-        self.ws_row = [ops.zeros(nlr * nbk, nbk) for _ in range(2)]
+        # (padded so that a row panel splits into `world` equal chunks for the all-links exchange)
+        self._ws_row_flat = [ops.zeros(-(-(nlr * nbk * nbk) // self.world) * self.world) for _ in range(2)]
+        self.ws_row = [f[:nlr * nbk * nbk].view(nlr * nbk, nbk) for f in self._ws_row_flat]
+        mode = os.environ.get("GEORGE_AMD_DIST_ROWXCHG", "auto")
+        self.row_a2a = self.live and self.Pc > 1 and (mode == "a2a" or (mode == "auto" and self.Pr > 1))
+        if self.row_a2a:
+            nmax = -(-(self.nt // self.Pr + 1) * nbk * nbk // self.world)       # largest chunk of any process row
+            self.ws_relay = [ops.zeros(self.Pr * nmax) for _ in range(2)]
+            self.ws_fwd = [ops.zeros(self.world * nmax) for _ in range(2)]
         self.ws_send = [ops.zeros(cmax0, nbk, nbk) for _ in range(2)]
         self.ws_gath = [[ops.zeros(cmax0, nbk, nbk) for _ in range(self.Pr)] for _ in range(2)] if self.Pr > 1 else None
         self.info = ops.zeros(1, dtype=torch.int64)
@@ -252,6 +260,48 @@ class BlockCyclicCholesky(object):
                     todo.append(lambda i=i, j=j: self.ops.kmat(x, self.n, yerr, i * nb, nb, j * nb, nb, self.tile(i, j)))
         self._fanout(todo)
 
+    # -- row panel over ALL links ---------------------------------------------------------------------
+    def _row_exchange(self, k, buf):
+        """Every process row r has one rank (in process column k % Pc) holding that row's part of
+        panel k, S_r doubles, which the other Pc - 1 ranks of the row need.  A broadcast inside the
+        row moves S_r over ONE xGMI link per hop (ring) -- and this transfer sits on the critical
+        path of every step.  The node is a full mesh, so use the other rows' GPUs as relays:
+          phase 1  each holder scatters its panel in `world` equal chunks, chunk i to rank i;
+          phase 2  every rank forwards the chunk it got from row r's holder to the members of row r.
+        Both are one all_to_all_single on the world group (uneven splits, zeros where nothing
+        moves); every link then carries S_r / world per phase instead of S_r."""
+        W, Pr, Pc, nb = self.world, self.Pr, self.Pc, self.nb
+        kc = k % Pc
+        cnt = [len([i for i in range(k + 1, self.nt) if i % Pr == r]) for r in range(Pr)]
+        chunk = [-(-(c * nb * nb) // W) for c in cnt]                      # doubles per chunk, per process row
+        if max(chunk) == 0:
+            return
+        holder = [self.grank(r, kc) for r in range(Pr)]
+        mine = self._ws_row_flat[buf]
+        me, my_r = self.rank, self.pr
+        # phase 1: holders scatter
+        relay = self.ws_relay[buf][:sum(chunk)]
+        in1 = [chunk[my_r]] * W if me == holder[my_r] else [0] * W
+        out1 = [chunk[q // Pc] if q == holder[q // Pc] else 0 for q in range(W)]
+        src1 = mine[:chunk[my_r] * W] if me == holder[my_r] else mine[:0]
+        self.dist.all_to_all_single(relay, src1, output_split_sizes=out1, input_split_sizes=in1)
+        # phase 2: forward; the same chunk goes to every member of its row (all_to_all_single sends
+        # slices of ONE buffer, so the chunk is replicated per destination: an HBM copy)
+        off = [sum(chunk[:r]) for r in range(Pr)]
+        in2 = [chunk[d // Pc] if d != holder[d // Pc] else 0 for d in range(W)]
+        fwd = self.ws_fwd[buf][:sum(in2)]
+        pos = 0
+        for d in range(W):
+            if in2[d]:
+                r = d // Pc
+                fwd[pos:pos + in2[d]].copy_(relay[off[r]:off[r] + chunk[r]])
+                pos += in2[d]
+        if me == holder[my_r]:
+            out2, dst2 = [0] * W, mine[:0]
+        else:
+            out2, dst2 = [chunk[my_r]] * W, mine[:chunk[my_r] * W]
+        self.dist.all_to_all_single(dst2, fwd, output_split_sizes=out2, input_split_sizes=in2)
+
     # -- P(k): factor panel k and distribute it; returns (li0, wrow, {j: P_j}) -----------------------
     def _panel(self, k, buf):
         nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
@@ -277,7 +327,9 @@ class BlockCyclicCholesky(object):
             panel = self.A[li0 * nb:, lk * nb:(lk + 1) * nb]
             ops.trsm(self.Lkk, self.dinv[k], panel)
             wrow.copy_(panel)
-        if Pc > 1 and m > 0:
+        if self.row_a2a:
+            self._row_exchange(k, buf)                 # (world collective: every rank, every step)
+        elif Pc > 1 and m > 0:
             self._bcast(wrow, self.grank(pr, kc), self.row_groups[pr])
         # column panel: tiles P_j, j > k, j % Pc == pc, gathered inside my process column
         mine = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == pr]

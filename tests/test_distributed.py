@@ -82,11 +82,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, nb, q):
+def _worker(rank, world, port, n, nb, q, xchg="auto"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["GEORGE_AMD_DIST_ROWXCHG"] = xchg          # row-panel transport: broadcast in the row / all-links exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import george_amd.kernels as K
@@ -118,12 +119,13 @@ def _worker(rank, world, port, n, nb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nb", [(2, 700, 128), (4, 1100, 128), (2, 900, 256), (4, 513, 128), (8, 1300, 128)])
-def test_block_cyclic_cholesky_gloo(world, n, nb):
+@pytest.mark.parametrize("world,n,nb,xchg", [(2, 700, 128, "auto"), (4, 1100, 128, "auto"), (2, 900, 256, "a2a"),
+                                             (4, 513, 128, "bcast"), (8, 1300, 128, "auto"), (8, 900, 128, "bcast")])
+def test_block_cyclic_cholesky_gloo(world, n, nb, xchg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, q, xchg)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
