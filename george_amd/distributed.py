@@ -8,9 +8,10 @@ proceeds right-looking, one tile column per step:
   P(k) "panel"   1. the owner of the diagonal tile factors it (gh_dev_potrf_block) and broadcasts
                     L_kk and its diagonal-block inverses down its process column;
                  2. the ranks of that process column TRSM their panel tiles (gh_dev_trsm_right);
-                 3. the panel travels: a broadcast along every process row (the "row panel"), then
-                    an all-gather inside every process column of the tiles that column needs
-                    transposed (the "column panel");
+                 3. the panel travels: along every process row (the "row panel": from 4 ranks up as
+                    a scatter to ALL ranks + forward, so that every xGMI link carries 1/world of it
+                    -- `_row_exchange`; else a broadcast inside the row), then an all-gather inside
+                    every process column of the tiles that column needs transposed ("column panel");
   U(k) "update"  4. every rank updates its own trailing tiles with fp64-MFMA GEMMs (gh_dev_gemm).
 
 With look-ahead (default on GPUs) U(k) is split: the tiles of block column k+1 first, then P(k+1)
