@@ -213,7 +213,7 @@ def main():
                     help="N (north-star target config: 65536, 1-D ExpSquared); spell it --size under "
                          "torch.distributed.run, whose own parser trips over the abbreviation --n")
     ap.add_argument("--nb", type=int, default=0, help="outer panel width (0 = library default)")
-    ap.add_argument("--cpu-n", type=int, default=12288, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=20480, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true", help="single-stream factorisation (profiling aid)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary N=16384 (configs[1]) measurement")
