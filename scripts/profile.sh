@@ -25,7 +25,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel
 cd "$R"
 for d in trace64k trace64k_nola trace16k pmc_fetch pmc_write cal_fetch cal_write pmc_mfma; do
   f=$(find "$OUT/$d" -name "*.db" | head -1)
-  case $d in trace16k) TMIN=4;; trace64k*|pmc_fetch|pmc_write) TMIN=8;; *) TMIN="";; esac
+  case $d in trace16k) TMIN=8;; trace64k*|pmc_fetch|pmc_write) TMIN=8;; *) TMIN="";; esac
   if [ -n "$f" ]; then python scripts/summarize_prof.py "$f" "$OUT/$d.md" $TMIN; fi
 done
 python scripts/traffic_from_pmc.py "$(find $OUT/pmc_fetch -name '*.db' | head -1)" "$(find $OUT/pmc_write -name '*.db' | head -1)" 65536 1024 "$OUT/traffic_N65536.json"
