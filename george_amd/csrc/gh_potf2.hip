@@ -95,51 +95,73 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   __syncthreads();
 
   // ================================================================ phase 1: Cholesky
-  for (int jb = 0; jb < 8; ++jb) {
+  // (a) diagonal block jb: ONE wavefront, register-resident: lane i (mod 16) holds row i of the
+  //     block in 16 VGPR pairs, a column's pivot and multipliers travel by v_readlane (SGPR
+  //     broadcast), the j/k loops are fully unrolled so every register index is static.  (The
+  //     first MFMA version did this through volatile LDS round trips: ~1100 cycles per column.)
+  auto diag_factor = [&](int jb) {
     const int c0 = 16 * jb;
-    // (a) diagonal block: wavefront 0 only; LDS operations of one wavefront execute in program
-    //     order, `volatile` keeps the compiler from caching or reordering them
-    //     Register-resident: lane i (mod 16) holds row i of the block in 16 VGPR pairs, a column's
-    //     pivot and multipliers travel by v_readlane (SGPR broadcast), the j/k loops are fully
-    //     unrolled so every register index is static.  (The first MFMA version did this through
-    //     volatile LDS round trips: ~1100 cycles per column, a third of the kernel.)
-    if (wave == 0) {
-      const int i = lane & 15;
-      double a[16];
+    const int i = lane & 15;
+    double a[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = (k <= i) ? s[PK(c0 + i, c0 + k)] : 0.0;
+    for (int k = 0; k < 16; ++k) a[k] = (k <= i) ? s[PK(c0 + i, c0 + k)] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double d = bcast_lane(a[j], j);
-        if (!(d > 0.0)) {                       // also catches NaN (uniform: d is a broadcast)
-          if (lane == 0 && fail_at < 0) fail_at = c0 + j;
-          d = 1.0;
-        }
-        // sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 seed (~2^-23) + two Newton steps and a final
-        // correction each: half the dependent chain of sqrt() followed by a division
-        double y = __builtin_amdgcn_rsq(d);
-        const double hd = 0.5 * d;
-        y = fma(y, fma(-hd * y, y, 0.5), y);
-        y = fma(y, fma(-hd * y, y, 0.5), y);
-        double ajj = d * y;
-        ajj = fma(0.5 * y, fma(-ajj, ajj, d), ajj);
-        const double inv = fma(fma(-ajj, y, 1.0), y, y);
-        if (lane == 0) rdiag[c0 + j] = inv;
-        a[j] = (i == j) ? ajj : a[j] * inv;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-          const double lkj = bcast_lane(a[j], k);
-          a[k] -= a[j] * lkj;                   // meaningful for i >= k; other lanes' values are never stored
-        }
+    for (int j = 0; j < 16; ++j) {
+      double d = bcast_lane(a[j], j);
+      if (!(d > 0.0)) {                         // also catches NaN (uniform: d is a broadcast)
+        if (lane == 0 && fail_at < 0) fail_at = c0 + j;
+        d = 1.0;
       }
-      if (lane < 16) {
+      // sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 seed (~2^-23) + two Newton steps and a final
+      // correction each: half the dependent chain of sqrt() followed by a division
+      double y = __builtin_amdgcn_rsq(d);
+      const double hd = 0.5 * d;
+      y = fma(y, fma(-hd * y, y, 0.5), y);
+      y = fma(y, fma(-hd * y, y, 0.5), y);
+      double ajj = d * y;
+      ajj = fma(0.5 * y, fma(-ajj, ajj, d), ajj);
+      const double inv = fma(fma(-ajj, y, 1.0), y, y);
+      if (lane == 0) rdiag[c0 + j] = inv;
+      a[j] = (i == j) ? ajj : a[j] * inv;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k <= i) s[PK(c0 + i, c0 + k)] = a[k];
+      for (int k = j + 1; k < 16; ++k) {
+        const double lkj = bcast_lane(a[j], k);
+        a[k] -= a[j] * lkj;                     // meaningful for i >= k; other lanes' values are never stored
       }
     }
-    __syncthreads();
-    if (jb == 7) break;
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k <= i) s[PK(c0 + i, c0 + k)] = a[k];
+    }
+  };
+  // (c) one 16x16 tile of the trailing update for step jb: C(ti,tj) -= P_ti P_tj^T, K = 16
+  auto update_tile = [&](int jb, int ti, int tj) {                // ti >= tj > jb (absolute tile indices)
+    const int c0 = 16 * jb, R0 = 16 * ti, C0 = 16 * tj;
+    const int cc = C0 + (lane & 15);
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = R0 + (lane >> 4) + 4 * r;
+      acc[r] = (cc <= rr) ? s[PK(rr, cc)] : 0.0;
+    }
+    acc = tile_mma<4>(acc, 0, 4,
+                      [&](int i, int k) { return -s[PK(R0 + i, c0 + k)]; },
+                      [&](int k, int j) { return s[PK(C0 + j, c0 + k)]; }, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = R0 + (lane >> 4) + 4 * r;
+      if (cc <= rr) s[PK(rr, cc)] = acc[r];
+    }
+  };
+  // Software pipeline over the 16-column steps: the trailing update of step jb first brings tile
+  // column jb+1 up to date (all wavefronts), then wavefront 0 factors diagonal block jb+1 WHILE
+  // wavefronts 1-3 finish the rest of the update -- the one-wavefront diagonal step (a fifth of
+  // this kernel) no longer idles the other three.
+  if (wave == 0) diag_factor(0);
+  __syncthreads();
+  for (int jb = 0; jb < 7; ++jb) {
+    const int c0 = 16 * jb;
     // (b) panel rows below the diagonal block: solve x D^T = a, one row per thread
     {
       const int r = c0 + 16 + tid;
@@ -163,30 +185,19 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
       }
     }
     __syncthreads();
-    // (c) trailing update of the lower 16x16 tiles: C(ti,tj) -= P_ti P_tj^T, K = 16
-    {
-      const int m = 7 - jb;                       // tile rows/cols remaining
+    // (c1) tile column jb+1
+    for (int ti = jb + 1 + wave; ti < 8; ti += 4) update_tile(jb, ti, jb + 1);
+    __syncthreads();
+    // (a) of step jb+1  ||  (c2) the tiles right of column jb+1
+    if (wave == 0) {
+      diag_factor(jb + 1);
+    } else {
+      const int m = 6 - jb;                       // tile rows/cols right of column jb+1
       const int ntiles = m * (m + 1) / 2;
-      for (int e = wave; e < ntiles; e += 4) {
+      for (int e = wave - 1; e < ntiles; e += 3) {
         int ti = 0, acc_t = 0;
         while (acc_t + ti + 1 <= e) { acc_t += ti + 1; ++ti; }
-        const int tj = e - acc_t;
-        const int R0 = 16 * (jb + 1 + ti), C0 = 16 * (jb + 1 + tj);
-        const int cc = C0 + (lane & 15);
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = R0 + (lane >> 4) + 4 * r;
-          acc[r] = (cc <= rr) ? s[PK(rr, cc)] : 0.0;
-        }
-        acc = tile_mma<4>(acc, 0, 4,
-                          [&](int i, int k) { return -s[PK(R0 + i, c0 + k)]; },
-                          [&](int k, int j) { return s[PK(C0 + j, c0 + k)]; }, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = R0 + (lane >> 4) + 4 * r;
-          if (cc <= rr) s[PK(rr, cc)] = acc[r];
-        }
+        update_tile(jb, jb + 2 + ti, jb + 2 + (e - acc_t));
       }
     }
     __syncthreads();
