@@ -29,6 +29,10 @@
 #include <vector>
 #include "gh_common.h"
 
+// gh_potf2.hip: batched 128x128 Cholesky + inverse of the factor (block b at A + b*stride_a)
+int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
+                            int nbatch, hipStream_t st);
+
 #define HCH 128          // rows per reduce/update chunk
 #define CPASS 256        // columns handled per pass of an apply (also the cap on a level's rank)
 
@@ -298,9 +302,27 @@ __global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* n
 }
 
 // ======================================================================== leaves
+// pitch == 0: leaf b is stored size x size at leaves[b].off; pitch > 0: in a pitch x pitch slot at
+// b * pitch^2, identity-padded (the batched Cholesky path below wants 128 x 128 blocks)
 __global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x,
-                                        const double* yerr, const LeafDesc* leaves, double* Lf) {
+                                        const double* yerr, const LeafDesc* leaves, double* Lf, int pitch) {
   const LeafDesc lf = leaves[blockIdx.x];
+  if (pitch > 0) {
+    double* slot = Lf + (long)blockIdx.x * pitch * pitch;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < pitch * pitch; e += gridDim.y * blockDim.x) {
+      const int r = e / pitch, c = e % pitch;
+      double v = (r == c) ? 1.0 : 0.0;
+      if (r < lf.size && c < lf.size) {
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        const double* pa = x + (long)(lf.start + lo) * nd;
+        const double* pb = x + (long)(lf.start + hi) * nd;
+        v = fast.ok ? gh_fast_value(fast, pa, pb) : gh_eval_value(prog, n_prog, pa, pb);
+        if (r == c) { const double e2 = yerr[lf.start + r]; v += e2 * e2; }
+      }
+      slot[e] = v;
+    }
+    return;
+  }
   const long tot = (long)lf.size * lf.size;
   for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.y * blockDim.x) {
     const int r = (int)(e / lf.size), c = (int)(e % lf.size);
@@ -311,6 +333,14 @@ __global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, GhFast f
     if (r == c) { const double e2 = yerr[lf.start + r]; v += e2 * e2; }              // hodlr.h:125, _hodlr.cpp:76
     Lf[lf.off + e] = v;
   }
+}
+
+// out[b] = 2 * sum_i log L_ii of the b-th 128 x 128 factored slot (identity padding adds 0)
+__global__ __launch_bounds__(128) void hodlr_leaf_logdet_kernel(const double* Lf, double* out) {
+  __shared__ double sh[8];
+  const double* slot = Lf + (long)blockIdx.x * 128 * 128;
+  const double v = hw_block_sum(log(slot[threadIdx.x * 129]), sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * v;
 }
 
 // Batched in-place inverse by Gauss-Jordan with partial (row) pivoting; one workgroup per matrix
@@ -525,6 +555,7 @@ struct gh_hodlr {
   std::vector<HLevel*> levels;
   std::vector<LeafDesc> leaves;
   int Rtot = 0, max_leaf = 0, max_chunks = 0, maxR = 0;
+  int leaf_pitch = 0;            // row pitch of the stored leaf inverses
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work;
   ~gh_hodlr() {
     for (auto* l : levels) delete l;
@@ -595,7 +626,7 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
   if (C <= 0) return GH_OK;
   for (int cp = 0; cp < C; cp += CPASS) {
     const int cw = std::min(CPASS, C - cp);
-    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_jobs.p, (int)h->leaves.size(), h->max_leaf, h->leaf_inv.d(), h->max_leaf, 1,
+    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_jobs.p, (int)h->leaves.size(), h->max_leaf, h->leaf_inv.d(), h->leaf_pitch, 1,
                        X, ldx, xcol0 + cp, h->Y.d(), CPASS, 0, cw, false));
     const long tot = h->n * cw;
     hipLaunchKernelGGL(hodlr_copyrows_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65535)), dim3(256), 0, h->st,
@@ -808,13 +839,53 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
 
   // ---- leaves: exact blocks -> explicit inverses + log-dets (hodlr.h:223-227, 87-89)
   double logdet = 0.0;
+  static const bool leaf_gj = getenv("GEORGE_AMD_HODLR_LEAF_GJ") != nullptr;
+  if (h->max_leaf <= 128 && !leaf_gj) {
+    // Leaves are symmetric positive definite and fit the dense solver's 128 x 128 diagonal-block
+    // kernel: build them identity-padded into 128 x 128 slots, factor + invert the factors as ONE
+    // batched launch of potf2_inv_mfma_kernel (79 us per block, a workgroup each), log-det from the
+    // factor's diagonal, K^-1 = L^-T L^-1 as one batched product.  (Gauss-Jordan with pivoting, the
+    // general path below, spends 7 ms on the 2048 leaves of C4; this one ~1.5 ms.)
+    const int nl = (int)h->leaves.size();
+    const size_t slot = (size_t)128 * 128;
+    GhBuf linv, d_ld, d_info;
+    GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
+    GH_CHECK(linv.ensure(nl * slot * sizeof(double)));
+    GH_CHECK(d_ld.ensure(nl * sizeof(double)));
+    GH_CHECK(d_info.ensure(sizeof(long long)));
+    GH_HIP(hipMemsetAsync(d_info.p, 0, sizeof(long long), st));
+    GH_CHECK(upload(h->d_leaves, h->leaves, st));
+    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
+                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
+    GH_HIP(hipGetLastError());
+    GH_CHECK(gh_launch_potf2_batched(h->leaf_inv.d(), 128, (int64_t)slot, linv.d(), (int64_t)slot, (long long*)d_info.p, nl, st));
+    hipLaunchKernelGGL(hodlr_leaf_logdet_kernel, dim3(nl), dim3(128), 0, st, h->leaf_inv.d(), d_ld.d());
+    GH_HIP(hipGetLastError());
+    std::vector<MMJob> prod(nl), jobs(nl);
+    for (int i = 0; i < nl; ++i) {
+      prod[i] = {(long)(i * slot), i * 128, i * 128, 128, 128};                       // slot_i = Linv_i^T Linv_i
+      jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
+    }
+    GhBuf d_prod;
+    GH_CHECK(upload(d_prod, prod, st));
+    GH_CHECK(launch_mm(h, (const MMJob*)d_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
+    GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+    std::vector<double> lds(nl);
+    long long info = 0;
+    GH_HIP(hipMemcpyAsync(lds.data(), d_ld.p, nl * sizeof(double), hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(&info, d_info.p, sizeof(long long), hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    if (info != 0) { gh_set_error("HODLR: a leaf block is not positive definite"); return GH_ERR_NOT_PD; }
+    for (double v : lds) logdet += v;
+    h->leaf_pitch = 128;
+  } else {
   {
     const int nl = (int)h->leaves.size();
     const long tot = h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
     GH_CHECK(h->leaf_inv.ensure(tot * sizeof(double)));
     GH_CHECK(upload(h->d_leaves, h->leaves, st));
     hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
-                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d());
+                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 0);
     GH_HIP(hipGetLastError());
     std::vector<long> offs(nl);
     std::vector<int> sizes(nl);
@@ -852,6 +923,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       std::swap(h->leaf_inv.bytes, packed.bytes);
       GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
     }
+  }
+    h->leaf_pitch = h->max_leaf;
   }
 
   // ---- factorisation sweep (hodlr.h:75-103, level-batched): leaves into every U, then levels bottom-up

@@ -64,8 +64,13 @@ __device__ __forceinline__ v4d tile_mma(v4d acc, int kk0, int kk1, FA fa, FB fb,
   return acc;
 }
 
+// blockIdx.x selects the block of a batch (stride_a / stride_d doubles apart; 0 for the single
+// diagonal block of the dense factorisation): the HODLR leaves are factored and inverted this way.
 __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda, double* dinv,
-                                                             long long* info, long long base) {
+                                                             long long* info, long long base,
+                                                             long stride_a, long stride_d) {
+  A += (long)blockIdx.x * stride_a;
+  dinv += (long)blockIdx.x * stride_d;
   __shared__ double s[T * (T + 1) / 2];
   __shared__ double inv16[8 * 16 * IP];
   __shared__ double rdiag[T];                   // 1 / L_jj, written as the pivots are taken
@@ -289,8 +294,17 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   }
 }
 
+int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
+                            int nbatch, hipStream_t st) {
+  if (nbatch <= 0) return GH_OK;
+  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, dinv, info, 0LL,
+                     (long)stride_a, (long)stride_d);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
 int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, long long base, hipStream_t st) {
-  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info, base);
+  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info, base, 0L, 0L);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
