@@ -294,6 +294,36 @@ def test_full_size_c2_properties():
     assert gp3.log_likelihood(y) == ll                                   # deterministic
 
 
+def test_full_size_c3_properties():
+    """BASELINE config C3's single-GPU part (N=65536, 1-D Matern32, the 34-GB matrix): the same
+    size-independent properties, the residual on a sample of row blocks (the full K would be 34 GB
+    through PCIe)."""
+    n = 65536
+    x, yerr, y = zoo.bench_data(n)
+    amp = np.var(y)
+    kernel = amp * kernels.Matern32Kernel(1.0)
+    gp = GP(kernel)
+    gp.compute(x, yerr)
+    ll = gp.log_likelihood(y)
+    assert np.isfinite(ll)
+    alpha = gp.apply_inverse(y)
+    X = x[:, None]
+    res = 0.0
+    for s in (0, 20480, 43008, n - 1024):
+        Kc = kernel.get_value(X[s:s + 1024], X)
+        Kc[np.arange(1024), np.arange(s, s + 1024)] += yerr[s:s + 1024] ** 2
+        res = max(res, np.abs(Kc @ alpha - y[s:s + 1024]).max())
+    assert res < 1e-7, res
+    assert np.isclose(gp.solver.dot_solve(y), y @ alpha, rtol=1e-9)
+    c = 3.0
+    gp2 = GP((c * amp) * kernels.Matern32Kernel(1.0))
+    gp2.compute(x, np.sqrt(c) * yerr)
+    assert abs(gp2.solver.log_determinant - (gp.solver.log_determinant + n * np.log(c))) < 1e-6 * n
+    gp3 = GP(kernel)
+    gp3.compute(x, yerr)
+    assert gp3.log_likelihood(y) == ll                                   # deterministic
+
+
 @pytest.mark.parametrize("n", [130, 1000, 5000, 20000])
 def test_chained_forward_solve_repeatable(n):
     """The forward sweep is ONE launch whose workgroups hand z blocks to each other through flags
