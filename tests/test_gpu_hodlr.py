@@ -139,10 +139,10 @@ def test_mid_size_vs_dense_and_numpy_restatement(n, min_size):
         assert max(h.solver.ranks()) <= 2 * max(max(v) for v in o.root.ranks().values()) + 8
 
 
-def test_c4_shape_properties():
-    """BASELINE config C4 at reduced N (65536 here; 262144 is run by bench/hodlr_bench): residual
-    of the solve against an independent device mat-vec on a row sample, determinism."""
-    n = 65536
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_c4_shape_properties(n):
+    """BASELINE config C4 (N=262144, tol=1e-10) and a quarter of it: residual of the solve against
+    an independent device mat-vec on a row sample, determinism."""
     x, yerr, y = zoo.bench_data(n)
     kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
     gp = GP(kernel, solver=HODLRSolver, tol=1e-10)
