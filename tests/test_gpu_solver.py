@@ -339,3 +339,33 @@ def test_chained_forward_solve_repeatable(n):
         assert s.dot_solve(r) == first
     full = float(r @ s.apply_inverse(r))
     assert abs(first - full) <= 1e-10 * abs(full)
+
+
+def test_full_size_c5_properties():
+    """BASELINE config C5 at full size (N=32768, 3-D, Matern52 + Constant): the fused predict()
+    against its definition through independent entry points, grad_log_likelihood() against central
+    differences of log_likelihood()."""
+    n, m = 32768, 64
+    rng = np.random.RandomState(1234)
+    x = rng.uniform(0, 1, (n, 3))
+    x = x[np.argsort(x[:, 0])]
+    y = np.sin(x.sum(axis=1))
+    t = rng.uniform(0, 1, (m, 3))
+    kernel = kernels.Matern52Kernel(0.5, ndim=3) + kernels.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)
+    gp = GP(kernel)
+    gp.compute(x, 0.1)
+    mu, var = gp.predict(y, t, return_var=True)
+    alpha = gp.apply_inverse(y)
+    Kts = kernel.get_value(t, x)                                     # (m, n) through value_general
+    assert np.allclose(mu, Kts @ alpha, rtol=1e-9, atol=1e-11)
+    KinvKst = gp.apply_inverse(np.ascontiguousarray(Kts.T))          # (n, m): multi-RHS solve
+    var_def = kernel.get_value(t, diag=True) - np.sum(Kts.T * KinvKst, axis=0)     # gp.py:539
+    assert np.allclose(var, var_def, rtol=1e-7, atol=1e-12)
+    g = gp.grad_log_likelihood(y)
+    p0 = gp.get_parameter_vector()
+    eps = 1e-5
+    for i in range(len(p0)):
+        p = p0.copy(); p[i] += eps; gp.set_parameter_vector(p); fp = gp.log_likelihood(y)
+        p = p0.copy(); p[i] -= eps; gp.set_parameter_vector(p); fm = gp.log_likelihood(y)
+        assert abs((fp - fm) / (2 * eps) - g[i]) <= 1e-5 * max(1.0, abs(g[i])), (i, (fp - fm) / (2 * eps), g[i])
+    gp.set_parameter_vector(p0)
