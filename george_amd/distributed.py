@@ -196,6 +196,7 @@ class BlockCyclicCholesky(object):
             self.ws_fwd = [ops.zeros(self.world * nmax) for _ in range(2)]
         self.ws_send = [ops.zeros(cmax0, nbk, nbk) for _ in range(2)]
         self.ws_gath = [[ops.zeros(cmax0, nbk, nbk) for _ in range(self.Pr)] for _ in range(2)] if self.Pr > 1 else None
+        self.ws_next = [ops.zeros(nbk, nbk) for _ in range(2)]      # tile k+1 of the column panel, ahead of the gather
         self.info = ops.zeros(1, dtype=torch.int64)
         self.logdet_dev = ops.zeros(1)
         self.log_determinant = None
@@ -304,7 +305,7 @@ class BlockCyclicCholesky(object):
         self.dist.all_to_all_single(dst2, fwd, output_split_sizes=out2, input_split_sizes=in2)
 
     # -- P(k): factor panel k and distribute it; returns (li0, wrow, {j: P_j}) -----------------------
-    def _panel(self, k, buf):
+    def _panel(self, k, buf, mark=None):
         nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
         ops = self.ops
         nloc_r = len(self.rows)
@@ -332,6 +333,22 @@ class BlockCyclicCholesky(object):
             self._row_exchange(k, buf)                 # (world collective: every rank, every step)
         elif Pc > 1 and m > 0:
             self._bcast(wrow, self.grank(pr, kc), self.row_groups[pr])
+        # The next panel only waits for block column k+1, whose update needs ONE tile of the column
+        # panel, P_{k+1}: send that one ahead (a tile to the Pr - 1 column peers of the process
+        # column that owns block column k+1) and let `mark` record "enough for block column k+1";
+        # the gather of all the other tiles then runs while that block column is updated.
+        pj_fast = {}
+        if pc == (k + 1) % Pc:
+            nxt = self.ws_next[buf]
+            src_pr = (k + 1) % Pr
+            if pr == src_pr:
+                s0 = (self.lrow[k + 1] - li0) * nb
+                nxt.copy_(wrow[s0:s0 + nb])
+            if Pr > 1:
+                self._bcast(nxt, self.grank(src_pr, pc), self.col_groups[pc])
+            pj_fast[k + 1] = nxt
+        if mark is not None:
+            mark()
         # column panel: tiles P_j, j > k, j % Pc == pc, gathered inside my process column
         mine = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == pr]
         cnt = [len([j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]) for mm in range(Pr)]
@@ -351,13 +368,15 @@ class BlockCyclicCholesky(object):
                 js = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]
                 for t, j in enumerate(js):
                     pj[j] = gathered[mm][t]
-        return li0, wrow, pj
+        return li0, wrow, pj, pj_fast
 
     # -- U(k) restricted to the given global tile columns ---------------------------------------------
-    def _update(self, panel, cols):
+    def _update(self, panel, cols, fast=False):
+        """fast: `cols` is block column k+1 alone, served by the tile that travelled ahead."""
         if panel is None:
             return
-        li0, wrow, pj = panel
+        li0, wrow, pj_full, pj_fast = panel
+        pj = pj_fast if fast else pj_full
         nb, nloc_r = self.nb, len(self.rows)
         todo = []
         for j in cols:
@@ -398,18 +417,29 @@ class BlockCyclicCholesky(object):
         else:
             s_main, s_side = ops.main_stream(), ops.make_side_stream()
             ops.wait(s_side, ops.event(s_main))                    # the build is complete
+            ev = {}
+
+            def mark():
+                ev["fast"] = ops.event(s_side)
+
             with ops.on(s_side):
-                panel = self._panel(0, 0)
+                panel = self._panel(0, 0, mark)
                 done = ops.event(s_side)
             for k in range(nt):
-                ops.wait(s_main, done)                             # panel k is here
-                if k == nt - 1:
-                    break
-                self._update(panel, [j for j in self.cols if j == k + 1])       # block column k+1 first
+                fast = ev.get("fast")
+                if k == nt - 1 or fast is None:
+                    ops.wait(s_main, done)                         # (the last panel is a diagonal tile only)
+                    if k == nt - 1:
+                        break
+                else:
+                    ops.wait(s_main, fast)                         # row panel + tile k+1 of the column panel are here
+                self._update(panel, [j for j in self.cols if j == k + 1], fast=True)      # block column k+1 first
                 ops.wait(s_side, ops.event(s_main))
+                done_k = done
                 with ops.on(s_side):
-                    nxt = self._panel(k + 1, (k + 1) % 2)
+                    nxt = self._panel(k + 1, (k + 1) % 2, mark)
                     done = ops.event(s_side)
+                ops.wait(s_main, done_k)                           # the whole column panel of step k
                 self._update(panel, [j for j in self.cols if j > k + 1])       # the rest, under P(k+1)
                 panel = nxt
         # scalars: log-det and failure flag
