@@ -581,10 +581,11 @@ extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, doub
 // halve the number of look-ahead hand-overs, but put more work into the latency-bound panel chain.
 // Measured (bench.py --nb, after the chain work of this round): 1024 wins from N = 16384 up
 // (N = 16384: 36.5 vs 37.8 ms, N = 20480: 60.7 vs 63.3 ms, N = 65536: 1437 vs 1480 ms), 512 at
-// N = 8192 (11.5 vs 11.6 ms), 256 nowhere.
+// N = 8192 (10.9 vs 11.2 ms), 1024 again at N <= 4096 (4.95 vs 5.03 ms at 4096, 1.16 vs 1.26 ms
+// at 1024: the fewer hand-overs between the streams the better), 128 and 256 nowhere.
 static int64_t panel_width(const gh_chol* s) {
   if (s->opts.nb > 0) return s->opts.nb;
-  return s->np >= 12288 ? 1024 : 512;
+  return (s->np >= 12288 || s->np <= 4096) ? 1024 : 512;
 }
 
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
