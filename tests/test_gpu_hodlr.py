@@ -157,3 +157,23 @@ def test_c4_shape_properties(n):
     gp2 = GP(kernel, solver=HODLRSolver, tol=1e-10)
     gp2.compute(x, yerr)
     assert gp2.log_likelihood(y) == ll
+
+
+@pytest.mark.parametrize("leaf_gj", [False, True])
+def test_hodlr_not_positive_definite_leaf(leaf_gj):
+    """A leaf block that is not positive definite must surface as LinAlgError (what GP.compute
+    catches, gp.py:356) from the batched-Cholesky leaf path; the Gauss-Jordan path (general leaves)
+    only fails on exactly singular blocks, so there the answer just has to be finite or an error."""
+    n = 512 if not leaf_gj else 600                      # leaves of 128 rows (Cholesky path) / 150 rows (Gauss-Jordan)
+    x = np.linspace(0, 3, n)[:, None]
+    k = kernels.CosineKernel(log_period=0.0)             # rank-2 kernel: every leaf is singular
+    s = HODLRSolver(k, tol=1e-10)
+    if not leaf_gj:
+        with pytest.raises(np.linalg.LinAlgError):
+            s.compute(x, np.zeros(n))
+        assert not s.computed
+    else:
+        try:
+            s.compute(x, np.zeros(n))
+        except (np.linalg.LinAlgError, RuntimeError):
+            assert not s.computed
