@@ -33,15 +33,36 @@ static inline int64_t gh_round_up(int64_t v, int64_t m) { return (v + m - 1) / m
 // true when p is device (HBM) memory
 bool gh_is_device_ptr(const void* p);
 
+// Cache of released device blocks for TRANSIENT buffers.  hipMalloc / hipFree cost 20-100 us each
+// and hipFree synchronises the device; the HODLR compute() makes ~180 short-lived allocations
+// (per-level job tables, batched-inverse scratch), 6 of its 28 ms.  Pooled buffers hand their block
+// back to the cache instead; a later request takes the smallest cached block that fits (and is not
+// more than 4x too large).  Only for buffers whose users all run on ONE stream (a block may be
+// reused while the previous user's kernels are still queued -- stream order then protects it).
+void* gh_pool_acquire(size_t bytes, size_t* capacity);     // nullptr on allocation failure
+void gh_pool_release(void* p, size_t capacity);
+
 // RAII device buffer
 struct GhBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool pooled = false;           // release into / acquire from the block cache above
   ~GhBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  void release() {
+    if (!p) return;
+    if (pooled) gh_pool_release(p, bytes); else (void)hipFree(p);
+    p = nullptr; bytes = 0;
+  }
   int ensure(size_t nbytes) {
     if (nbytes <= bytes && p) return GH_OK;
     release();
+    if (pooled) {
+      size_t cap = 0;
+      p = gh_pool_acquire(nbytes ? nbytes : 8, &cap);
+      if (!p) { gh_set_error("hipMalloc of %zu bytes failed", nbytes); return GH_ERR_NOMEM; }
+      bytes = cap;
+      return GH_OK;
+    }
     hipError_t e = hipMalloc(&p, nbytes ? nbytes : 8);
     if (e != hipSuccess) { p = nullptr; gh_set_error("hipMalloc of %zu bytes failed: %s", nbytes, hipGetErrorString(e)); return GH_ERR_NOMEM; }
     bytes = nbytes;
@@ -49,6 +70,7 @@ struct GhBuf {
   }
   double* d() const { return (double*)p; }
 };
+struct GhPooledBuf : GhBuf { GhPooledBuf() { pooled = true; } };
 
 // copy `count` doubles from src (host or device) into device memory dst
 int gh_to_device(double* dst, const double* src, size_t count, hipStream_t st);

@@ -540,7 +540,7 @@ struct HNode { int start, size, half, level, is_leaf; };
 struct HLevel {
   std::vector<int> node_ids;
   int R = 0, off = 0, nchunks = 0;
-  GhBuf d_nodes, d_chunks, d_crange, d_red_jobs, d_upd_jobs, d_smul_jobs, d_ranks, sinv;
+  GhPooledBuf d_nodes, d_chunks, d_crange, d_red_jobs, d_upd_jobs, d_smul_jobs, d_ranks, sinv;   // (one stream: h->st)
   std::vector<int> ranks;
 };
 
@@ -650,7 +650,7 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
   std::vector<long> sc(nb);
   long tot = 0;
   for (int i = 0; i < nb; ++i) { sc[i] = tot; tot += sizes[i]; }
-  GhBuf d_offs, d_sizes, d_sc, d_sd, d_si, d_ld, d_fail;
+  GhPooledBuf d_offs, d_sizes, d_sc, d_sd, d_si, d_ld, d_fail;
   GH_CHECK(upload(d_offs, offs, h->st));
   GH_CHECK(upload(d_sizes, sizes, h->st));
   GH_CHECK(upload(d_sc, sc, h->st));
@@ -723,7 +723,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // ---- ACA level by level into column-major scratch, ranks back to the host
   const int rcap = h->opts.max_rank;
   const int nlev = (int)h->levels.size();
-  GhBuf Tcm, idx, aca_sync, aca_part;
+  GhPooledBuf Tcm, idx, aca_sync, aca_part;
   if (nlev > 0) {
     GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
     GH_CHECK(idx.ensure((size_t)n * sizeof(int)));
@@ -774,7 +774,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     h->maxR = std::max(h->maxR, L->R);
     // keep this level's factors in a compact buffer (rows of the whole range x R) until Rtot is known
     if (L->R > 0) {
-      levelB[l] = new GhBuf();
+      levelB[l] = new GhPooledBuf();
       GH_CHECK(levelB[l]->ensure((size_t)n * L->R * sizeof(double)));
       GH_HIP(hipMemsetAsync(levelB[l]->p, 0, (size_t)n * L->R * sizeof(double), st));
       hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, 8), dim3(256), 0, st, Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
@@ -848,7 +848,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // general path below, spends 7 ms on the 2048 leaves of C4; this one ~1.5 ms.)
     const int nl = (int)h->leaves.size();
     const size_t slot = (size_t)128 * 128;
-    GhBuf linv, d_ld, d_info;
+    GhPooledBuf linv, d_ld, d_info;
     GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
     GH_CHECK(linv.ensure(nl * slot * sizeof(double)));
     GH_CHECK(d_ld.ensure(nl * sizeof(double)));
@@ -866,7 +866,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       prod[i] = {(long)(i * slot), i * 128, i * 128, 128, 128};                       // slot_i = Linv_i^T Linv_i
       jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
     }
-    GhBuf d_prod;
+    GhPooledBuf d_prod;
     GH_CHECK(upload(d_prod, prod, st));
     GH_CHECK(launch_mm(h, (const MMJob*)d_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
     GH_CHECK(upload(h->d_leaf_jobs, jobs, st));

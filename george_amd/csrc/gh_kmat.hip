@@ -42,6 +42,56 @@ bool gh_is_device_ptr(const void* p) {
   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+// ------------------------------------------------------------------ block cache (gh_common.h)
+#include <map>
+#include <mutex>
+namespace {
+struct BlockCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks[16];      // per device, keyed by capacity
+  size_t cached_bytes[16] = {0};
+  static constexpr size_t kMaxCached = (size_t)8 << 30;   // per device; beyond it blocks are really freed
+};
+BlockCache g_cache;
+}
+void* gh_pool_acquire(size_t bytes, size_t* capacity) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    auto& m = g_cache.free_blocks[dev];
+    auto it = m.lower_bound(bytes);
+    if (it != m.end() && it->first <= 4 * bytes + 4096) {
+      void* p = it->second;
+      *capacity = it->first;
+      g_cache.cached_bytes[dev] -= it->first;
+      m.erase(it);
+      return p;
+    }
+  }
+  const size_t cap = (bytes + 255) & ~(size_t)255;
+  void* p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  *capacity = cap;
+  return p;
+}
+void gh_pool_release(void* p, size_t capacity) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    if (g_cache.cached_bytes[dev] + capacity <= BlockCache::kMaxCached) {
+      g_cache.free_blocks[dev].emplace(capacity, p);
+      g_cache.cached_bytes[dev] += capacity;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
 int gh_to_device(double* dst, const double* src, size_t count, hipStream_t st) {
   if (count == 0) return GH_OK;
   GH_HIP(hipMemcpyAsync(dst, src, count * sizeof(double),
