@@ -121,7 +121,8 @@ __device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoc
       if (wall_clock64() - t0 > 200000000LL || aca_ldi(fail)) { good = 0; break; }     // 100 MHz ticks: 2 s
     }
     if (!good) atomicExch(fail, 1);
-    __threadfence();
+    // (no acquire fence: everything another cluster member wrote is read with agent-scope atomic
+    //  loads, which go past this XCD's caches; a fence here would invalidate the L2 at every barrier)
     ok = good;
   }
   __syncthreads();
