@@ -451,10 +451,14 @@ __global__ __launch_bounds__(256) void hodlr_mm_kernel(MMArgs a) {
   const int m0 = blockIdx.y * 32;
   if (m0 >= job.m) return;
   const int c0 = blockIdx.z * 64, tid = threadIdx.x;
-  const int c = tid & 63, rq = tid >> 6;
-  double acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+  // 32 x 64 tile on the matrix pipe: wavefront w takes the 16-row block w & 1 and the two 16-column
+  // blocks 2 (w >> 1), 2 (w >> 1) + 1; operands are staged in LDS exactly as for the VALU loop this
+  // replaced (8 FMAs per staged element and lane -> 2 MFMAs per 4 k)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int bi = wave & 1, bj = 2 * (wave >> 1);
+  typedef double mm_v4d __attribute__((ext_vector_type(4)));
+  mm_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   const bool rfast = (a.a_rs == 1);
   for (int k0 = 0; k0 < job.kd; k0 += 32) {
 #pragma unroll
@@ -474,23 +478,24 @@ __global__ __launch_bounds__(256) void hodlr_mm_kernel(MMArgs a) {
       Bs[k * 64 + cc] = v;
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const double bv = Bs[k * 64 + c];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += As[(rq + 4 * j) * 33 + k] * bv;
+    for (int kk = 0; kk < 8; ++kk) {
+      const double av = As[(16 * bi + fr) * 33 + 4 * kk + fk];
+      const double b0 = Bs[(4 * kk + fk) * 64 + 16 * bj + fr];
+      const double b1 = Bs[(4 * kk + fk) * 64 + 16 * bj + 16 + fr];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
     }
     __syncthreads();
   }
-  if (c0 + c < a.C) {
+  // f64 MFMA C/D map: row = (lane >> 4) + 4 reg, col = lane & 15
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = m0 + rq + 4 * j;
-      if (r < job.m) {
-        double* o = a.O + (long)(job.o_row + r) * a.ldo + a.o_col0 + c0 + c;
-        *o = a.subtract ? (*o - acc[j]) : acc[j];
-      }
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 16 * bi + fk + 4 * r;
+    if (row >= job.m) continue;
+    double* o = a.O + (long)(job.o_row + row) * a.ldo + a.o_col0 + c0 + 16 * bj + fr;
+    if (c0 + 16 * bj + fr < a.C) o[0] = a.subtract ? (o[0] - acc0[r]) : acc0[r];
+    if (c0 + 16 * bj + 16 + fr < a.C) o[16] = a.subtract ? (o[16] - acc1[r]) : acc1[r];
   }
 }
 // Tsum[node][0:R] = sum of the partials of its half-1 chunks, [R:2R] = half-0 chunks (hodlr.h:247-249)
