@@ -191,6 +191,17 @@ class BlockCyclicCholesky(object):
         mode = os.environ.get("GEORGE_AMD_DIST_ROWXCHG", "auto")
         self.row_a2a = self.live and self.Pc > 1 and (mode == "a2a" or (mode == "auto" and self.Pr > 1))
         if self.row_a2a:
+            # capability probe: an uneven all_to_all_single (with empty slots) on the world group; a
+            # backend that cannot do it raises here on EVERY rank, and all fall back to the broadcast
+            try:
+                w = self.world
+                probe_in = ops.zeros(w - 1)
+                probe_out = ops.zeros(w - 1)
+                splits = [0 if q == self.rank else 1 for q in range(w)]
+                dist.all_to_all_single(probe_out, probe_in, output_split_sizes=splits, input_split_sizes=splits)
+            except (RuntimeError, NotImplementedError, TypeError):
+                self.row_a2a = False
+        if self.row_a2a:
             nmax = -(-(self.nt // self.Pr + 1) * nbk * nbk // self.world)       # largest chunk of any process row
             self.ws_relay = [ops.zeros(self.Pr * nmax) for _ in range(2)]
             self.ws_fwd = [ops.zeros(self.world * nmax) for _ in range(2)]
