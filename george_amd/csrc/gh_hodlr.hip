@@ -505,6 +505,7 @@ __global__ void hodlr_sum_kernel(const double* P, const int* crange /* [node][ha
   const int cb = crange[(node * 2 + half) * 2], ce = crange[(node * 2 + half) * 2 + 1];
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double v = 0.0;
+#pragma unroll 8                                  // (loads of 8 chunks in flight; the sum stays in chunk order)
     for (int ch = cb; ch < ce; ++ch) v += P[((long)ch * R + k) * Cp + c];
     Tsum[((long)node * 2 * R + row) * Cp + c] = v;
   }
@@ -529,12 +530,16 @@ __global__ void hodlr_copyrows_kernel(const double* Y, long ldy, double* X, long
     X[i * ldx + x_col0 + c] = Y[i * ldy + c];
   }
 }
+// out[blockIdx.x] = sum over this workgroup's contiguous slice of a[i] * b[i] (b == nullptr: of a[i]);
+// called twice: 256 slices, then one workgroup over the 256 partials -- fixed order, reproducible
 __global__ __launch_bounds__(256) void hodlr_dot_kernel(const double* a, const double* b, long n, double* out) {
   __shared__ double sh[4];
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   double v = 0.0;
-  for (long i = threadIdx.x; i < n; i += 256) v += a[i] * b[i];
+  for (long i = lo + threadIdx.x; i < hi; i += 256) v += b ? a[i] * b[i] : a[i];
   v = hw_block_sum(v, sh);
-  if (threadIdx.x == 0) out[0] = v;
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 __global__ void hodlr_eye_kernel(double* p, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -562,7 +567,7 @@ struct gh_hodlr {
   std::vector<LeafDesc> leaves;
   int Rtot = 0, max_leaf = 0, max_chunks = 0, maxR = 0;
   int leaf_pitch = 0;            // row pitch of the stored leaf inverses
-  GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work;
+  GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   ~gh_hodlr() {
     for (auto* l : levels) delete l;
     if (st) (void)hipStreamDestroy(st);
@@ -783,7 +788,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       levelB[l] = new GhPooledBuf();
       GH_CHECK(levelB[l]->ensure((size_t)n * L->R * sizeof(double)));
       GH_HIP(hipMemsetAsync(levelB[l]->p, 0, (size_t)n * L->R * sizeof(double), st));
-      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, 8), dim3(256), 0, st, Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
+      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, std::max(8, std::min(512, 2048 / nn))), dim3(256), 0, st, Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
                          (const int*)L->d_ranks.p, L->R, levelB[l]->d(), levelB[l]->d(), (long)L->R, 0);
       GH_HIP(hipGetLastError());
     }
@@ -986,7 +991,9 @@ extern "C" int gh_hodlr_dot_solve(gh_hodlr* h, const double* y, double* out) {
   GH_CHECK(gh_to_device(h->rhs.d(), y, (size_t)h->n, h->st));
   GH_CHECK(gh_to_device(h->work.d(), y, (size_t)h->n, h->st));
   GH_CHECK(solve_all(h, h->rhs.d(), 1, 1));
-  hipLaunchKernelGGL(hodlr_dot_kernel, dim3(1), dim3(256), 0, h->st, h->work.d(), h->rhs.d(), (long)h->n, h->scal.d());
+  GH_CHECK(h->dotp.ensure(256 * sizeof(double)));
+  hipLaunchKernelGGL(hodlr_dot_kernel, dim3(256), dim3(256), 0, h->st, h->work.d(), h->rhs.d(), (long)h->n, h->dotp.d());
+  hipLaunchKernelGGL(hodlr_dot_kernel, dim3(1), dim3(256), 0, h->st, h->dotp.d(), (const double*)nullptr, 256L, h->scal.d());
   GH_HIP(hipGetLastError());
   double v = 0.0;
   GH_HIP(hipMemcpyAsync(&v, h->scal.d(), sizeof(double), hipMemcpyDeviceToHost, h->st));
