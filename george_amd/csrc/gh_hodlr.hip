@@ -98,6 +98,10 @@ struct AcaShared {
   int shi[8];
   double coef[ACA_MAXR];
   int s_i;
+  // eight-candidates search (one-workgroup nodes)
+  int cand_k[8], cand_i[8], cand_tail[8], cand_bestn[8];
+  double cand_best[8];
+  unsigned long long cand_st[8];
 };
 __device__ __forceinline__ double aca_ld(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -134,7 +138,7 @@ template <bool FAST>
 __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
-    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail) {
+    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi) {
   __shared__ AcaShared sh;
   const int node = blockIdx.x / G, g = blockIdx.x % G;
   const LvlNode nodev = nodes[node];
@@ -159,7 +163,77 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     bool got = false;
     int j = -1;
     double pivot = 0.0;
-    while (remaining > 0) {
+    // One-workgroup nodes test EIGHT candidate rows per pass, one per wavefront.  Towards the end of
+    // a node's ACA every remaining row is below the 1e-14 threshold and the search walks through
+    // all of them before giving up (hodlr.h:159-191 does too): one row per pass made levels 8 and 9
+    // of C4 cost 2.6 ms for rank-3 blocks.  Same result as the one-by-one search: the candidates
+    // are drawn in the same order, the first that passes wins, and the draws after it are undone
+    // (row permutation and generator state restored).
+    while (multi && G == 1 && remaining > 0 && rank <= 32 && rank + 8 <= rcap) {
+      const int NC = remaining < 8 ? remaining : 8;
+      if (tid == 0) {
+        for (int c = 0; c < NC; ++c) {
+          st += 0x9E3779B97F4A7C15ull;
+          unsigned long long z = st;
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+          z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+          z ^= z >> 31;
+          const int k = (int)(z % (unsigned long long)(remaining - c));
+          sh.cand_k[c] = k;
+          sh.cand_i[c] = idx[row0 + k];
+          sh.cand_tail[c] = idx[row0 + remaining - c - 1];
+          idx[row0 + k] = sh.cand_tail[c];
+          sh.cand_st[c] = st;
+        }
+      }
+      __syncthreads();
+      const int lane = tid & 63, wave = tid >> 6;
+      if (wave < NC) {
+        const int i = sh.cand_i[wave];
+        double* cw = sh.coef + wave * 32;
+        for (int k = lane; k < rank; k += 64) cw[k] = Tcm[(long)k * N + row0 + i];
+        __builtin_amdgcn_s_waitcnt(0);                // (own wavefront's LDS writes, read back below)
+        __builtin_amdgcn_wave_barrier();
+        double best = -1.0;
+        int bestn = -1;
+        const double* xi = x + (long)(row0 + i) * nd;
+        for (int n = lane; n < n_cols; n += 64) {
+          double v = FAST ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
+                          : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
+          for (int k = 0; k < rank; ++k) v -= cw[k] * Tcm[(long)k * N + col0 + n];
+          Tcm[(long)(rank + wave) * N + col0 + n] = v;
+          const double a = fabs(v);
+          if (a > best) { best = a; bestn = n; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {          // largest value, smallest column on ties
+          const double ov = __shfl_down(best, off, 64);
+          const int oi = __shfl_down(bestn, off, 64);
+          if (ov > best || (ov == best && oi >= 0 && (bestn < 0 || oi < bestn))) { best = ov; bestn = oi; }
+        }
+        if (lane == 0) { sh.cand_best[wave] = best; sh.cand_bestn[wave] = bestn; }
+      }
+      __syncthreads();
+      int chosen = -1;
+      for (int c = 0; c < NC; ++c)
+        if (sh.cand_best[c] >= 1e-14) { chosen = c; break; }                           // hodlr.h:191
+      if (chosen < 0) { remaining -= NC; __syncthreads(); continue; }
+      if (tid == 0) {                                 // undo the draws after the chosen one, last first
+        for (int c = NC - 1; c > chosen; --c) {
+          idx[row0 + sh.cand_k[c]] = sh.cand_i[c];
+          idx[row0 + remaining - c - 1] = sh.cand_tail[c];
+        }
+      }
+      st = sh.cand_st[chosen];                        // (every thread keeps the generator state in step)
+      remaining -= chosen + 1;
+      j = sh.cand_bestn[chosen];
+      if (chosen > 0)
+        for (int n = tid; n < n_cols; n += nt) Tcm[(long)rank * N + col0 + n] = Tcm[(long)(rank + chosen) * N + col0 + n];
+      __syncthreads();
+      pivot = Tcm[(long)rank * N + col0 + j];
+      got = true;
+      break;
+    }
+    while (!got && remaining > 0) {
       if (g == 0 && tid == 0) {
         st += 0x9E3779B97F4A7C15ull;
         unsigned long long z = st;
@@ -764,11 +838,12 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     unsigned* d_bars = (unsigned*)aca_sync.p;
     int* d_sel = (int*)(d_bars + nn);
     int* d_fail = d_sel + nn;
+    static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
 #define GH_ACA_LAUNCH(F)                                                                                          \
     hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(),  \
                        k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p,   \
                        (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
-                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail)
+                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail, aca_multi)
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
