@@ -175,6 +175,16 @@ class _Node(object):
             self.children[1].solve(x)
         self._apply_inverse(x, 0)
 
+    def nodes(self, out=None, level=0):
+        """(level, start, size, rank) of every internal node in construction (pre-)order --
+        the same walk as oracle/hodlr_ref_driver.cpp ``nodes()``."""
+        out = [] if out is None else out
+        if not self.is_leaf:
+            out.append([level, self.start, self.size, self.rank])
+            for c in self.children:
+                c.nodes(out, level + 1)
+        return out
+
     def ranks(self, out=None, level=0):
         out = {} if out is None else out
         if not self.is_leaf:

@@ -12,8 +12,12 @@ Loads the *real* reference (dfm/george) for oracle pinning:
   plus the compiled ``kernel_interface``.  Only possible in the build
   container; returns ``None`` when ``/root/reference`` is absent.
 
-The reference's ``_hodlr`` extension cannot be built (Eigen submodule is
-empty), so it is replaced by a stub whose solver raises on construction.
+* ``load_hodlr()`` -- the reference's HODLR solver: its unmodified
+  ``include/george/hodlr.h`` compiled against ``oracle/mini_eigen`` behind
+  ``oracle/hodlr_ref_driver.cpp`` (the reference's ``_hodlr.cpp`` needs the real
+  Eigen, an empty un-vendored submodule).  Installed as ``george.solvers._hodlr``
+  by ``load_reference()``, so the reference's own ``HODLRSolver`` Python class
+  (and its tests) run on it.
 """
 import glob
 import importlib.util
@@ -48,6 +52,21 @@ def load_kernel_interface():
     return mod.KernelInterface
 
 
+def load_hodlr():
+    """Return the ``HODLRSolver`` interface class of oracle/_ref/_hodlr (same methods as the
+    reference's ``george.solvers._hodlr.HODLRSolver`` plus ``nodes()``), or None if not built."""
+    if "_george_ref_hodlr" in sys.modules:
+        return sys.modules["_george_ref_hodlr"].HODLRSolver
+    hits = glob.glob(os.path.join(HERE, "_ref", "_hodlr*.so"))
+    if not hits:
+        return None
+    spec = importlib.util.spec_from_file_location("_hodlr", hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["_george_ref_hodlr"] = mod
+    return mod.HODLRSolver
+
+
 def load_reference():
     """Import the reference package as ``george`` (build container only)."""
     if "george" in sys.modules and getattr(sys.modules["george"], "_is_oracle_ref", False):
@@ -75,10 +94,10 @@ def load_reference():
 
     class _NoHODLR(object):
         def __init__(self, *a, **k):
-            raise ImportError("reference _hodlr needs Eigen (un-vendored submodule); not buildable here")
+            raise ImportError("oracle/_ref/_hodlr is not built (make -C oracle)")
 
     hod = types.ModuleType("george.solvers._hodlr")
-    hod.HODLRSolver = _NoHODLR
+    hod.HODLRSolver = load_hodlr() or _NoHODLR
     sys.modules["george.solvers._hodlr"] = hod
 
     spec.loader.exec_module(pkg)

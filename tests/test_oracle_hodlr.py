@@ -1,0 +1,122 @@
+"""Pin the HODLR oracle (CPU, no GPU).
+
+``oracle/_ref/_hodlr`` is the reference's own ``include/george/hodlr.h`` -- unmodified, compiled
+where it lies against ``oracle/mini_eigen`` (stand-in for the absent Eigen submodule) behind
+``oracle/hodlr_ref_driver.cpp`` -- so the mt19937 / ``uniform_int_distribution`` row draws, the
+accept / stop decisions, the ranks and the log-determinant are the reference's.  Its outputs on
+``zoo.hodlr_configs`` are committed as ``tests/golden/hodlr.npz`` (``oracle/gen_golden_hodlr.py``).
+The NumPy restatement ``oracle/hodlr_np.py`` is pinned to those, and -- where the shared object is
+present -- the shared object is checked against the goldens and the dense answer again."""
+import os
+
+import numpy as np
+import pytest
+
+import zoo
+from oracle import hodlr_np, ref_loader, solver_np
+import george_amd.kernels as AK
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = zoo.hodlr_configs(AK)
+# the exhausted-rows case is O(n^3) in the restatement too (rank 600 Woodbury cores): keep it, it is the point
+NAMES = list(CONFIGS)
+
+
+@pytest.fixture(scope="module")
+def golden_hodlr():
+    return np.load(os.path.join(ROOT, "tests", "golden", "hodlr.npz"))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_numpy_restatement_matches_reference_hodlr(name, golden_hodlr):
+    g = golden_hodlr
+    kernel, x, yerr, y, kw = CONFIGS[name]
+    o = hodlr_np.HODLROracle(kernel, force_port=True, **kw)
+    o.compute(np.ascontiguousarray(x.reshape(len(x), -1)), yerr)
+    ref_nodes = g[name + "/nodes"]
+    mine = np.array(o.root.nodes(), dtype=np.int64).reshape(-1, 4)
+    assert mine.shape == ref_nodes.shape
+    assert np.array_equal(mine[:, :3], ref_nodes[:, :3])                      # same tree
+    # same draw sequence => same ranks; a stop decision that sits within rounding of its threshold
+    # may flip (plain-loop sums here, LAPACK/BLAS sums there) and shifts the draws after it
+    drift = np.abs(mine[:, 3] - ref_nodes[:, 3])
+    assert drift.max(initial=0) <= 2 and (drift > 0).mean() <= 0.1, (name, mine[drift > 0], ref_nodes[drift > 0])
+    ld = float(g[name + "/logdet"])
+    assert abs(o.log_determinant - ld) <= 1e-9 * abs(ld)
+    a = o.apply_inverse(y)
+    # two rank-r approximations that differ in the last accepted term: error ~ tol * cond
+    rel = np.abs(a - g[name + "/alpha"]).max() / np.abs(g[name + "/alpha"]).max()
+    assert rel <= max(1e-6, 10 * kw["tol"]), (name, rel)
+
+
+def test_restatement_ranks_identical_away_from_threshold(golden_hodlr):
+    """Where no decision is marginal the whole rank list is reproduced exactly."""
+    for name in ("scaling2000_default", "C4_3000_tol1e-4_seed7", "m32_exhausted"):
+        kernel, x, yerr, y, kw = CONFIGS[name]
+        o = hodlr_np.HODLROracle(kernel, force_port=True, **kw)
+        o.compute(np.ascontiguousarray(x.reshape(len(x), -1)), yerr)
+        assert np.array_equal(np.array(o.root.nodes()), golden_hodlr[name + "/nodes"]), name
+
+
+def test_exhausted_rows_take_the_trivial_factorisation(golden_hodlr):
+    """hodlr.h:160-176: rank = min(n_rows, n_cols) at every internal node of this case."""
+    nodes = golden_hodlr["m32_exhausted/nodes"]
+    assert np.array_equal(nodes[:, 3], nodes[:, 2] // 2)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_build_reproduces_goldens(name, golden_hodlr):
+    H = ref_loader.load_hodlr()
+    if H is None:
+        pytest.skip("oracle/_ref/_hodlr not built")
+    kernel, x, yerr, y, kw = CONFIGS[name]
+    h = H()
+    h.compute(kernel, np.ascontiguousarray(x.reshape(len(x), -1)), yerr, **kw)   # OUR spec objects, the reference's parser
+    assert h.computed
+    assert np.array_equal(np.array(h.nodes(), dtype=np.int64).reshape(-1, 4), golden_hodlr[name + "/nodes"])
+    assert h.log_determinant == float(golden_hodlr[name + "/logdet"])
+    assert np.array_equal(h.apply_inverse(y)[:, 0], golden_hodlr[name + "/alpha"])
+
+
+def test_reference_build_against_dense_and_published_scalar():
+    H = ref_loader.load_hodlr()
+    if H is None:
+        pytest.skip("oracle/_ref/_hodlr not built")
+    # the reference's own criterion (tests/test_solvers.py:29-62)
+    kernel, x, yerr, y, kw = CONFIGS["solver1000"]
+    X = x[:, None]
+    h = H()
+    h.compute(kernel, X, yerr, **kw)
+    d = solver_np.DenseOracle(kernel)
+    d.compute(X, yerr)
+    assert np.allclose(h.log_determinant, d.log_determinant)
+    assert np.allclose(h.apply_inverse(y)[:, 0], d.apply_inverse(y))
+    K = solver_np.kernel_matrix(kernel, X)
+    K[np.diag_indices_from(K)] += yerr ** 2
+    assert np.allclose(h.apply_inverse(K), np.eye(len(x)))
+    assert np.allclose(h.get_inverse(), np.linalg.inv(K))
+    # docs/tutorials/scaling.rst:91 -- HODLR at N=100: 133.946394912
+    kernel, x, yerr, y = zoo.gp_configs(AK)["scaling100"]
+    h = H()
+    h.compute(kernel, x[:, None], np.sqrt(yerr ** 2 + 1.25e-12))                # gp.py:330 (default white noise)
+    ll = -0.5 * (len(x) * np.log(2 * np.pi) + h.log_determinant) - 0.5 * h.dot_solve(y)
+    assert abs(ll - 133.946394912) < 5e-9
+    with pytest.raises(RuntimeError):
+        H().dot_solve(y)                                                         # george::not_computed
+    with pytest.raises(RuntimeError):
+        h.compute(kernel, np.zeros((10, 3)), np.ones(10))                        # george::dimension_mismatch
+
+
+def test_reference_hodlr_python_class_runs_on_the_build():
+    """The reference's own ``george.solvers.hodlr.HODLRSolver`` on top of the build (container only)."""
+    george = ref_loader.load_reference()
+    if george is None or ref_loader.load_hodlr() is None:
+        pytest.skip("/root/reference not present (GPU box)")
+    x, yerr, y, amp = zoo.scaling_data(1500)
+    k = amp * george.kernels.ExpSquaredKernel(1.0)
+    gb = george.GP(k)
+    gb.compute(x, yerr)
+    gh = george.GP(k, solver=george.HODLRSolver, tol=1e-10)
+    gh.compute(x, yerr)
+    assert np.allclose(gb.log_likelihood(y), gh.log_likelihood(y))
+    assert np.allclose(gb.predict(y, x[:50], return_cov=False), gh.predict(y, x[:50], return_cov=False))

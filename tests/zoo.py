@@ -92,3 +92,32 @@ def gp_configs(K):
     x, yerr, y = bench_data(700, ndim=3)
     out["C5small"] = (K.Matern52Kernel(0.5, ndim=3) + K.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3), x, yerr, y)
     return out
+
+
+def hodlr_configs(K):
+    """HODLR cases: name -> (kernel, x, yerr, y, dict(min_size, tol, seed)).  Shapes follow the
+    reference's HODLR tests (tests/test_solvers.py:29-75, tests/test_gp.py HODLR parametrisations,
+    docs/tutorials/scaling.rst) and BASELINE config C4 at reduced size."""
+    out = {}
+    rng = np.random.RandomState(1234)
+    x = np.sort(10 * rng.randn(1000))
+    out["solver1000"] = (1.0 * K.ExpSquaredKernel(1.0), x, np.ones(1000), np.sin(x), dict(min_size=100, tol=1e-10, seed=42))
+    x, yerr, y, amp = scaling_data(2000)
+    out["scaling2000_default"] = (amp * K.ExpSquaredKernel(1.0), x, yerr, y, dict(min_size=100, tol=0.1, seed=42))
+    for n in (4096, 8192):
+        x, yerr, y = bench_data(n)
+        out["C4_%d" % n] = (np.var(y) * K.ExpSquaredKernel(1.0), x, yerr, y, dict(min_size=100, tol=1e-10, seed=42))
+    x, yerr, y = bench_data(3000)
+    out["C4_3000_tol1e-4_seed7"] = (np.var(y) * K.ExpSquaredKernel(1.0), x, yerr, y, dict(min_size=64, tol=1e-4, seed=7))
+    # exactly low-rank block (Matern-3/2 on sorted 1-D inputs is rank 2 off the diagonal): with a tight
+    # tolerance every remaining residual row falls under the 1e-14 pivot threshold, the reference runs
+    # out of rows and returns the exact block ("trivial factorisation", hodlr.h:160-176)
+    x, yerr, y = bench_data(1200)
+    out["m32_exhausted"] = (np.var(y) * K.Matern32Kernel(1.0), x, yerr, y, dict(min_size=100, tol=1e-8, seed=3))
+    # ranks grow with the dimension (docs/user/solvers.rst:40-42)
+    x, yerr, y = bench_data(2000, ndim=3)
+    out["c5like3d"] = (K.Matern52Kernel(0.5, ndim=3) + K.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3), x, yerr, y,
+                       dict(min_size=100, tol=1e-6, seed=42))
+    x, yerr, y = bench_data(2000, ndim=2)
+    out["expsq2d"] = (0.7 * K.ExpSquaredKernel([0.3, 0.5], ndim=2), x, yerr, y, dict(min_size=100, tol=1e-8, seed=11))
+    return out
