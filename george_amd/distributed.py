@@ -60,6 +60,48 @@ def _new_group(dist, ranks):
     return dist.new_group(ranks)
 
 
+# Sub-communicators and the all-to-all capability are a property of the process group, not of one
+# factorisation: `GP.compute` builds a new solver at every optimiser evaluation (gp.py:327), and a
+# `new_group` per call would leak RCCL communicators and pay their set-up plus the probe each time.
+# Keyed by (world, Pr, Pc); every rank creates every group, in the same order, exactly once.
+_GROUP_CACHE = {}
+
+
+def _grid_groups(dist, world, Pr, Pc):
+    key = (world, Pr, Pc, id(dist.group.WORLD))          # (a re-initialised process group gets fresh sub-groups)
+    hit = _GROUP_CACHE.get(key)
+    if hit is None:
+        rows = [_new_group(dist, [r * Pc + c for c in range(Pc)]) for r in range(Pr)]
+        cols = [_new_group(dist, [r * Pc + c for r in range(Pr)]) for c in range(Pc)]
+        hit = _GROUP_CACHE[key] = {"rows": rows, "cols": cols, "a2a": None}
+    return hit
+
+
+def _a2a_capable(dist, ops, cache, world, rank):
+    """Uneven all_to_all_single (with empty slots) on the world group; a backend that cannot do it
+    raises here on EVERY rank, and all fall back to the in-row broadcast.  Probed once per group set."""
+    if cache["a2a"] is None:
+        try:
+            probe_in = ops.zeros(max(world - 1, 1))
+            probe_out = ops.zeros(max(world - 1, 1))
+            splits = [0 if q == rank else 1 for q in range(world)]
+            dist.all_to_all_single(probe_out[:world - 1], probe_in[:world - 1], output_split_sizes=splits, input_split_sizes=splits)
+            cache["a2a"] = True
+        except (RuntimeError, NotImplementedError, TypeError):
+            cache["a2a"] = False
+    return cache["a2a"]
+
+
+def clear_caches():
+    """Forget cached sub-groups and solver workspaces (call before destroy_process_group)."""
+    _GROUP_CACHE.clear()
+    _CHOL_CACHE.clear()
+
+
+_CHOL_CACHE = {}          # (n, nb, world, rank, device, lookahead, group) -> [parked BlockCyclicCholesky workspaces]
+_CHOL_CACHE_MAX = 2       # parked workspaces in total
+
+
 def grid_shape(world):
     """Pr x Pc with Pr <= Pc, as square as the world size allows."""
     pr = int(math.isqrt(world))
@@ -110,6 +152,23 @@ class HipTileOps(object):
         self.N.check(self.N.lib.gh_dev_gemm(c.data_ptr(), c.stride(0), a.data_ptr(), a.stride(0), b.data_ptr(),
                                             b.stride(0), c.shape[0], c.shape[1], a.shape[1], -1.0, 1.0, 0, self._st()))
 
+    def gemm(self, c, a, b, alpha=1.0, beta=0.0, a_t=False, b_t=False):
+        """c = beta*c + alpha * op(a) @ op(b); all extents multiples of 128 (include/george_amd.h gh_dev_gemm:
+        its native operand form is A(m,k) row-major and B(n,k) row-major, i.e. ``a @ b.T``)."""
+        m, n = c.shape
+        k = a.shape[0] if a_t else a.shape[1]
+        flags = (1 if a_t else 0) | (0 if b_t else 2)          # GH_GEMM_A_MMAJOR | GH_GEMM_B_NMAJOR
+        self.N.check(self.N.lib.gh_dev_gemm(c.data_ptr(), c.stride(0), a.data_ptr(), a.stride(0), b.data_ptr(),
+                                            b.stride(0), m, n, k, float(alpha), float(beta), flags, self._st()))
+
+    def set_kernel(self, kernel_spec):
+        """Re-flatten the kernel (hyper-parameters change at every optimiser step; the ops object and
+        its streams are kept)."""
+        from .program import DeviceKernel
+        self.dk = DeviceKernel(kernel_spec)
+        if self.dk.ndim != self.ndim:
+            raise RuntimeError("dimension mismatch")
+
     def gemv(self, a, x, y, alpha, beta):
         """y = beta*y + alpha * a @ x"""
         self.N.check(self.N.lib.gh_dev_gemv(a.data_ptr(), a.stride(0), a.shape[0], a.shape[1], 0,
@@ -125,6 +184,19 @@ class HipTileOps(object):
             self._trsv_scratch = self.torch.zeros(n // 128 + 1, dtype=self.torch.int32, device=self.device)
         self.N.check(self.N.lib.gh_dev_trsv_lower(l.data_ptr(), l.stride(0), dinv.data_ptr(), n, w.data_ptr(), z.data_ptr(),
                                                   self._trsv_scratch.data_ptr(), self._st()))
+        # the chain's time-out flag sits behind the block flags and is cleared by the next call:
+        # fold it into an accumulator on the same stream, read back once per sweep (check_trsv)
+        if getattr(self, "_trsv_fail", None) is None:
+            self._trsv_fail = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
+        self._trsv_fail += self._trsv_scratch[n // 128:n // 128 + 1]
+
+    def check_trsv(self):
+        """Raise if a chained solve gave up waiting (its z would be garbage): the kernel sets the flag
+        after a 2 s stall."""
+        f = getattr(self, "_trsv_fail", None)
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            raise RuntimeError("george_amd HIP backend failure: forward solve: a workgroup waited more than 2 s for its predecessor")
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -189,18 +261,10 @@ class BlockCyclicCholesky(object):
         self._ws_row_flat = [ops.zeros(-(-(nlr * nbk * nbk) // self.world) * self.world) for _ in range(2)]
         self.ws_row = [f[:nlr * nbk * nbk].view(nlr * nbk, nbk) for f in self._ws_row_flat]
         mode = os.environ.get("GEORGE_AMD_DIST_ROWXCHG", "auto")
+        groups = _grid_groups(dist, self.world, self.Pr, self.Pc) if (self.live and self.world > 1) else None
         self.row_a2a = self.live and self.Pc > 1 and (mode == "a2a" or (mode == "auto" and self.Pr > 1))
         if self.row_a2a:
-            # capability probe: an uneven all_to_all_single (with empty slots) on the world group; a
-            # backend that cannot do it raises here on EVERY rank, and all fall back to the broadcast
-            try:
-                w = self.world
-                probe_in = ops.zeros(w - 1)
-                probe_out = ops.zeros(w - 1)
-                splits = [0 if q == self.rank else 1 for q in range(w)]
-                dist.all_to_all_single(probe_out, probe_in, output_split_sizes=splits, input_split_sizes=splits)
-            except (RuntimeError, NotImplementedError, TypeError):
-                self.row_a2a = False
+            self.row_a2a = _a2a_capable(dist, ops, groups, self.world, self.rank)
         if self.row_a2a:
             nmax = -(-(self.nt // self.Pr + 1) * nbk * nbk // self.world)       # largest chunk of any process row
             self.ws_relay = [ops.zeros(self.Pr * nmax) for _ in range(2)]
@@ -214,15 +278,11 @@ class BlockCyclicCholesky(object):
         self.computed = False
         self.profile = False          # record HIP events around every trailing update (bench.py roofline)
         self._upd = []                # (event before, event after, flops launched) per _update call
-        # sub-communicators: every rank creates every group, in the same order
+        self._tl = []                 # (step, [events: start, panel factored, row panel here, column panel here])
+        # sub-communicators (created once per process group, _grid_groups)
         self.row_groups, self.col_groups = [None] * self.Pr, [None] * self.Pc
-        if self.live and self.world > 1:
-            for r in range(self.Pr):
-                g = _new_group(dist, [r * self.Pc + c for c in range(self.Pc)])
-                self.row_groups[r] = g
-            for c in range(self.Pc):
-                g = _new_group(dist, [r * self.Pc + c for r in range(self.Pr)])
-                self.col_groups[c] = g
+        if groups is not None:
+            self.row_groups, self.col_groups = groups["rows"], groups["cols"]
 
     # -- helpers ---------------------------------------------------------------------------------
     def grank(self, pr, pc):
@@ -322,6 +382,8 @@ class BlockCyclicCholesky(object):
         nloc_r = len(self.rows)
         kr, kc = k % Pr, k % Pc
         in_col = (pc == kc)
+        timed = self.profile and getattr(ops, "has_streams", False)
+        tl = [ops.event(ops.main_stream(), timing=True)] if timed else None
         if pr == kr and in_col:
             akk = self.tile(k, k)
             ops.potrf(akk, self.dinv[k], self.info, k * nb)
@@ -340,6 +402,8 @@ class BlockCyclicCholesky(object):
             panel = self.A[li0 * nb:, lk * nb:(lk + 1) * nb]
             ops.trsm(self.Lkk, self.dinv[k], panel)
             wrow.copy_(panel)
+        if timed:
+            tl.append(ops.event(ops.main_stream(), timing=True))       # potrf + L_kk broadcast + column TRSM
         if self.row_a2a:
             self._row_exchange(k, buf)                 # (world collective: every rank, every step)
         elif Pc > 1 and m > 0:
@@ -358,6 +422,8 @@ class BlockCyclicCholesky(object):
             if Pr > 1:
                 self._bcast(nxt, self.grank(src_pr, pc), self.col_groups[pc])
             pj_fast[k + 1] = nxt
+        if timed:
+            tl.append(ops.event(ops.main_stream(), timing=True))       # row panel + tile k+1 have travelled
         if mark is not None:
             mark()
         # column panel: tiles P_j, j > k, j % Pc == pc, gathered inside my process column
@@ -379,6 +445,9 @@ class BlockCyclicCholesky(object):
                 js = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]
                 for t, j in enumerate(js):
                     pj[j] = gathered[mm][t]
+        if timed:
+            tl.append(ops.event(ops.main_stream(), timing=True))       # column panel gathered
+            self._tl.append((k, tl))
         return li0, wrow, pj, pj_fast
 
     # -- U(k) restricted to the given global tile columns ---------------------------------------------
@@ -405,6 +474,18 @@ class BlockCyclicCholesky(object):
             flops = sum(2.0 * (nloc_r - self._first_local_row_at_least(j)) * nb * nb * nb
                         for j in cols if self._first_local_row_at_least(j) < nloc_r)
             self._upd.append((e0, self.ops.event(self.ops.main_stream(), timing=True), flops))
+
+    def timeline(self):
+        """Per-step milliseconds on THIS rank since the last call (profile = True): the chain
+        potrf -> column TRSM ("panel"), row-panel transfer + tile sent ahead ("exchange"), column-panel
+        all-gather ("gather"), and the trailing updates ("update", from update_profile's events)."""
+        self.ops.sync()
+        steps = [{"k": k, "panel_ms": e[0].elapsed_time(e[1]), "exchange_ms": e[1].elapsed_time(e[2]),
+                  "gather_ms": e[2].elapsed_time(e[3])} for k, e in self._tl if len(e) == 4]
+        self._tl = []
+        return {"steps": len(steps), "panel_ms": sum(s["panel_ms"] for s in steps),
+                "exchange_ms": sum(s["exchange_ms"] for s in steps), "gather_ms": sum(s["gather_ms"] for s in steps),
+                "per_step": steps}
 
     def update_profile(self):
         """(milliseconds, flops, calls) of the trailing updates recorded since the last call."""
@@ -500,13 +581,122 @@ class BlockCyclicCholesky(object):
                 zloc[lk * nb:(lk + 1) * nb].copy_(zk)
         if self.live and self.world > 1:
             self.dist.all_reduce(acc)
+        if hasattr(ops, "check_trsv"):
+            ops.check_trsv()
         return float(acc.item())
 
 
+    # -- K^-1 B, L^-1 B, r @ L^T on the sharded factor ------------------------------------------------
+    def _tile_solve(self, k, blk, trans):
+        """blk (nb x rp) <- L_kk^-1 blk  (trans: L_kk^-T blk), blocked substitution over the 128-blocks
+        of the diagonal tile with their stored inverses -- GEMMs only."""
+        ops, nb = self.ops, self.nb
+        L, dinv = self.tile(k, k), self.dinv[k]
+        nq = nb // 128
+        tmp = ops.zeros(128, blk.shape[1])
+        order = range(nq) if not trans else range(nq - 1, -1, -1)
+        for q in order:
+            bq = blk[q * 128:(q + 1) * 128]
+            ops.gemm(tmp, dinv[q], bq, 1.0, 0.0, a_t=trans)
+            bq.copy_(tmp)
+            if not trans and q + 1 < nq:
+                ops.gemm(blk[(q + 1) * 128:], L[(q + 1) * 128:, q * 128:(q + 1) * 128], bq, -1.0, 1.0)
+            if trans and q > 0:
+                ops.gemm(blk[:q * 128], L[q * 128:(q + 1) * 128, :q * 128], bq, -1.0, 1.0, a_t=True)
+
+    def solve(self, B, forward=True, backward=True):
+        """B: (nt*nb x rp) right-hand sides, replicated on every rank (rp a multiple of 128); returns
+        L^-1 B, L^-T B or K^-1 B = L^-T L^-1 B, replicated.  Tile row k of the forward sweep:
+        the ranks of process row k % Pr fold their local tiles L[k, j<k] into a partial sum, reduced
+        onto the diagonal owner, which solves with L_kk and broadcasts Z_k to everybody; the backward
+        sweep mirrors it with the tile column (partials from process column k % Pc, L[i>k, k]^T X_i).
+        (basic.py:72-87: cho_solve = both sweeps.)"""
+        nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
+        ops, live = self.ops, self.live and self.world > 1
+        X = B.clone()
+        rp = X.shape[1]
+        part = ops.zeros(nb, rp)
+        if forward:
+            for k in range(nt):
+                kr, kc = k % Pr, k % Pc
+                owner = self.grank(kr, kc)
+                xk = X[k * nb:(k + 1) * nb]
+                if pr == kr:
+                    part.zero_()
+                    lk = self.lrow[k]
+                    for j in self.cols:
+                        if j < k:
+                            lj = self.lcol[j]
+                            ops.gemm(part, self.A[lk * nb:(lk + 1) * nb, lj * nb:(lj + 1) * nb], X[j * nb:(j + 1) * nb], 1.0, 1.0)
+                    if Pc > 1 and live:
+                        self.dist.reduce(part, dst=owner, group=self.row_groups[pr])
+                    if pc == kc:
+                        xk -= part
+                        self._tile_solve(k, xk, False)
+                if live:
+                    self.dist.broadcast(xk, src=owner)
+        if backward:
+            for k in range(nt - 1, -1, -1):
+                kr, kc = k % Pr, k % Pc
+                owner = self.grank(kr, kc)
+                xk = X[k * nb:(k + 1) * nb]
+                if pc == kc:
+                    part.zero_()
+                    lk = self.lcol[k]
+                    for i in self.rows:
+                        if i > k:
+                            li = self.lrow[i]
+                            ops.gemm(part, self.A[li * nb:(li + 1) * nb, lk * nb:(lk + 1) * nb], X[i * nb:(i + 1) * nb], 1.0, 1.0, a_t=True)
+                    if Pr > 1 and live:
+                        self.dist.reduce(part, dst=owner, group=self.col_groups[pc])
+                    if pr == kr:
+                        xk -= part
+                        self._tile_solve(k, xk, True)
+                if live:
+                    self.dist.broadcast(xk, src=owner)
+        return X
+
+    def apply_sqrt_t(self, Rt):
+        """Rt: (nt*nb x rp) = r^T, replicated; returns (r @ L^T)^T = L @ r^T, replicated
+        (basic.py:104-114 with U = L^T).  Tile row k: partial sums of L[k, j<=k] Rt_j over process row
+        k % Pr, reduced onto the diagonal owner and broadcast."""
+        nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
+        ops, live = self.ops, self.live and self.world > 1
+        out = ops.zeros(*Rt.shape)
+        part = ops.zeros(nb, Rt.shape[1])
+        for k in range(nt):
+            kr, kc = k % Pr, k % Pc
+            owner = self.grank(kr, kc)
+            if pr == kr:
+                part.zero_()
+                lk = self.lrow[k]
+                for j in self.cols:
+                    if j <= k:
+                        lj = self.lcol[j]
+                        t = self.A[lk * nb:(lk + 1) * nb, lj * nb:(lj + 1) * nb]
+                        if j == k:
+                            t = self.torch.tril(t)        # (the factorisation leaves the tile's upper 128-blocks untouched)
+                        ops.gemm(part, t, Rt[j * nb:(j + 1) * nb], 1.0, 1.0)
+                if Pc > 1 and live:
+                    self.dist.reduce(part, dst=owner, group=self.row_groups[pr])
+                if pc == kc:
+                    out[k * nb:(k + 1) * nb].copy_(part)
+            if live:
+                self.dist.broadcast(out[k * nb:(k + 1) * nb], src=owner)
+        return out
+
+
 class DistributedBasicSolver(object):
-    """Solver plugin with the BasicSolver protocol subset the log-likelihood needs
-    (``compute`` / ``log_determinant`` / ``dot_solve`` / ``computed``), sharded over the process
-    group.  ``GP(kernel, solver=DistributedBasicSolver, nb=512)`` works unchanged on every rank."""
+    """Solver plugin with the BasicSolver protocol (reference src/george/solvers/basic.py:51-121:
+    ``compute`` / ``log_determinant`` / ``computed`` / ``dot_solve`` / ``apply_inverse`` /
+    ``get_inverse`` / ``apply_sqrt``), sharded over the process group.
+    ``GP(kernel, solver=DistributedBasicSolver, nb=512)`` works unchanged on every rank; inputs and
+    results are replicated (every rank passes the same arrays and gets the same answers).
+
+    The block-cyclic workspace (local tiles, panel buffers, streams) is parked when a solver is
+    dropped and picked up by the next solver of the same (n, nb, world, device) -- `GP.compute`
+    makes a new solver at every optimiser evaluation -- and sub-communicators are created once per
+    process group."""
 
     def __init__(self, kernel, nb=512, device=None, ops=None, lookahead=None):
         self.kernel, self.nb = kernel, nb
@@ -516,18 +706,56 @@ class DistributedBasicSolver(object):
         self.computed = False
         self.log_determinant = None
 
-    def _make_ops(self):
-        if self._ops is not None:
-            return self._ops
+    def _get_chol(self, n):
+        import torch.distributed as dist
+        live = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if live else 1
+        rank = dist.get_rank() if live else 0
+        if self._ops is not None:                       # caller-supplied tile ops (CPU tests): no caching
+            return BlockCyclicCholesky(self._ops, n, self.nb, lookahead=self._lookahead)
         import torch
         dev = self._device if self._device is not None else torch.cuda.current_device()
-        return HipTileOps(dev, self.kernel)
+        key = (n, self.nb, world, rank, dev, self._lookahead, id(dist.group.WORLD) if live else 0)
+        if getattr(self, "_chol", None) is not None and self._key == key:
+            chol = self._chol                           # recompute on the same solver object
+        else:
+            self._release()
+            free = _CHOL_CACHE.get(key)
+            chol = free.pop() if free else None
+        if chol is None:
+            chol = BlockCyclicCholesky(HipTileOps(dev, self.kernel), n, self.nb, lookahead=self._lookahead)
+        else:
+            chol.ops.set_kernel(self.kernel)
+            chol.computed = False
+        self._key = key
+        return chol
+
+    def _release(self):
+        """Park the workspace for the next solver of the same shape (at most _CHOL_CACHE_MAX parked
+        workspaces in total; the rest is freed)."""
+        chol, key = getattr(self, "_chol", None), getattr(self, "_key", None)
+        self._chol = None
+        if chol is None or key is None or self._ops is not None:
+            return
+        try:
+            if sum(len(v) for v in _CHOL_CACHE.values()) < _CHOL_CACHE_MAX:
+                _CHOL_CACHE.setdefault(key, []).append(chol)
+        except Exception:
+            pass
+
+    def __del__(self):
+        self._release()
 
     def compute(self, x, yerr):
-        ops = self._make_ops()
         x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2:
+            raise ValueError("x must be (nsamples, ndim)")
         yerr = np.ascontiguousarray(np.zeros(len(x)) + yerr, dtype=np.float64)
-        self._chol = BlockCyclicCholesky(ops, len(x), self.nb, lookahead=self._lookahead)
+        self.computed = False
+        self._chol = self._get_chol(len(x))
+        ops = self._chol.ops
+        if x.shape[1] != ops.ndim:
+            raise RuntimeError("dimension mismatch")
         self._n = len(x)
         xd, ed = ops.to_device(x), ops.to_device(yerr)
         self._chol.build(xd, ed)
@@ -535,13 +763,56 @@ class DistributedBasicSolver(object):
         self.log_determinant = self._chol.log_determinant
         self.computed = True
 
-    def dot_solve(self, y):
-        if not self.computed:
+    def _need(self):
+        if not self.computed or getattr(self, "_chol", None) is None:
             raise RuntimeError("you must call 'compute' first")
-        ops = self._chol.ops
-        ypad = np.zeros(self._chol.nt * self._chol.nb)
+        return self._chol
+
+    def dot_solve(self, y):
+        chol = self._need()
+        ypad = np.zeros(chol.nt * chol.nb)
         ypad[:self._n] = np.asarray(y, dtype=np.float64).reshape(-1)
-        return self._chol.dot_solve(ops.to_device(ypad))
+        return chol.dot_solve(chol.ops.to_device(ypad))
+
+    def _padded(self, y2):
+        """(n, r) host array -> zero-padded (nt*nb, rp) device matrix, rp a multiple of 128"""
+        chol = self._chol
+        r = y2.shape[1]
+        buf = np.zeros((chol.nt * chol.nb, -(-r // 128) * 128))
+        buf[:self._n, :r] = y2
+        return chol.ops.to_device(buf)
+
+    def apply_inverse(self, y, in_place=False):
+        """basic.py:72-87: ``y`` is (n,) or (n, nrhs)."""
+        chol = self._need()
+        ya = np.asarray(y, dtype=np.float64)
+        if ya.ndim < 1 or ya.ndim > 2 or ya.shape[0] != self._n:
+            raise ValueError("dimension mismatch")
+        y2 = ya.reshape(self._n, -1)
+        if y2.shape[1] == 0:
+            return ya.copy()
+        X = chol.solve(self._padded(y2))
+        out = X[:self._n, :y2.shape[1]].cpu().numpy().reshape(ya.shape)
+        if in_place and isinstance(y, np.ndarray) and y.dtype == np.float64:
+            y[...] = out
+            return y
+        return np.ascontiguousarray(out)
+
+    def get_inverse(self):
+        """basic.py:116-121."""
+        return self.apply_inverse(np.eye(self._n), in_place=True)
+
+    def apply_sqrt(self, r):
+        """basic.py:104-114: ``r @ U`` with ``U^T U = K`` (U = L^T)."""
+        chol = self._need()
+        r = np.asarray(r, dtype=np.float64)
+        one_d = r.ndim == 1
+        r2 = r.reshape(1, -1) if one_d else r
+        if r2.shape[1] != self._n:
+            raise ValueError("dimension mismatch")
+        out = chol.apply_sqrt_t(self._padded(np.ascontiguousarray(r2.T)))
+        res = np.ascontiguousarray(out[:self._n, :r2.shape[0]].cpu().numpy().T)
+        return res[0] if one_d else res
 
 
 class DistributedDenseJob(object):
@@ -571,6 +842,7 @@ class DistributedDenseJob(object):
 
     def reset_profile(self):
         self.chol.update_profile()
+        self.chol.timeline()
 
     def close(self):
         pass

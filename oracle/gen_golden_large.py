@@ -20,6 +20,12 @@ Memory: the reference hands ``cholesky`` a C-contiguous K, which f2py copies int
 (68.7 GB at N=65536).  K is exactly symmetric (``kernel_interface.cpp:62-77`` writes both halves),
 so the Fortran-ordered *view* ``K.T`` holds the same values and the same ``dpotrf('U')`` runs in place.
 
+N = 65536: the whole-matrix ``dpotrf`` of this image's SciPy/OpenBLAS is broken at that size (silently
+wrong on a trivially SPD matrix, oracle/potrf_probe.py), i.e. the reference's ``basic.py:68`` cannot
+produce these numbers here at all; they come from the same LAPACK/BLAS routines applied to
+8192-column blocks (``blocked_cholesky_lower``; bit-identical log-likelihood to the whole-matrix call
+where both work, checked at N = 3000 with 512-column blocks).
+
     OPENBLAS_NUM_THREADS=6 python -m oracle.gen_golden_large [names...]
 """
 import json
@@ -44,6 +50,67 @@ TINY = 1.25e-12                      # src/george/gp.py:19
 def _save(res):
     with open(OUT, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
+
+
+def blocked_cholesky_lower(K, nb=8192):
+    """In-place lower Cholesky of the C-contiguous symmetric K by LAPACK/BLAS calls on blocks of at most
+    n x nb elements: dpotrf on the diagonal block, dtrsm on the rows below, dgemm on the trailing
+    block columns -- LAPACK's own right-looking blocked algorithm, written out.  Used where the
+    whole-matrix ``dpotrf`` of this image's OpenBLAS cannot be (see main())."""
+    from scipy.linalg import solve_triangular
+    n = len(K)
+    for k in range(0, n, nb):
+        e = min(k + nb, n)
+        Lkk = cholesky(K[k:e, k:e], lower=True, check_finite=False)
+        K[k:e, k:e] = Lkk
+        if e < n:
+            # P <- P L_kk^-T
+            K[e:, k:e] = solve_triangular(Lkk, K[e:, k:e].T, lower=True, check_finite=False).T
+            for j in range(e, n, nb):
+                je = min(j + nb, n)
+                K[j:, j:je] -= K[j:, k:e] @ K[j:je, k:e].T
+    return K
+
+
+def blocked_solve_lower(L, b, nb=8192, trans=False):
+    from scipy.linalg import solve_triangular
+    n = len(L)
+    x = np.array(b, dtype=np.float64, copy=True)
+    starts = list(range(0, n, nb))
+    if not trans:
+        for k in starts:
+            e = min(k + nb, n)
+            x[k:e] = solve_triangular(L[k:e, k:e], x[k:e], lower=True, check_finite=False)
+            if e < n:
+                x[e:] -= L[e:, k:e] @ x[k:e]
+    else:
+        for k in reversed(starts):
+            e = min(k + nb, n)
+            x[k:e] = solve_triangular(L[k:e, k:e], x[k:e], lower=True, trans=1, check_finite=False)
+            if k > 0:
+                x[:k] -= L[k:e, :k].T @ x[k:e]
+    return x
+
+
+def dense_case_blocked(kernel, x, yerr, y):
+    """Same quantities as dense_case() with the factorisation done block-wise."""
+    n = len(x)
+    x2 = np.ascontiguousarray(x.reshape(n, -1))
+    t0 = time.time()
+    K = kernel.get_value(x2)
+    t_build = time.time() - t0
+    K[np.diag_indices_from(K)] += yerr ** 2 + TINY
+    t0 = time.time()
+    L = blocked_cholesky_lower(K)
+    t_fac = time.time() - t0
+    logdet = 2 * np.sum(np.log(np.diag(L)))
+    z = blocked_solve_lower(L, y)
+    alpha = blocked_solve_lower(L, z, trans=True)
+    q = float(np.dot(y, alpha))
+    ll = -0.5 * (n * np.log(2 * np.pi) + logdet) - 0.5 * q
+    return {"n": n, "logdet": float(logdet), "loglike": float(ll), "quad": q,
+            "alpha_stride": max(n // 64, 1), "alpha": [float(v) for v in alpha[::max(n // 64, 1)]],
+            "seconds_build": t_build, "seconds_factor": t_fac, "factorisation": "blocked (dpotrf/dtrsm/dgemm on 8192-column blocks)"}
 
 
 def dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=False, t=None):
@@ -110,7 +177,15 @@ def main():
             n, cls = {"C2": (16384, K.ExpSquaredKernel), "M32_20k": (20480, K.Matern32Kernel),
                       "NS": (65536, K.ExpSquaredKernel), "C3": (65536, K.Matern32Kernel)}[name]
             x, yerr, y = zoo.bench_data(n)
-            res[name] = dense_case(george, np.var(y) * cls(1.0), x, yerr, y)
+            if n >= 65536:
+                # basic.py:68 as written cannot be used at this size in this image: SciPy 1.15.3's
+                # whole-matrix dpotrf (OpenBLAS 0.3.28, 32-bit LAPACK ints, n*n = 2^32) is wrong for
+                # n = 65536 -- oracle/potrf_probe.py: A = I + 1e-3 * ones gives log|A| = 4.1759 instead
+                # of log(1 + 65.536) = 4.1977 and no error, and the ExpSquared matrix of this config
+                # "fails" at the 19425-th minor.  The same LAPACK/BLAS kernels are applied block-wise.
+                res[name] = dense_case_blocked(np.var(y) * cls(1.0), x, yerr, y)
+            else:
+                res[name] = dense_case(george, np.var(y) * cls(1.0), x, yerr, y)
         res[name]["seconds_total"] = time.time() - t0
         res[name]["generator"] = "oracle/gen_golden_large.py (reference C++ evaluator + scipy %s LAPACK)" % (
             __import__("scipy").__version__)

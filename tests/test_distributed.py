@@ -60,6 +60,11 @@ class NumpyTileOps(object):
     def gemm_nt(self, c, a, b):
         c -= a @ b.T
 
+    def gemm(self, c, a, b, alpha=1.0, beta=0.0, a_t=False, b_t=False):
+        A = a.T if a_t else a
+        B = b.T if b_t else b
+        c.copy_(beta * c + alpha * (A @ B) if beta != 0.0 else alpha * (A @ B))
+
     def gemv(self, a, x, y, alpha, beta):
         y.copy_(beta * y + alpha * (a @ x) if beta != 0.0 else alpha * (a @ x))
 
@@ -99,6 +104,18 @@ def _worker(rank, world, port, n, nb, q, xchg="auto"):
         solver = DistributedBasicSolver(kernel, nb=nb, ops=NumpyTileOps(kernel))
         solver.compute(x[:, None], 0.1)
         quad = solver.dot_solve(y)
+        # the rest of the solver protocol on the sharded factor (basic.py:72-121)
+        Y3 = np.stack([y, np.cos(3 * x), x ** 2], axis=1)
+        alpha = solver.apply_inverse(y)
+        alpha3 = solver.apply_inverse(Y3)
+        sq = solver.apply_sqrt(Y3.T.copy())
+        inv = solver.get_inverse() if n <= 900 else None
+        # a second solver of the same shape picks up the parked workspace / cached sub-groups
+        from george_amd import distributed as D
+        ngroups = len(D._GROUP_CACHE)
+        again = DistributedBasicSolver(kernel, nb=nb, ops=NumpyTileOps(kernel))
+        again.compute(x[:, None], 0.1)
+        assert len(D._GROUP_CACHE) == ngroups and again.log_determinant == solver.log_determinant
         # every rank must hold the same scalars
         t = torch.tensor([solver.log_determinant, quad], dtype=torch.float64)
         lo, hi = t.clone(), t.clone()
@@ -114,7 +131,7 @@ def _worker(rank, world, port, n, nb, q, xchg="auto"):
             raised = True
         assert raised
         if rank == 0:
-            q.put((solver.log_determinant, quad, grid_shape(world)))
+            q.put((solver.log_determinant, quad, grid_shape(world), alpha, alpha3, sq, inv))
     finally:
         dist.destroy_process_group()
 
@@ -128,10 +145,16 @@ def test_block_cyclic_cholesky_gloo(world, n, nb, xchg):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, q, xchg)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
+    try:
+        # (read BEFORE joining: a child that has put large arrays cannot exit until they are consumed)
+        logdet, quad, grid, alpha, alpha3, sq, inv = q.get(timeout=600)
+    finally:
+        for p in procs:
+            p.join(120)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    logdet, quad, grid = q.get(timeout=10)
     assert grid == {2: (1, 2), 4: (2, 2), 8: (2, 4)}[world]
     # dense reference
     sys.path.insert(0, ROOT)
@@ -144,6 +167,13 @@ def test_block_cyclic_cholesky_gloo(world, n, nb, xchg):
     Kd = kernels_np.value_symmetric(kernel, x[:, None]) + 0.01 * np.eye(n)
     assert abs(logdet - np.linalg.slogdet(Kd)[1]) < 1e-8 * n
     assert abs(quad - y @ np.linalg.solve(Kd, y)) < 1e-8 * abs(quad)
+    Y3 = np.stack([y, np.cos(3 * x), x ** 2], axis=1)
+    assert alpha.shape == (n,) and np.allclose(alpha, np.linalg.solve(Kd, y), rtol=1e-8, atol=1e-10)
+    assert alpha3.shape == (n, 3) and np.allclose(alpha3, np.linalg.solve(Kd, Y3), rtol=1e-8, atol=1e-9)
+    U = np.linalg.cholesky(Kd).T                                     # basic.py:114: r @ U, U^T U = K
+    assert sq.shape == (3, n) and np.allclose(sq, Y3.T @ U, rtol=1e-9, atol=1e-10)
+    if inv is not None:
+        assert np.allclose(inv, np.linalg.inv(Kd), rtol=1e-7, atol=1e-9)
 
 
 def test_single_process_degenerate_grid():
@@ -162,3 +192,7 @@ def test_single_process_degenerate_grid():
     assert abs(s.log_determinant - np.linalg.slogdet(Kd)[1]) < 1e-8 * n
     y = np.cos(x)
     assert abs(s.dot_solve(y) - y @ np.linalg.solve(Kd, y)) < 1e-8
+    assert np.allclose(s.apply_inverse(y), np.linalg.solve(Kd, y), rtol=1e-9, atol=1e-11)
+    assert np.allclose(s.apply_sqrt(y), y @ np.linalg.cholesky(Kd).T, rtol=1e-10, atol=1e-12)
+    with pytest.raises(RuntimeError):
+        DistributedBasicSolver(kernel, nb=128, ops=NumpyTileOps(kernel)).apply_inverse(y)
