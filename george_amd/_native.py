@@ -111,6 +111,14 @@ SIGNATURES = {
     "gh_chol_get_inverse": (C.c_int, [_vp, _dp]),
     "gh_chol_predict": (C.c_int, [_vp, _vp, _dp, _dp, _i64, _dp, _dp, _dp]),
     "gh_chol_grad": (C.c_int, [_vp, _vp, _dp, _dp, _dp, _dp, _dp]),
+    "gh_chol_objective": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, _dp, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    _dp, _dp, _dp]),
+    "gh_chol_factor_size": (_i64, [_vp]),
+    "gh_chol_dinv_size": (_i64, [_vp]),
+    "gh_chol_export_factor": (C.c_int, [_vp, _dp, _dp]),
+    "gh_chol_import_factor": (C.c_int, [_vp, _i64, _i32, _dp, _dp, _dp, C.c_double]),
+    "gh_chol_trim": (None, [_vp]),
+    "gh_chol_release_buffers": (None, [_vp]),
     "gh_chol_get_profile": (C.c_int, [_vp, C.POINTER(gh_chol_profile)]),
     "gh_hodlr_create": (C.c_int, [C.POINTER(gh_hodlr_opts), C.POINTER(_vp)]),
     "gh_hodlr_destroy": (None, [_vp]),

@@ -132,6 +132,58 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* a, const double*
   if (threadIdx.x == 0) out[0] = v;
 }
 
+// Two-stage versions for long vectors: `part[g]` = the g-th contiguous slice, then one workgroup adds
+// the slices in index order (fixed order: bitwise reproducible).  One workgroup walking 65536
+// diagonal entries, each in its own cache line, took 195 us; the dot product 97 us.
+__global__ __launch_bounds__(256) void logdet_part_kernel(const double* A, long lda, long n, double* part) {
+  __shared__ double sh[4];
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double v = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) v += log(A[i * lda + i]);
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(256) void dot_part_kernel(const double* a, const double* b, long n, double* part) {
+  __shared__ double sh[4];
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double v = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) v += a[i] * b[i];
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+// out[0] (+)= scale * sum_{g < m} part[g], m <= 64, added in index order by one lane
+__global__ void reduce_final_kernel(const double* part, int m, double scale, double* out, int accumulate) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double v = 0.0;
+  for (int g = 0; g < m; ++g) v += part[g];
+  out[0] = (accumulate ? out[0] : 0.0) + scale * v;
+}
+#define RED_SLICES 64
+static int launch_logdet(const double* A, long lda, long n, double* out, double* part, hipStream_t st) {
+  const int g = (int)std::min<long>(RED_SLICES, (n + 2047) / 2048);
+  if (g <= 1) {
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out, 0);
+  } else {
+    hipLaunchKernelGGL(logdet_part_kernel, dim3(g), dim3(256), 0, st, A, lda, n, part);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, part, g, 2.0, out, 0);
+  }
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+static int launch_dot(const double* a, const double* b, long n, double* out, double* part, hipStream_t st) {
+  const int g = (int)std::min<long>(RED_SLICES, (n + 4095) / 4096);
+  if (g <= 1) {
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, a, b, n, out);
+  } else {
+    hipLaunchKernelGGL(dot_part_kernel, dim3(g), dim3(256), 0, st, a, b, n, part);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, part, g, 1.0, out, 0);
+  }
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
 // ======================================================== single-RHS solves
 // Forward step j of L z = y (right-looking).  Every workgroup recomputes
 // z_j = L_jj^-1 w_j from the current working vector w (128x128 mat-vec from L2), workgroup 0
@@ -762,8 +814,10 @@ static int factor(gh_chol* s) {
   return GH_OK;
 }
 
-extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
-                               const double* yerr, double* logdet_out) {
+// Everything of compute() up to and including the log-det launch, enqueued on s->st without a
+// host synchronisation; compute_finish() reads the scalars back.
+struct ComputeCtx { long e_all = -1, e_build = -1; };
+static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim, const double* yerr, ComputeCtx& c) {
   if (!s || !k || !x || !yerr || n <= 0) { gh_set_error("bad argument to compute"); return GH_ERR_BAD_ARG; }
   if (ndim != k->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
   GH_CHECK(set_device(s));
@@ -776,33 +830,31 @@ extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_
   GH_CHECK(s->dinv.ensure((size_t)(np / T) * T * T * sizeof(double)));
   GH_CHECK(s->x.ensure((size_t)n * ndim * sizeof(double)));
   GH_CHECK(s->yerr.ensure((size_t)n * sizeof(double)));
-  GH_CHECK(s->scal.ensure(64));
+  GH_CHECK(s->scal.ensure(256 * sizeof(double)));      // [0] log-det, [1] quadratic form, [8..72) and [72..136) slice sums
   hipStream_t st = s->st;
   memset(&s->prof, 0, sizeof(s->prof));
   s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear();
   const bool prof = s->opts.profile != 0;
-  const long e_all = prof ? s->next_ev() : -1;
-  const long e_build = prof ? s->next_ev() : -1;
-  if (e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_all].a, st));
+  c.e_all = prof ? s->next_ev() : -1;
+  c.e_build = prof ? s->next_ev() : -1;
+  if (c.e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_all].a, st));
   GH_CHECK(gh_to_device(s->x.d(), x, (size_t)n * ndim, st));
   GH_CHECK(gh_to_device(s->yerr.d(), yerr, (size_t)n, st));
   GH_HIP(hipMemsetAsync(s->d_info, 0, sizeof(long long), st));
-  if (e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_build].a, st));
+  if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].a, st));
   GH_CHECK(gh_launch_kmat(k, s->x.d(), n, s->x.d(), n, s->yerr.d(), s->A.d(), np, np, np, 0, 0, true, true, st));
-  if (e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_build].b, st));
+  if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].b, st));
   GH_CHECK(factor(s));
-  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, s->A.d(), (long)np, (long)np, s->scal.d(), 0);
-  GH_HIP(hipGetLastError());
-  if (e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[e_all].b, st));
-  double ld_host = 0.0;
-  long long info_host = 0;
-  GH_HIP(hipMemcpyAsync(&ld_host, s->scal.d(), sizeof(double), hipMemcpyDeviceToHost, st));
-  GH_HIP(hipMemcpyAsync(&info_host, s->d_info, sizeof(long long), hipMemcpyDeviceToHost, st));
-  GH_HIP(hipStreamSynchronize(st));
-  if (prof && e_all >= 0 && e_build >= 0) {
+  GH_CHECK(launch_logdet(s->A.d(), np, np, s->scal.d(), s->scal.d() + 8, st));
+  if (c.e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_all].b, st));
+  return GH_OK;
+}
+// after the stream has been synchronised and logdet / info copied to the host
+static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long long info_host, double* logdet_out) {
+  if (s->opts.profile && c.e_all >= 0 && c.e_build >= 0) {
     float ms = 0;
-    GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[e_all].a, s->ev_pool[e_all].b)); s->prof.ms_total = ms;
-    GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[e_build].a, s->ev_pool[e_build].b)); s->prof.ms_build = ms;
+    GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[c.e_all].a, s->ev_pool[c.e_all].b)); s->prof.ms_total = ms;
+    GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[c.e_build].a, s->ev_pool[c.e_build].b)); s->prof.ms_build = ms;
     for (size_t i : s->ev_trailing) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_trailing += ms; }
     for (size_t i : s->ev_panel) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_panel += ms; }
   }
@@ -815,6 +867,19 @@ extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_
   s->computed = true;
   if (logdet_out) *logdet_out = ld_host;
   return GH_OK;
+}
+
+extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                               const double* yerr, double* logdet_out) {
+  ComputeCtx c;
+  GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
+  hipStream_t st = s->st;
+  double ld_host = 0.0;
+  long long info_host = 0;
+  GH_HIP(hipMemcpyAsync(&ld_host, s->scal.d(), sizeof(double), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipMemcpyAsync(&info_host, s->d_info, sizeof(long long), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipStreamSynchronize(st));
+  return compute_finish(s, c, ld_host, info_host, logdet_out);
 }
 
 static int need_computed(gh_chol* s) {
@@ -830,16 +895,19 @@ static int load_vec(gh_chol* s, GhBuf& buf, const double* src) {
   return gh_to_device(buf.d(), src, (size_t)s->n, s->st);
 }
 // z = L^-1 w  (w is destroyed)
-static int trsv_forward(gh_chol* s, double* w, double* z) {
+// (defer: enqueue only; the caller reads the time-out flag back itself, chain_fail_flag())
+static int trsv_forward(gh_chol* s, double* w, double* z, bool defer = false) {
   const int64_t nt = s->np / T;
   static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;       // A/B arm: one launch per block row
   if (!stepwise) {
-    GH_CHECK(s->chain.ensure((size_t)(nt + 1) * sizeof(unsigned)));
+    // forward and backward sweeps keep separate flag sets, [0, nt] and [nt + 1, 2 nt + 1]
+    GH_CHECK(s->chain.ensure((size_t)(2 * nt + 2) * sizeof(unsigned)));
     GH_HIP(hipMemsetAsync(s->chain.p, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
     unsigned* flags = (unsigned*)s->chain.p;
     hipLaunchKernelGGL(trsv_fwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, s->st,
                        s->A.d(), (long)s->np, s->dinv.d(), w, z, flags, (int*)(flags + nt));
     GH_HIP(hipGetLastError());
+    if (defer) return GH_OK;
     int failed = 0;
     GH_HIP(hipMemcpyAsync(&failed, flags + nt, sizeof(int), hipMemcpyDeviceToHost, s->st));
     GH_HIP(hipStreamSynchronize(s->st));
@@ -854,16 +922,17 @@ static int trsv_forward(gh_chol* s, double* w, double* z) {
   return GH_OK;
 }
 // x = L^-T w  (w is destroyed)
-static int trsv_backward(gh_chol* s, double* w, double* x) {
+static int trsv_backward(gh_chol* s, double* w, double* x, bool defer = false) {
   const int64_t nt = s->np / T;
   static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;
   if (!stepwise) {
-    GH_CHECK(s->chain.ensure((size_t)(nt + 1) * sizeof(unsigned)));
-    GH_HIP(hipMemsetAsync(s->chain.p, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
-    unsigned* flags = (unsigned*)s->chain.p;
+    GH_CHECK(s->chain.ensure((size_t)(2 * nt + 2) * sizeof(unsigned)));
+    unsigned* flags = (unsigned*)s->chain.p + (nt + 1);
+    GH_HIP(hipMemsetAsync(flags, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
     hipLaunchKernelGGL(trsv_bwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, s->st,
                        s->A.d(), (long)s->np, s->dinv.d(), (int)nt, w, x, flags, (int*)(flags + nt));
     GH_HIP(hipGetLastError());
+    if (defer) return GH_OK;
     int failed = 0;
     GH_HIP(hipMemcpyAsync(&failed, flags + nt, sizeof(int), hipMemcpyDeviceToHost, s->st));
     GH_HIP(hipStreamSynchronize(s->st));
@@ -887,8 +956,7 @@ extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
   const long e = s->opts.profile ? s->next_ev() : -1;
   if (e >= 0) GH_HIP(hipEventRecord(s->ev_pool[e].a, s->st));
   GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d()));
-  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s->st, s->v1.d(), s->v1.d(), (long)s->np, s->scal.d() + 1);
-  GH_HIP(hipGetLastError());
+  GH_CHECK(launch_dot(s->v1.d(), s->v1.d(), (long)s->np, s->scal.d() + 1, s->scal.d() + 72, s->st));
   if (e >= 0) GH_HIP(hipEventRecord(s->ev_pool[e].b, s->st));
   double v = 0.0;
   GH_HIP(hipMemcpyAsync(&v, s->scal.d() + 1, sizeof(double), hipMemcpyDeviceToHost, s->st));
@@ -1105,4 +1173,136 @@ extern "C" int gh_chol_grad(gh_chol* s, gh_kernel* k, const uint32_t* which, con
   if (diagA) GH_CHECK(gh_from_device(diagA, ddiag, (size_t)n, st));
   GH_HIP(hipStreamSynchronize(st));
   return GH_OK;
+}
+
+// ============================================================ fused objective
+// nll and its gradient (gp.py:470-480; the optimiser loop of docs/tutorials/hyper.rst:131-152) as
+// ONE call: build K -> factor -> log-det -> z = L^-1 r (used for r^T K^-1 r = |z|^2 AND, through
+// the backward sweep, for alpha) -> K^-1 -> 1/2 sum A_ij dK_ij/dtheta.  Nothing is synchronised
+// until the very end; only scalars and N-vectors reach the host.  `grad == NULL`: the
+// log-likelihood pieces only (compute + dot_solve without the second sweep and the inverse).
+extern "C" int gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                                 const double* yerr, const double* r, const uint32_t* which,
+                                 double* logdet, double* quad, double* grad, double* alpha, double* diagA) {
+  if (!r || !logdet || !quad) { gh_set_error("bad argument to objective"); return GH_ERR_BAD_ARG; }
+  if (grad && !which) { gh_set_error("objective: gradient requested without a parameter mask"); return GH_ERR_BAD_ARG; }
+  ComputeCtx c;
+  GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
+  hipStream_t st = s->st;
+  const int64_t np = s->np, nt = np / T;
+  const bool want_alpha = grad || alpha || diagA;
+  GH_CHECK(load_vec(s, s->v0, r));
+  GH_CHECK(s->v1.ensure((size_t)np * sizeof(double)));
+  GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d(), true));
+  GH_CHECK(launch_dot(s->v1.d(), s->v1.d(), (long)np, s->scal.d() + 1, s->scal.d() + 72, st));
+  double* dgrad = nullptr;
+  double* ddiag = nullptr;
+  if (want_alpha) {
+    GH_CHECK(s->v2.ensure((size_t)np * sizeof(double)));
+    GH_CHECK(trsv_backward(s, s->v1.d(), s->v2.d(), true));                          // alpha (v1 is consumed)
+  }
+  if (grad || diagA) {
+    GH_CHECK(s->work.ensure((size_t)np * np * sizeof(double)));
+    GH_CHECK(s->work2.ensure((size_t)np * np * sizeof(double)));
+    GH_CHECK(inverse_lower(s, s->work.d(), s->work2.d()));
+    GH_CHECK(s->v0.ensure((size_t)std::max<int64_t>(np, GH_MAX_GRAD) * sizeof(double)));
+    dgrad = s->v0.d();
+    ddiag = s->v1.d();
+    static const uint32_t none[GH_MAX_GRAD] = {0};
+    GH_CHECK(gh_launch_kgrad_reduce(k, grad ? which : none, s->x.d(), n, s->v2.d(), s->work.d(), np, dgrad, ddiag, s->scratch, st));
+  }
+  static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;
+  double host[2] = {0.0, 0.0};
+  long long info_host = 0;
+  int fail_f = 0, fail_b = 0;
+  GH_HIP(hipMemcpyAsync(host, s->scal.d(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipMemcpyAsync(&info_host, s->d_info, sizeof(long long), hipMemcpyDeviceToHost, st));
+  if (!stepwise) {
+    const unsigned* flags = (const unsigned*)s->chain.p;
+    GH_HIP(hipMemcpyAsync(&fail_f, flags + nt, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (want_alpha) GH_HIP(hipMemcpyAsync(&fail_b, flags + (nt + 1) + nt, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  if (grad && k->size > 0) GH_CHECK(gh_from_device(grad, dgrad, (size_t)k->size, st));
+  if (alpha) GH_CHECK(gh_from_device(alpha, s->v2.d(), (size_t)n, st));
+  if (diagA) GH_CHECK(gh_from_device(diagA, ddiag, (size_t)n, st));
+  GH_HIP(hipStreamSynchronize(st));
+  GH_CHECK(compute_finish(s, c, host[0], info_host, logdet));
+  if (fail_f || fail_b) { gh_set_error("objective: a chained solve waited more than 2 s for its predecessor"); return GH_ERR_HIP; }
+  *quad = host[1];
+  return GH_OK;
+}
+
+// ============================================================ factor export / import
+// The reference's BasicSolver survives pickling COMPUTED (tests/test_pickle.py:21-36: its factor is a
+// NumPy array).  Here the factor lives in HBM, so it is packed on the device -- row i of the lower
+// triangle at offset i (i + 1) / 2, N (N + 1) / 2 doubles -- and copied out, together with the
+// inverses of the 128 x 128 diagonal blocks (Np / 128 x 128 x 128) that every solve multiplies by.
+__global__ void pack_lower_kernel(const double* A, long ld, long n, double* out) {
+  const long i = blockIdx.x;
+  const double* row = A + i * ld;
+  double* o = out + i * (i + 1) / 2;
+  for (long j = threadIdx.x; j <= i; j += blockDim.x) o[j] = row[j];
+}
+__global__ void unpack_lower_kernel(const double* in, long n, double* A, long ld, long np) {
+  const long i = blockIdx.x;                     // row of the padded matrix
+  double* row = A + i * ld;
+  if (i < n) {
+    const double* src = in + i * (i + 1) / 2;
+    for (long j = threadIdx.x; j < np; j += blockDim.x) row[j] = (j <= i) ? src[j] : 0.0;
+  } else {
+    for (long j = threadIdx.x; j < np; j += blockDim.x) row[j] = (j == i) ? 1.0 : 0.0;      // identity padding
+  }
+}
+extern "C" int64_t gh_chol_factor_size(const gh_chol* s) { return s ? s->n * (s->n + 1) / 2 : 0; }
+extern "C" int64_t gh_chol_dinv_size(const gh_chol* s) { return s ? (s->np / T) * T * T : 0; }
+extern "C" int gh_chol_export_factor(gh_chol* s, double* packed_lower, double* dinv_out) {
+  GH_CHECK(need_computed(s));
+  if (!packed_lower || !dinv_out) { gh_set_error("null output"); return GH_ERR_BAD_ARG; }
+  const int64_t n = s->n, np = s->np;
+  const size_t cnt = (size_t)n * (n + 1) / 2;
+  GH_CHECK(s->work.ensure(cnt * sizeof(double)));
+  hipLaunchKernelGGL(pack_lower_kernel, dim3((unsigned)n), dim3(256), 0, s->st, s->A.d(), (long)np, (long)n, s->work.d());
+  GH_HIP(hipGetLastError());
+  GH_CHECK(gh_from_device(packed_lower, s->work.d(), cnt, s->st));
+  GH_CHECK(gh_from_device(dinv_out, s->dinv.d(), (size_t)(np / T) * T * T, s->st));
+  GH_HIP(hipStreamSynchronize(s->st));
+  return GH_OK;
+}
+extern "C" int gh_chol_import_factor(gh_chol* s, int64_t n, int32_t ndim, const double* x, const double* packed_lower,
+                                     const double* dinv_in, double logdet) {
+  if (!s || n <= 0 || ndim <= 0 || !x || !packed_lower || !dinv_in) { gh_set_error("bad argument to import_factor"); return GH_ERR_BAD_ARG; }
+  GH_CHECK(set_device(s));
+  s->computed = false;
+  const int64_t np = gh_round_up(n, T);
+  s->n = n; s->np = np; s->ndim = ndim; s->info = 0;
+  const size_t cnt = (size_t)n * (n + 1) / 2;
+  GH_CHECK(s->A.ensure((size_t)np * np * sizeof(double)));
+  GH_CHECK(s->dinv.ensure((size_t)(np / T) * T * T * sizeof(double)));
+  GH_CHECK(s->x.ensure((size_t)n * ndim * sizeof(double)));
+  GH_CHECK(s->scal.ensure(256 * sizeof(double)));
+  GH_CHECK(s->work.ensure(cnt * sizeof(double)));
+  GH_CHECK(gh_to_device(s->x.d(), x, (size_t)n * ndim, s->st));
+  GH_CHECK(gh_to_device(s->work.d(), packed_lower, cnt, s->st));
+  GH_CHECK(gh_to_device(s->dinv.d(), dinv_in, (size_t)(np / T) * T * T, s->st));
+  hipLaunchKernelGGL(unpack_lower_kernel, dim3((unsigned)np), dim3(256), 0, s->st, s->work.d(), (long)n, s->A.d(), (long)np, (long)np);
+  GH_HIP(hipGetLastError());
+  GH_HIP(hipStreamSynchronize(s->st));
+  s->logdet = logdet;
+  s->computed = true;
+  return GH_OK;
+}
+extern "C" void gh_chol_release_buffers(gh_chol* s) {
+  // frees everything but the handle itself (streams, events); the next compute() re-allocates
+  if (!s) return;
+  (void)hipSetDevice(s->opts.device);
+  if (s->st) (void)hipStreamSynchronize(s->st);
+  s->computed = false;
+  for (GhBuf* b : {&s->A, &s->dinv, &s->x, &s->yerr, &s->v0, &s->v1, &s->v2, &s->rhs, &s->work, &s->work2, &s->scratch, &s->chain}) b->release();
+}
+extern "C" void gh_chol_trim(gh_chol* s) {
+  // frees the transient N x N / N x M work buffers of predict / grad / get_inverse, keeps the factor
+  if (!s) return;
+  (void)hipSetDevice(s->opts.device);
+  if (s->st) (void)hipStreamSynchronize(s->st);
+  for (GhBuf* b : {&s->rhs, &s->work, &s->work2, &s->scratch}) b->release();
 }

@@ -137,6 +137,18 @@ class GP(ModelSet):
     def _residual(self, y):
         return np.ascontiguousarray(self._check_dimensions(y) - self._call_mean(self._x), dtype=np.float64)
 
+    def _residual_quiet(self, y, quiet):
+        """Residual for the likelihood entry points: a wrongly shaped ``y`` ALWAYS raises; only a failing
+        mean function is silenced by ``quiet`` (gp.py:383-392).  Returns None when silenced."""
+        yv = self._check_dimensions(y)
+        try:
+            mu = self._call_mean(self._x)
+        except ValueError:
+            if quiet:
+                return None
+            raise
+        return np.ascontiguousarray(yv - mu, dtype=np.float64)
+
     def _compute_alpha(self, y, cache):
         if not cache:
             return self.solver.apply_inverse(self._residual(y), in_place=True).flatten()
@@ -180,12 +192,9 @@ class GP(ModelSet):
         """-1/2 r^T K^-1 r - 1/2 log|K| - N/2 log 2 pi   (gp.py:369-397)."""
         if not self.recompute(quiet=quiet):
             return -np.inf
-        try:
-            r = self._residual(y)
-        except ValueError:
-            if quiet:
-                return -np.inf
-            raise
+        r = self._residual_quiet(y, quiet)
+        if r is None:
+            return -np.inf
         ll = self._const - 0.5 * self.solver.dot_solve(r)
         return ll if np.isfinite(ll) else -np.inf
 
@@ -193,12 +202,9 @@ class GP(ModelSet):
         """Gradient wrt the unfrozen parameters, ordered mean | white_noise | kernel (gp.py:406-468)."""
         if not self.recompute(quiet=quiet):
             return np.zeros(len(self), dtype=np.float64)
-        try:
-            r = self._residual(y)
-        except ValueError:
-            if quiet:
-                return np.zeros(len(self), dtype=np.float64)
-            raise
+        r = self._residual_quiet(y, quiet)
+        if r is None:
+            return np.zeros(len(self), dtype=np.float64)
 
         n_wn, n_k = len(self.white_noise), len(self.kernel)
         fused = callable(getattr(self.solver, "grad", None))
@@ -215,7 +221,12 @@ class GP(ModelSet):
                 diagA = np.diag(A)
                 if n_k:
                     kgrad = 0.5 * np.einsum("ijk,ij", self.kernel.get_gradient(self._x), A)
+        return self._assemble_grad(alpha, diagA, kgrad, quiet)
 
+    def _assemble_grad(self, alpha, diagA, kgrad, quiet):
+        """mean | white_noise | kernel blocks of the gradient from alpha, diag(alpha alpha^T - K^-1) and
+        the kernel block (gp.py:443-466)."""
+        n_wn, n_k = len(self.white_noise), len(self.kernel)
         grad = np.empty(len(self))
         at = 0
         n_m = len(self.mean)
@@ -237,17 +248,104 @@ class GP(ModelSet):
             grad[at:at + n_k] = kgrad
         return grad
 
+    # -- the optimiser objective (gp.py:470-480; docs/tutorials/hyper.rst:131-152) ----------------
+    # ``minimize(gp.nll, p0, jac=gp.grad_nll, args=(y,))`` asks for the value and then the gradient at
+    # every iterate.  With a solver that offers ``objective`` (the HIP BasicSolver) each iterate is ONE
+    # fused device call -- build, factor, one forward solve shared by r^T K^-1 r and alpha, K^-1,
+    # gradient reduction, one synchronisation -- instead of compute + dot_solve + grad with the matrix
+    # factored twice (the reference marks the model dirty again when grad_nll re-sets the same vector):
+    # once a gradient has been asked for, ``nll`` computes it eagerly and ``grad_nll`` at the same
+    # (vector, y) returns it.  ``nll_and_grad`` is the explicit one-call form (``jac=True``).
+    def set_parameter_vector(self, vector, include_frozen=False):
+        if self._computed and self.solver is not None and not self.kernel.dirty:
+            v = np.asarray(vector, dtype=np.float64)
+            cur = self.get_parameter_vector(include_frozen=include_frozen)
+            if v.shape == cur.shape and np.array_equal(v, cur):
+                return                                  # same point: keep the factorisation
+        super(GP, self).set_parameter_vector(vector, include_frozen=include_frozen)
+
+    def _fused_capable(self):
+        return (callable(getattr(self.solver_type, "objective", None))
+                and hasattr(self, "_x") and hasattr(self, "_yerr2"))
+
+    def _objective(self, y, want_grad, quiet):
+        """(log-likelihood, gradient | None) at the current parameters through the solver's fused entry
+        point; (-inf, zeros) where the reference's quiet mode returns them."""
+        bad = (-np.inf, np.zeros(len(self)) if want_grad else None)
+        r = self._residual_quiet(y, quiet)
+        if r is None:
+            return bad
+        n_wn, n_k = len(self.white_noise), len(self.kernel)
+        need_A = want_grad and (n_wn or n_k)
+        self.solver = self.solver_type(self.kernel, **(self.solver_kwargs))
+        sigma = np.sqrt(self._yerr2 + np.exp(self._call_white_noise(self._x)))
+        which = self.kernel.unfrozen_mask.astype(np.uint32)
+        try:
+            if need_A:
+                logdet, quad, kg_full, alpha, diagA = self.solver.objective(self._x, sigma, r, which, want_grad=True)
+            else:
+                logdet, quad, kg_full, alpha, diagA = self.solver.objective(self._x, sigma, r, which, want_grad=False)
+        except (ValueError, np.linalg.LinAlgError):
+            if quiet:
+                return bad
+            raise
+        self._const = -0.5 * (len(self._x) * np.log(2 * np.pi) + logdet)
+        self.computed = True
+        self._alpha = None
+        ll = self._const - 0.5 * quad
+        ll = ll if np.isfinite(ll) else -np.inf
+        if not want_grad:
+            return ll, None
+        if not need_A:                                   # only mean parameters vary: alpha is all that is needed
+            alpha = self.solver.apply_inverse(r).flatten()
+            return ll, self._assemble_grad(alpha, None, None, quiet)
+        kgrad = kg_full[self.kernel.unfrozen_mask] if n_k else None
+        return ll, self._assemble_grad(alpha, diagA, kgrad, quiet)
+
+    def nll_and_grad(self, vector, y, quiet=True):
+        """``(nll(vector, y), grad_nll(vector, y))`` from one fused device call."""
+        self.set_parameter_vector(vector)
+        if not np.isfinite(self.log_prior()):
+            return np.inf, np.zeros(len(vector))
+        if self.computed or not self._fused_capable():
+            return -self.log_likelihood(y, quiet=quiet), -self.grad_log_likelihood(y, quiet=quiet)
+        ll, g = self._objective(y, True, quiet)
+        self._obj_cache = (np.array(vector, dtype=np.float64), np.array(y, dtype=np.float64), g)
+        return -ll, -g
+
+    def _cached_grad(self, vector, y):
+        c = getattr(self, "_obj_cache", None)
+        if c is None or not self.computed:
+            return None
+        v, yy = np.asarray(vector, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        if v.shape == c[0].shape and yy.shape == c[1].shape and np.array_equal(v, c[0]) and np.array_equal(yy, c[1]):
+            return c[2]
+        return None
+
     def nll(self, vector, y, quiet=True):
         self.set_parameter_vector(vector)
         if not np.isfinite(self.log_prior()):
             return np.inf
-        return -self.log_likelihood(y, quiet=quiet)
+        if self.computed or not self._fused_capable():
+            return -self.log_likelihood(y, quiet=quiet)
+        want_grad = getattr(self, "_grad_seen", False)
+        ll, g = self._objective(y, want_grad, quiet)
+        self._obj_cache = (np.array(vector, dtype=np.float64), np.array(y, dtype=np.float64), g) if want_grad else None
+        return -ll
 
     def grad_nll(self, vector, y, quiet=True):
+        self._grad_seen = True
         self.set_parameter_vector(vector)
         if not np.isfinite(self.log_prior()):
             return np.zeros(len(vector))
-        return -self.grad_log_likelihood(y, quiet=quiet)
+        g = self._cached_grad(vector, y)
+        if g is not None:
+            return -g
+        if self.computed or not self._fused_capable():
+            return -self.grad_log_likelihood(y, quiet=quiet)
+        ll, g = self._objective(y, True, quiet)
+        self._obj_cache = (np.array(vector, dtype=np.float64), np.array(y, dtype=np.float64), g)
+        return -g
 
     def predict(self, y, t, return_cov=True, return_var=False, cache=True, kernel=None):
         """Conditional mean and (co)variance at ``t``  (gp.py:482-545)."""

@@ -18,6 +18,8 @@ from ..program import DeviceKernel
 
 __all__ = ["BasicSolver"]
 
+import atexit
+
 
 class BasicSolver(object):
 
@@ -28,6 +30,7 @@ class BasicSolver(object):
         self._opts = dict(device=int(device), nb=int(nb), profile=bool(profile), lookahead=bool(lookahead))
         self._handle = None
         self._dk = None
+        self._factor_state = None
 
     # -- properties (basic.py:25-49)
     @property
@@ -49,8 +52,19 @@ class BasicSolver(object):
     # -- lifetime.  `GP.compute` instantiates a NEW solver on every call (gp.py:327) -- thousands of
     # times inside an optimiser loop -- so native handles (and the N x N device buffers they own)
     # are recycled through a small per-configuration pool instead of being hipMalloc'ed each time.
+    # A handle keeps every buffer it ever grew (the factor, and after grad / get_inverse / predict up
+    # to three more N x N work arrays: ~100 GB at N = 65536), so a handle is TRIMMED to its factor
+    # before it is parked, at most _POOL_MAX handles are parked per option set and at most
+    # _POOL_MAX_BYTES of factor storage in total (larger ones are freed outright);
+    # ``BasicSolver.release_pool()`` empties the pool, and it is emptied at interpreter exit.
     _POOL = {}
     _POOL_MAX = 2
+    _POOL_MAX_BYTES = 48 << 30
+    # ``pickle`` of a computed solver carries the factor (reference behaviour, tests/test_pickle.py:21-36)
+    # up to this many points (8 GB of packed lower triangle at 46340); beyond it the state drops the
+    # factor and the solver comes back un-computed, like the reference's own native solver does
+    # (solvers/hodlr.py:69-76).  Set to 0 to always drop, to None to always keep.
+    PICKLE_FACTOR_MAX_N = 32768
 
     def _pool_key(self):
         return tuple(sorted(self._opts.items()))
@@ -69,12 +83,18 @@ class BasicSolver(object):
             self._handle = h
         return self._handle
 
+    @staticmethod
+    def _pooled_bytes():
+        return sum(8 * int(N.lib.gh_chol_size(h)) ** 2 for free in BasicSolver._POOL.values() for h in free)
+
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
             try:
                 free = BasicSolver._POOL.setdefault(self._pool_key(), [])
-                if len(free) < BasicSolver._POOL_MAX:
+                mine = 8 * int(N.lib.gh_chol_size(h)) ** 2
+                if len(free) < BasicSolver._POOL_MAX and BasicSolver._pooled_bytes() + mine <= BasicSolver._POOL_MAX_BYTES:
+                    N.lib.gh_chol_trim(h)              # keep the factor-sized buffers, drop the work arrays
                     free.append(h)
                 else:
                     N.lib.gh_chol_destroy(h)
@@ -82,17 +102,51 @@ class BasicSolver(object):
                 pass
             self._handle = None
 
-    # pickling drops the device factor and flags the solver uncomputed, the precedent the
-    # reference sets for its own native solver (solvers/hodlr.py:69-76)
+    @classmethod
+    def release_pool(cls):
+        """Destroy every parked native handle (frees their device memory)."""
+        for free in cls._POOL.values():
+            while free:
+                try:
+                    N.lib.gh_chol_destroy(free.pop())
+                except Exception:
+                    pass
+        cls._POOL.clear()
+
+    # Pickling.  The reference's BasicSolver pickles computed (its factor is a NumPy array,
+    # basic.py:68; tests/test_pickle.py:21-36); here the factor is downloaded (packed lower triangle +
+    # diagonal-block inverses) into the state and uploaded again on first use after unpickling.
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_handle"] = None
         state["_dk"] = None
-        state["_computed"] = False
+        state.pop("_factor_state", None)
+        keep = self._computed and self._handle is not None and (
+            BasicSolver.PICKLE_FACTOR_MAX_N is None or self._n <= BasicSolver.PICKLE_FACTOR_MAX_N)
+        if keep:
+            h = self._handle
+            L = np.empty(int(N.lib.gh_chol_factor_size(h)))
+            dinv = np.empty(int(N.lib.gh_chol_dinv_size(h)))
+            N.check(N.lib.gh_chol_export_factor(h, N.ptr(L), N.ptr(dinv)))
+            state["_factor_state"] = (L, dinv)
+        elif self._computed and getattr(self, "_factor_state", None) is not None:
+            state["_factor_state"] = self._factor_state       # unpickled and never used: pass it on
+        else:
+            state["_computed"] = False
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault("_factor_state", None)
+
+    def _restore(self):
+        """Upload a pickled factor into a fresh native handle (first use after unpickling)."""
+        L, dinv = self._factor_state
+        self._dk = DeviceKernel(self.kernel)
+        h = self._ensure_handle()
+        N.check(N.lib.gh_chol_import_factor(h, self._n, self._x_host.shape[1], N.ptr(self._x_host), N.ptr(L), N.ptr(dinv),
+                                            float(self._log_det)))
+        self._factor_state = None
 
     # -- the solver protocol
     def compute(self, x, yerr):
@@ -107,12 +161,49 @@ class BasicSolver(object):
             raise RuntimeError("dimension mismatch")
         h = self._ensure_handle()
         logdet = C.c_double(0.0)
+        self._factor_state = None
         N.check(N.lib.gh_chol_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
         self._n = len(x)
+        self._x_host = x                     # (the inputs travel with a pickled factor: predict / grad need them)
         self.log_determinant = logdet.value
         self.computed = True
 
+    def objective(self, x, yerr, r, which=None, want_grad=True):
+        """``compute(x, yerr)`` + ``r^T K^-1 r`` + (optionally) the kernel part of the gradient of the
+        log-likelihood in ONE device call (gh_chol_objective; gp.py:470-480 with :303-337, :369-397,
+        :429-466).  Returns ``(log_det, quad, grad_all | None, alpha | None, diagA | None)`` and leaves
+        the solver computed."""
+        x = N.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError("x must be (nsamples, ndim)")
+        n = len(x)
+        yerr = N.as_f64(np.zeros(n) + yerr)
+        r = N.as_f64(r).reshape(-1)
+        if len(r) != n:
+            raise ValueError("dimension mismatch")
+        self._computed = False
+        self._factor_state = None
+        self._dk = DeviceKernel(self.kernel)
+        if x.shape[1] != self._dk.ndim:
+            raise RuntimeError("dimension mismatch")
+        h = self._ensure_handle()
+        logdet, quad = C.c_double(0.0), C.c_double(0.0)
+        g = alpha = diagA = wh = None
+        if want_grad:
+            wh = np.ascontiguousarray(np.ones(max(self._dk.size, 1)) if which is None else which, dtype=np.uint32)
+            g = np.zeros(max(self._dk.size, 1))
+            alpha, diagA = np.empty(n), np.empty(n)
+        N.check(N.lib.gh_chol_objective(h, self._dk.handle, N.ptr(x), n, x.shape[1], N.ptr(yerr), N.ptr(r), N.ptr(wh),
+                                        C.byref(logdet), C.byref(quad), N.ptr(g), N.ptr(alpha), N.ptr(diagA)))
+        self._n = n
+        self._x_host = x
+        self.log_determinant = logdet.value
+        self.computed = True
+        return logdet.value, quad.value, (g[:self._dk.size] if g is not None else None), alpha, diagA
+
     def _need(self):
+        if self._computed and self._handle is None and getattr(self, "_factor_state", None) is not None:
+            self._restore()
         if not self._computed or self._handle is None:
             raise RuntimeError("you must call 'compute' first")
         return self._handle
@@ -198,3 +289,6 @@ class BasicSolver(object):
         N.check(N.lib.gh_chol_get_profile(self._need(), C.byref(p)))
         return dict(ms_total=p.ms_total, ms_build=p.ms_build, ms_panel=p.ms_panel, ms_trailing=p.ms_trailing,
                     trailing_flops=p.trailing_flops, n_trailing=p.n_trailing, ms_solve=p.ms_solve)
+
+
+atexit.register(BasicSolver.release_pool)

@@ -181,6 +181,31 @@ int  gh_chol_predict(gh_chol* s, gh_kernel* k, const double* r /* n: y - mean */
  * for the parameters selected by `which` (others 0); diagA (n) = diag(A). */
 int  gh_chol_grad(gh_chol* s, gh_kernel* k, const uint32_t* which, const double* r,
                   double* grad /* size */, double* alpha /* n or NULL */, double* diagA /* n or NULL */);
+/* Fused hyper-parameter objective: GP.nll + GP.grad_nll (src/george/gp.py:470-480, i.e. compute
+ * gp.py:303-337 + log_likelihood :369-397 + the kernel part of grad_log_likelihood :429-466) as ONE
+ * device-resident call with one synchronisation: build K, factor, *logdet = log|K|,
+ * *quad = r^T K^-1 r, and -- when grad != NULL -- alpha = K^-1 r (from the same forward solve),
+ * K^-1 and grad[p] = 1/2 sum_ij A_ij dK_ij/dtheta_p for the parameters selected by `which`.
+ * grad / alpha / diagA may be NULL; the handle is left computed (solve / predict may follow). */
+int  gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                       const double* yerr, const double* r /* n: y - mean */, const uint32_t* which,
+                       double* logdet, double* quad, double* grad /* size or NULL */,
+                       double* alpha /* n or NULL */, double* diagA /* n or NULL */);
+/* Checkpointing of the device factor (the reference's BasicSolver pickles COMPUTED,
+ * tests/test_pickle.py:21-36, because its factor is a NumPy array, basic.py:68): the lower
+ * triangle of L packed by rows (gh_chol_factor_size() = n (n + 1) / 2 doubles) and the inverses of
+ * its 128 x 128 diagonal blocks (gh_chol_dinv_size() doubles).  import_factor() rebuilds a computed
+ * handle from them plus the inputs x (n, ndim) that predict / grad evaluate kernels against. */
+int64_t gh_chol_factor_size(const gh_chol* s);
+int64_t gh_chol_dinv_size(const gh_chol* s);
+int  gh_chol_export_factor(gh_chol* s, double* packed_lower, double* dinv_out);
+int  gh_chol_import_factor(gh_chol* s, int64_t n, int32_t ndim, const double* x,
+                           const double* packed_lower, const double* dinv_in, double logdet);
+/* memory management of a long-lived handle: trim() frees the transient work buffers of predict /
+ * grad / get_inverse (up to 3 x 8 N^2 bytes) and keeps the factor; release_buffers() frees
+ * everything but the handle (streams, events) -- the next compute() re-allocates. */
+void gh_chol_trim(gh_chol* s);
+void gh_chol_release_buffers(gh_chol* s);
 /* profile counters of the last compute(): see george_amd/csrc/gh_chol.hip */
 typedef struct gh_chol_profile {
   double ms_total;          /* build + factor, device time                     */

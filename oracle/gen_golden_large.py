@@ -20,10 +20,10 @@ Memory: the reference hands ``cholesky`` a C-contiguous K, which f2py copies int
 (68.7 GB at N=65536).  K is exactly symmetric (``kernel_interface.cpp:62-77`` writes both halves),
 so the Fortran-ordered *view* ``K.T`` holds the same values and the same ``dpotrf('U')`` runs in place.
 
-N = 65536: the whole-matrix ``dpotrf`` of this image's SciPy/OpenBLAS is broken at that size (silently
-wrong on a trivially SPD matrix, oracle/potrf_probe.py), i.e. the reference's ``basic.py:68`` cannot
-produce these numbers here at all; they come from the same LAPACK/BLAS routines applied to
-8192-column blocks (``blocked_cholesky_lower``; bit-identical log-likelihood to the whole-matrix call
+N >= 32768: the whole-matrix ``dpotrf`` of this image's SciPy/OpenBLAS is broken at large sizes (silently
+wrong on a trivially SPD matrix at n = 65536, oracle/potrf_probe.py; spurious "not positive definite"
+on the NS and C5 matrices), i.e. the reference's ``basic.py:68`` cannot produce these numbers here at
+all; they come from the same LAPACK/BLAS routines applied to 8192-column blocks (``blocked_cholesky_lower``; bit-identical log-likelihood to the whole-matrix call
 where both work, checked at N = 3000 with 512-column blocks).
 
     OPENBLAS_NUM_THREADS=6 python -m oracle.gen_golden_large [names...]
@@ -92,29 +92,9 @@ def blocked_solve_lower(L, b, nb=8192, trans=False):
     return x
 
 
-def dense_case_blocked(kernel, x, yerr, y):
-    """Same quantities as dense_case() with the factorisation done block-wise."""
-    n = len(x)
-    x2 = np.ascontiguousarray(x.reshape(n, -1))
-    t0 = time.time()
-    K = kernel.get_value(x2)
-    t_build = time.time() - t0
-    K[np.diag_indices_from(K)] += yerr ** 2 + TINY
-    t0 = time.time()
-    L = blocked_cholesky_lower(K)
-    t_fac = time.time() - t0
-    logdet = 2 * np.sum(np.log(np.diag(L)))
-    z = blocked_solve_lower(L, y)
-    alpha = blocked_solve_lower(L, z, trans=True)
-    q = float(np.dot(y, alpha))
-    ll = -0.5 * (n * np.log(2 * np.pi) + logdet) - 0.5 * q
-    return {"n": n, "logdet": float(logdet), "loglike": float(ll), "quad": q,
-            "alpha_stride": max(n // 64, 1), "alpha": [float(v) for v in alpha[::max(n // 64, 1)]],
-            "seconds_build": t_build, "seconds_factor": t_fac, "factorisation": "blocked (dpotrf/dtrsm/dgemm on 8192-column blocks)"}
-
-
-def dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=False, t=None):
-    """GP.compute + log_likelihood (gp.py:303-337,369-397) with basic.py's LAPACK calls, in place."""
+def dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=False, t=None, blocked=False):
+    """GP.compute + log_likelihood (gp.py:303-337,369-397) with basic.py's LAPACK calls, in place
+    (``blocked``: the same routines on 8192-column blocks, see main())."""
     n = len(x)
     x2 = np.ascontiguousarray(x.reshape(n, -1))
     t0 = time.time()
@@ -122,29 +102,35 @@ def dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=False, t=None):
     t_build = time.time() - t0
     K[np.diag_indices_from(K)] += yerr ** 2 + TINY                   # basic.py:65 with gp.py:330
     t0 = time.time()
-    U = cholesky(K.T, overwrite_a=True, lower=False, check_finite=False)     # basic.py:68
-    assert np.shares_memory(U, K)
+    if blocked:
+        L = blocked_cholesky_lower(K)
+        diag = np.diag(L)
+        solve = lambda b: blocked_solve_lower(L, blocked_solve_lower(L, b), trans=True)
+    else:
+        U = cholesky(K.T, overwrite_a=True, lower=False, check_finite=False)     # basic.py:68
+        assert np.shares_memory(U, K)
+        diag = np.diag(U)
+        solve = lambda b: cho_solve((U, False), b, check_finite=False)           # basic.py:87
     t_fac = time.time() - t0
-    logdet = 2 * np.sum(np.log(np.diag(U)))                          # basic.py:69
-    alpha = cho_solve((U, False), y, check_finite=False)             # basic.py:87
+    logdet = 2 * np.sum(np.log(diag))                                # basic.py:69
+    alpha = solve(y)
     q = float(np.dot(y, alpha))                                      # basic.py:102
     ll = -0.5 * (n * np.log(2 * np.pi) + logdet) - 0.5 * q           # gp.py:333-335,396
     out = {"n": n, "logdet": float(logdet), "loglike": float(ll), "quad": q,
            "alpha_stride": max(n // 64, 1), "alpha": [float(v) for v in alpha[::max(n // 64, 1)]],
-           "seconds_build": t_build, "seconds_factor": t_fac}
+           "seconds_build": t_build, "seconds_factor": t_fac,
+           "factorisation": "blocked (dpotrf/dtrsm/dgemm on 8192-column blocks)" if blocked else "whole-matrix dpotrf (basic.py:68)"}
     if t is not None:                                                # gp.py:532-541
         Kxs = kernel.get_value(t, x2)
         mu = np.dot(Kxs, alpha)
-        KinvKxs = cho_solve((U, False), Kxs.T, check_finite=False)
+        KinvKxs = solve(np.ascontiguousarray(Kxs.T))
         var = kernel.get_value(t, diag=True) - np.sum(Kxs.T * KinvKxs, axis=0)
         out["t"] = [[float(v) for v in row] for row in t]
         out["mu"] = [float(v) for v in mu]
         out["var"] = [float(v) for v in var]
     if want_inverse_for_grad:                                        # gp.py:436-437,465-466, blocked over rows
         t0 = time.time()
-        Kinv = np.eye(n)
-        Kinv = cho_solve((U, False), Kinv, overwrite_b=True, check_finite=False)    # basic.py:121
-        del U, K
+        Kinv = solve(np.eye(n))                                      # basic.py:121
         ki = kernel.kernel
         which = np.ones(kernel.full_size, dtype=np.uint32)
         g = np.zeros(kernel.full_size)
@@ -172,18 +158,21 @@ def main():
             x, yerr, y = zoo.bench_data(32768, ndim=3)
             kernel = K.Matern52Kernel(0.5, ndim=3) + K.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)
             t = np.random.RandomState(4321).uniform(0, 1, (4096, 3))[:64].copy()
-            res[name] = dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=True, t=t)
+            res[name] = dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=True, t=t, blocked=True)
         else:
             n, cls = {"C2": (16384, K.ExpSquaredKernel), "M32_20k": (20480, K.Matern32Kernel),
                       "NS": (65536, K.ExpSquaredKernel), "C3": (65536, K.Matern32Kernel)}[name]
             x, yerr, y = zoo.bench_data(n)
-            if n >= 65536:
-                # basic.py:68 as written cannot be used at this size in this image: SciPy 1.15.3's
-                # whole-matrix dpotrf (OpenBLAS 0.3.28, 32-bit LAPACK ints, n*n = 2^32) is wrong for
-                # n = 65536 -- oracle/potrf_probe.py: A = I + 1e-3 * ones gives log|A| = 4.1759 instead
-                # of log(1 + 65.536) = 4.1977 and no error, and the ExpSquared matrix of this config
-                # "fails" at the 19425-th minor.  The same LAPACK/BLAS kernels are applied block-wise.
-                res[name] = dense_case_blocked(np.var(y) * cls(1.0), x, yerr, y)
+            if n >= 32768:
+                # basic.py:68 as written cannot be used at these sizes in this image: SciPy 1.15.3's
+                # whole-matrix dpotrf (OpenBLAS 0.3.28, threaded) goes wrong somewhere above n = 20480
+                # -- oracle/potrf_probe.py: at n = 65536, A = I + 1e-3 * ones gives log|A| = 4.1759
+                # instead of log(1 + 65.536) = 4.1977 and no error; the ExpSquared matrix of NS "fails"
+                # at the 19425-th minor and the C5 matrix (n = 32768) at the 15425-th, although both
+                # have smallest eigenvalue >= yerr^2 = 0.01.  The same LAPACK/BLAS kernels are applied
+                # block-wise instead (8192 columns at a time), which agrees with the whole-matrix call
+                # bit for bit where that one works.
+                res[name] = dense_case(george, np.var(y) * cls(1.0), x, yerr, y, blocked=True)
             else:
                 res[name] = dense_case(george, np.var(y) * cls(1.0), x, yerr, y)
         res[name]["seconds_total"] = time.time() - t0

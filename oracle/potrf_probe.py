@@ -6,8 +6,9 @@ log|A| = log(1 + 1e-3 n) exactly.
     -> n 65536 ok logdet 4.175879788749634 exact 4.197743154566386   (build container, 7 threads, 237 s)
 
 i.e. at n = 65536 (n * n = 2^32) the factorisation returns without error and is WRONG in the third
-digit; at n = 16384 / 20480 / 32768 it is right.  oracle/gen_golden_large.py therefore factors the
-N = 65536 configurations block-wise."""
+digit (it is right at n = 16384 and 20480, where gen_golden_large.py's results agree with the HIP path
+and with the block-wise factorisation).  oracle/gen_golden_large.py therefore factors the
+configurations with N >= 32768 block-wise."""
 import numpy as np, time, sys
 from scipy.linalg import cholesky
 n = int(sys.argv[1])

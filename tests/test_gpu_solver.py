@@ -218,16 +218,159 @@ def test_not_positive_definite_maps_to_linalgerror():
         BasicSolver(k).apply_inverse(np.zeros(3))     # "you must call 'compute' first"
 
 
-def test_pickle_roundtrip(seed=1234):                                   # tests/test_pickle.py
+def _fake_compute(arg, *args, **kwargs):
+    assert 0, "Unpickled GP shouldn't need to be computed"
+
+
+def test_pickle_keeps_the_factor(N=50, seed=123):                       # tests/test_pickle.py:21-36, BasicSolver/True
     np.random.seed(seed)
-    gp = GP(0.5 * kernels.ExpSquaredKernel(0.3))
-    x = np.sort(np.random.rand(100))
-    y = np.sin(7 * x)
-    gp.compute(x, 0.1)
+    kernel = 0.1 * kernels.ExpSquaredKernel(1.5)
+    gp = GP(kernel, solver=BasicSolver)
+    x = np.random.rand(100)
+    gp.compute(x, 1e-2)
+    ll = gp.log_likelihood(np.sin(x))
+    mu, var = gp.predict(np.sin(x), np.linspace(0, 1, 7), return_var=True)
+    g = gp.grad_log_likelihood(np.sin(x))
+    s = pickle.dumps(gp, -1)
+    gp = pickle.loads(s)
+    gp.compute = _fake_compute
+    assert gp.computed
+    with pytest.warns(DeprecationWarning):
+        assert gp.lnlikelihood(np.sin(x)) == ll                            # the very same factor: same bits
+    mu2, var2 = gp.predict(np.sin(x), np.linspace(0, 1, 7), return_var=True)
+    assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
+    assert np.allclose(gp.grad_log_likelihood(np.sin(x)), g, rtol=1e-12, atol=0)
+    # a pickle of the unpickled-and-untouched object carries the factor on
+    gp3 = pickle.loads(pickle.dumps(pickle.loads(s), -1))
+    gp3.compute = _fake_compute
+    assert gp3.log_likelihood(np.sin(x)) == ll
+
+
+def test_pickle_roundtrip_mid_size_and_threshold(seed=1234):
+    np.random.seed(seed)
+    x, yerr, y = zoo.bench_data(1500)                                      # not a multiple of 128: padding path
+    gp = GP(np.var(y) * kernels.Matern32Kernel(1.0))
+    gp.compute(x, yerr)
     ll = gp.log_likelihood(y)
+    a = gp.apply_inverse(y)
     gp2 = pickle.loads(pickle.dumps(gp, -1))
-    assert not gp2.computed                   # device factor dropped -> recomputed transparently
-    assert np.isclose(gp2.log_likelihood(y), ll, rtol=1e-12)
+    assert gp2.computed and gp2.log_likelihood(y) == ll and np.array_equal(gp2.apply_inverse(y), a)
+    assert np.array_equal(gp2.solver.apply_sqrt(np.ones(1500)), gp.solver.apply_sqrt(np.ones(1500)))
+    # above the size threshold the factor is dropped, as the reference's native solver does (hodlr.py:69-76)
+    old = BasicSolver.PICKLE_FACTOR_MAX_N
+    BasicSolver.PICKLE_FACTOR_MAX_N = 1000
+    try:
+        gp4 = pickle.loads(pickle.dumps(gp, -1))
+    finally:
+        BasicSolver.PICKLE_FACTOR_MAX_N = old
+    assert not gp4.computed
+    assert np.isclose(gp4.log_likelihood(y), ll, rtol=1e-12)                # recomputed transparently
+
+
+# ------------------------------------------------------------------ fused objective (gp.py:470-480)
+@pytest.mark.parametrize("fit_mean,fit_wn", [(False, False), (True, True)])
+def test_fused_objective_matches_separate_calls(fit_mean, fit_wn):
+    x, yerr, y = zoo.bench_data(700, ndim=3)
+    def make():
+        kernel = kernels.Matern52Kernel(0.5, ndim=3) + kernels.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)
+        kw = dict(mean=0.3, fit_mean=True) if fit_mean else {}
+        if fit_wn:
+            kw.update(white_noise=np.log(0.05), fit_white_noise=True)
+        gp = GP(kernel, **kw)
+        gp.compute(x, yerr)
+        return gp
+    ref, gp = make(), make()
+    p = ref.get_parameter_vector() + 0.05
+    ref.set_parameter_vector(p)
+    ll0, g0 = ref.log_likelihood(y), ref.grad_log_likelihood(y)            # separate calls (compute / dot_solve / grad)
+    v, g = gp.nll_and_grad(p, y)                                           # ONE device call
+    assert abs(v + ll0) <= 1e-12 * abs(ll0)
+    np.testing.assert_allclose(-g, g0, rtol=1e-10, atol=1e-10)
+    assert gp.computed
+    # optimiser call pattern: value then gradient at every iterate; after the first gradient request
+    # nll computes the gradient eagerly and grad_nll at the same point is served from it
+    gp = make()
+    calls = []
+    real = BasicSolver.objective
+    def spy(self, *a, **k):
+        calls.append(k.get("want_grad", True))
+        return real(self, *a, **k)
+    BasicSolver.objective = spy
+    try:
+        for step in range(3):
+            q = p + 0.01 * step
+            v = gp.nll(q, y)
+            g = gp.grad_nll(q, y)
+            ref.set_parameter_vector(q)
+            assert abs(v + ref.log_likelihood(y)) <= 1e-12 * abs(v)
+            np.testing.assert_allclose(-g, ref.grad_log_likelihood(y), rtol=1e-10, atol=1e-10)
+    finally:
+        BasicSolver.objective = real
+    # step 0: a value-only fused call (no gradient had been asked for yet; its gradient then comes from
+    # the factor already on the device); from then on ONE fused call per iterate
+    assert calls == [False, True, True], calls
+
+
+def test_objective_quiet_and_errors():
+    k = kernels.CosineKernel(log_period=0.0)                               # singular without noise
+    x = np.linspace(0, 3, 200)
+    gp = GP(k, white_noise=-1000.0)
+    gp.compute(x[:5], 1.0)
+    gp._x, gp._yerr2 = np.ascontiguousarray(x[:, None]), np.zeros(200)
+    gp.kernel.dirty = True
+    p = gp.get_parameter_vector()
+    assert gp.nll(p, np.sin(x)) == np.inf
+    gp.kernel.dirty = True
+    assert np.all(gp.grad_nll(p, np.sin(x)) == 0.0)
+    gp.kernel.dirty = True
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.nll(p, np.sin(x), quiet=False)
+    # a wrongly shaped y is an error even in quiet mode (only mean-function failures are silenced)
+    gp2 = GP(1.0 * kernels.ExpSquaredKernel(1.0))
+    gp2.compute(x, 0.1)
+    with pytest.raises(ValueError):
+        gp2.log_likelihood(np.zeros(7), quiet=True)
+    with pytest.raises(ValueError):
+        gp2.nll(gp2.get_parameter_vector() + 0.1, np.zeros(7))
+    with pytest.raises(ValueError):
+        gp2.grad_log_likelihood(np.zeros((200, 2)), quiet=True)
+
+
+def test_handle_pool_is_trimmed_and_releasable():
+    x, yerr, y = zoo.bench_data(1024)
+    gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+    gp.compute(x, yerr)
+    gp.grad_log_likelihood(y)                                              # grows the N x N work buffers
+    ll = gp.log_likelihood(y)
+    del gp
+    import gc
+    gc.collect()
+    assert sum(len(v) for v in BasicSolver._POOL.values()) >= 1
+    BasicSolver.release_pool()
+    assert sum(len(v) for v in BasicSolver._POOL.values()) == 0
+    gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+    gp.compute(x, yerr)
+    assert gp.log_likelihood(y) == ll
+
+
+def test_stepwise_trsv_arm_still_works():
+    """GEORGE_AMD_TRSV_STEPS selects the one-launch-per-block-row solves (the fallback should the
+    chained kernels' in-order dispatch assumption ever fail): keep it exercised."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import numpy as np, zoo\n"
+            "from george_amd import GP, kernels\n"
+            "x, yerr, y = zoo.bench_data(1500)\n"
+            "gp = GP(np.var(y) * kernels.Matern32Kernel(1.0)); gp.compute(x, yerr)\n"
+            "print(repr(float(gp.log_likelihood(y))), repr(float(y @ gp.apply_inverse(y))))\n") % (root, root)
+    outs = []
+    for env in ({}, {"GEORGE_AMD_TRSV_STEPS": "1"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([float(v) for v in r.stdout.split()[-2:]])
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-11 * abs(outs[0][0])
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-9 * abs(outs[0][1])
 
 
 def test_tutorial_kernel_family():                                      # tests/test_tutorial.py
