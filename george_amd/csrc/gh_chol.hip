@@ -470,9 +470,15 @@ struct gh_chol {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;             // high-priority panel stream (look-ahead)
   hipStream_t st3 = nullptr;             // second panel stream: rows-below TRSM beside the potf2 chain
+  hipStream_t st4 = nullptr;             // third panel stream: in-panel rows >= j+2 (everything off the potf2 chain)
   hipEvent_t ev_diag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_aux = nullptr;
+  hipEvent_t ev_p1[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_b[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;
   hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
+  hipStream_t st_crit = nullptr;         // exclusive mode: potf2 chain confined to the CUs st_mask leaves out
+  hipStream_t st_sa = nullptr;           // exclusive mode: rows-below TRSM on the SAME CUs as the trailing update
+  hipStream_t st_sb = nullptr;           // exclusive mode + inner split: in-panel rows >= j+2, same CUs again
   int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
   hipEvent_t ev_xfer = nullptr;
   hipEvent_t ev_sync[3] = {nullptr, nullptr, nullptr};
@@ -502,9 +508,16 @@ struct gh_chol {
     for (auto& e : ev_sync) if (e) (void)hipEventDestroy(e);
     if (ev_xfer) (void)hipEventDestroy(ev_xfer);
     if (ev_aux) (void)hipEventDestroy(ev_aux);
+    if (ev_aux2) (void)hipEventDestroy(ev_aux2);
     for (auto& e : ev_diag) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_p1) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_b) if (e) (void)hipEventDestroy(e);
+    if (st4) (void)hipStreamDestroy(st4);
     if (st3) (void)hipStreamDestroy(st3);
     if (st_mask) (void)hipStreamDestroy(st_mask);
+    if (st_crit) (void)hipStreamDestroy(st_crit);
+    if (st_sa) (void)hipStreamDestroy(st_sa);
+    if (st_sb) (void)hipStreamDestroy(st_sb);
     if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -538,6 +551,13 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
                 hipEventCreateWithFlags(&s->ev_aux, hipEventDisableTiming) == hipSuccess;
       for (auto& e : s->ev_diag) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); if (s->st3) (void)hipStreamDestroy(s->st3); s->st3 = nullptr; }
+      if (s->st3) {
+        bool ok4 = hipStreamCreateWithPriority(&s->st4, hipStreamNonBlocking, hi) == hipSuccess &&
+                   hipEventCreateWithFlags(&s->ev_aux2, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : s->ev_p1) ok4 = ok4 && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : s->ev_b) ok4 = ok4 && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok4) { (void)hipGetLastError(); if (s->st4) (void)hipStreamDestroy(s->st4); s->st4 = nullptr; }
+      }
     }
   }
   if (hipMalloc((void**)&s->d_info, sizeof(long long)) != hipSuccess) { delete s; gh_set_error("hipMalloc failed"); return GH_ERR_HIP; }
@@ -640,6 +660,68 @@ static int64_t panel_width(const gh_chol* s) {
   return (s->np >= 12288 || s->np <= 4096) ? 1024 : 512;
 }
 
+// The panel with ONLY the potf2 chain on the critical stream.  Step j of the 128-column blocks:
+//   st  (critical): potf2(j) -> row block j+1 alone: P1 = A[j+1, j] L_jj^-T, A[j+1, j+1] -= P1 P1^T
+//                   -> potf2(j+1) ...  (two one-tile launches between consecutive potf2 calls)
+//   sb  (st4)     : the in-panel rows >= j+2:  P2 = A[j+2.., j] L_jj^-T  and
+//                   A[j+2.., j+1..] -= P2 [P1; P2]^T   (full rectangle: the few strictly-upper tiles it
+//                   also writes are never read), beside potf2(j+1)
+//   sa  (st3)     : the rows BELOW the panel, column block j (as before)
+// Dependencies: sb's update needs P1 (ev_p1[j]); the critical TRSM of row block j+2 at step j+1
+// needs sb's update of step j (ev_b[j]); sa needs L[j, 0..j) final, which potf2(j)'s event covers
+// (the critical stream has waited for every ev_b before it).  With the whole TRSM + update of the
+// remaining panel rows on the critical stream (the previous arm, GEORGE_AMD_NO_PANEL_INNER_SPLIT)
+// a chain link cost potf2 + 2 launches of up to 84 workgroups; now potf2 + 2 launches of 2.
+static int panel_step_split(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
+  double* A = s->A.d();
+  const int64_t np = s->np, ld = np;
+  double* dinv = s->dinv.d() + (k0 / T) * T * T;
+  const int64_t m = np - (k0 + nb);
+  static const bool side_prio = getenv("GEORGE_AMD_PANEL_SIDE_PRIO") != nullptr;   // side streams: unmasked high priority
+  const bool excl = s->st_crit && st == s->st_crit && !side_prio;
+  hipStream_t sa = excl ? s->st_sa : s->st3, sb = excl ? s->st_sb : s->st4;
+  double* Ak = blk(A, ld, k0, k0);
+  double* B = blk(A, ld, k0 + nb, k0);
+  GH_HIP(hipEventRecord(s->ev_aux, st));
+  if (m > 0) GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
+  GH_HIP(hipStreamWaitEvent(sb, s->ev_aux, 0));
+  for (int64_t j0 = 0; j0 < nb; j0 += T) {
+    const int j = (int)(j0 / T);
+    double* dj = dinv + j * T * T;
+    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
+    GH_HIP(hipEventRecord(s->ev_diag[j], st));
+    if (m > 0) {
+      GH_HIP(hipStreamWaitEvent(sa, s->ev_diag[j], 0));
+      double* Xj = B + j0;
+      if (j0 > 0) GH_CHECK(gemm_nt(sa, Xj, ld, B, ld, Ak + j0 * ld, ld, m, T, j0, -1.0, 1.0, false));
+      GH_CHECK(gemm_nt(sa, Xj, ld, Xj, ld, dj, T, m, T, T, 1.0, 0.0, false));
+    }
+    const int64_t rem = nb - (j0 + T);
+    if (rem <= 0) break;
+    if (j > 0) GH_HIP(hipStreamWaitEvent(st, s->ev_b[j - 1], 0));         // A[j+1, j] carries step j-1's update
+    double* P1 = blk(Ak, ld, j0 + T, j0);
+    GH_CHECK(gemm_nt(st, P1, ld, P1, ld, dj, T, T, T, T, 1.0, 0.0, false));
+    GH_HIP(hipEventRecord(s->ev_p1[j], st));
+    GH_CHECK(gemm_nt(st, blk(Ak, ld, j0 + T, j0 + T), ld, P1, ld, P1, ld, T, T, T, -1.0, 1.0, true));
+    const int64_t rem2 = rem - T;
+    if (rem2 > 0) {
+      GH_HIP(hipStreamWaitEvent(sb, s->ev_diag[j], 0));
+      double* P2 = blk(Ak, ld, j0 + 2 * T, j0);
+      GH_CHECK(gemm_nt(sb, P2, ld, P2, ld, dj, T, rem2, T, T, 1.0, 0.0, false));
+      GH_HIP(hipStreamWaitEvent(sb, s->ev_p1[j], 0));
+      GH_CHECK(gemm_nt(sb, blk(Ak, ld, j0 + 2 * T, j0 + T), ld, P2, ld, P1, ld, rem2, rem, T, -1.0, 1.0, false));
+    }
+    GH_HIP(hipEventRecord(s->ev_b[j], sb));
+  }
+  if (m > 0) {
+    GH_HIP(hipEventRecord(s->ev_aux, sa));
+    GH_HIP(hipStreamWaitEvent(st, s->ev_aux, 0));
+  }
+  GH_HIP(hipEventRecord(s->ev_aux2, sb));
+  GH_HIP(hipStreamWaitEvent(st, s->ev_aux2, 0));
+  return GH_OK;
+}
+
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
 static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   double* A = s->A.d();
@@ -647,7 +729,13 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   double* dinv = s->dinv.d() + (k0 / T) * T * T;
   const int64_t m = np - (k0 + nb);
   static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
-  if (!s->st3 || st != s->st2 || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
+  static const bool no_inner0 = getenv("GEORGE_AMD_NO_PANEL_INNER_SPLIT") != nullptr;
+  const bool on_panel_stream = (st == s->st2) || (s->st_crit && st == s->st_crit);
+  static const bool inner = getenv("GEORGE_AMD_PANEL_INNER_SPLIT") != nullptr;     // measured slower (cross-stream waits): off
+  (void)no_inner0;
+  if (inner && s->st4 && on_panel_stream && (st == s->st2 || s->st_sb) && nb / T <= 8 && nb > T && !no_split && !use_simple_potf2())
+    return panel_step_split(s, st, k0, nb);
+  if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
     if (m > 0) GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
     return GH_OK;
@@ -655,7 +743,8 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   // Look-ahead panels: the potf2 chain of the diagonal block stays on `st`; the TRSM of the rows
   // below runs on a second panel stream, column block j as soon as L_jj^-1 exists, so that only
   // the last block's TRSM is left when the chain ends (instead of all nb/128 of them).
-  hipStream_t sa = s->st3;
+  static const bool side_prio1 = getenv("GEORGE_AMD_PANEL_SIDE_PRIO") != nullptr;
+  hipStream_t sa = (s->st_crit && st == s->st_crit && !side_prio1) ? s->st_sa : s->st3;
   double* Ak = blk(A, ld, k0, k0);
   double* B = blk(A, ld, k0 + nb, k0);
   GH_HIP(hipEventRecord(s->ev_aux, st));
@@ -705,6 +794,9 @@ static hipStream_t trailing_stream(gh_chol* s) {
   if (want <= 0 || want >= 128) return s->st;
   if (s->mask_reserved != want) {
     if (s->st_mask) { (void)hipStreamSynchronize(s->st_mask); (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr; }
+    if (s->st_crit) { (void)hipStreamSynchronize(s->st_crit); (void)hipStreamDestroy(s->st_crit); s->st_crit = nullptr; }
+    if (s->st_sa) { (void)hipStreamSynchronize(s->st_sa); (void)hipStreamDestroy(s->st_sa); s->st_sa = nullptr; }
+    if (s->st_sb) { (void)hipStreamSynchronize(s->st_sb); (void)hipStreamDestroy(s->st_sb); s->st_sb = nullptr; }
     s->mask_reserved = want;                                       // (a failed creation is not retried)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->opts.device) == hipSuccess && prop.multiProcessorCount > 2 * want) {
@@ -712,6 +804,20 @@ static hipStream_t trailing_stream(gh_chol* s) {
       std::vector<uint32_t> mask(words, 0u);
       for (int c = want; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
       if (hipExtStreamCreateWithCUMask(&s->st_mask, words, mask.data()) != hipSuccess) { s->st_mask = nullptr; (void)hipGetLastError(); }
+      // Exclusive mode (GEORGE_AMD_PANEL_EXCLUSIVE): the potf2 chain gets the reserved CUs to ITSELF
+      // (a stream masked to exactly those), and the rows-below TRSM -- throughput work -- joins the
+      // trailing update on the others; without it the high-priority panel streams are unmasked and
+      // their workgroups may still land beside SYRK wavefronts.
+      static const bool exclusive = getenv("GEORGE_AMD_PANEL_EXCLUSIVE") != nullptr;
+      if (s->st_mask && exclusive && s->st3) {
+        std::vector<uint32_t> inv(words, 0u);
+        for (int c = 0; c < want; ++c) inv[c / 32] |= (1u << (c % 32));
+        if (hipExtStreamCreateWithCUMask(&s->st_crit, words, inv.data()) != hipSuccess) { s->st_crit = nullptr; (void)hipGetLastError(); }
+        if (s->st_crit && hipExtStreamCreateWithCUMask(&s->st_sa, words, mask.data()) != hipSuccess) {
+          (void)hipGetLastError(); (void)hipStreamDestroy(s->st_crit); s->st_crit = nullptr; s->st_sa = nullptr;
+        }
+        if (s->st_crit && s->st4 && hipExtStreamCreateWithCUMask(&s->st_sb, words, mask.data()) != hipSuccess) { s->st_sb = nullptr; (void)hipGetLastError(); }
+      }
     }
     if (s->st_mask && !s->ev_xfer && hipEventCreateWithFlags(&s->ev_xfer, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError(); (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr;
@@ -721,7 +827,8 @@ static hipStream_t trailing_stream(gh_chol* s) {
 }
 
 static int factor_lookahead(gh_chol* s) {
-  hipStream_t sm = trailing_stream(s), sp = s->st2;
+  hipStream_t sm = trailing_stream(s);
+  hipStream_t sp = (sm != s->st && s->st_crit) ? s->st_crit : s->st2;
   if (sm != s->st) {                                               // everything queued so far (the build) first
     GH_HIP(hipEventRecord(s->ev_xfer, s->st));
     GH_HIP(hipStreamWaitEvent(sm, s->ev_xfer, 0));
