@@ -22,7 +22,12 @@
 // Differences from the reference that stay inside its own tolerance criterion (tests compare to
 // the dense answer with allclose): one RNG stream per node (the reference threads ONE mt19937
 // through the pre-order construction, so the row choices differ); partial-pivot LU / Gauss-Jordan
-// instead of Eigen FullPivLU / LDLT; ranks capped at opts.max_rank.
+// instead of Eigen FullPivLU / LDLT; a block whose residual rows have ALL dropped under the 1e-14
+// pivot threshold keeps its low-rank factors where the reference switches to the exact block
+// (hodlr.h:160-176; same block to 1e-14 per entry, rank r instead of min(rows, cols)).  Ranks grow
+// as far as the tolerance asks, up to RANK_CAP = 1024 (the scratch starts at 256 columns and a
+// level is redone with twice as many when a block is cut short); a block that would need more, or
+// more than a caller-given opts.max_rank, is an ERROR (GH_ERR_BAD_ARG), never a silent truncation.
 #include <math.h>
 #include <string.h>
 #include <algorithm>
@@ -34,7 +39,8 @@ int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* di
                             int nbatch, hipStream_t st);
 
 #define HCH 128          // rows per reduce/update chunk
-#define CPASS 256        // columns handled per pass of an apply (also the cap on a level's rank)
+#define CPASS 256        // columns handled per pass of an apply
+#define RANK_CAP 1024    // hard ceiling on a block's ACA rank (scratch n x rank, 2 rank x 2 rank cores)
 
 // ------------------------------------------------------------------ device structs
 struct LvlNode { int start, half, size, pad; };
@@ -80,7 +86,9 @@ __device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* s
 // (Tcm[k*N + i]): for a node, entries at its first-half rows hold V(:,k) (the block's columns),
 // at its second-half rows U(:,k).
 #define ACA_THREADS 512
-#define ACA_MAXR 512
+#define ACA_MAXR 2048          // coefficient slots in LDS: rank <= 2048 (one-workgroup nodes) / 1024 (clusters)
+#define ACA_NC 64              // candidate rows tested per search pass once the search has started failing
+#define ACA_LIDX 2048          // row permutations of one-workgroup nodes live in LDS up to this many rows
 // One node is worked on by a CLUSTER of G workgroups (blockIdx.x = node * G + g): the top levels
 // have 1, 2, 4, ... nodes with blocks of N/2, N/4, ... rows, and one workgroup per node left the
 // single workgroup of level 0 with 70 % of the whole HODLR compute() at N = 262144.  Workgroup g
@@ -98,11 +106,18 @@ struct AcaShared {
   int shi[8];
   double coef[ACA_MAXR];
   int s_i;
-  // eight-candidates search (one-workgroup nodes)
-  int cand_k[8], cand_i[8], cand_tail[8], cand_bestn[8];
-  double cand_best[8];
-  unsigned long long cand_st[8];
+  // batched candidate search (one-workgroup nodes)
+  int cand_k[ACA_NC], cand_i[ACA_NC], cand_tail[ACA_NC], cand_bestn[ACA_NC];
+  double cand_best[ACA_NC];
+  unsigned long long cand_st[ACA_NC];
+  unsigned short lidx[ACA_LIDX];
+  double pivv;
 };
+// stores of values that another workgroup of the cluster will read: agent-scope atomics (write-through,
+// visible to the other XCDs' atomic loads once s_waitcnt has seen them complete) -- no release fence
+__device__ __forceinline__ void aca_st(double* p, double v, bool shared_w) {
+  if (shared_w) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 __device__ __forceinline__ double aca_ld(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -110,13 +125,19 @@ __device__ __forceinline__ int aca_ldi(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // cluster barrier number `epoch` (0, 1, 2, ...) on counter `bar`; returns false on time-out
-__device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoch, int* fail) {
+__device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoch, int* fail, int fence) {
   if (G == 1) { __syncthreads(); return true; }
   __shared__ int ok;
+  // Release side without a fence: everything this workgroup wrote for the others went out as
+  // agent-scope atomic stores (aca_st), and s_waitcnt makes every lane's stores complete before the
+  // arrival is counted.  __threadfence() here writes this XCD's L2 back at every barrier -- three
+  // per ACA step, 128 workgroups: 60 us per barrier, 2.8 of the 7 ms of ACA time at N = 262144.
+  // (GEORGE_AMD_HODLR_FENCE=1 restores it.)
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(bar, 1u);
+    if (fence) __threadfence();
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = (unsigned)G * (epoch + 1u);
     const long long t0 = wall_clock64();
     int good = 1;
@@ -138,7 +159,7 @@ template <bool FAST>
 __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
-    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi) {
+    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc) {
   __shared__ AcaShared sh;
   const int node = blockIdx.x / G, g = blockIdx.x % G;
   const LvlNode nodev = nodes[node];
@@ -146,16 +167,24 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   const int row0 = nodev.start + nodev.half, n_rows = nodev.size - nodev.half;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int t0 = g * nt + tid, ts = G * nt;            // this thread's first column/row and its stride
+  const bool sw = G > 1;                               // values other workgroups read go out as atomics
   unsigned* bar = bars + node;
   double* mypart = part + ((long)node * G + g) * pstride;
   const double* allpart = part + (long)node * G * pstride;
   unsigned epoch = 0;
-  int max_rank = n_rows < n_cols ? n_rows : n_cols;
+  const int full_rank = n_rows < n_cols ? n_rows : n_cols;
+  int max_rank = full_rank;
   if (max_rank > rcap) max_rank = rcap;
-  if (g == 0) for (int t = tid; t < n_rows; t += nt) idx[row0 + t] = t;
+  // one-workgroup nodes keep the row permutation in LDS (the candidate draws are a serial chain of
+  // dependent reads and writes: ~1 us each through HBM, 64 of them per search pass)
+  const bool lperm = (G == 1) && n_rows <= ACA_LIDX;
+  if (lperm) { for (int t = tid; t < n_rows; t += nt) sh.lidx[t] = (unsigned short)t; }
+  else if (g == 0) { for (int t = tid; t < n_rows; t += nt) idx[row0 + t] = t; }
   int remaining = n_rows, rank = 0;
+  int batch = 8;                                       // candidates per search pass: 8, then ACA_NC once a pass has failed
   double norm = 0.0;
   const double tol2 = tol * tol;
+  bool converged = false;
   unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)node * 0x9E3779B97F4A7C15ull);
   __syncthreads();
   while (rank < max_rank) {
@@ -163,14 +192,17 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     bool got = false;
     int j = -1;
     double pivot = 0.0;
-    // One-workgroup nodes test EIGHT candidate rows per pass, one per wavefront.  Towards the end of
-    // a node's ACA every remaining row is below the 1e-14 threshold and the search walks through
-    // all of them before giving up (hodlr.h:159-191 does too): one row per pass made levels 8 and 9
-    // of C4 cost 2.6 ms for rank-3 blocks.  Same result as the one-by-one search: the candidates
-    // are drawn in the same order, the first that passes wins, and the draws after it are undone
-    // (row permutation and generator state restored).
-    while (multi && G == 1 && remaining > 0 && rank <= 32 && rank + 8 <= rcap) {
-      const int NC = remaining < 8 ? remaining : 8;
+    // One-workgroup nodes test a BATCH of candidate rows per pass, wavefront w the candidates
+    // w, w + 8, ...  Towards the end of a node's ACA every remaining row is below the 1e-14
+    // threshold and the search walks through all of them before giving up (hodlr.h:159-191 does
+    // too): one row per pass made levels 8 and 9 of C4 cost 2.6 ms for rank-3 blocks, eight per pass
+    // 0.75 + 0.6 ms; after the first pass without a hit the batch grows to 64.  Same result as the
+    // one-by-one search: the candidates are drawn in the same order, the first that passes wins,
+    // and the draws after it are undone (row permutation and generator state restored).
+    while (multi && lperm && remaining > 0 && rank <= 32) {
+      int NC = remaining < batch ? remaining : batch;
+      if (rank + NC > rcap) NC = rcap - rank;
+      if (NC < 1) break;
       if (tid == 0) {
         for (int c = 0; c < NC; ++c) {
           st += 0x9E3779B97F4A7C15ull;
@@ -180,17 +212,18 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
           z ^= z >> 31;
           const int k = (int)(z % (unsigned long long)(remaining - c));
           sh.cand_k[c] = k;
-          sh.cand_i[c] = idx[row0 + k];
-          sh.cand_tail[c] = idx[row0 + remaining - c - 1];
-          idx[row0 + k] = sh.cand_tail[c];
+          sh.cand_i[c] = sh.lidx[k];
+          sh.cand_tail[c] = sh.lidx[remaining - c - 1];
+          sh.lidx[k] = (unsigned short)sh.cand_tail[c];
           sh.cand_st[c] = st;
         }
       }
       __syncthreads();
       const int lane = tid & 63, wave = tid >> 6;
-      if (wave < NC) {
-        const int i = sh.cand_i[wave];
+      for (int c = wave; c < NC; c += 8) {
+        const int i = sh.cand_i[c];
         double* cw = sh.coef + wave * 32;
+        __builtin_amdgcn_wave_barrier();              // (the previous candidate's reads of cw are done)
         for (int k = lane; k < rank; k += 64) cw[k] = Tcm[(long)k * N + row0 + i];
         __builtin_amdgcn_s_waitcnt(0);                // (own wavefront's LDS writes, read back below)
         __builtin_amdgcn_wave_barrier();
@@ -201,7 +234,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
           double v = FAST ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
                           : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
           for (int k = 0; k < rank; ++k) v -= cw[k] * Tcm[(long)k * N + col0 + n];
-          Tcm[(long)(rank + wave) * N + col0 + n] = v;
+          Tcm[(long)(rank + c) * N + col0 + n] = v;
           const double a = fabs(v);
           if (a > best) { best = a; bestn = n; }
         }
@@ -210,17 +243,17 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
           const int oi = __shfl_down(bestn, off, 64);
           if (ov > best || (ov == best && oi >= 0 && (bestn < 0 || oi < bestn))) { best = ov; bestn = oi; }
         }
-        if (lane == 0) { sh.cand_best[wave] = best; sh.cand_bestn[wave] = bestn; }
+        if (lane == 0) { sh.cand_best[c] = best; sh.cand_bestn[c] = bestn; }
       }
       __syncthreads();
       int chosen = -1;
       for (int c = 0; c < NC; ++c)
         if (sh.cand_best[c] >= 1e-14) { chosen = c; break; }                           // hodlr.h:191
-      if (chosen < 0) { remaining -= NC; __syncthreads(); continue; }
+      if (chosen < 0) { remaining -= NC; batch = ACA_NC; __syncthreads(); continue; }
       if (tid == 0) {                                 // undo the draws after the chosen one, last first
         for (int c = NC - 1; c > chosen; --c) {
-          idx[row0 + sh.cand_k[c]] = sh.cand_i[c];
-          idx[row0 + remaining - c - 1] = sh.cand_tail[c];
+          sh.lidx[sh.cand_k[c]] = (unsigned short)sh.cand_i[c];
+          sh.lidx[remaining - c - 1] = (unsigned short)sh.cand_tail[c];
         }
       }
       st = sh.cand_st[chosen];                        // (every thread keeps the generator state in step)
@@ -241,12 +274,13 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z ^= z >> 31;
         const int k = (int)(z % (unsigned long long)remaining);
-        const int pick = idx[row0 + k];
-        idx[row0 + k] = idx[row0 + remaining - 1];
-        sel[node] = pick;
+        int pick;
+        if (lperm) { pick = sh.lidx[k]; sh.lidx[k] = sh.lidx[remaining - 1]; }
+        else { pick = idx[row0 + k]; idx[row0 + k] = idx[row0 + remaining - 1]; }
+        if (sw) __hip_atomic_store(sel + node, pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else sel[node] = pick;
       }
       --remaining;
-      if (!aca_barrier(bar, G, epoch, fail)) return;                                  // B1: row chosen
+      if (!aca_barrier(bar, G, epoch, fail, fence)) return;                           // B1: row chosen
       const int i = (G == 1) ? sel[node] : aca_ldi(sel + node);
       for (int k = tid; k < rank; k += nt) sh.coef[k] = aca_ld(Tcm + (long)k * N + row0 + i);   // U(i, 0:rank)
       __syncthreads();
@@ -257,38 +291,49 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
         double v = FAST ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
                         : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
         for (int k = 0; k < rank; ++k) v -= sh.coef[k] * Tcm[(long)k * N + col0 + n];
-        Tcm[(long)rank * N + col0 + n] = v;
+        Tcm[(long)rank * N + col0 + n] = v;           // (rewritten after the pivot is known: owner-only so far)
         const double a = fabs(v);
         if (a > best) { best = a; bestn = n; }
       }
       hw_block_argmax(best, bestn, sh.shd, sh.shi);
       if (G > 1) {
         if (tid == 0) {
-          mypart[0] = best;
-          mypart[1] = (double)bestn;
-          mypart[2] = bestn >= 0 ? Tcm[(long)rank * N + col0 + bestn] : 0.0;         // (this workgroup wrote it)
+          aca_st(mypart + 0, best, true);
+          aca_st(mypart + 1, (double)bestn, true);
+          aca_st(mypart + 2, bestn >= 0 ? Tcm[(long)rank * N + col0 + bestn] : 0.0, true);   // (this workgroup wrote it)
         }
-        if (!aca_barrier(bar, G, epoch, fail)) return;                                // B2: pivot search
-        best = -1.0; bestn = -1;
-        for (int q = 0; q < G; ++q) {                                                 // largest value, smallest column on ties
-          const double bv = aca_ld(allpart + (long)q * pstride);
-          const int bn = (int)aca_ld(allpart + (long)q * pstride + 1);
-          if (bn >= 0 && (bv > best || (bv == best && (bestn < 0 || bn < bestn)))) {
-            best = bv; bestn = bn; bestv = aca_ld(allpart + (long)q * pstride + 2);
-          }
+        if (!aca_barrier(bar, G, epoch, fail, fence)) return;                         // B2: pivot search
+        // every workgroup reduces the same G candidates with the same tree (thread q takes member q's):
+        // largest value, smallest column on ties.  (A serial loop of 3 G device-scope loads in EVERY
+        // thread was most of the 185 us an ACA step of the root node took.)
+        double cv = -1.0, cvv = 0.0;
+        int cn = -1;
+        if (tid < G) {
+          cv = aca_ld(allpart + (long)tid * pstride);
+          cn = (int)aca_ld(allpart + (long)tid * pstride + 1);
+          cvv = aca_ld(allpart + (long)tid * pstride + 2);
+          if (cn < 0) cv = -1.0;
         }
+        best = cv; bestn = cn;
+        hw_block_argmax(best, bestn, sh.shd, sh.shi);
+        if (tid < G && cn >= 0 && cn == bestn) sh.pivv = cvv;      // (columns are owned by one workgroup: a unique writer)
+        __syncthreads();
+        bestv = bestn >= 0 ? sh.pivv : 0.0;
       } else {
         bestv = bestn >= 0 ? Tcm[(long)rank * N + col0 + bestn] : 0.0;
       }
       if (best >= 1e-14) { got = true; j = bestn; pivot = bestv; break; }              // hodlr.h:191
     }
-    if (!got) break;       // rows exhausted: keep what we have (residual rows all < 1e-14)
+    // rows exhausted: every residual row tested below 1e-14 in absolute value -- keep the factors we
+    // have (the reference returns the exact block as a rank-min(rows, cols) "trivial factorisation",
+    // hodlr.h:160-176; the two represent the same block to 1e-14 per entry)
+    if (!got) { converged = true; break; }
     // ---- normalise the row by its pivot, build the column (hodlr.h:194-199)
     __syncthreads();
     double vn2 = 0.0;
     for (int n = t0; n < n_cols; n += ts) {
       const double v = Tcm[(long)rank * N + col0 + n] / pivot;
-      Tcm[(long)rank * N + col0 + n] = v;
+      aca_st(Tcm + (long)rank * N + col0 + n, v, sw);
       vn2 += v * v;
     }
     for (int k = tid; k < rank; k += nt) sh.coef[k] = aca_ld(Tcm + (long)k * N + col0 + j);    // V(j, 0:rank)
@@ -299,11 +344,12 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       double u = FAST ? gh_fast_value(fast, x + (long)(row0 + m) * nd, xj)
                       : gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
       for (int k = 0; k < rank; ++k) u -= sh.coef[k] * Tcm[(long)k * N + row0 + m];
-      Tcm[(long)rank * N + row0 + m] = u;
+      aca_st(Tcm + (long)rank * N + row0 + m, u, sw);
       un2 += u * u;
     }
     ++rank;
-    if (rank >= max_rank) break;                                                       // hodlr.h:203
+    if (rank >= full_rank) { converged = true; break; }                                // hodlr.h:203
+    if (rank >= max_rank) break;                                                       // rank cap: NOT converged
     un2 = hw_block_sum(un2, sh.shd);
     vn2 = hw_block_sum(vn2, sh.shd);
     // cross terms |u_new . u_k|, |v_new . v_k|, k < rank-1, of the norm estimate (hodlr.h:210-214):
@@ -328,7 +374,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
         const double a = hw_block_sum(du[q], sh.shd);
         const double b = hw_block_sum(dv[q], sh.shd);
         if (G > 1) {
-          if (tid == 0 && k0 + q < rank - 1) { mypart[6 + 2 * (k0 + q)] = a; mypart[7 + 2 * (k0 + q)] = b; }
+          if (tid == 0 && k0 + q < rank - 1) { aca_st(mypart + 6 + 2 * (k0 + q), a, true); aca_st(mypart + 7 + 2 * (k0 + q), b, true); }
         } else {
           if (fabs(a) > maxu) maxu = fabs(a);
           if (fabs(b) > maxv) maxv = fabs(b);
@@ -336,15 +382,23 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       }
     }
     if (G > 1) {
-      if (tid == 0) { mypart[3] = un2; mypart[4] = vn2; }     // (slots 0-2 may still be read by a slow member)
-      if (!aca_barrier(bar, G, epoch, fail)) return;                                  // B3: norms
-      un2 = 0.0; vn2 = 0.0;
-      for (int q = 0; q < G; ++q) { un2 += aca_ld(allpart + (long)q * pstride + 3); vn2 += aca_ld(allpart + (long)q * pstride + 4); }
-      for (int k = tid; k < rank - 1; k += nt) {
-        double a = 0.0, b = 0.0;
-        for (int q = 0; q < G; ++q) { a += aca_ld(allpart + (long)q * pstride + 6 + 2 * k); b += aca_ld(allpart + (long)q * pstride + 7 + 2 * k); }
-        sh.coef[k] = fabs(a);                 // (coef is free here: reloaded at the next step)
-        sh.coef[ACA_MAXR / 2 + k] = fabs(b);
+      if (tid == 0) { aca_st(mypart + 3, un2, true); aca_st(mypart + 4, vn2, true); }     // (slots 0-2 may still be read by a slow member)
+      if (!aca_barrier(bar, G, epoch, fail, fence)) return;                           // B3: norms
+      {
+        double pu = 0.0, pv = 0.0;
+        if (tid < G) { pu = aca_ld(allpart + (long)tid * pstride + 3); pv = aca_ld(allpart + (long)tid * pstride + 4); }
+        un2 = hw_block_sum(pu, sh.shd);
+        vn2 = hw_block_sum(pv, sh.shd);
+      }
+      {
+        const int lane = tid & 63, wave = tid >> 6;          // wavefront w sums the G shares of the dot products k = w, w + 8, ...
+        for (int k = wave; k < rank - 1; k += (nt >> 6)) {
+          double a = 0.0, b = 0.0;
+          for (int q = lane; q < G; q += 64) { a += aca_ld(allpart + (long)q * pstride + 6 + 2 * k); b += aca_ld(allpart + (long)q * pstride + 7 + 2 * k); }
+          a = hw_wave_sum(a);
+          b = hw_wave_sum(b);
+          if (lane == 0) { sh.coef[k] = fabs(a); sh.coef[ACA_MAXR / 2 + k] = fabs(b); }   // (coef is free here: reloaded at the next step)
+        }
       }
       __syncthreads();
       for (int k = 0; k < rank - 1; ++k) {
@@ -354,11 +408,14 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       __syncthreads();
     }
     const double rowcol = un2 * vn2;
-    if (rowcol < tol2 * norm) break;                                                   // hodlr.h:206-207
+    if (rowcol < tol2 * norm) { converged = true; break; }                             // hodlr.h:206-207
     norm += rowcol;
     if (rank > 1) norm += 2.0 * maxu + 2.0 * maxv;
   }
-  if (g == 0 && tid == 0) ranks[node] = rank;
+  if (g == 0 && tid == 0) {
+    ranks[node] = rank;
+    if (!converged && rank < full_rank) atomicExch(trunc, 1);     // stopped by the cap, not by the tolerance
+  }
 }
 
 // B (rows of this level's nodes x R, row-major, ld = R) <- first rank columns of Tcm, zero padded
@@ -641,6 +698,7 @@ struct gh_hodlr {
   std::vector<LeafDesc> leaves;
   int Rtot = 0, max_leaf = 0, max_chunks = 0, maxR = 0;
   int leaf_pitch = 0;            // row pitch of the stored leaf inverses
+  int cpass = CPASS;             // columns per apply pass = row pitch of P / Tsum / Tout / Y (>= the largest level rank)
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   ~gh_hodlr() {
     for (auto* l : levels) delete l;
@@ -657,8 +715,8 @@ extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
   if (opts) h->opts = *opts;
   else { h->opts.min_size = 100; h->opts.tol = 0.1; h->opts.seed = 42; }
   if (h->opts.min_size < 1) h->opts.min_size = 1;
-  if (h->opts.max_rank <= 0) h->opts.max_rank = 256;
-  if (h->opts.max_rank > CPASS) h->opts.max_rank = CPASS;      // one column pass holds a level's R columns
+  if (h->opts.max_rank < 0) h->opts.max_rank = 0;              // 0: as much as the tolerance asks for, up to RANK_CAP
+  if (h->opts.max_rank > RANK_CAP) h->opts.max_rank = RANK_CAP;
   if (hipSetDevice(h->opts.device) != hipSuccess || hipStreamCreate(&h->st) != hipSuccess) {
     delete h; gh_set_error("cannot initialise HIP device %d", opts ? opts->device : 0); return GH_ERR_HIP;
   }
@@ -689,9 +747,9 @@ static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const
 static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, int C, const double* U, long ldu) {
   if (L->R == 0 || C <= 0) return GH_OK;
   const int R = L->R, nn = (int)L->node_ids.size();
-  for (int cp = 0; cp < C; cp += CPASS) {
-    const int cw = std::min(CPASS, C - cp);
-    const long Cp = CPASS;
+  for (int cp = 0; cp < C; cp += h->cpass) {
+    const int cw = std::min(h->cpass, C - cp);
+    const long Cp = h->cpass;
     // reduce: P[chunk] = V_chunk^T X_chunk
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + L->off, 1, h->Rtot,
                        X, ldx, xcol0 + cp, h->P.d(), Cp, 0, cw, false));
@@ -709,13 +767,13 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
 // X rows of every leaf <- K_leaf^-1 X
 static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
   if (C <= 0) return GH_OK;
-  for (int cp = 0; cp < C; cp += CPASS) {
-    const int cw = std::min(CPASS, C - cp);
+  for (int cp = 0; cp < C; cp += h->cpass) {
+    const int cw = std::min(h->cpass, C - cp);
     GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_jobs.p, (int)h->leaves.size(), h->max_leaf, h->leaf_inv.d(), h->leaf_pitch, 1,
-                       X, ldx, xcol0 + cp, h->Y.d(), CPASS, 0, cw, false));
+                       X, ldx, xcol0 + cp, h->Y.d(), h->cpass, 0, cw, false));
     const long tot = h->n * cw;
     hipLaunchKernelGGL(hodlr_copyrows_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 65535)), dim3(256), 0, h->st,
-                       h->Y.d(), (long)CPASS, X, ldx, xcol0 + cp, (long)h->n, cw);
+                       h->Y.d(), (long)h->cpass, X, ldx, xcol0 + cp, (long)h->n, cw);
     GH_HIP(hipGetLastError());
   }
   return GH_OK;
@@ -806,13 +864,17 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   for (auto& lf : h->leaves) h->max_leaf = std::max(h->max_leaf, lf.size);
 
   // ---- ACA level by level into column-major scratch, ranks back to the host
-  const int rcap = h->opts.max_rank;
+  // column capacity of the scratch: the caller's cap, else 256 to start with (doubled, up to RANK_CAP,
+  // whenever a block of a level is cut short by it -- that level is then redone)
+  const bool user_cap = h->opts.max_rank > 0;
+  int rcap = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
   const int nlev = (int)h->levels.size();
   GhPooledBuf Tcm, idx, aca_sync, aca_part;
   if (nlev > 0) {
     GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
     GH_CHECK(idx.ensure((size_t)n * sizeof(int)));
   }
+  static const int aca_fence = getenv("GEORGE_AMD_HODLR_FENCE") ? 1 : 0;
   std::vector<GhBuf*> levelB(nlev, nullptr);
   struct Cleanup { std::vector<GhBuf*>& v; ~Cleanup() { for (auto* b : v) delete b; } } cleanup{levelB};
   h->Rtot = 0; h->maxR = 0; h->max_chunks = 0;
@@ -825,34 +887,53 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(L->d_ranks.ensure(nn * sizeof(int)));
     // cluster size: as many workgroups per node as keep the whole grid resident (nodes * G <= 256)
     // and leave every workgroup at least two columns per thread
+    // ... and leave every thread `ept` columns: a cluster barrier costs ~60 us with 128 members
+    // whatever the release protocol (the arrivals and the polls are device-scope atomics on one
+    // line), and an ACA step is three of them, so clusters are kept as small as the per-thread work
+    // allows (GEORGE_AMD_HODLR_EPT, elements per thread; 2 = as many workgroups as possible)
     int G = 1;
     if (!getenv("GEORGE_AMD_HODLR_NO_CLUSTER")) {
+      static const int ept = getenv("GEORGE_AMD_HODLR_EPT") ? std::max(1, atoi(getenv("GEORGE_AMD_HODLR_EPT"))) : 2;
       int min_half = INT32_MAX;
       for (int q = 0; q < nn; ++q) min_half = std::min(min_half, ln[q].half);
-      while (G * 2 * nn <= 256 && (long)(G * 2) * ACA_THREADS * 2 <= min_half) G *= 2;
+      while (G * 2 * nn <= 256 && (long)(G * 2) * ACA_THREADS * ept <= min_half) G *= 2;
     }
     const int pstride = 8 + 2 * ACA_MAXR;
-    GH_CHECK(aca_sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + sizeof(int)));
+    GH_CHECK(aca_sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
     GH_CHECK(aca_part.ensure((size_t)nn * G * pstride * sizeof(double)));
-    GH_HIP(hipMemsetAsync(aca_sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + sizeof(int), st));
+  redo_level:
+    GH_HIP(hipMemsetAsync(aca_sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), st));
     unsigned* d_bars = (unsigned*)aca_sync.p;
     int* d_sel = (int*)(d_bars + nn);
     int* d_fail = d_sel + nn;
+    int* d_trunc = d_fail + 1;
     static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
 #define GH_ACA_LAUNCH(F)                                                                                          \
     hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(),  \
                        k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p,   \
                        (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
-                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail, aca_multi)
+                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_trunc)
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
-    int aca_failed = 0;
-    GH_HIP(hipMemcpyAsync(&aca_failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    int aca_flags[2] = {0, 0};                       // [0] barrier time-out, [1] a block was cut short by the column capacity
+    GH_HIP(hipMemcpyAsync(aca_flags, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     L->ranks.resize(nn);
     GH_HIP(hipMemcpyAsync(L->ranks.data(), L->d_ranks.p, nn * sizeof(int), hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));
-    if (aca_failed) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", l); return GH_ERR_HIP; }
+    if (aca_flags[0]) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", l); return GH_ERR_HIP; }
+    if (aca_flags[1]) {
+      // hodlr.h:147 lets the rank grow to min(rows, cols); a cut-short block would be a silently wrong answer
+      if (user_cap || rcap >= RANK_CAP) {
+        gh_set_error("HODLR: an off-diagonal block of level %d needs a rank above %d to reach tol = %g (%s); "
+                     "the factorisation is not usable", l, rcap, h->opts.tol,
+                     user_cap ? "opts.max_rank" : "the solver's ceiling: loosen tol, raise min_size or use the dense solver");
+        return GH_ERR_BAD_ARG;
+      }
+      rcap = std::min(2 * rcap, RANK_CAP);
+      GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
+      goto redo_level;
+    }
     L->R = 0;
     for (int r : L->ranks) L->R = std::max(L->R, r);
     L->off = h->Rtot;
@@ -917,10 +998,11 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   {
     size_t maxnodes = 1;
     for (auto* L : h->levels) maxnodes = std::max(maxnodes, L->node_ids.size() * (size_t)std::max(L->R, 1));
-    GH_CHECK(h->P.ensure((size_t)std::max(h->max_chunks, 1) * std::max(h->maxR, 1) * CPASS * sizeof(double)));
-    GH_CHECK(h->Tsum.ensure(maxnodes * 2 * CPASS * sizeof(double)));
-    GH_CHECK(h->Tout.ensure(maxnodes * 2 * CPASS * sizeof(double)));
-    GH_CHECK(h->Y.ensure((size_t)n * CPASS * sizeof(double)));
+    h->cpass = std::max(CPASS, (h->maxR + 63) / 64 * 64);       // the core build handles a level's R columns in ONE pass
+    GH_CHECK(h->P.ensure((size_t)std::max(h->max_chunks, 1) * std::max(h->maxR, 1) * h->cpass * sizeof(double)));
+    GH_CHECK(h->Tsum.ensure(maxnodes * 2 * h->cpass * sizeof(double)));
+    GH_CHECK(h->Tout.ensure(maxnodes * 2 * h->cpass * sizeof(double)));
+    GH_CHECK(h->Y.ensure((size_t)n * h->cpass * sizeof(double)));
   }
 
   // ---- leaves: exact blocks -> explicit inverses + log-dets (hodlr.h:223-227, 87-89)
@@ -1021,10 +1103,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     const int R = L->R, nn = (int)L->node_ids.size();
     // S = I + [0, V1^T U1; V0^T U0, 0] with the CURRENT U of this level
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + L->off, 1, Rtot,
-                       h->UA.d(), Rtot, L->off, h->P.d(), CPASS, 0, R, false));
-    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)CPASS, R, h->Tsum.d());
+                       h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R, false));
+    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
     GH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)CPASS, R, L->sinv.d());
+    hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)h->cpass, R, L->sinv.d());
     GH_HIP(hipGetLastError());
     std::vector<long> offs(nn);
     std::vector<int> sizes(nn, 2 * R);

@@ -19,6 +19,9 @@ __all__ = ["HODLRSolver"]
 class HODLRSolver(BasicSolver):
 
     def __init__(self, kernel, min_size=100, tol=0.1, seed=42, device=0, max_rank=0):
+        # max_rank = 0: ranks grow as far as ``tol`` asks (hodlr.h:147), up to the solver's ceiling of
+        # 1024; a block that needs more -- or more than an explicit ``max_rank`` -- raises ValueError
+        # instead of being truncated.
         self.min_size = min_size
         self.tol = tol
         self.seed = seed
@@ -100,7 +103,25 @@ class HODLRSolver(BasicSolver):
         N.check(N.lib.gh_hodlr_ranks(self._need(), buf, 65536, C.byref(cnt)))
         return list(buf[:cnt.value])
 
+    # pickling drops the factor and flags the solver un-computed (hodlr.py:69-76)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handle"] = None
+        state["_dk"] = None
+        state["_factor_state"] = None
+        state["_computed"] = False
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def _need(self):
+        if not self._computed or self._handle is None:
+            raise RuntimeError("you must call 'compute' first")
+        return self._handle
+
     # the fused dense-only extensions do not apply
     predict = None
     grad = None
     profile = None
+    objective = None

@@ -107,6 +107,12 @@ def hodlr_configs(K):
     for n in (4096, 8192):
         x, yerr, y = bench_data(n)
         out["C4_%d" % n] = (np.var(y) * K.ExpSquaredKernel(1.0), x, yerr, y, dict(min_size=100, tol=1e-10, seed=42))
+    # the point DENSITY of the full C4 (262144 points on [0, 10]): the deep blocks span so little of the
+    # kernel's length scale that every residual row falls under 1e-14 after three or four terms, and
+    # the reference takes its exact "trivial factorisation" there (rank = block size)
+    rng = np.random.RandomState(99)
+    x = np.sort(rng.uniform(0, 10 * 4096 / 262144.0, 4096))
+    out["C4_density_4096"] = (0.5 * K.ExpSquaredKernel(1.0), x, 0.1 * np.ones(4096), np.sin(40 * x), dict(min_size=100, tol=1e-10, seed=42))
     x, yerr, y = bench_data(3000)
     out["C4_3000_tol1e-4_seed7"] = (np.var(y) * K.ExpSquaredKernel(1.0), x, yerr, y, dict(min_size=64, tol=1e-4, seed=7))
     # exactly low-rank block (Matern-3/2 on sorted 1-D inputs is rank 2 off the diagonal): with a tight
@@ -118,6 +124,10 @@ def hodlr_configs(K):
     x, yerr, y = bench_data(2000, ndim=3)
     out["c5like3d"] = (K.Matern52Kernel(0.5, ndim=3) + K.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3), x, yerr, y,
                        dict(min_size=100, tol=1e-6, seed=42))
+    # rank beyond 256 (400 at the root in the reference build)
+    x, yerr, y = bench_data(4096, ndim=3)
+    out["c5like3d_4096_rank400"] = (K.Matern52Kernel(0.5, ndim=3) + K.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3), x, yerr, y,
+                                    dict(min_size=100, tol=1e-7, seed=42))
     x, yerr, y = bench_data(2000, ndim=2)
     out["expsq2d"] = (0.7 * K.ExpSquaredKernel([0.3, 0.5], ndim=2), x, yerr, y, dict(min_size=100, tol=1e-8, seed=11))
     return out
