@@ -10,6 +10,12 @@
 //   * the binary tree (hodlr.h:48: internal iff size/2 >= min_size) is built on the host;
 //   * ACA for all nodes of a level runs as one launch, one workgroup per node, evaluating kernel
 //     rows/columns on the fly (gh_eval.h) -- the N x N matrix is never formed;
+//   * (layout note) V is only ever read one level at a time, so VA is stored LEVEL-MAJOR: level l is a
+//     contiguous N x R_l row-major block at element offset N * off_l; U is needed both ways -- all
+//     shallower levels at once during the factorisation sweep (row-major N x Rtot, UA) and one level
+//     at a time in every solve (a level-major copy UL made once at the end of compute()).  With both
+//     in the row-major form every level pass of a solve touched all 5 cache lines of a 75-column row
+//     for the 3-15 columns it needed.
 //   * U and V of every level live in two N x Rtot row-major arrays (UA, VA): column block l holds
 //     level l, row i the point i (rows [start, start+half) of a node hold its U_[0] / V_[0], the
 //     rest U_[1] / V_[1], zero-padded to the level's max rank).  "Apply the inverse of level l to
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
 
 // B (rows of this level's nodes x R, row-major, ld = R) <- first rank columns of Tcm, zero padded
 __global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* nodes, const int* ranks,
-                                     int R, double* UA, double* VA, long ld, int off) {
+                                     int R, double* UA, long ld, long off, double* VA, long ldv, long offv) {
   const LvlNode nd = nodes[blockIdx.x];
   const int rk = ranks[blockIdx.x];
   const long tot = (long)nd.size * R;
@@ -429,7 +435,16 @@ __global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* n
     const long i = nd.start + r;
     const double v = (k < rk) ? Tcm[(long)k * N + i] : 0.0;
     UA[i * ld + off + k] = v;
-    VA[i * ld + off + k] = v;
+    if (VA) VA[i * ldv + offv + k] = v;
+  }
+}
+// UL (level-major) <- UA (row-major n x Rtot): column c of row i goes to UL[colbase[c] + i * colld[c]]
+__global__ void hodlr_relayout_kernel(const double* UA, long n, int Rtot, const long* colbase, const int* colld, double* UL) {
+  const long tot = n * Rtot;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const long i = e / Rtot;
+    const int c = (int)(e % Rtot);
+    UL[colbase[c] + i * colld[c]] = UA[e];
   }
 }
 
@@ -573,14 +588,12 @@ struct MMArgs {
   const double* A; long a_rs, a_cs;
   const double* B; long ldb, b_col0;
   double* O; long ldo, o_col0;
-  int C, subtract;
+  int C, subtract, mtiles;
 };
 __global__ __launch_bounds__(256) void hodlr_mm_kernel(MMArgs a) {
   __shared__ double As[32 * 33];
   __shared__ double Bs[32 * 64];
   const MMJob job = a.jobs[blockIdx.x];
-  const int m0 = blockIdx.y * 32;
-  if (m0 >= job.m) return;
   const int c0 = blockIdx.z * 64, tid = threadIdx.x;
   // 32 x 64 tile on the matrix pipe: wavefront w takes the 16-row block w & 1 and the two 16-column
   // blocks 2 (w >> 1), 2 (w >> 1) + 1; operands are staged in LDS exactly as for the VALU loop this
@@ -589,44 +602,48 @@ __global__ __launch_bounds__(256) void hodlr_mm_kernel(MMArgs a) {
   const int fr = lane & 15, fk = lane >> 4;
   const int bi = wave & 1, bj = 2 * (wave >> 1);
   typedef double mm_v4d __attribute__((ext_vector_type(4)));
-  mm_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   const bool rfast = (a.a_rs == 1);
-  for (int k0 = 0; k0 < job.kd; k0 += 32) {
+  for (int mt = 0; mt < a.mtiles; ++mt) {
+    const int m0 = (blockIdx.y * a.mtiles + mt) * 32;
+    if (m0 >= job.m) break;                                   // (uniform)
+    mm_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < job.kd; k0 += 32) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + 256 * q;
-      const int r = rfast ? (e & 31) : (e >> 5), k = rfast ? (e >> 5) : (e & 31);
-      double v = 0.0;
-      if (m0 + r < job.m && k0 + k < job.kd) v = a.A[job.a_off + (long)(m0 + r) * a.a_rs + (long)(k0 + k) * a.a_cs];
-      As[r * 33 + k] = v;
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        const int r = rfast ? (e & 31) : (e >> 5), k = rfast ? (e >> 5) : (e & 31);
+        double v = 0.0;
+        if (m0 + r < job.m && k0 + k < job.kd) v = a.A[job.a_off + (long)(m0 + r) * a.a_rs + (long)(k0 + k) * a.a_cs];
+        As[r * 33 + k] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = tid + 256 * q;
+        const int k = e >> 6, cc = e & 63;
+        double v = 0.0;
+        if (k0 + k < job.kd && c0 + cc < a.C) v = a.B[(long)(job.b_row + k0 + k) * a.ldb + a.b_col0 + c0 + cc];
+        Bs[k * 64 + cc] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const double av = As[(16 * bi + fr) * 33 + 4 * kk + fk];
+        const double b0 = Bs[(4 * kk + fk) * 64 + 16 * bj + fr];
+        const double b1 = Bs[(4 * kk + fk) * 64 + 16 * bj + 16 + fr];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
+      }
+      __syncthreads();
     }
+    // f64 MFMA C/D map: row = (lane >> 4) + 4 reg, col = lane & 15
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = tid + 256 * q;
-      const int k = e >> 6, cc = e & 63;
-      double v = 0.0;
-      if (k0 + k < job.kd && c0 + cc < a.C) v = a.B[(long)(job.b_row + k0 + k) * a.ldb + a.b_col0 + c0 + cc];
-      Bs[k * 64 + cc] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * bi + fk + 4 * r;
+      if (row >= job.m) continue;
+      double* o = a.O + (long)(job.o_row + row) * a.ldo + a.o_col0 + c0 + 16 * bj + fr;
+      if (c0 + 16 * bj + fr < a.C) o[0] = a.subtract ? (o[0] - acc0[r]) : acc0[r];
+      if (c0 + 16 * bj + 16 + fr < a.C) o[16] = a.subtract ? (o[16] - acc1[r]) : acc1[r];
     }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const double av = As[(16 * bi + fr) * 33 + 4 * kk + fk];
-      const double b0 = Bs[(4 * kk + fk) * 64 + 16 * bj + fr];
-      const double b1 = Bs[(4 * kk + fk) * 64 + 16 * bj + 16 + fr];
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // f64 MFMA C/D map: row = (lane >> 4) + 4 reg, col = lane & 15
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = m0 + 16 * bi + fk + 4 * r;
-    if (row >= job.m) continue;
-    double* o = a.O + (long)(job.o_row + row) * a.ldo + a.o_col0 + c0 + 16 * bj + fr;
-    if (c0 + 16 * bj + fr < a.C) o[0] = a.subtract ? (o[0] - acc0[r]) : acc0[r];
-    if (c0 + 16 * bj + 16 + fr < a.C) o[16] = a.subtract ? (o[16] - acc1[r]) : acc1[r];
   }
 }
 // Tsum[node][0:R] = sum of the partials of its half-1 chunks, [R:2R] = half-0 chunks (hodlr.h:247-249)
@@ -683,12 +700,21 @@ struct HLevel {
   std::vector<int> node_ids;
   int R = 0, off = 0, nchunks = 0;
   GhPooledBuf d_nodes, d_chunks, d_crange, d_red_jobs, d_upd_jobs, d_smul_jobs, d_ranks, sinv;   // (one stream: h->st)
+  GhPooledBuf d_gj_offs, d_gj_sizes, d_gj_sc, d_updl_jobs;
   std::vector<int> ranks;
+  // The job tables depend on the tree and on (R, off, Rtot) only: inside an optimiser loop neither
+  // changes from one compute() to the next, and re-uploading them (~9 small copies per level, each a
+  // host round trip) was ~1 ms of the 12 ms of a C4 compute.
+  bool nodes_up = false;
+  int tab_R = -1, tab_off = -1, gj_R = -1;
+  long tab_Rtot = -1;
 };
 
 struct gh_hodlr {
   gh_hodlr_opts opts;
   hipStream_t st = nullptr;
+  hipStream_t st_b = nullptr;    // second stream: ACA of the one-workgroup-per-node levels beside the clustered ones
+  hipEvent_t ev_b = nullptr;
   int64_t n = 0;
   int ndim = 0;
   bool computed = false;
@@ -700,11 +726,21 @@ struct gh_hodlr {
   int leaf_pitch = 0;            // row pitch of the stored leaf inverses
   int cpass = CPASS;             // columns per apply pass = row pitch of P / Tsum / Tout / Y (>= the largest level rank)
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
+  GhBuf d_leaf_prod;
+  GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (solves) and its column map
+  long col_Rtot = -1;
+  std::vector<int> col_sig;
+  GhBuf ld_all, flags;           // log|det| of every factored block of a compute(); [0] Gauss-Jordan failure, [2..3] leaf info
   ~gh_hodlr() {
     for (auto* l : levels) delete l;
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (st_b) (void)hipStreamDestroy(st_b);
     if (st) (void)hipStreamDestroy(st);
   }
-  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); }
+  int64_t tree_n = -1;
+  int tree_min = -1;
+  bool leaf_tab_up = false;
+  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); tree_n = -1; leaf_tab_up = false; col_Rtot = -1; col_sig.clear(); }
 };
 
 extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
@@ -732,26 +768,31 @@ static int upload(GhBuf& buf, const std::vector<Tv>& v, hipStream_t st) {
   return GH_OK;
 }
 
+// mtiles: 32-row tiles of a job handled by ONE workgroup (the update passes: 4, i.e. a whole 128-row
+// chunk -- 8192 workgroups of one tiny tile each spent their 50 us on being dispatched)
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
-                     const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract) {
+                     const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1) {
   if (njobs <= 0 || C <= 0 || max_m <= 0) return GH_OK;
   MMArgs a;
+  a.mtiles = mtiles;
   a.jobs = jobs; a.A = A; a.a_rs = a_rs; a.a_cs = a_cs; a.B = B; a.ldb = ldb; a.b_col0 = b_col0;
   a.O = O; a.ldo = ldo; a.o_col0 = o_col0; a.C = C; a.subtract = subtract ? 1 : 0;
-  hipLaunchKernelGGL(hodlr_mm_kernel, dim3(njobs, (max_m + 31) / 32, (C + 63) / 64), dim3(256), 0, h->st, a);
+  hipLaunchKernelGGL(hodlr_mm_kernel, dim3(njobs, ((max_m + 31) / 32 + mtiles - 1) / mtiles, (C + 63) / 64), dim3(256), 0, h->st, a);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
 
 // X[:, xcol0 : xcol0+C] <- (level lv)^-1 applied (hodlr.h:244-253 for every node of the level)
+// (U == nullptr: the level-major copy UL is used -- solves; else the row-major UA with pitch ldu)
 static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, int C, const double* U, long ldu) {
   if (L->R == 0 || C <= 0) return GH_OK;
   const int R = L->R, nn = (int)L->node_ids.size();
+  const double* Vl = h->VA.d() + (long)h->n * L->off;
   for (int cp = 0; cp < C; cp += h->cpass) {
     const int cw = std::min(h->cpass, C - cp);
     const long Cp = h->cpass;
     // reduce: P[chunk] = V_chunk^T X_chunk
-    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + L->off, 1, h->Rtot,
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, Vl, 1, R,
                        X, ldx, xcol0 + cp, h->P.d(), Cp, 0, cw, false));
     hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, cw, h->Tsum.d());
     GH_HIP(hipGetLastError());
@@ -759,8 +800,12 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
                        h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, cw, false));
     // update: X_chunk -= U_chunk * Tout[half]
-    GH_CHECK(launch_mm(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, HCH, U + L->off, ldu, 1,
-                       h->Tout.d(), Cp, 0, X, ldx, xcol0 + cp, cw, true));
+    if (U)
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, HCH, U + L->off, ldu, 1,
+                         h->Tout.d(), Cp, 0, X, ldx, xcol0 + cp, cw, true, HCH / 32));
+    else
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_updl_jobs.p, L->nchunks, HCH, h->UL.d() + (long)h->n * L->off, R, 1,
+                         h->Tout.d(), Cp, 0, X, ldx, xcol0 + cp, cw, true, HCH / 32));
   }
   return GH_OK;
 }
@@ -782,26 +827,31 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
 static int solve_all(gh_hodlr* h, double* X, long ldx, int C) {
   GH_CHECK(apply_leaves(h, X, ldx, 0, C));
   for (int l = (int)h->levels.size() - 1; l >= 0; --l)
-    GH_CHECK(apply_level(h, h->levels[l], X, ldx, 0, C, h->UA.d(), h->Rtot));
+    GH_CHECK(apply_level(h, h->levels[l], X, ldx, 0, C, nullptr, 0));
   return GH_OK;
 }
 
+// enqueue only: logdet[b] of matrix b goes to d_logdet[b] (device), a singular block raises h->flags[0]
+// (tables: device copies of offs / sizes / scratch offsets kept by the caller; *tables_valid says they
+//  already hold this batch's values)
 static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& offs, const std::vector<int>& sizes,
-                           std::vector<double>& logdets) {
+                           double* d_logdet, GhBuf* const* tables = nullptr, bool tables_valid = false) {
   const int nb = (int)sizes.size();
   if (nb == 0) return GH_OK;
   std::vector<long> sc(nb);
   long tot = 0;
   for (int i = 0; i < nb; ++i) { sc[i] = tot; tot += sizes[i]; }
-  GhPooledBuf d_offs, d_sizes, d_sc, d_sd, d_si, d_ld, d_fail;
-  GH_CHECK(upload(d_offs, offs, h->st));
-  GH_CHECK(upload(d_sizes, sizes, h->st));
-  GH_CHECK(upload(d_sc, sc, h->st));
+  GhPooledBuf l_offs, l_sizes, l_sc, d_sd, d_si;
+  GhBuf& d_offs = tables ? *tables[0] : (GhBuf&)l_offs;
+  GhBuf& d_sizes = tables ? *tables[1] : (GhBuf&)l_sizes;
+  GhBuf& d_sc = tables ? *tables[2] : (GhBuf&)l_sc;
+  if (!tables || !tables_valid) {
+    GH_CHECK(upload(d_offs, offs, h->st));
+    GH_CHECK(upload(d_sizes, sizes, h->st));
+    GH_CHECK(upload(d_sc, sc, h->st));
+  }
   GH_CHECK(d_sd.ensure(tot * sizeof(double)));
   GH_CHECK(d_si.ensure(tot * sizeof(int)));
-  GH_CHECK(d_ld.ensure(nb * sizeof(double)));
-  GH_CHECK(d_fail.ensure(sizeof(int)));
-  GH_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), h->st));
   // dynamic LDS for the in-LDS path: the largest matrix of the batch if it fits (<= 144 KiB), else none
   int nmax = 0;
   for (int v : sizes) nmax = std::max(nmax, v);
@@ -815,14 +865,8 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
     }
   }
   hipLaunchKernelGGL(gj_inverse_kernel, dim3(nb), dim3(256), lds_bytes, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p,
-                     d_sd.d(), (int*)d_si.p, (const long*)d_sc.p, d_ld.d(), (int*)d_fail.p, (int)(lds_bytes / sizeof(double)));
+                     d_sd.d(), (int*)d_si.p, (const long*)d_sc.p, d_logdet, (int*)h->flags.p, (int)(lds_bytes / sizeof(double)));
   GH_HIP(hipGetLastError());
-  logdets.resize(nb);
-  int fail = 0;
-  GH_HIP(hipMemcpyAsync(logdets.data(), d_ld.p, nb * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  GH_HIP(hipMemcpyAsync(&fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
-  GH_HIP(hipStreamSynchronize(h->st));
-  if (fail != 0) { gh_set_error("HODLR: singular block encountered (matrix %d)", fail - 1); return GH_ERR_NOT_PD; }
   return GH_OK;
 }
 
@@ -835,7 +879,6 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   GH_CHECK(k->upload());
   hipStream_t st = h->st;
   h->computed = false;
-  h->reset_tree();
   h->n = n; h->ndim = ndim;
   GH_CHECK(h->x.ensure((size_t)n * ndim * sizeof(double)));
   GH_CHECK(h->yerr.ensure((size_t)n * sizeof(double)));
@@ -843,54 +886,147 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   GH_CHECK(gh_to_device(h->yerr.d(), yerr, (size_t)n, st));
   GH_CHECK(h->scal.ensure(64));
 
-  // ---- tree (hodlr.h:47-64), breadth first
+  // ---- tree (hodlr.h:47-64), breadth first; kept from the previous compute() when n and min_size are the same
   const int min_size = h->opts.min_size;
-  h->nodes.push_back({0, (int)n, (int)n / 2, 0, 0});
-  for (size_t q = 0; q < h->nodes.size(); ++q) {
-    HNode nd = h->nodes[q];
-    if (nd.half >= min_size) {
-      h->nodes.push_back({nd.start, nd.half, nd.half / 2, nd.level + 1, 0});
-      h->nodes.push_back({nd.start + nd.half, nd.size - nd.half, (nd.size - nd.half) / 2, nd.level + 1, 0});
-      if ((int)h->levels.size() <= nd.level) h->levels.resize(nd.level + 1, nullptr);
-      if (!h->levels[nd.level]) h->levels[nd.level] = new HLevel();
-      h->levels[nd.level]->node_ids.push_back((int)q);
-    } else {
-      h->nodes[q].is_leaf = 1;
-      long off = h->leaves.empty() ? 0 : h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
-      h->leaves.push_back({nd.start, nd.size, off});
+  if (h->tree_n != n || h->tree_min != min_size) {
+    h->reset_tree();
+    h->nodes.push_back({0, (int)n, (int)n / 2, 0, 0});
+    for (size_t q = 0; q < h->nodes.size(); ++q) {
+      HNode nd = h->nodes[q];
+      if (nd.half >= min_size) {
+        h->nodes.push_back({nd.start, nd.half, nd.half / 2, nd.level + 1, 0});
+        h->nodes.push_back({nd.start + nd.half, nd.size - nd.half, (nd.size - nd.half) / 2, nd.level + 1, 0});
+        if ((int)h->levels.size() <= nd.level) h->levels.resize(nd.level + 1, nullptr);
+        if (!h->levels[nd.level]) h->levels[nd.level] = new HLevel();
+        h->levels[nd.level]->node_ids.push_back((int)q);
+      } else {
+        h->nodes[q].is_leaf = 1;
+        long off = h->leaves.empty() ? 0 : h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
+        h->leaves.push_back({nd.start, nd.size, off});
+      }
     }
+    h->tree_n = n; h->tree_min = min_size;
   }
   h->max_leaf = 0;
   for (auto& lf : h->leaves) h->max_leaf = std::max(h->max_leaf, lf.size);
 
-  // ---- ACA level by level into column-major scratch, ranks back to the host
-  // column capacity of the scratch: the caller's cap, else 256 to start with (doubled, up to RANK_CAP,
-  // whenever a block of a level is cut short by it -- that level is then redone)
+  // ---- ACA of every level into column-major scratch, ranks back to the host
+  // Column capacity of the scratch: the caller's cap, else 256 to start with (doubled, up to RANK_CAP,
+  // for a level one of whose blocks is cut short by it -- that level is then redone).
+  // The levels are independent, so they are all ENQUEUED before the host looks at any result: the
+  // clustered levels (several workgroups per node, spin barriers: they must not share the chip with
+  // another spinning grid) one after the other on the solver's stream, the one-workgroup-per-node
+  // levels beside them on a second stream; one synchronisation instead of one per level (each cost
+  // a ~60 us bubble, and levels 8-10 of C4 -- 1.4 ms -- now run under levels 0-7).  Every level
+  // gets its own n x rcap scratch; if that is more than 12 GiB in total the levels share one and go
+  // one at a time.
   const bool user_cap = h->opts.max_rank > 0;
-  int rcap = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
+  const int rcap0 = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
   const int nlev = (int)h->levels.size();
-  GhPooledBuf Tcm, idx, aca_sync, aca_part;
-  if (nlev > 0) {
-    GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
-    GH_CHECK(idx.ensure((size_t)n * sizeof(int)));
-  }
   static const int aca_fence = getenv("GEORGE_AMD_HODLR_FENCE") ? 1 : 0;
+  static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
+  static const bool aca_serial = getenv("GEORGE_AMD_HODLR_SERIAL_LEVELS") != nullptr;
+  const bool concurrent = !aca_serial && nlev > 1 && (double)n * rcap0 * sizeof(double) * nlev <= 12.0 * (1u << 30);
+  if (concurrent && !h->st_b) {
+    if (hipStreamCreateWithFlags(&h->st_b, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_b = nullptr; }
+  }
+  struct AcaLevel { GhPooledBuf Tcm, idx, sync, part; int G = 1, rcap = 0; int flags[2] = {0, 0}; };
+  std::vector<AcaLevel> al(nlev);
+  GhPooledBuf shared_Tcm;
   std::vector<GhBuf*> levelB(nlev, nullptr);
   struct Cleanup { std::vector<GhBuf*>& v; ~Cleanup() { for (auto* b : v) delete b; } } cleanup{levelB};
+  const int pstride = 8 + 2 * ACA_MAXR;
+  // enqueue the ACA of level l with column capacity rc on stream sx (no synchronisation)
+  auto enqueue_level = [&](int l, int rc, hipStream_t sx) -> int {
+    HLevel* L = h->levels[l];
+    AcaLevel& a = al[l];
+    const int nn = (int)L->node_ids.size();
+    a.rcap = rc;
+    GhBuf& T = (concurrent ? (GhBuf&)a.Tcm : (GhBuf&)shared_Tcm);
+    GH_CHECK(T.ensure((size_t)n * rc * sizeof(double)));
+    GH_CHECK(a.idx.ensure((size_t)n * sizeof(int)));
+    GH_CHECK(a.sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
+    GH_CHECK(a.part.ensure((size_t)nn * a.G * pstride * sizeof(double)));
+    GH_HIP(hipMemsetAsync(a.sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), sx));
+    unsigned* d_bars = (unsigned*)a.sync.p;
+    int* d_sel = (int*)(d_bars + nn);
+    int* d_fail = d_sel + nn;
+#define GH_ACA_LAUNCH(F)                                                                                          \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * a.G), dim3(ACA_THREADS), 0, sx, k->d_nodes, (int)k->nodes.size(),  \
+                       k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, T.d(), (long)n, rc, (int*)a.idx.p,     \
+                       (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
+                       a.G, d_bars, a.part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_fail + 1)
+    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+#undef GH_ACA_LAUNCH
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  };
+  // flags and ranks of level l back to the host (a device-to-host copy into pageable memory holds the
+  // host until the stream gets there, so these are issued only after EVERY level has been enqueued)
+  auto fetch_level = [&](int l, hipStream_t sx) -> int {
+    HLevel* L = h->levels[l];
+    AcaLevel& a = al[l];
+    const int nn = (int)L->node_ids.size();
+    int* d_fail = (int*)((unsigned*)a.sync.p + nn) + nn;
+    L->ranks.resize(nn);
+    GH_HIP(hipMemcpyAsync(a.flags, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, sx));
+    GH_HIP(hipMemcpyAsync(L->ranks.data(), L->d_ranks.p, nn * sizeof(int), hipMemcpyDeviceToHost, sx));
+    return GH_OK;
+  };
+  // after a synchronisation: validate level l, redo it with more columns while a block is cut short
+  auto settle_level = [&](int l) -> int {
+    AcaLevel& a = al[l];
+    for (;;) {
+      if (a.flags[0]) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", l); return GH_ERR_HIP; }
+      if (!a.flags[1]) return GH_OK;
+      // hodlr.h:147 lets the rank grow to min(rows, cols); a cut-short block would be a silently wrong answer
+      if (user_cap || a.rcap >= RANK_CAP) {
+        gh_set_error("HODLR: an off-diagonal block of level %d needs a rank above %d to reach tol = %g (%s); "
+                     "the factorisation is not usable", l, a.rcap, h->opts.tol,
+                     user_cap ? "opts.max_rank" : "the solver's ceiling: loosen tol, raise min_size or use the dense solver");
+        return GH_ERR_BAD_ARG;
+      }
+      GH_CHECK(enqueue_level(l, std::min(2 * a.rcap, RANK_CAP), st));
+      GH_CHECK(fetch_level(l, st));
+      GH_HIP(hipStreamSynchronize(st));
+    }
+  };
+  auto rank_of_level = [&](int l) {
+    HLevel* L = h->levels[l];
+    L->R = 0;
+    for (int r : L->ranks) L->R = std::max(L->R, r);
+    L->off = h->Rtot;
+    h->Rtot += L->R;
+    h->maxR = std::max(h->maxR, L->R);
+  };
+  // serial mode only (one scratch shared by the levels): park the level's factors in a compact buffer
+  auto compact_level = [&](int l) -> int {
+    HLevel* L = h->levels[l];
+    const int nn = (int)L->node_ids.size();
+    rank_of_level(l);
+    if (L->R > 0) {
+      levelB[l] = new GhPooledBuf();
+      GH_CHECK(levelB[l]->ensure((size_t)n * L->R * sizeof(double)));
+      GH_HIP(hipMemsetAsync(levelB[l]->p, 0, (size_t)n * L->R * sizeof(double), st));
+      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, std::max(8, std::min(512, 2048 / nn))), dim3(256), 0, st, shared_Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
+                         (const int*)L->d_ranks.p, L->R, levelB[l]->d(), (long)L->R, 0L, (double*)nullptr, 0L, 0L);
+      GH_HIP(hipGetLastError());
+    }
+    return GH_OK;
+  };
   h->Rtot = 0; h->maxR = 0; h->max_chunks = 0;
   for (int l = 0; l < nlev; ++l) {
     HLevel* L = h->levels[l];
     const int nn = (int)L->node_ids.size();
     std::vector<LvlNode> ln(nn);
     for (int q = 0; q < nn; ++q) { const HNode& nd = h->nodes[L->node_ids[q]]; ln[q] = {nd.start, nd.half, nd.size, 0}; }
-    GH_CHECK(upload(L->d_nodes, ln, st));
+    if (!L->nodes_up) { GH_CHECK(upload(L->d_nodes, ln, st)); L->nodes_up = true; }
     GH_CHECK(L->d_ranks.ensure(nn * sizeof(int)));
     // cluster size: as many workgroups per node as keep the whole grid resident (nodes * G <= 256)
-    // and leave every workgroup at least two columns per thread
-    // ... and leave every thread `ept` columns: a cluster barrier costs ~60 us with 128 members
-    // whatever the release protocol (the arrivals and the polls are device-scope atomics on one
-    // line), and an ACA step is three of them, so clusters are kept as small as the per-thread work
-    // allows (GEORGE_AMD_HODLR_EPT, elements per thread; 2 = as many workgroups as possible)
+    // and leave every thread `ept` columns (GEORGE_AMD_HODLR_EPT; measured at C4: 2 -> 12.5 ms,
+    // 4 -> 13.1, 8 -> 14.1, 16 -> 16.0: the step is bound by per-thread memory latency, not by the
+    // barriers, so more and smaller workgroups win)
     int G = 1;
     if (!getenv("GEORGE_AMD_HODLR_NO_CLUSTER")) {
       static const int ept = getenv("GEORGE_AMD_HODLR_EPT") ? std::max(1, atoi(getenv("GEORGE_AMD_HODLR_EPT"))) : 2;
@@ -898,57 +1034,28 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       for (int q = 0; q < nn; ++q) min_half = std::min(min_half, ln[q].half);
       while (G * 2 * nn <= 256 && (long)(G * 2) * ACA_THREADS * ept <= min_half) G *= 2;
     }
-    const int pstride = 8 + 2 * ACA_MAXR;
-    GH_CHECK(aca_sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
-    GH_CHECK(aca_part.ensure((size_t)nn * G * pstride * sizeof(double)));
-  redo_level:
-    GH_HIP(hipMemsetAsync(aca_sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), st));
-    unsigned* d_bars = (unsigned*)aca_sync.p;
-    int* d_sel = (int*)(d_bars + nn);
-    int* d_fail = d_sel + nn;
-    int* d_trunc = d_fail + 1;
-    static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
-#define GH_ACA_LAUNCH(F)                                                                                          \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(),  \
-                       k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, Tcm.d(), (long)n, rcap, (int*)idx.p,   \
-                       (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
-                       G, d_bars, aca_part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_trunc)
-    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
-#undef GH_ACA_LAUNCH
-    GH_HIP(hipGetLastError());
-    int aca_flags[2] = {0, 0};                       // [0] barrier time-out, [1] a block was cut short by the column capacity
-    GH_HIP(hipMemcpyAsync(aca_flags, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    L->ranks.resize(nn);
-    GH_HIP(hipMemcpyAsync(L->ranks.data(), L->d_ranks.p, nn * sizeof(int), hipMemcpyDeviceToHost, st));
+    al[l].G = G;
+  }
+  if (concurrent && h->st_b) {
+    GH_HIP(hipEventRecord(h->ev_b, st));                   // x and the node tables are uploaded
+    GH_HIP(hipStreamWaitEvent(h->st_b, h->ev_b, 0));
+    for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
+    GH_HIP(hipEventRecord(h->ev_b, h->st_b));
+    GH_HIP(hipStreamWaitEvent(st, h->ev_b, 0));
+    for (int l = 0; l < nlev; ++l) GH_CHECK(fetch_level(l, st));
     GH_HIP(hipStreamSynchronize(st));
-    if (aca_flags[0]) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", l); return GH_ERR_HIP; }
-    if (aca_flags[1]) {
-      // hodlr.h:147 lets the rank grow to min(rows, cols); a cut-short block would be a silently wrong answer
-      if (user_cap || rcap >= RANK_CAP) {
-        gh_set_error("HODLR: an off-diagonal block of level %d needs a rank above %d to reach tol = %g (%s); "
-                     "the factorisation is not usable", l, rcap, h->opts.tol,
-                     user_cap ? "opts.max_rank" : "the solver's ceiling: loosen tol, raise min_size or use the dense solver");
-        return GH_ERR_BAD_ARG;
-      }
-      rcap = std::min(2 * rcap, RANK_CAP);
-      GH_CHECK(Tcm.ensure((size_t)n * rcap * sizeof(double)));
-      goto redo_level;
-    }
-    L->R = 0;
-    for (int r : L->ranks) L->R = std::max(L->R, r);
-    L->off = h->Rtot;
-    h->Rtot += L->R;
-    h->maxR = std::max(h->maxR, L->R);
-    // keep this level's factors in a compact buffer (rows of the whole range x R) until Rtot is known
-    if (L->R > 0) {
-      levelB[l] = new GhPooledBuf();
-      GH_CHECK(levelB[l]->ensure((size_t)n * L->R * sizeof(double)));
-      GH_HIP(hipMemsetAsync(levelB[l]->p, 0, (size_t)n * L->R * sizeof(double), st));
-      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, std::max(8, std::min(512, 2048 / nn))), dim3(256), 0, st, Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
-                         (const int*)L->d_ranks.p, L->R, levelB[l]->d(), levelB[l]->d(), (long)L->R, 0);
-      GH_HIP(hipGetLastError());
+    for (int l = 0; l < nlev; ++l) { GH_CHECK(settle_level(l)); rank_of_level(l); }
+  } else {
+    for (int l = 0; l < nlev; ++l) {
+      GH_CHECK(enqueue_level(l, rcap0, st));
+      GH_CHECK(fetch_level(l, st));
+      GH_HIP(hipStreamSynchronize(st));
+      GH_CHECK(settle_level(l));
+      GH_CHECK(compact_level(l));
     }
   }
+  GhPooledBuf& Tcm = shared_Tcm;
+  GhPooledBuf idx;
   Tcm.release();
   idx.release();
 
@@ -962,12 +1069,22 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     HLevel* L = h->levels[l];
     if (L->R == 0) continue;
     const int R = L->R, nn = (int)L->node_ids.size();
-    // scatter the compact level buffer into column block [off, off+R) of UA and VA
-    GH_HIP(hipMemcpy2DAsync(h->UA.d() + L->off, Rtot * sizeof(double), levelB[l]->p, R * sizeof(double), R * sizeof(double), n, hipMemcpyDeviceToDevice, st));
-    GH_HIP(hipMemcpy2DAsync(h->VA.d() + L->off, Rtot * sizeof(double), levelB[l]->p, R * sizeof(double), R * sizeof(double), n, hipMemcpyDeviceToDevice, st));
+    if (levelB[l]) {
+      // (serial mode) scatter the compact level buffer into column block [off, off+R) of UA and VA
+      GH_HIP(hipMemcpy2DAsync(h->UA.d() + L->off, Rtot * sizeof(double), levelB[l]->p, R * sizeof(double), R * sizeof(double), n, hipMemcpyDeviceToDevice, st));
+      GH_HIP(hipMemcpyAsync(h->VA.d() + (long)n * L->off, levelB[l]->p, (size_t)n * R * sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else {
+      // every rank is known by now: the level's scratch goes straight into its column block (22 strided
+      // device copies per compute() before)
+      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, std::max(8, std::min(512, 2048 / nn))), dim3(256), 0, st, al[l].Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
+                         (const int*)L->d_ranks.p, R, h->UA.d(), (long)Rtot, (long)L->off, h->VA.d(), (long)R, (long)n * L->off);
+      GH_HIP(hipGetLastError());
+    }
+    GH_CHECK(L->sinv.ensure((size_t)nn * 4 * R * R * sizeof(double)));
+    if (L->tab_R == R && L->tab_off == L->off && L->tab_Rtot == Rtot) { h->max_chunks = std::max(h->max_chunks, L->nchunks); continue; }
     std::vector<Chunk> chunks;
     std::vector<int> crange(nn * 4);
-    std::vector<MMJob> red, upd, smul(nn);
+    std::vector<MMJob> red, upd, updl, smul(nn);
     for (int q = 0; q < nn; ++q) {
       const HNode& nd = h->nodes[L->node_ids[q]];
       for (int half = 0; half < 2; ++half) {
@@ -978,8 +1095,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
           const int nr = std::min(HCH, cnt - s);
           const int ch = (int)chunks.size();
           chunks.push_back({q, half, r0 + s, nr});
-          red.push_back({(long)(r0 + s) * Rtot, r0 + s, ch * R, R, nr});                 // A = VA rows (transposed access)
+          red.push_back({(long)(r0 + s) * R, r0 + s, ch * R, R, nr});                    // A = V_l rows (level-major block, transposed access)
           upd.push_back({(long)(r0 + s) * Rtot, q * 2 * R + (half == 0 ? 0 : R), r0 + s, nr, R});
+          updl.push_back({(long)(r0 + s) * R, q * 2 * R + (half == 0 ? 0 : R), r0 + s, nr, R});      // same against UL
         }
         crange[(q * 2 + half) * 2 + 1] = (int)chunks.size();
       }
@@ -991,8 +1109,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(upload(L->d_crange, crange, st));
     GH_CHECK(upload(L->d_red_jobs, red, st));
     GH_CHECK(upload(L->d_upd_jobs, upd, st));
+    GH_CHECK(upload(L->d_updl_jobs, updl, st));
     GH_CHECK(upload(L->d_smul_jobs, smul, st));
-    GH_CHECK(L->sinv.ensure((size_t)nn * 4 * R * R * sizeof(double)));
+    L->tab_R = R; L->tab_off = L->off; L->tab_Rtot = Rtot;
   }
   GH_HIP(hipStreamSynchronize(st));          // levelB buffers are freed when `cleanup` goes out of scope
   {
@@ -1006,7 +1125,16 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   }
 
   // ---- leaves: exact blocks -> explicit inverses + log-dets (hodlr.h:223-227, 87-89)
-  double logdet = 0.0;
+  // log|det| of every factored block (leaves, then the cores level by level) is collected in ld_all
+  // on the device and summed on the host after the ONE synchronisation that ends compute(); failure
+  // flags likewise (flags[0]: singular Gauss-Jordan block, flags[2..3]: leaf Cholesky info).
+  size_t n_blocks = h->leaves.size();
+  for (auto* L : h->levels) n_blocks += L->node_ids.size();
+  GH_CHECK(h->ld_all.ensure(std::max<size_t>(n_blocks, 1) * sizeof(double)));
+  GH_CHECK(h->flags.ensure(4 * sizeof(int)));
+  GH_HIP(hipMemsetAsync(h->ld_all.p, 0, std::max<size_t>(n_blocks, 1) * sizeof(double), st));
+  GH_HIP(hipMemsetAsync(h->flags.p, 0, 4 * sizeof(int), st));
+  size_t ld_at = 0;
   static const bool leaf_gj = getenv("GEORGE_AMD_HODLR_LEAF_GJ") != nullptr;
   if (h->max_leaf <= 128 && !leaf_gj) {
     // Leaves are symmetric positive definite and fit the dense solver's 128 x 128 diagonal-block
@@ -1016,35 +1144,29 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // general path below, spends 7 ms on the 2048 leaves of C4; this one ~1.5 ms.)
     const int nl = (int)h->leaves.size();
     const size_t slot = (size_t)128 * 128;
-    GhPooledBuf linv, d_ld, d_info;
+    GhPooledBuf linv;
     GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
     GH_CHECK(linv.ensure(nl * slot * sizeof(double)));
-    GH_CHECK(d_ld.ensure(nl * sizeof(double)));
-    GH_CHECK(d_info.ensure(sizeof(long long)));
-    GH_HIP(hipMemsetAsync(d_info.p, 0, sizeof(long long), st));
-    GH_CHECK(upload(h->d_leaves, h->leaves, st));
+    long long* d_info = (long long*)((int*)h->flags.p + 2);
+    if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
     hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
                        h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
     GH_HIP(hipGetLastError());
-    GH_CHECK(gh_launch_potf2_batched(h->leaf_inv.d(), 128, (int64_t)slot, linv.d(), (int64_t)slot, (long long*)d_info.p, nl, st));
-    hipLaunchKernelGGL(hodlr_leaf_logdet_kernel, dim3(nl), dim3(128), 0, st, h->leaf_inv.d(), d_ld.d());
+    GH_CHECK(gh_launch_potf2_batched(h->leaf_inv.d(), 128, (int64_t)slot, linv.d(), (int64_t)slot, d_info, nl, st));
+    hipLaunchKernelGGL(hodlr_leaf_logdet_kernel, dim3(nl), dim3(128), 0, st, h->leaf_inv.d(), h->ld_all.d() + ld_at);
+    ld_at += nl;
     GH_HIP(hipGetLastError());
     std::vector<MMJob> prod(nl), jobs(nl);
     for (int i = 0; i < nl; ++i) {
       prod[i] = {(long)(i * slot), i * 128, i * 128, 128, 128};                       // slot_i = Linv_i^T Linv_i
       jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
     }
-    GhPooledBuf d_prod;
-    GH_CHECK(upload(d_prod, prod, st));
-    GH_CHECK(launch_mm(h, (const MMJob*)d_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
-    GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
-    std::vector<double> lds(nl);
-    long long info = 0;
-    GH_HIP(hipMemcpyAsync(lds.data(), d_ld.p, nl * sizeof(double), hipMemcpyDeviceToHost, st));
-    GH_HIP(hipMemcpyAsync(&info, d_info.p, sizeof(long long), hipMemcpyDeviceToHost, st));
-    GH_HIP(hipStreamSynchronize(st));
-    if (info != 0) { gh_set_error("HODLR: a leaf block is not positive definite"); return GH_ERR_NOT_PD; }
-    for (double v : lds) logdet += v;
+    if (!h->leaf_tab_up) {
+      GH_CHECK(upload(h->d_leaf_prod, prod, st));
+      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+      h->leaf_tab_up = true;
+    }
+    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
     h->leaf_pitch = 128;
   } else {
   {
@@ -1063,9 +1185,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       jobs[i] = {h->leaves[i].off, h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
     }
     GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
-    std::vector<double> lds;
-    GH_CHECK(batched_inverse(h, h->leaf_inv.d(), offs, sizes, lds));
-    for (double v : lds) logdet += v;
+    GH_CHECK(batched_inverse(h, h->leaf_inv.d(), offs, sizes, h->ld_all.d() + ld_at));
+    ld_at += nl;
   }
   // leaf job rows use a per-job A stride = its own size: encode through a_rs = 0 -> handled below
   // (hodlr_mm_kernel takes one a_rs per launch, so leaves are launched with a_rs = max_leaf after
@@ -1102,7 +1223,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     if (L->R == 0) continue;
     const int R = L->R, nn = (int)L->node_ids.size();
     // S = I + [0, V1^T U1; V0^T U0, 0] with the CURRENT U of this level
-    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + L->off, 1, Rtot,
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off, 1, R,
                        h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R, false));
     hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
     GH_HIP(hipGetLastError());
@@ -1111,13 +1232,47 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     std::vector<long> offs(nn);
     std::vector<int> sizes(nn, 2 * R);
     for (int q = 0; q < nn; ++q) offs[q] = (long)q * 4 * R * R;
-    std::vector<double> lds;
-    GH_CHECK(batched_inverse(h, L->sinv.d(), offs, sizes, lds));
-    for (double v : lds) logdet += v;
+    {
+      GhBuf* const tabs[3] = {&L->d_gj_offs, &L->d_gj_sizes, &L->d_gj_sc};
+      GH_CHECK(batched_inverse(h, L->sinv.d(), offs, sizes, h->ld_all.d() + ld_at, tabs, L->gj_R == R));
+      L->gj_R = R;
+    }
+    ld_at += nn;
     // apply this level's inverse to the U's of all shallower levels: columns [0, off)
     GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
   }
+  // level-major copy of the final U for the solves
+  if (h->Rtot > 0) {
+    GH_CHECK(h->UL.ensure((size_t)n * Rtot * sizeof(double)));
+    std::vector<long> colbase(Rtot);
+    std::vector<int> colld(Rtot);
+    for (auto* L : h->levels)
+      for (int kk = 0; kk < L->R; ++kk) { colbase[L->off + kk] = (long)n * L->off + kk; colld[L->off + kk] = L->R; }
+    // (cached like the job tables: same ranks, same map)
+    bool same = h->col_Rtot == Rtot && h->col_sig.size() == h->levels.size();
+    for (size_t q = 0; same && q < h->levels.size(); ++q) same = h->col_sig[q] == h->levels[q]->R;
+    if (!same) {
+      GH_CHECK(upload(h->d_colbase, colbase, st));
+      GH_CHECK(upload(h->d_colld, colld, st));
+      h->col_Rtot = Rtot;
+      h->col_sig.clear();
+      for (auto* L : h->levels) h->col_sig.push_back(L->R);
+    }
+    hipLaunchKernelGGL(hodlr_relayout_kernel, dim3(2048), dim3(256), 0, st, h->UA.d(), (long)n, (int)Rtot,
+                       (const long*)h->d_colbase.p, (const int*)h->d_colld.p, h->UL.d());
+    GH_HIP(hipGetLastError());
+  }
+  std::vector<double> ld_host(std::max<size_t>(n_blocks, 1), 0.0);
+  int fl[4] = {0, 0, 0, 0};
+  GH_HIP(hipMemcpyAsync(ld_host.data(), h->ld_all.p, std::max<size_t>(n_blocks, 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipMemcpyAsync(fl, h->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   GH_HIP(hipStreamSynchronize(st));
+  long long leaf_info = 0;
+  memcpy(&leaf_info, fl + 2, sizeof(long long));
+  if (leaf_info != 0) { gh_set_error("HODLR: a leaf block is not positive definite"); return GH_ERR_NOT_PD; }
+  if (fl[0] != 0) { gh_set_error("HODLR: singular block encountered (matrix %d of its batch)", fl[0] - 1); return GH_ERR_NOT_PD; }
+  double logdet = 0.0;
+  for (size_t i = 0; i < ld_at; ++i) logdet += ld_host[i];          // leaves first, then the cores bottom-up: fixed order
   h->logdet = logdet;
   h->computed = true;
   if (logdet_out) *logdet_out = logdet;
