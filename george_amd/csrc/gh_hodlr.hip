@@ -646,6 +646,114 @@ __global__ __launch_bounds__(256) void hodlr_mm_kernel(MMArgs a) {
     }
   }
 }
+// ------------------------------------------------------------ narrow right-hand sides (C <= 8)
+// The tile kernel above does a full 32 x 64 x 32 block of matrix-pipe work per staged slab whatever
+// the real extents: for ONE right-hand side (every log-likelihood evaluation) 63 of its 64 columns
+// are padding, and a level pass of a solve cost ~50 us for a few MFLOP.  These do the same three
+// steps with plain FMAs on exactly the data there is.
+#define MV_C 8
+// P[(o_row + r) * Cp + c] = sum_k V(r, k) X(b_row + k, c);  V(r, k) at A[a_off + r + k * R]  (level-major V block)
+__global__ __launch_bounds__(256) void hodlr_mv_reduce_kernel(const MMJob* jobs, const double* A, int R, const double* X, long ldx,
+                                                              long xcol0, double* P, long Cp, int C) {
+  __shared__ double part[8][32][MV_C];
+  const MMJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, r = tid & 31, pt = tid >> 5;
+  for (int r0 = 0; r0 < R; r0 += 32) {
+    double acc[MV_C];
+#pragma unroll
+    for (int c = 0; c < MV_C; ++c) acc[c] = 0.0;
+    if (r0 + r < R) {
+      for (int k = pt; k < job.kd; k += 8) {
+        const double v = A[job.a_off + (long)k * R + r0 + r];
+        const double* xr = X + (long)(job.b_row + k) * ldx + xcol0;
+#pragma unroll
+        for (int c = 0; c < MV_C; ++c) if (c < C) acc[c] += v * xr[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MV_C; ++c) part[pt][r][c] = acc[c];
+    __syncthreads();
+    if (pt == 0 && r0 + r < R) {
+      for (int c = 0; c < C; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part[q][r][c];
+        P[(long)(job.o_row + r0 + r) * Cp + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+// X(o_row + i, c) -= sum_k U(i, k) T(b_row + k, c);  U(i, k) at A[a_off + i * a_rs + k], i < m, k < kd <= 32
+__global__ __launch_bounds__(128) void hodlr_mv_update_kernel(const MMJob* jobs, const double* A, long a_rs, const double* T, long Cp,
+                                                              double* X, long ldx, long xcol0, int C) {
+  __shared__ double ts[32 * MV_C];
+  const MMJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < job.kd * C; e += 128) ts[(e / C) * MV_C + (e % C)] = T[(long)(job.b_row + e / C) * Cp + (e % C)];
+  __syncthreads();
+  if (tid >= job.m) return;
+  double acc[MV_C];
+#pragma unroll
+  for (int c = 0; c < MV_C; ++c) acc[c] = 0.0;
+  const double* ur = A + job.a_off + (long)tid * a_rs;
+  for (int k = 0; k < job.kd; ++k) {
+    const double u = ur[k];
+#pragma unroll
+    for (int c = 0; c < MV_C; ++c) acc[c] += u * ts[k * MV_C + c];
+  }
+  double* xr = X + (long)(job.o_row + tid) * ldx + xcol0;
+#pragma unroll
+  for (int c = 0; c < MV_C; ++c) if (c < C) xr[c] -= acc[c];
+}
+// X rows of leaf b <- Kinv_b X rows (in place: the leaf's rows are staged in LDS first); leaf size <= 256
+__global__ __launch_bounds__(256) void hodlr_mv_leaf_kernel(const MMJob* jobs, const double* Kinv, long pitch, double* X, long ldx,
+                                                            long xcol0, int C) {
+  __shared__ double xs[256 * MV_C];
+  const MMJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = job.m;
+  for (int e = tid; e < n * C; e += 256) xs[(e / C) * MV_C + (e % C)] = X[(long)(job.b_row + e / C) * ldx + xcol0 + (e % C)];
+  __syncthreads();
+  for (int i = wave; i < n; i += 4) {
+    const double* row = Kinv + job.a_off + (long)i * pitch;
+    double acc[MV_C];
+#pragma unroll
+    for (int c = 0; c < MV_C; ++c) acc[c] = 0.0;
+    for (int k = lane; k < n; k += 64) {
+      const double a = row[k];
+#pragma unroll
+      for (int c = 0; c < MV_C; ++c) acc[c] += a * xs[k * MV_C + c];
+    }
+#pragma unroll
+    for (int c = 0; c < MV_C; ++c) {
+      if (c < C) {
+        const double v = hw_wave_sum(acc[c]);
+        if (lane == 0) X[(long)(job.o_row + i) * ldx + xcol0 + c] = v;
+      }
+    }
+  }
+}
+// Tsum for narrow right-hand sides: 32 threads per column each add a contiguous slice of the chunks,
+// one thread then adds the 32 slice sums in order (the serial walk over up to N/256 chunks by a
+// single active lane took 55-60 us at the top levels)
+__global__ __launch_bounds__(256) void hodlr_sum_narrow_kernel(const double* P, const int* crange, int R, long Cp, int C, double* Tsum) {
+  __shared__ double sl[32][MV_C];
+  const int node = blockIdx.x, row = blockIdx.y;
+  const int half = row < R ? 1 : 0, k = row < R ? row : row - R;
+  const int cb = crange[(node * 2 + half) * 2], ce = crange[(node * 2 + half) * 2 + 1];
+  const int c = threadIdx.x & 7, sidx = threadIdx.x >> 3;
+  const int per = (ce - cb + 31) / 32;
+  const int lo = cb + sidx * per, hi = lo + per < ce ? lo + per : ce;
+  double v = 0.0;
+  if (c < C) for (int ch = lo; ch < hi; ++ch) v += P[((long)ch * R + k) * Cp + c];
+  sl[sidx][c] = v;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double t = 0.0;
+    for (int q = 0; q < 32; ++q) t += sl[q][threadIdx.x];
+    Tsum[((long)node * 2 * R + row) * Cp + threadIdx.x] = t;
+  }
+}
 // Tsum[node][0:R] = sum of the partials of its half-1 chunks, [R:2R] = half-0 chunks (hodlr.h:247-249)
 __global__ void hodlr_sum_kernel(const double* P, const int* crange /* [node][half][2] */, int R, long Cp, int C, double* Tsum) {
   const int node = blockIdx.x, row = blockIdx.y;          // row in [0, 2R)
@@ -788,6 +896,22 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
   if (L->R == 0 || C <= 0) return GH_OK;
   const int R = L->R, nn = (int)L->node_ids.size();
   const double* Vl = h->VA.d() + (long)h->n * L->off;
+  static const bool no_narrow = getenv("GEORGE_AMD_HODLR_NO_NARROW") != nullptr;
+  if (C <= MV_C && R <= 32 && !no_narrow) {
+    const long Cp = h->cpass;
+    const double* Ub = U ? U + L->off : h->UL.d() + (long)h->n * L->off;
+    const long u_rs = U ? ldu : R;
+    const MMJob* uj = (const MMJob*)(U ? L->d_upd_jobs.p : L->d_updl_jobs.p);
+    hipLaunchKernelGGL(hodlr_mv_reduce_kernel, dim3(L->nchunks), dim3(256), 0, h->st, (const MMJob*)L->d_red_jobs.p, Vl, R, X, ldx, xcol0,
+                       h->P.d(), Cp, C);
+    hipLaunchKernelGGL(hodlr_sum_narrow_kernel, dim3(nn, 2 * R), dim3(256), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, C, h->Tsum.d());
+    GH_HIP(hipGetLastError());
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
+                       h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, C, false));
+    hipLaunchKernelGGL(hodlr_mv_update_kernel, dim3(L->nchunks), dim3(128), 0, h->st, uj, Ub, u_rs, h->Tout.d(), Cp, X, ldx, xcol0, C);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
   for (int cp = 0; cp < C; cp += h->cpass) {
     const int cw = std::min(h->cpass, C - cp);
     const long Cp = h->cpass;
@@ -812,6 +936,13 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
 // X rows of every leaf <- K_leaf^-1 X
 static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
   if (C <= 0) return GH_OK;
+  static const bool no_narrow = getenv("GEORGE_AMD_HODLR_NO_NARROW") != nullptr;
+  if (C <= MV_C && h->max_leaf <= 256 && !no_narrow) {
+    hipLaunchKernelGGL(hodlr_mv_leaf_kernel, dim3((unsigned)h->leaves.size()), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p,
+                       h->leaf_inv.d(), (long)h->leaf_pitch, X, ldx, xcol0, C);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
   for (int cp = 0; cp < C; cp += h->cpass) {
     const int cw = std::min(h->cpass, C - cp);
     GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_jobs.p, (int)h->leaves.size(), h->max_leaf, h->leaf_inv.d(), h->leaf_pitch, 1,

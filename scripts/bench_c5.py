@@ -1,8 +1,8 @@
 """BASELINE config C5: N=32768, 3-D isotropic metric, Matern52 + ConstantKernel, predict() mean+var at
 M=4096 test points and grad_log_likelihood, fp64, one MI355X."""
-import json, sys, time
+import json, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from george_amd import GP, kernels
 
 def main(n=32768, m=4096):
