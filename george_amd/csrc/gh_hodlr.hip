@@ -94,7 +94,7 @@ __device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* s
 #define ACA_THREADS 512
 #define ACA_MAXR 2048          // coefficient slots in LDS: rank <= 2048 (one-workgroup nodes) / 1024 (clusters)
 #define ACA_NC 64              // candidate rows tested per search pass once the search has started failing
-#define ACA_LIDX 2048          // row permutations of one-workgroup nodes live in LDS up to this many rows
+#define ACA_LIDX 4096          // row permutations of one-workgroup nodes live in LDS up to this many rows
 // One node is worked on by a CLUSTER of G workgroups (blockIdx.x = node * G + g): the top levels
 // have 1, 2, 4, ... nodes with blocks of N/2, N/4, ... rows, and one workgroup per node left the
 // single workgroup of level 0 with 70 % of the whole HODLR compute() at N = 262144.  Workgroup g
@@ -161,13 +161,31 @@ __device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoc
   return ok != 0;
 }
 
+// Several levels in ONE launch: workgroups [wg0, wg0 + nwg) work on the level described by a segment
+// (the per-level arguments of the kernel are then taken from it).  The clustered levels of a tree
+// are launched this way, 256 workgroups in all, so that every cluster is resident whatever the
+// others do; launched one after the other they were 3 of the 9 ms of a C4 compute().
+struct AcaSeg {
+  const LvlNode* nodes; double* Tcm; int* idx; int* ranks; unsigned* bars; double* part; int* sel; int* fail; int* trunc;
+  int level, G, wg0, nwg;
+};
 template <bool FAST>
 __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
-    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc) {
+    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc,
+    const AcaSeg* segs, int nseg) {
   __shared__ AcaShared sh;
-  const int node = blockIdx.x / G, g = blockIdx.x % G;
+  int bid = blockIdx.x;
+  if (segs) {
+    int q = 0;
+    while (q + 1 < nseg && bid >= segs[q].wg0 + segs[q].nwg) ++q;
+    const AcaSeg sg = segs[q];
+    nodes = sg.nodes; Tcm = sg.Tcm; idx = sg.idx; ranks = sg.ranks; bars = sg.bars; part = sg.part; sel = sg.sel;
+    fail = sg.fail; trunc = sg.trunc; level = sg.level; G = sg.G;
+    bid -= sg.wg0;
+  }
+  const int node = bid / G, g = bid % G;
   const LvlNode nodev = nodes[node];
   const int col0 = nodev.start, n_cols = nodev.half;
   const int row0 = nodev.start + nodev.half, n_rows = nodev.size - nodev.half;
@@ -835,6 +853,7 @@ struct gh_hodlr {
   int cpass = CPASS;             // columns per apply pass = row pitch of P / Tsum / Tout / Y (>= the largest level rank)
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   GhBuf d_leaf_prod;
+  GhBuf d_aca_segs;
   GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (solves) and its column map
   long col_Rtot = -1;
   std::vector<int> col_sig;
@@ -1041,6 +1060,108 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   h->max_leaf = 0;
   for (auto& lf : h->leaves) h->max_leaf = std::max(h->max_leaf, lf.size);
 
+  // ---- leaves: exact blocks -> explicit inverses + log-dets (hodlr.h:223-227, 87-89)
+  // log|det| of every factored block (leaves, then the cores level by level) is collected in ld_all
+  // on the device and summed on the host after the ONE synchronisation that ends compute(); failure
+  // flags likewise (flags[0]: singular Gauss-Jordan block, flags[2..3]: leaf Cholesky info).
+  size_t n_blocks = h->leaves.size();
+  for (auto* L : h->levels) n_blocks += L->node_ids.size();
+  GH_CHECK(h->ld_all.ensure(std::max<size_t>(n_blocks, 1) * sizeof(double)));
+  GH_CHECK(h->flags.ensure(4 * sizeof(int)));
+  GH_HIP(hipMemsetAsync(h->ld_all.p, 0, std::max<size_t>(n_blocks, 1) * sizeof(double), st));
+  GH_HIP(hipMemsetAsync(h->flags.p, 0, 4 * sizeof(int), st));
+  size_t ld_at = 0;
+  // The leaf stage (build, batched Cholesky + inverse, K^-1 = L^-T L^-1: 1.4 ms at C4) depends on
+  // nothing the ACA produces, so it is issued on the second stream under the ACA of the top levels.
+  GhPooledBuf linv;                              // (lives until the final synchronisation: two streams touch it)
+  bool leaves_done = false;
+  auto leaf_stage = [&](hipStream_t st) -> int {
+    struct StreamSwap { gh_hodlr* h; hipStream_t keep; ~StreamSwap() { h->st = keep; } } swap_guard{h, h->st};
+    h->st = st;                                  // (launch_mm / batched_inverse issue on h->st)
+  static const bool leaf_gj = getenv("GEORGE_AMD_HODLR_LEAF_GJ") != nullptr;
+  if (h->max_leaf <= 128 && !leaf_gj) {
+    // Leaves are symmetric positive definite and fit the dense solver's 128 x 128 diagonal-block
+    // kernel: build them identity-padded into 128 x 128 slots, factor + invert the factors as ONE
+    // batched launch of potf2_inv_mfma_kernel (79 us per block, a workgroup each), log-det from the
+    // factor's diagonal, K^-1 = L^-T L^-1 as one batched product.  (Gauss-Jordan with pivoting, the
+    // general path below, spends 7 ms on the 2048 leaves of C4; this one ~1.5 ms.)
+    const int nl = (int)h->leaves.size();
+    const size_t slot = (size_t)128 * 128;
+    GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
+    GH_CHECK(linv.ensure(nl * slot * sizeof(double)));
+    long long* d_info = (long long*)((int*)h->flags.p + 2);
+    if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
+    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
+                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
+    GH_HIP(hipGetLastError());
+    GH_CHECK(gh_launch_potf2_batched(h->leaf_inv.d(), 128, (int64_t)slot, linv.d(), (int64_t)slot, d_info, nl, st));
+    hipLaunchKernelGGL(hodlr_leaf_logdet_kernel, dim3(nl), dim3(128), 0, st, h->leaf_inv.d(), h->ld_all.d() + ld_at);
+    ld_at += nl;
+    GH_HIP(hipGetLastError());
+    std::vector<MMJob> prod(nl), jobs(nl);
+    for (int i = 0; i < nl; ++i) {
+      prod[i] = {(long)(i * slot), i * 128, i * 128, 128, 128};                       // slot_i = Linv_i^T Linv_i
+      jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
+    }
+    if (!h->leaf_tab_up) {
+      GH_CHECK(upload(h->d_leaf_prod, prod, st));
+      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+      h->leaf_tab_up = true;
+    }
+    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
+    h->leaf_pitch = 128;
+  } else {
+  {
+    const int nl = (int)h->leaves.size();
+    const long tot = h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
+    GH_CHECK(h->leaf_inv.ensure(tot * sizeof(double)));
+    GH_CHECK(upload(h->d_leaves, h->leaves, st));
+    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
+                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 0);
+    GH_HIP(hipGetLastError());
+    std::vector<long> offs(nl);
+    std::vector<int> sizes(nl);
+    std::vector<MMJob> jobs(nl);
+    for (int i = 0; i < nl; ++i) {
+      offs[i] = h->leaves[i].off; sizes[i] = h->leaves[i].size;
+      jobs[i] = {h->leaves[i].off, h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
+    }
+    GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+    GH_CHECK(batched_inverse(h, h->leaf_inv.d(), offs, sizes, h->ld_all.d() + ld_at));
+    ld_at += nl;
+  }
+  // leaf job rows use a per-job A stride = its own size: encode through a_rs = 0 -> handled below
+  // (hodlr_mm_kernel takes one a_rs per launch, so leaves are launched with a_rs = max_leaf after
+  //  re-packing: simpler -- store every leaf inverse with row pitch max_leaf)
+  // NOTE: leaf inverses were produced with pitch == size; repack to pitch max_leaf when sizes differ.
+  {
+    bool uniform = true;
+    for (auto& lf : h->leaves) if (lf.size != h->max_leaf) uniform = false;
+    if (!uniform) {
+      const int nl = (int)h->leaves.size(), ml = h->max_leaf;
+      GhBuf packed;
+      GH_CHECK(packed.ensure((size_t)nl * ml * ml * sizeof(double)));
+      GH_HIP(hipMemsetAsync(packed.p, 0, (size_t)nl * ml * ml * sizeof(double), st));
+      std::vector<MMJob> jobs(nl);
+      for (int i = 0; i < nl; ++i) {
+        const LeafDesc& lf = h->leaves[i];
+        GH_HIP(hipMemcpy2DAsync(packed.d() + (size_t)i * ml * ml, ml * sizeof(double), h->leaf_inv.d() + lf.off,
+                                lf.size * sizeof(double), lf.size * sizeof(double), lf.size, hipMemcpyDeviceToDevice, st));
+        jobs[i] = {(long)i * ml * ml, lf.start, lf.start, lf.size, lf.size};
+      }
+      GH_HIP(hipStreamSynchronize(st));
+      std::swap(h->leaf_inv.p, packed.p);
+      std::swap(h->leaf_inv.bytes, packed.bytes);
+      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+    }
+  }
+    h->leaf_pitch = h->max_leaf;
+  }
+
+    leaves_done = true;
+    return GH_OK;
+  };
+
   // ---- ACA of every level into column-major scratch, ranks back to the host
   // Column capacity of the scratch: the caller's cap, else 256 to start with (doubled, up to RANK_CAP,
   // for a level one of whose blocks is cut short by it -- that level is then redone).
@@ -1069,7 +1190,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   struct Cleanup { std::vector<GhBuf*>& v; ~Cleanup() { for (auto* b : v) delete b; } } cleanup{levelB};
   const int pstride = 8 + 2 * ACA_MAXR;
   // enqueue the ACA of level l with column capacity rc on stream sx (no synchronisation)
-  auto enqueue_level = [&](int l, int rc, hipStream_t sx) -> int {
+  // buffers of level l for column capacity rc, counters cleared on stream sx
+  auto prepare_level = [&](int l, int rc, hipStream_t sx) -> int {
     HLevel* L = h->levels[l];
     AcaLevel& a = al[l];
     const int nn = (int)L->node_ids.size();
@@ -1080,6 +1202,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(a.sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
     GH_CHECK(a.part.ensure((size_t)nn * a.G * pstride * sizeof(double)));
     GH_HIP(hipMemsetAsync(a.sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), sx));
+    return GH_OK;
+  };
+  // enqueue the ACA of level l with column capacity rc on stream sx (no synchronisation)
+  auto enqueue_level = [&](int l, int rc, hipStream_t sx) -> int {
+    HLevel* L = h->levels[l];
+    AcaLevel& a = al[l];
+    const int nn = (int)L->node_ids.size();
+    GH_CHECK(prepare_level(l, rc, sx));
+    GhBuf& T = (concurrent ? (GhBuf&)a.Tcm : (GhBuf&)shared_Tcm);
     unsigned* d_bars = (unsigned*)a.sync.p;
     int* d_sel = (int*)(d_bars + nn);
     int* d_fail = d_sel + nn;
@@ -1087,7 +1218,36 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * a.G), dim3(ACA_THREADS), 0, sx, k->d_nodes, (int)k->nodes.size(),  \
                        k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, T.d(), (long)n, rc, (int*)a.idx.p,     \
                        (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
-                       a.G, d_bars, a.part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_fail + 1)
+                       a.G, d_bars, a.part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_fail + 1,            \
+                       (const AcaSeg*)nullptr, 0)
+    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+#undef GH_ACA_LAUNCH
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  };
+  // all clustered levels `cl` as ONE launch of at most 256 workgroups (al[l].G already balanced)
+  auto enqueue_fused = [&](const std::vector<int>& cl, int rc, hipStream_t sx) -> int {
+    std::vector<AcaSeg> segs;
+    int wg = 0;
+    for (int l : cl) {
+      HLevel* L = h->levels[l];
+      AcaLevel& a = al[l];
+      const int nn = (int)L->node_ids.size();
+      GH_CHECK(prepare_level(l, rc, sx));
+      unsigned* d_bars = (unsigned*)a.sync.p;
+      int* d_sel = (int*)(d_bars + nn);
+      int* d_fail = d_sel + nn;
+      segs.push_back({(const LvlNode*)L->d_nodes.p, a.Tcm.d(), (int*)a.idx.p, (int*)L->d_ranks.p, d_bars, a.part.d(), d_sel,
+                      d_fail, d_fail + 1, l, a.G, wg, nn * a.G});
+      wg += nn * a.G;
+    }
+    GH_CHECK(upload(h->d_aca_segs, segs, sx));
+#define GH_ACA_LAUNCH(F)                                                                                          \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(ACA_THREADS), 0, sx, k->d_nodes, (int)k->nodes.size(),    \
+                       k->fast, ndim, h->x.d(), (const LvlNode*)nullptr, (double*)nullptr, (long)n, rc, (int*)nullptr, \
+                       (int*)nullptr, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, 0,                     \
+                       1, (unsigned*)nullptr, (double*)nullptr, pstride, (int*)nullptr, (int*)nullptr, aca_multi, aca_fence, \
+                       (int*)nullptr, (const AcaSeg*)h->d_aca_segs.p, (int)segs.size())
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
@@ -1170,7 +1330,53 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   if (concurrent && h->st_b) {
     GH_HIP(hipEventRecord(h->ev_b, st));                   // x and the node tables are uploaded
     GH_HIP(hipStreamWaitEvent(h->st_b, h->ev_b, 0));
-    for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
+    // Clustered levels: one launch, the 256 workgroup slots dealt so that the per-thread load is as even
+    // as it gets (start from <= 32 workgroups per level, then keep doubling the cluster of the level
+    // whose threads carry most columns).
+    std::vector<int> cl;
+    static const bool no_fused = getenv("GEORGE_AMD_HODLR_NO_FUSED_ACA") != nullptr;
+    for (int l = 0; l < nlev; ++l) if (al[l].G > 1) cl.push_back(l);
+    if (cl.size() >= 2 && !no_fused) {
+      std::vector<int> gmax(nlev, 1), half(nlev, 1);
+      int total = 0;
+      for (int l : cl) {
+        const int nn = (int)h->levels[l]->node_ids.size();
+        gmax[l] = al[l].G;
+        int mh = INT32_MAX;
+        for (int id : h->levels[l]->node_ids) mh = std::min(mh, h->nodes[id].half);
+        half[l] = mh;
+        int G = 1;
+        while (G * 2 <= gmax[l] && nn * G * 2 <= 32) G *= 2;
+        al[l].G = G;
+        if (G > 1) total += nn * G;              // (a level left with one workgroup per node goes to the other stream)
+      }
+      for (;;) {
+        int best = -1;
+        double load = 0.0;
+        for (int l : cl) {
+          const int nn = (int)h->levels[l]->node_ids.size();
+          if (al[l].G < 2 || al[l].G * 2 > gmax[l] || total + nn * al[l].G > 256) continue;
+          const double ld = (double)half[l] / al[l].G;
+          if (ld > load) { load = ld; best = l; }
+        }
+        if (best < 0) break;
+        total += (int)h->levels[best]->node_ids.size() * al[best].G;
+        al[best].G *= 2;
+      }
+      std::vector<int> fused, single;
+      for (int l : cl) (al[l].G > 1 ? fused : single).push_back(l);
+      if (getenv("GEORGE_AMD_HODLR_DEBUG")) {
+        for (int l : cl) fprintf(stderr, "[hodlr] level %d: nodes %d half %d G %d (max %d)\n", l, (int)h->levels[l]->node_ids.size(), half[l], al[l].G, gmax[l]);
+        fprintf(stderr, "[hodlr] total %d\n", total);
+      }
+      GH_CHECK(enqueue_fused(fused, rcap0, st));
+      for (int l : single) GH_CHECK(enqueue_level(l, rcap0, h->st_b));
+      for (int l = 0; l < nlev; ++l) if (gmax[l] == 1) GH_CHECK(enqueue_level(l, rcap0, h->st_b));
+    } else {
+      for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
+    }
+    static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
+    if (!leaves_after) GH_CHECK(leaf_stage(h->st_b));
     GH_HIP(hipEventRecord(h->ev_b, h->st_b));
     GH_HIP(hipStreamWaitEvent(st, h->ev_b, 0));
     for (int l = 0; l < nlev; ++l) GH_CHECK(fetch_level(l, st));
@@ -1255,97 +1461,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(h->Y.ensure((size_t)n * h->cpass * sizeof(double)));
   }
 
-  // ---- leaves: exact blocks -> explicit inverses + log-dets (hodlr.h:223-227, 87-89)
-  // log|det| of every factored block (leaves, then the cores level by level) is collected in ld_all
-  // on the device and summed on the host after the ONE synchronisation that ends compute(); failure
-  // flags likewise (flags[0]: singular Gauss-Jordan block, flags[2..3]: leaf Cholesky info).
-  size_t n_blocks = h->leaves.size();
-  for (auto* L : h->levels) n_blocks += L->node_ids.size();
-  GH_CHECK(h->ld_all.ensure(std::max<size_t>(n_blocks, 1) * sizeof(double)));
-  GH_CHECK(h->flags.ensure(4 * sizeof(int)));
-  GH_HIP(hipMemsetAsync(h->ld_all.p, 0, std::max<size_t>(n_blocks, 1) * sizeof(double), st));
-  GH_HIP(hipMemsetAsync(h->flags.p, 0, 4 * sizeof(int), st));
-  size_t ld_at = 0;
-  static const bool leaf_gj = getenv("GEORGE_AMD_HODLR_LEAF_GJ") != nullptr;
-  if (h->max_leaf <= 128 && !leaf_gj) {
-    // Leaves are symmetric positive definite and fit the dense solver's 128 x 128 diagonal-block
-    // kernel: build them identity-padded into 128 x 128 slots, factor + invert the factors as ONE
-    // batched launch of potf2_inv_mfma_kernel (79 us per block, a workgroup each), log-det from the
-    // factor's diagonal, K^-1 = L^-T L^-1 as one batched product.  (Gauss-Jordan with pivoting, the
-    // general path below, spends 7 ms on the 2048 leaves of C4; this one ~1.5 ms.)
-    const int nl = (int)h->leaves.size();
-    const size_t slot = (size_t)128 * 128;
-    GhPooledBuf linv;
-    GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
-    GH_CHECK(linv.ensure(nl * slot * sizeof(double)));
-    long long* d_info = (long long*)((int*)h->flags.p + 2);
-    if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
-    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
-                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
-    GH_HIP(hipGetLastError());
-    GH_CHECK(gh_launch_potf2_batched(h->leaf_inv.d(), 128, (int64_t)slot, linv.d(), (int64_t)slot, d_info, nl, st));
-    hipLaunchKernelGGL(hodlr_leaf_logdet_kernel, dim3(nl), dim3(128), 0, st, h->leaf_inv.d(), h->ld_all.d() + ld_at);
-    ld_at += nl;
-    GH_HIP(hipGetLastError());
-    std::vector<MMJob> prod(nl), jobs(nl);
-    for (int i = 0; i < nl; ++i) {
-      prod[i] = {(long)(i * slot), i * 128, i * 128, 128, 128};                       // slot_i = Linv_i^T Linv_i
-      jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
-    }
-    if (!h->leaf_tab_up) {
-      GH_CHECK(upload(h->d_leaf_prod, prod, st));
-      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
-      h->leaf_tab_up = true;
-    }
-    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
-    h->leaf_pitch = 128;
-  } else {
-  {
-    const int nl = (int)h->leaves.size();
-    const long tot = h->leaves.back().off + (long)h->leaves.back().size * h->leaves.back().size;
-    GH_CHECK(h->leaf_inv.ensure(tot * sizeof(double)));
-    GH_CHECK(upload(h->d_leaves, h->leaves, st));
-    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
-                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 0);
-    GH_HIP(hipGetLastError());
-    std::vector<long> offs(nl);
-    std::vector<int> sizes(nl);
-    std::vector<MMJob> jobs(nl);
-    for (int i = 0; i < nl; ++i) {
-      offs[i] = h->leaves[i].off; sizes[i] = h->leaves[i].size;
-      jobs[i] = {h->leaves[i].off, h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
-    }
-    GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
-    GH_CHECK(batched_inverse(h, h->leaf_inv.d(), offs, sizes, h->ld_all.d() + ld_at));
-    ld_at += nl;
-  }
-  // leaf job rows use a per-job A stride = its own size: encode through a_rs = 0 -> handled below
-  // (hodlr_mm_kernel takes one a_rs per launch, so leaves are launched with a_rs = max_leaf after
-  //  re-packing: simpler -- store every leaf inverse with row pitch max_leaf)
-  // NOTE: leaf inverses were produced with pitch == size; repack to pitch max_leaf when sizes differ.
-  {
-    bool uniform = true;
-    for (auto& lf : h->leaves) if (lf.size != h->max_leaf) uniform = false;
-    if (!uniform) {
-      const int nl = (int)h->leaves.size(), ml = h->max_leaf;
-      GhBuf packed;
-      GH_CHECK(packed.ensure((size_t)nl * ml * ml * sizeof(double)));
-      GH_HIP(hipMemsetAsync(packed.p, 0, (size_t)nl * ml * ml * sizeof(double), st));
-      std::vector<MMJob> jobs(nl);
-      for (int i = 0; i < nl; ++i) {
-        const LeafDesc& lf = h->leaves[i];
-        GH_HIP(hipMemcpy2DAsync(packed.d() + (size_t)i * ml * ml, ml * sizeof(double), h->leaf_inv.d() + lf.off,
-                                lf.size * sizeof(double), lf.size * sizeof(double), lf.size, hipMemcpyDeviceToDevice, st));
-        jobs[i] = {(long)i * ml * ml, lf.start, lf.start, lf.size, lf.size};
-      }
-      GH_HIP(hipStreamSynchronize(st));
-      std::swap(h->leaf_inv.p, packed.p);
-      std::swap(h->leaf_inv.bytes, packed.bytes);
-      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
-    }
-  }
-    h->leaf_pitch = h->max_leaf;
-  }
+  // ---- leaves (enqueued above, beside the ACA, when the levels run concurrently)
+  if (!leaves_done) GH_CHECK(leaf_stage(st));
 
   // ---- factorisation sweep (hodlr.h:75-103, level-batched): leaves into every U, then levels bottom-up
   if (h->Rtot > 0) GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot));
