@@ -475,6 +475,8 @@ struct gh_chol {
   hipEvent_t ev_p1[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_b[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;
+  hipEvent_t ev_ub = nullptr;                  // deep look-ahead: rows below the next panel's diagonal block updated
+  std::vector<hipEvent_t> ev_p, ev_w, ev_nf;   // deep look-ahead: panel j factored / W(j) done / U(j, j+2) done
   hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
   hipStream_t st_crit = nullptr;         // exclusive mode: potf2 chain confined to the CUs st_mask leaves out
   hipStream_t st_sa = nullptr;           // exclusive mode: rows-below TRSM on the SAME CUs as the trailing update
@@ -509,6 +511,8 @@ struct gh_chol {
     if (ev_xfer) (void)hipEventDestroy(ev_xfer);
     if (ev_aux) (void)hipEventDestroy(ev_aux);
     if (ev_aux2) (void)hipEventDestroy(ev_aux2);
+    if (ev_ub) (void)hipEventDestroy(ev_ub);
+    for (auto* v : {&ev_p, &ev_w, &ev_nf}) for (auto e : *v) (void)hipEventDestroy(e);
     for (auto& e : ev_diag) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_p1) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -723,7 +727,9 @@ static int panel_step_split(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) 
 }
 
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
-static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
+// rows_ready (optional): the rows BELOW the nb x nb diagonal block are up to date only once this event
+// has fired (deep look-ahead updates them on another stream); the diagonal block itself is ready.
+static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEvent_t rows_ready = nullptr) {
   double* A = s->A.d();
   const int64_t np = s->np, ld = np;
   double* dinv = s->dinv.d() + (k0 / T) * T * T;
@@ -737,18 +743,22 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
     return panel_step_split(s, st, k0, nb);
   if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
-    if (m > 0) GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
+    if (m > 0) {
+      if (rows_ready) GH_HIP(hipStreamWaitEvent(st, rows_ready, 0));
+      GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
+    }
     return GH_OK;
   }
   // Look-ahead panels: the potf2 chain of the diagonal block stays on `st`; the TRSM of the rows
   // below runs on a second panel stream, column block j as soon as L_jj^-1 exists, so that only
   // the last block's TRSM is left when the chain ends (instead of all nb/128 of them).
-  static const bool side_prio1 = getenv("GEORGE_AMD_PANEL_SIDE_PRIO") != nullptr;
-  hipStream_t sa = (s->st_crit && st == s->st_crit && !side_prio1) ? s->st_sa : s->st3;
+  static const bool side_masked = getenv("GEORGE_AMD_PANEL_SIDE_MASKED") != nullptr;   // A/B: rows-below TRSM on the SYRK's CUs, normal priority
+  hipStream_t sa = (s->st_crit && st == s->st_crit && side_masked) ? s->st_sa : s->st3;
   double* Ak = blk(A, ld, k0, k0);
   double* B = blk(A, ld, k0 + nb, k0);
   GH_HIP(hipEventRecord(s->ev_aux, st));
   GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
+  if (rows_ready) GH_HIP(hipStreamWaitEvent(sa, rows_ready, 0));
   for (int64_t j0 = 0; j0 < nb; j0 += T) {
     double* dj = dinv + (j0 / T) * T * T;
     GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
@@ -808,7 +818,7 @@ static hipStream_t trailing_stream(gh_chol* s) {
       // (a stream masked to exactly those), and the rows-below TRSM -- throughput work -- joins the
       // trailing update on the others; without it the high-priority panel streams are unmasked and
       // their workgroups may still land beside SYRK wavefronts.
-      static const bool exclusive = getenv("GEORGE_AMD_PANEL_EXCLUSIVE") != nullptr;
+      static const bool exclusive = getenv("GEORGE_AMD_PANEL_EXCLUSIVE") && atoi(getenv("GEORGE_AMD_PANEL_EXCLUSIVE")) != 0;
       if (s->st_mask && exclusive && s->st3) {
         std::vector<uint32_t> inv(words, 0u);
         for (int c = 0; c < want; ++c) inv[c / 32] |= (1u << (c % 32));
@@ -892,8 +902,131 @@ static int factor_lookahead(gh_chol* s) {
   return GH_OK;
 }
 
+// Look-ahead of depth d.  After panel j is factored, its trailing update is issued per block column
+// for the d columns next to it and as ONE lower-triangular SYRK for the rest:
+//   chain stream `sp` : panel(j) -> U(j, j+1) -> panel(j+1) -> ...            (the critical path)
+//   near stream  `sn` : U(j, j+2), ..., U(j, j+d)                             (narrow GEMMs, high priority)
+//   main stream  `sm` : W(j) = U(j, j+d+1 ...)                                (the wide SYRK)
+// U(j, c): A[c0:, c0:c0+nb_c] -= L[c0:, j-panel] L[c0:c0+nb_c, j-panel]^T.  Every column receives its
+// updates in panel order: U(j, c) follows U(j-1, c), which is the previous launch of the same
+// stream except at the window's edges -- U(j, j+1) follows U(j-1, j+1) from the near stream (event
+// ev_nf[j-1]), U(j, j+d) follows W(j-1) (event ev_w[j-1]) -- and everything of panel j follows
+// ev_p[j].  With d = 1 the chain can start panel j+1 only when W(j-1) is over, so at sizes where the
+// early SYRKs outlast a panel and the late ones do not (N ~ 8k-24k) the total is the SUM of the
+// larger of the two per step; with d > 1 the chain runs up to d panels ahead during the SYRK-bound
+// early steps and spends that lead in the chain-bound late ones.
+static int factor_lookahead_deep(gh_chol* s, int depth) {
+  hipStream_t sm = trailing_stream(s), sn = s->st4;
+  // the potf2 chain on CUs of its own where the trailing update leaves some out (small matrices)
+  hipStream_t sp = (sm != s->st && s->st_crit) ? s->st_crit : s->st2;
+  double* A = s->A.d();
+  const int64_t np = s->np, ld = np, NB = panel_width(s);
+  const int P = (int)((np + NB - 1) / NB);
+  // (measured at N = 16384, depth 1: whole block column on the chain 34.8 ms; diagonal block on the chain +
+  //  rows below on the near stream 35.6; the same with the chain on CUs of its own 48.5 -- the in-panel
+  //  GEMMs crawl on 32 CUs; all three kept selectable)
+  static const bool no_usplit = getenv("GEORGE_AMD_BCOL_SPLIT") == nullptr;
+  const bool prof = s->opts.profile != 0;
+  while ((int)s->ev_p.size() < P) {
+    hipEvent_t e[3];
+    for (auto& x : e) GH_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    s->ev_p.push_back(e[0]); s->ev_w.push_back(e[1]); s->ev_nf.push_back(e[2]);
+  }
+  auto c0 = [&](int c) { return (int64_t)c * NB; };
+  auto nbc = [&](int c) { return std::min<int64_t>(NB, np - c0(c)); };
+  bool rows_split = false;
+  if (!s->ev_ub) GH_HIP(hipEventCreateWithFlags(&s->ev_ub, hipEventDisableTiming));
+  auto narrow = [&](hipStream_t st, int j, int c) -> int {         // U(j, c)
+    const double* Pj = blk(A, ld, c0(c), c0(j));
+    return gemm_nt(st, blk(A, ld, c0(c), c0(c)), ld, Pj, ld, Pj, ld, np - c0(c), nbc(c), nbc(j), -1.0, 1.0, false);
+  };
+  // everything queued so far (the build, on s->st) before any of the three streams starts
+  GH_HIP(hipEventRecord(s->ev_sync[0], s->st));
+  GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
+  GH_HIP(hipStreamWaitEvent(sn, s->ev_sync[0], 0));
+  if (sm != s->st) GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[0], 0));
+  for (int j = 0; j < P; ++j) {
+    // ---- chain: column j is complete once U(j-1, j) has run (issued at the end of the previous turn)
+    {
+      const long ep = prof ? s->next_ev() : -1;
+      if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
+      GH_CHECK(panel_step(s, sp, c0(j), nbc(j), (j >= 1 && rows_split) ? s->ev_ub : nullptr));
+      if (ep >= 0) GH_HIP(hipEventRecord(s->ev_pool[ep].b, sp));
+      GH_HIP(hipEventRecord(s->ev_p[j], sp));
+    }
+    if (j + 1 >= P) break;
+    // ---- U(j, j+1): only its diagonal block (nb x nb, lower tiles) is on the chain -- that is all the
+    // potf2 chain of panel j+1 needs; the rows below it go to the near stream and are awaited by the
+    // rows-below TRSM of panel j+1 (ev_ub).  As one launch on the chain it was 5.7 of the chain's 28 ms
+    // at N = 16384.
+    const hipEvent_t prev = (j >= 1) ? (depth >= 2 ? s->ev_nf[j - 1] : s->ev_w[j - 1]) : nullptr;
+    if (prev) GH_HIP(hipStreamWaitEvent(sp, prev, 0));
+    rows_split = !no_usplit && np - c0(j + 1) > nbc(j + 1);
+    if (rows_split) {
+      const int64_t k1 = c0(j + 1), nb1 = nbc(j + 1);
+      const double* Pd = blk(A, ld, k1, c0(j));
+      GH_CHECK(gemm_nt(sp, blk(A, ld, k1, k1), ld, Pd, ld, Pd, ld, nb1, nb1, nbc(j), -1.0, 1.0, true));
+      GH_HIP(hipStreamWaitEvent(sn, s->ev_p[j], 0));
+      if (prev) GH_HIP(hipStreamWaitEvent(sn, prev, 0));
+      const double* Pb = blk(A, ld, k1 + nb1, c0(j));
+      GH_CHECK(gemm_nt(sn, blk(A, ld, k1 + nb1, k1), ld, Pb, ld, Pd, ld, np - (k1 + nb1), nb1, nbc(j), -1.0, 1.0, false));
+      GH_HIP(hipEventRecord(s->ev_ub, sn));
+    } else {
+      GH_CHECK(narrow(sp, j, j + 1));
+    }
+    // ---- U(j, j+2 .. j+d) on the near stream
+    const int last_near = std::min(j + depth, P - 1);
+    if (j + 2 <= last_near || (depth >= 2 && j + 2 <= P - 1)) GH_HIP(hipStreamWaitEvent(sn, s->ev_p[j], 0));
+    for (int c = j + 2; c <= last_near; ++c) {
+      if (c == j + depth && j >= 1) GH_HIP(hipStreamWaitEvent(sn, s->ev_w[j - 1], 0));      // column c was inside W(j-1)
+      GH_CHECK(narrow(sn, j, c));
+      if (c == j + 2) GH_HIP(hipEventRecord(s->ev_nf[j], sn));
+    }
+    if (depth >= 2 && j + 2 > last_near) GH_HIP(hipEventRecord(s->ev_nf[j], sn));        // (nothing to do: keep the event defined)
+    // ---- W(j): the rest, one lower-triangular SYRK on the main stream
+    const int cw = j + depth + 1;
+    GH_HIP(hipStreamWaitEvent(sm, s->ev_p[j], 0));
+    if (cw <= P - 1) {
+      const int64_t kw = c0(cw), m2 = np - kw;
+      const long et = prof ? s->next_ev() : -1;
+      if (et >= 0) { GH_HIP(hipEventRecord(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); }
+      const double* P2 = blk(A, ld, kw, c0(j));
+      GH_CHECK(gemm_nt(sm, blk(A, ld, kw, kw), ld, P2, ld, P2, ld, m2, m2, nbc(j), -1.0, 1.0, true));
+      if (et >= 0) GH_HIP(hipEventRecord(s->ev_pool[et].b, sm));
+      const double tiles = (double)(m2 / T) * (m2 / T + 1) / 2.0;
+      s->prof.trailing_flops += tiles * 2.0 * T * T * (double)nbc(j);
+      s->prof.n_trailing += 1;
+    }
+    GH_HIP(hipEventRecord(s->ev_w[j], sm));
+  }
+  // join: the handle's stream continues after all three
+  GH_HIP(hipEventRecord(s->ev_sync[1], sp));
+  GH_HIP(hipStreamWaitEvent(s->st, s->ev_sync[1], 0));
+  GH_HIP(hipEventRecord(s->ev_sync[2], sn));
+  GH_HIP(hipStreamWaitEvent(s->st, s->ev_sync[2], 0));
+  if (sm != s->st) {
+    GH_HIP(hipEventRecord(s->ev_xfer, sm));
+    GH_HIP(hipStreamWaitEvent(s->st, s->ev_xfer, 0));
+  }
+  return GH_OK;
+}
+
+static int lookahead_depth(const gh_chol* s) {
+  static const int forced = getenv("GEORGE_AMD_LOOKAHEAD_DEPTH") ? atoi(getenv("GEORGE_AMD_LOOKAHEAD_DEPTH")) : -1;
+  if (forced >= 0) return forced;
+  // depth 1 in this formulation (block column j+1 updated on the chain stream itself, the wide SYRK
+  // alone on the main stream) beats the older scheme (block column on the main stream, depth "0") by
+  // 7-12 % from N = 4096 to 16384 and is level with it above; deeper windows lose (size sweep in
+  // profiles/r02/lookahead_depth_sweep.md): the narrow GEMMs of the window compete with the potf2 chain
+  return 1;
+}
+
 static int factor(gh_chol* s) {
-  if (s->opts.lookahead && s->st2) return factor_lookahead(s);
+  if (s->opts.lookahead && s->st2) {
+    const int d = lookahead_depth(s);
+    if (d >= 1 && s->st4) return factor_lookahead_deep(s, d);
+    return factor_lookahead(s);
+  }
   hipStream_t st = s->st;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);
