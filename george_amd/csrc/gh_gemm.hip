@@ -792,6 +792,25 @@ extern "C" int gh_microbench_suite(double* out, int n) {
 __global__ void copy16_kernel(const double2* __restrict__ in, double2* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i];
 }
+// four 16-byte loads in flight per lane before the first store, non-temporal stores (the copy is
+// streamed once: no point in keeping it in the L2s)
+__global__ __launch_bounds__(256) void copy16x4_kernel(const double2* __restrict__ in, double2* __restrict__ out, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long base = (long)blockIdx.x * 256 * 4 + threadIdx.x; base < n; base += stride) {
+    double2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (base + 256 * q < n) ? in[base + 256 * q] : double2{0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (base + 256 * q < n) {
+        __builtin_nontemporal_store(v[q].x, &out[base + 256 * q].x);
+        __builtin_nontemporal_store(v[q].y, &out[base + 256 * q].y);
+      }
+  }
+}
+// Best of a few launch shapes of a 2 GiB -> 2 GiB device copy, read + written bytes per second.
+// (The plain grid-stride copy16_kernel with 2048 workgroups gives 4.6-4.9 TB/s; it stays the kernel
+// the FETCH_SIZE / WRITE_SIZE calibration passes of scripts/profile_r02.sh look for.)
 extern "C" int gh_microbench_hbm_copy(double* gbps_out) {
   if (gh_device_count() <= 0) { gh_set_error("no HIP device"); return GH_ERR_HIP; }
   const long n = 1L << 27;   // 2 GiB in + 2 GiB out
@@ -801,15 +820,26 @@ extern "C" int gh_microbench_hbm_copy(double* gbps_out) {
   GH_HIP(hipMemset(a, 0, n * sizeof(double2)));
   hipEvent_t e0, e1;
   GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1));
-  hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, 0, a, b, n);
-  GH_HIP(hipDeviceSynchronize());
-  GH_HIP(hipEventRecord(e0, 0));
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, 0, a, b, n);
-  GH_HIP(hipEventRecord(e1, 0));
-  GH_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  GH_HIP(hipEventElapsedTime(&ms, e0, e1));
-  *gbps_out = 5.0 * 2.0 * n * sizeof(double2) / (ms * 1e-3) * 1e-9;
+  double best = 0.0;
+  for (int variant = 0; variant < 6; ++variant) {
+    const int grids[6] = {256 * 8, 256 * 8, 256 * 16, 256 * 32, 256 * 64, 256 * 128};
+    auto launch = [&]() {
+      if (variant == 0) hipLaunchKernelGGL(copy16_kernel, dim3(grids[0]), dim3(256), 0, 0, a, b, n);
+      else hipLaunchKernelGGL(copy16x4_kernel, dim3(grids[variant]), dim3(256), 0, 0, a, b, n);
+    };
+    launch();
+    GH_HIP(hipDeviceSynchronize());
+    GH_HIP(hipEventRecord(e0, 0));
+    for (int r = 0; r < 5; ++r) launch();
+    GH_HIP(hipEventRecord(e1, 0));
+    GH_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double rate = 5.0 * 2.0 * n * sizeof(double2) / (ms * 1e-3) * 1e-9;
+    if (getenv("GEORGE_AMD_MICROBENCH_VERBOSE")) fprintf(stderr, "[hbm copy] variant %d grid %d: %.0f GB/s\n", variant, grids[variant], rate);
+    if (rate > best) best = rate;
+  }
+  *gbps_out = best;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
   return GH_OK;
 }
