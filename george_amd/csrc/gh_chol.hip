@@ -568,7 +568,14 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   *out = s;
   return GH_OK;
 }
-extern "C" void gh_chol_destroy(gh_chol* s) { if (s) { (void)hipSetDevice(s->opts.device); delete s; } }
+extern "C" void gh_chol_destroy(gh_chol* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->opts.device);
+  // entry points that were handed DEVICE output pointers return with copies still queued: drain the
+  // handle's streams before its buffers go back to the allocator / the block cache
+  for (hipStream_t st : {s->st, s->st2, s->st3, s->st4, s->st_mask}) if (st) (void)hipStreamSynchronize(st);
+  delete s;
+}
 extern "C" int64_t gh_chol_info(const gh_chol* s) { return s ? s->info : 0; }
 extern "C" int64_t gh_chol_size(const gh_chol* s) { return s ? s->n : 0; }
 extern "C" int gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out) {

@@ -886,7 +886,15 @@ extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
   *out = h;
   return GH_OK;
 }
-extern "C" void gh_hodlr_destroy(gh_hodlr* h) { if (h) { (void)hipSetDevice(h->opts.device); delete h; } }
+extern "C" void gh_hodlr_destroy(gh_hodlr* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->opts.device);
+  // pooled blocks may be re-acquired by another handle on another stream: nothing of this handle's may
+  // still be queued when they are released
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  if (h->st_b) (void)hipStreamSynchronize(h->st_b);
+  delete h;
+}
 
 template <typename Tv>
 static int upload(GhBuf& buf, const std::vector<Tv>& v, hipStream_t st) {
