@@ -416,14 +416,37 @@ def main():
         if world == 1:
             p = job.profile()
             if p.n_trailing > 0 and p.ms_trailing > 0:
-                ach = p.trailing_flops / (p.ms_trailing * 1e-3) * 1e-12
-                out["roofline"] = {
-                    "kernel": "gemm_f64_mfma_dma<k-major, k-major, lower> (trailing SYRK update)",
-                    "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                    "launches": int(p.n_trailing), "avg_launch_ms": p.ms_trailing / p.n_trailing,
-                    "algorithmic_flops_per_launch": p.trailing_flops / p.n_trailing,
-                }
+                ach_syrk = p.trailing_flops / (p.ms_trailing * 1e-3) * 1e-12
+                union = getattr(p, "ms_update_union", 0.0)
+                if union > 0 and p.update_flops > 0:
+                    # The trailing update A22 -= L21 L21^T is issued as one wide lower-triangular launch per
+                    # panel on the main stream plus the block-column launch U(j, j+1) on the panel-chain
+                    # stream, and the two overlap: a wide launch's own start-to-end time then contains the
+                    # share of the chip it lent to the other.  achieved = algorithmic flops of ALL these
+                    # launches / the time during which any of them was running (union of their HIP-event
+                    # intervals, each taken on the stream the launch went to).
+                    ach = p.update_flops / (union * 1e-3) * 1e-12
+                    nl = int(p.n_trailing)
+                    out["roofline"] = {
+                        "kernel": "gemm_f64_mfma_dma<k-major, k-major, *> (trailing update A22 -= L21 L21^T: the wide lower-"
+                                  "triangular SYRK launches + the block-column launches that overlap them)",
+                        "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                        "busy_ms_per_step": union, "algorithmic_flops_per_step": p.update_flops,
+                        "wide_syrk_launches_alone": {
+                            "launches": nl, "avg_launch_ms": p.ms_trailing / nl,
+                            "algorithmic_flops_per_launch": p.trailing_flops / nl, "achieved": ach_syrk,
+                            "frac": ach_syrk / PEAK_FP64_MFMA_TFLOPS,
+                            "note": "start-to-end time of each wide launch, block-column launches of the chain stream "
+                                    "running beside it included"}}
+                else:
+                    out["roofline"] = {
+                        "kernel": "gemm_f64_mfma_dma<k-major, k-major, lower> (trailing SYRK update)",
+                        "bound": "mfma", "achieved": ach_syrk, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach_syrk / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                        "launches": int(p.n_trailing), "avg_launch_ms": p.ms_trailing / p.n_trailing,
+                        "algorithmic_flops_per_launch": p.trailing_flops / p.n_trailing,
+                    }
                 out["roofline"].update(pmc_traffic(args.n))
             out["phases_ms"] = {"total_compute": p.ms_total, "kernel_matrix_build": p.ms_build,
                                 "panel_factor_trsm": p.ms_panel, "trailing_syrk": p.ms_trailing,

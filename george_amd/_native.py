@@ -41,7 +41,8 @@ class gh_chol_opts(C.Structure):
 class gh_chol_profile(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_panel", C.c_double),
                 ("ms_trailing", C.c_double), ("trailing_flops", C.c_double), ("n_trailing", C.c_int64),
-                ("ms_solve", C.c_double), ("reserved", C.c_double * 4)]
+                ("ms_solve", C.c_double), ("ms_update_union", C.c_double), ("update_flops", C.c_double),
+                ("reserved", C.c_double * 2)]
 
 
 class gh_hodlr_opts(C.Structure):

@@ -494,7 +494,7 @@ struct gh_chol {
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
-  std::vector<size_t> ev_trailing, ev_panel;
+  std::vector<size_t> ev_trailing, ev_panel, ev_update;   // ev_update: EVERY trailing-update launch (wide SYRKs and block-column GEMMs)
   // returns an index into ev_pool (the vector may grow, so never keep pointers), or -1
   long next_ev() {
     if (ev_used == ev_pool.size()) {
@@ -945,7 +945,15 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   if (!s->ev_ub) GH_HIP(hipEventCreateWithFlags(&s->ev_ub, hipEventDisableTiming));
   auto narrow = [&](hipStream_t st, int j, int c) -> int {         // U(j, c)
     const double* Pj = blk(A, ld, c0(c), c0(j));
-    return gemm_nt(st, blk(A, ld, c0(c), c0(c)), ld, Pj, ld, Pj, ld, np - c0(c), nbc(c), nbc(j), -1.0, 1.0, false);
+    const long eu = prof ? s->next_ev() : -1;
+    if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, st)); s->ev_update.push_back((size_t)eu); }
+    GH_CHECK(gemm_nt(st, blk(A, ld, c0(c), c0(c)), ld, Pj, ld, Pj, ld, np - c0(c), nbc(c), nbc(j), -1.0, 1.0, false));
+    if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, st));
+    // (algorithmic flops of the block column: its lower part only -- the strictly-upper tiles of the
+    //  diagonal block are computed for convenience and never read)
+    const double tr = (double)(np - c0(c)) / T, tc = (double)nbc(c) / T;
+    s->prof.update_flops += (tr * tc - tc * (tc - 1.0) / 2.0) * 2.0 * T * T * (double)nbc(j);
+    return GH_OK;
   };
   // everything queued so far (the build, on s->st) before any of the three streams starts
   GH_HIP(hipEventRecord(s->ev_sync[0], s->st));
@@ -996,12 +1004,13 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     if (cw <= P - 1) {
       const int64_t kw = c0(cw), m2 = np - kw;
       const long et = prof ? s->next_ev() : -1;
-      if (et >= 0) { GH_HIP(hipEventRecord(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); }
+      if (et >= 0) { GH_HIP(hipEventRecord(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); s->ev_update.push_back((size_t)et); }
       const double* P2 = blk(A, ld, kw, c0(j));
       GH_CHECK(gemm_nt(sm, blk(A, ld, kw, kw), ld, P2, ld, P2, ld, m2, m2, nbc(j), -1.0, 1.0, true));
       if (et >= 0) GH_HIP(hipEventRecord(s->ev_pool[et].b, sm));
       const double tiles = (double)(m2 / T) * (m2 / T + 1) / 2.0;
       s->prof.trailing_flops += tiles * 2.0 * T * T * (double)nbc(j);
+      s->prof.update_flops += tiles * 2.0 * T * T * (double)nbc(j);
       s->prof.n_trailing += 1;
     }
     GH_HIP(hipEventRecord(s->ev_w[j], sm));
@@ -1080,7 +1089,7 @@ static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n,
   GH_CHECK(s->scal.ensure(256 * sizeof(double)));      // [0] log-det, [1] quadratic form, [8..72) and [72..136) slice sums
   hipStream_t st = s->st;
   memset(&s->prof, 0, sizeof(s->prof));
-  s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear();
+  s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear(); s->ev_update.clear();
   const bool prof = s->opts.profile != 0;
   c.e_all = prof ? s->next_ev() : -1;
   c.e_build = prof ? s->next_ev() : -1;
@@ -1103,6 +1112,26 @@ static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long 
     GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[c.e_all].a, s->ev_pool[c.e_all].b)); s->prof.ms_total = ms;
     GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[c.e_build].a, s->ev_pool[c.e_build].b)); s->prof.ms_build = ms;
     for (size_t i : s->ev_trailing) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_trailing += ms; }
+    // time during which ANY trailing-update launch (wide SYRK on the main stream, block-column GEMM on the
+    // chain stream) was running: union of their event intervals, measured from the start of compute()
+    if (!s->ev_update.empty()) {
+      std::vector<std::pair<float, float>> iv;
+      for (size_t i : s->ev_update) {
+        float a = 0, b = 0;
+        GH_HIP(hipEventElapsedTime(&a, s->ev_pool[c.e_all].a, s->ev_pool[i].a));
+        GH_HIP(hipEventElapsedTime(&b, s->ev_pool[c.e_all].a, s->ev_pool[i].b));
+        iv.emplace_back(a, b);
+      }
+      std::sort(iv.begin(), iv.end());
+      double tot = 0.0;
+      float lo = iv[0].first, hi = iv[0].second;
+      for (size_t q = 1; q < iv.size(); ++q) {
+        if (iv[q].first > hi) { tot += hi - lo; lo = iv[q].first; hi = iv[q].second; }
+        else if (iv[q].second > hi) hi = iv[q].second;
+      }
+      tot += hi - lo;
+      s->prof.ms_update_union = tot;
+    }
     for (size_t i : s->ev_panel) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_panel += ms; }
   }
   if (info_host != 0) {

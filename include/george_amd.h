@@ -215,7 +215,10 @@ typedef struct gh_chol_profile {
   double trailing_flops;    /* algorithmic flops of those launches             */
   int64_t n_trailing;       /* number of trailing-update launches              */
   double ms_solve;          /* last dot_solve / solve                          */
-  double reserved[4];
+  double ms_update_union;   /* time during which ANY trailing-update launch ran (wide SYRKs on the main
+                             * stream + block-column GEMMs on the chain stream): union of their intervals */
+  double update_flops;      /* algorithmic flops of all those launches          */
+  double reserved[2];
 } gh_chol_profile;
 int  gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out);
 
