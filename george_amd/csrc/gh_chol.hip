@@ -481,6 +481,8 @@ struct gh_chol {
   hipStream_t st_crit = nullptr;         // exclusive mode: potf2 chain confined to the CUs st_mask leaves out
   hipStream_t st_sa = nullptr;           // exclusive mode: rows-below TRSM on the SAME CUs as the trailing update
   hipStream_t st_sb = nullptr;           // exclusive mode + inner split: in-panel rows >= j+2, same CUs again
+
+
   int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
   hipEvent_t ev_xfer = nullptr;
   hipEvent_t ev_sync[3] = {nullptr, nullptr, nullptr};
@@ -489,7 +491,7 @@ struct gh_chol {
   bool computed = false;
   int64_t info = 0;
   double logdet = 0.0;
-  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
+  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain, pflags;
   long long* d_info = nullptr;
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
@@ -522,6 +524,8 @@ struct gh_chol {
     if (st_crit) (void)hipStreamDestroy(st_crit);
     if (st_sa) (void)hipStreamDestroy(st_sa);
     if (st_sb) (void)hipStreamDestroy(st_sb);
+
+
     if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -734,6 +738,10 @@ static int panel_step_split(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) 
 }
 
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
+// gh_gemm.hip: the whole panel as two persistent flag-driven launches
+int gh_launch_panel_fused(double* A, int64_t ld, int64_t np, int64_t k0, int64_t nb, double* dinv, long long* info,
+                          unsigned* flags, hipStream_t sc, hipStream_t si, hipStream_t sw);
+
 // rows_ready (optional): the rows BELOW the nb x nb diagonal block are up to date only once this event
 // has fired (deep look-ahead updates them on another stream); the diagonal block itself is ready.
 static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEvent_t rows_ready = nullptr) {
@@ -748,6 +756,28 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEve
   (void)no_inner0;
   if (inner && s->st4 && on_panel_stream && (st == s->st2 || s->st_sb) && nb / T <= 8 && nb > T && !no_split && !use_simple_potf2())
     return panel_step_split(s, st, k0, nb);
+  // A/B arm GEORGE_AMD_PANEL_FUSED: the whole panel as two persistent flag-driven launches (gh_gemm.hip,
+  // panel_server_kernel / panel_worker_kernel).  Correct (bit-level agreement with the launch chain) but
+  // not faster: 1.32 vs 1.11 ms at N = 1024, 37.2 vs 35.1 ms at N = 16384 -- between two potf2 calls the
+  // two 128^3 products of ONE workgroup (30 us) and two release/acquire hand-overs replace two launches
+  // of 2-112 workgroups (27 us + gaps), and potf2 itself (80 of the ~120 us link) is unchanged.
+  static const int fused = getenv("GEORGE_AMD_PANEL_FUSED") ? atoi(getenv("GEORGE_AMD_PANEL_FUSED")) : 0;
+  if (fused && s->st3 && on_panel_stream && nb / T <= 8 && !use_simple_potf2() && np - k0 <= 24576) {
+    // server (potf2 chain) on the chain stream, workers (every row block of the column strip) on the side stream
+    GH_CHECK(s->pflags.ensure(64 * sizeof(unsigned)));
+    GH_HIP(hipMemsetAsync(s->pflags.p, 0, 64 * sizeof(unsigned), st));
+    GH_HIP(hipEventRecord(s->ev_aux, st));
+    GH_HIP(hipStreamWaitEvent(s->st3, s->ev_aux, 0));
+    if (rows_ready) GH_HIP(hipStreamWaitEvent(s->st3, rows_ready, 0));
+    // (Tried: server and in-panel workers on streams masked to the CUs the trailing update leaves out, so
+    //  that potf2 never shares a CU -- every second compute() on a handle then failed with a non-positive
+    //  pivot in the second panel, with or without host synchronisations at the panel's end and with an
+    //  agent acquire at the top of both kernels; cause not found.  Not kept.)
+    GH_CHECK(gh_launch_panel_fused(A, ld, np, k0, nb, dinv, s->d_info, (unsigned*)s->pflags.p, st, s->st3, s->st3));
+    GH_HIP(hipEventRecord(s->ev_aux, s->st3));
+    GH_HIP(hipStreamWaitEvent(st, s->ev_aux, 0));
+    return GH_OK;
+  }
   if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
     if (m > 0) {
@@ -766,10 +796,17 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEve
   GH_HIP(hipEventRecord(s->ev_aux, st));
   GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
   if (rows_ready) GH_HIP(hipStreamWaitEvent(sa, rows_ready, 0));
+  // A/B arm GEORGE_AMD_POTF2_EXCL: ONLY the potf2 launches go to the stream masked to the CUs the
+  // trailing update leaves out (a potf2 workgroup beside SYRK wavefronts takes 130-150 us instead of
+  // 80); the GEMMs of the chain stay where they are.  Costs two cross-stream hand-overs per 128 columns.
+  static const bool potf2_excl = getenv("GEORGE_AMD_POTF2_EXCL") != nullptr;
+  hipStream_t sq = (potf2_excl && s->st_crit && st != s->st_crit) ? s->st_crit : st;
+  if (sq != st) GH_HIP(hipStreamWaitEvent(sq, s->ev_aux, 0));
   for (int64_t j0 = 0; j0 < nb; j0 += T) {
     double* dj = dinv + (j0 / T) * T * T;
-    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
-    GH_HIP(hipEventRecord(s->ev_diag[j0 / T], st));
+    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, sq));
+    GH_HIP(hipEventRecord(s->ev_diag[j0 / T], sq));
+    if (sq != st) GH_HIP(hipStreamWaitEvent(st, s->ev_diag[j0 / T], 0));
     GH_HIP(hipStreamWaitEvent(sa, s->ev_diag[j0 / T], 0));
     double* Xj = B + j0;
     if (j0 > 0) GH_CHECK(gemm_nt(sa, Xj, ld, B, ld, Ak + j0 * ld, ld, m, T, j0, -1.0, 1.0, false));
@@ -779,6 +816,7 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEve
       double* P = blk(Ak, ld, j0 + T, j0);
       GH_CHECK(gemm_nt(st, P, ld, P, ld, dj, T, rem, T, T, 1.0, 0.0, false));
       GH_CHECK(gemm_nt(st, blk(Ak, ld, j0 + T, j0 + T), ld, P, ld, P, ld, rem, rem, T, -1.0, 1.0, true));
+      if (sq != st) { GH_HIP(hipEventRecord(s->ev_p1[j0 / T], st)); GH_HIP(hipStreamWaitEvent(sq, s->ev_p1[j0 / T], 0)); }
     }
   }
   GH_HIP(hipEventRecord(s->ev_aux, sa));
@@ -825,7 +863,8 @@ static hipStream_t trailing_stream(gh_chol* s) {
       // (a stream masked to exactly those), and the rows-below TRSM -- throughput work -- joins the
       // trailing update on the others; without it the high-priority panel streams are unmasked and
       // their workgroups may still land beside SYRK wavefronts.
-      static const bool exclusive = getenv("GEORGE_AMD_PANEL_EXCLUSIVE") && atoi(getenv("GEORGE_AMD_PANEL_EXCLUSIVE")) != 0;
+      static const bool exclusive = (getenv("GEORGE_AMD_PANEL_EXCLUSIVE") && atoi(getenv("GEORGE_AMD_PANEL_EXCLUSIVE")) != 0) ||
+                                    getenv("GEORGE_AMD_POTF2_EXCL") != nullptr;
       if (s->st_mask && exclusive && s->st3) {
         std::vector<uint32_t> inv(words, 0u);
         for (int c = 0; c < want; ++c) inv[c / 32] |= (1u << (c % 32));
@@ -834,6 +873,8 @@ static hipStream_t trailing_stream(gh_chol* s) {
           (void)hipGetLastError(); (void)hipStreamDestroy(s->st_crit); s->st_crit = nullptr; s->st_sa = nullptr;
         }
         if (s->st_crit && s->st4 && hipExtStreamCreateWithCUMask(&s->st_sb, words, mask.data()) != hipSuccess) { s->st_sb = nullptr; (void)hipGetLastError(); }
+
+
       }
     }
     if (s->st_mask && !s->ev_xfer && hipEventCreateWithFlags(&s->ev_xfer, hipEventDisableTiming) != hipSuccess) {

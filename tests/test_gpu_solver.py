@@ -353,6 +353,28 @@ def test_handle_pool_is_trimmed_and_releasable():
     assert gp.log_likelihood(y) == ll
 
 
+def test_fused_panel_arm_agrees():
+    """GEORGE_AMD_PANEL_FUSED=1: the panel as two persistent flag-driven launches (server + workers,
+    release/acquire hand-overs).  Same arithmetic in the same order as the launch chain: same bits,
+    also on repeated factorisations with one handle."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "for n in (1000, 4096, 9000):\n"
+            "    job = bench.DenseJob(n, 0, 0, profile=False)\n"
+            "    print(' '.join(repr(float(job.step())) for _ in range(3)))\n"
+            "    job.close()\n") % root
+    outs = []
+    for env in ({}, {"GEORGE_AMD_PANEL_FUSED": "1"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-3:])
+    assert outs[0] == outs[1], outs
+    for line in outs[1]:
+        assert len(set(line.split())) == 1, line                         # repeatable
+
+
 def test_stepwise_trsv_arm_still_works():
     """GEORGE_AMD_TRSV_STEPS selects the one-launch-per-block-row solves (the fallback should the
     chained kernels' in-order dispatch assumption ever fail): keep it exercised."""
