@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void panel_server_kernel(PanelArgs p) {
   __syncthreads();
   for (int j = 0; j < p.nblk; ++j) {
     if (j > 0 && !panel_wait(p.flags, PF_DIAG + j)) return;
-    const bool ok = gh_potf2::potf2_body(p.A + (long)j * 128 * p.ld + (long)j * 128, p.ld, p.dinv + (long)j * 128 * 128,
+    const bool ok = gh_potf2::potf2_body<32>(p.A + (long)j * 128 * p.ld + (long)j * 128, p.ld, p.dinv + (long)j * 128 * 128,
                                          p.info, p.base + (long long)j * 128, s, inv16, rdiag, &fail_at);
     if (!ok) {                                        // (uniform) not positive definite: release everybody
       __syncthreads();

@@ -773,15 +773,34 @@ __global__ __launch_bounds__(256) void hodlr_sum_narrow_kernel(const double* P, 
   }
 }
 // Tsum[node][0:R] = sum of the partials of its half-1 chunks, [R:2R] = half-0 chunks (hodlr.h:247-249)
-__global__ void hodlr_sum_kernel(const double* P, const int* crange /* [node][half][2] */, int R, long Cp, int C, double* Tsum) {
+// blockDim = 64 x NS: NS threads per column each add a contiguous slice of the node's chunks, the first
+// then adds the NS slice sums in order (fixed order: reproducible).  The top levels have up to N/256
+// chunks per half: as one thread per column this walk took 55-60 us per launch.
+#define SUM_NS 8
+__global__ __launch_bounds__(64 * SUM_NS) void hodlr_sum_kernel(const double* P, const int* crange /* [node][half][2] */, int R, long Cp, int C, double* Tsum) {
+  __shared__ double sl[SUM_NS][64];
   const int node = blockIdx.x, row = blockIdx.y;          // row in [0, 2R)
   const int half = row < R ? 1 : 0, k = row < R ? row : row - R;
   const int cb = crange[(node * 2 + half) * 2], ce = crange[(node * 2 + half) * 2 + 1];
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int lane = threadIdx.x & 63, sidx = threadIdx.x >> 6;
+  const int per = (ce - cb + SUM_NS - 1) / SUM_NS;
+  const int lo = cb + sidx * per, hi = lo + per < ce ? lo + per : ce;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
     double v = 0.0;
+    if (c < C) {
 #pragma unroll 8                                  // (loads of 8 chunks in flight; the sum stays in chunk order)
-    for (int ch = cb; ch < ce; ++ch) v += P[((long)ch * R + k) * Cp + c];
-    Tsum[((long)node * 2 * R + row) * Cp + c] = v;
+      for (int ch = lo; ch < hi; ++ch) v += P[((long)ch * R + k) * Cp + c];
+    }
+    sl[sidx][lane] = v;
+    __syncthreads();
+    if (sidx == 0 && c < C) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < SUM_NS; ++q) t += sl[q][lane];
+      Tsum[((long)node * 2 * R + row) * Cp + c] = t;
+    }
+    __syncthreads();
   }
 }
 // S = [[I, V1^T U1], [V0^T U0, I]]  (hodlr.h:229-232) from Tsum (C == R)
@@ -841,6 +860,8 @@ struct gh_hodlr {
   hipStream_t st = nullptr;
   hipStream_t st_b = nullptr;    // second stream: ACA of the one-workgroup-per-node levels beside the clustered ones
   hipEvent_t ev_b = nullptr;
+  hipStream_t st_c = nullptr;    // third stream: the leaf stage, beside both ACA streams
+  hipEvent_t ev_c = nullptr;
   int64_t n = 0;
   int ndim = 0;
   bool computed = false;
@@ -862,6 +883,8 @@ struct gh_hodlr {
     for (auto* l : levels) delete l;
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (st_b) (void)hipStreamDestroy(st_b);
+    if (ev_c) (void)hipEventDestroy(ev_c);
+    if (st_c) (void)hipStreamDestroy(st_c);
     if (st) (void)hipStreamDestroy(st);
   }
   int64_t tree_n = -1;
@@ -893,6 +916,7 @@ extern "C" void gh_hodlr_destroy(gh_hodlr* h) {
   // still be queued when they are released
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->st_b) (void)hipStreamSynchronize(h->st_b);
+  if (h->st_c) (void)hipStreamSynchronize(h->st_c);
   delete h;
 }
 
@@ -945,7 +969,7 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
     // reduce: P[chunk] = V_chunk^T X_chunk
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, Vl, 1, R,
                        X, ldx, xcol0 + cp, h->P.d(), Cp, 0, cw, false));
-    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, cw, h->Tsum.d());
+    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, cw, h->Tsum.d());
     GH_HIP(hipGetLastError());
     // core: Tout = S^-1 Tsum
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
@@ -1384,7 +1408,20 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
     }
     static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
-    if (!leaves_after) GH_CHECK(leaf_stage(h->st_b));
+    if (!leaves_after) {
+      if (!h->st_c) {
+        if (hipStreamCreateWithFlags(&h->st_c, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_c = nullptr; }
+      }
+      if (h->st_c) {
+        GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));       // (ev_b still holds "inputs uploaded": recorded above, not yet re-recorded)
+        GH_CHECK(leaf_stage(h->st_c));
+        GH_HIP(hipEventRecord(h->ev_c, h->st_c));
+        GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0));
+      } else {
+        GH_CHECK(leaf_stage(h->st_b));
+      }
+    }
     GH_HIP(hipEventRecord(h->ev_b, h->st_b));
     GH_HIP(hipStreamWaitEvent(st, h->ev_b, 0));
     for (int l = 0; l < nlev; ++l) GH_CHECK(fetch_level(l, st));
@@ -1478,13 +1515,28 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     HLevel* L = h->levels[l];
     if (L->R == 0) continue;
     const int R = L->R, nn = (int)L->node_ids.size();
-    // S = I + [0, V1^T U1; V0^T U0, 0] with the CURRENT U of this level
-    GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off, 1, R,
-                       h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R, false));
-    hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
-    GH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)h->cpass, R, L->sinv.d());
-    GH_HIP(hipGetLastError());
+    // S = I + [0, V1^T U1; V0^T U0, 0] with the CURRENT U of this level.  The products V_l^T U that the
+    // core needs (columns [off, off + R)) and the ones that applying this level's inverse to the shallower
+    // levels' U needs (columns [0, off)) read the same V_l chunks and neighbouring columns of the same U
+    // rows: ONE reduce + sum over columns [0, off + R) serves both (two launches fewer per level).
+    static const bool no_merge = getenv("GEORGE_AMD_HODLR_NO_MERGED_REDUCE") != nullptr;
+    const int Call = L->off + R;
+    const bool merged = !no_merge && Call <= h->cpass;
+    if (merged) {
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off, 1, R,
+                         h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call, false));
+      hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, Call, h->Tsum.d());
+      GH_HIP(hipGetLastError());
+      hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d() + L->off, (long)h->cpass, R, L->sinv.d());
+      GH_HIP(hipGetLastError());
+    } else {
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off, 1, R,
+                         h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R, false));
+      hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
+      GH_HIP(hipGetLastError());
+      hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)h->cpass, R, L->sinv.d());
+      GH_HIP(hipGetLastError());
+    }
     std::vector<long> offs(nn);
     std::vector<int> sizes(nn, 2 * R);
     for (int q = 0; q < nn; ++q) offs[q] = (long)q * 4 * R * R;
@@ -1495,7 +1547,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     }
     ld_at += nn;
     // apply this level's inverse to the U's of all shallower levels: columns [0, off)
-    GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
+    if (merged && L->off > 0) {
+      // (Tsum already holds V_l^T U[:, 0:off]: core product and update only)
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
+                         h->Tsum.d(), h->cpass, 0, h->Tout.d(), h->cpass, 0, L->off, false));
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, HCH, h->UA.d() + L->off, Rtot, 1,
+                         h->Tout.d(), h->cpass, 0, h->UA.d(), Rtot, 0, L->off, true, HCH / 32));
+    } else {
+      GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
+    }
   }
   // level-major copy of the final U for the solves
   if (h->Rtot > 0) {

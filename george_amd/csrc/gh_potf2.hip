@@ -39,14 +39,28 @@ __global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda
   __shared__ double inv16[8 * 16 * IP];
   __shared__ double rdiag[T];                   // 1 / L_jj, written as the pivots are taken
   __shared__ int fail_at;
-  (void)gh_potf2::potf2_body(A, lda, dinv, info, base, s, inv16, rdiag, &fail_at);
+  (void)gh_potf2::potf2_body<32>(A, lda, dinv, info, base, s, inv16, rdiag, &fail_at);
+}
+// batched form (HODLR leaves): 75 KB of LDS, two workgroups per CU
+__global__ __launch_bounds__(256) void potf2_inv_mfma_batched_kernel(double* A, long lda, double* dinv,
+                                                                     long long* info, long stride_a, long stride_d) {
+  A += (long)blockIdx.x * stride_a;
+  dinv += (long)blockIdx.x * stride_d;
+  __shared__ double s[T * (T + 1) / 2];
+  __shared__ double scr[GH_POTF2_INV_DOUBLES_NARROW];
+  __shared__ double rdiag[T];
+  __shared__ int fail_at;
+  (void)gh_potf2::potf2_body<16>(A, lda, dinv, info, 0LL, s, scr, rdiag, &fail_at);
 }
 
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
                             int nbatch, hipStream_t st) {
   if (nbatch <= 0) return GH_OK;
-  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, dinv, info, 0LL,
-                     (long)stride_a, (long)stride_d);
+  static const bool wide = getenv("GEORGE_AMD_POTF2_BATCH_WIDE") != nullptr;      // A/B: the 83-KB kernel, one workgroup per CU
+  if (wide) hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, dinv, info, 0LL,
+                               (long)stride_a, (long)stride_d);
+  else hipLaunchKernelGGL(potf2_inv_mfma_batched_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, dinv, info,
+                          (long)stride_a, (long)stride_d);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }

@@ -49,8 +49,12 @@ __device__ __forceinline__ v4d tile_mma(v4d acc, int kk0, int kk1, FA fa, FB fb,
 
 #define GH_POTF2_S_DOUBLES (128 * 129 / 2)
 #define GH_POTF2_INV_DOUBLES (8 * 16 * 17)
+#define GH_POTF2_INV_DOUBLES_NARROW (64 * 16)
 // s: T(T+1)/2 doubles, inv16: 8*16*IP doubles, rdiag: T doubles, fail_at_p: one int -- all LDS.
 // Returns false when the block is not positive definite (then *info is set) or an earlier one was not.
+// CWMAX: widest column chunk of the doubling products (32: scratch 64 x 32 doubles; 16: 64 x 16, two more
+// barrier pairs per block, but 75 instead of 83 KB of LDS -- TWO workgroups per CU for batched launches).
+template <int CWMAX = 32>
 __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, long long* info, long long base,
                                            double* s, double* inv16, double* rdiag, int* fail_at_p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -233,7 +237,7 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
   double* scr = inv16;
   for (int sz = 16; sz <= 64; sz *= 2) {
     const int tps = sz / 16;                      // tiles per side of a block
-    const int cw = sz < 32 ? sz : 32, tpc = cw / 16;   // chunk width, tile columns per chunk
+    const int cw = sz < CWMAX ? sz : CWMAX, tpc = cw / 16;   // chunk width, tile columns per chunk
     const int npair = 64 / sz;
     for (int c0 = 0; c0 < sz; c0 += cw) {
       const int njobs = npair * tps * tpc;
