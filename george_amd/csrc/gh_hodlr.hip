@@ -862,6 +862,12 @@ struct gh_hodlr {
   hipEvent_t ev_b = nullptr;
   hipStream_t st_c = nullptr;    // third stream: the leaf stage, beside both ACA streams
   hipEvent_t ev_c = nullptr;
+  std::vector<hipEvent_t> aca_ev;        // timing stamps of the side items of the last compute(), two per item
+  size_t aca_ev_used = 0;
+  std::vector<int> aca_items;            // level per item (-1: leaf stage), in stamp order
+  hipEvent_t aca_fused_ev[2] = {nullptr, nullptr};
+  bool aca_timed = false;
+  std::vector<double> aca_ms;            // measured milliseconds: [0..nlev) levels, [nlev] fused launch, [nlev+1] leaf stage
   int64_t n = 0;
   int ndim = 0;
   bool computed = false;
@@ -885,12 +891,14 @@ struct gh_hodlr {
     if (st_b) (void)hipStreamDestroy(st_b);
     if (ev_c) (void)hipEventDestroy(ev_c);
     if (st_c) (void)hipStreamDestroy(st_c);
+    for (auto& e : aca_ev) (void)hipEventDestroy(e);
+    for (auto& e : aca_fused_ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
   }
   int64_t tree_n = -1;
   int tree_min = -1;
   bool leaf_tab_up = false;
-  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); tree_n = -1; leaf_tab_up = false; col_Rtot = -1; col_sig.clear(); }
+  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); tree_n = -1; leaf_tab_up = false; col_Rtot = -1; col_sig.clear(); aca_ms.clear(); }
 };
 
 extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
@@ -1401,31 +1409,76 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         for (int l : cl) fprintf(stderr, "[hodlr] level %d: nodes %d half %d G %d (max %d)\n", l, (int)h->levels[l]->node_ids.size(), half[l], al[l].G, gmax[l]);
         fprintf(stderr, "[hodlr] total %d\n", total);
       }
+      if (h->aca_fused_ev[0] == nullptr) { GH_HIP(hipEventCreate(&h->aca_fused_ev[0])); GH_HIP(hipEventCreate(&h->aca_fused_ev[1])); }
+      GH_HIP(hipEventRecord(h->aca_fused_ev[0], st));
       GH_CHECK(enqueue_fused(fused, rcap0, st));
-      for (int l : single) GH_CHECK(enqueue_level(l, rcap0, h->st_b));
-      for (int l = 0; l < nlev; ++l) if (gmax[l] == 1) GH_CHECK(enqueue_level(l, rcap0, h->st_b));
-    } else {
-      for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
-    }
-    static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
-    if (!leaves_after) {
+      GH_HIP(hipEventRecord(h->aca_fused_ev[1], st));
+      h->aca_timed = true;
+      // The one-workgroup-per-node levels and the leaf stage are independent of the fused launch and of
+      // each other, but HIP multiplexes streams onto 4 hardware queues (3 seen by this library: more
+      // streams than that just share a queue and serialise -- measured: a "fourth stream" ran its kernels
+      // behind the fused launch).  So: three queues -- the solver's stream (fused launch first) and two
+      // side streams -- and the items are dealt longest-first onto the least loaded queue, with the
+      // durations MEASURED in the previous compute() of this handle (HIP events; a default guess the
+      // first time): ranks, and with them the cost profile, hardly move inside an optimiser loop.
       if (!h->st_c) {
         if (hipStreamCreateWithFlags(&h->st_c, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_c = nullptr; }
       }
-      if (h->st_c) {
-        GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));       // (ev_b still holds "inputs uploaded": recorded above, not yet re-recorded)
-        GH_CHECK(leaf_stage(h->st_c));
-        GH_HIP(hipEventRecord(h->ev_c, h->st_c));
-        GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0));
-      } else {
-        GH_CHECK(leaf_stage(h->st_b));
+      static const bool leaves_after0 = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
+      std::vector<int> ones = single;
+      for (int l = 0; l < nlev; ++l) if (gmax[l] == 1) ones.push_back(l);
+      struct Item { int level; double cost; };             // level -1: the leaf stage
+      std::vector<Item> items;
+      const bool have = (int)h->aca_ms.size() == nlev + 2;     // [0..nlev): levels, [nlev]: fused launch, [nlev+1]: leaf stage
+      for (int l : ones) items.push_back({l, have && h->aca_ms[l] > 0 ? h->aca_ms[l] : 1.0});
+      if (!leaves_after0) items.push_back({-1, have && h->aca_ms[nlev + 1] > 0 ? h->aca_ms[nlev + 1] : 1.2});
+      std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
+      hipStream_t qs[3] = {st, h->st_b, h->st_c ? h->st_c : h->st_b};
+      double load[3] = {have && h->aca_ms[nlev] > 0 ? h->aca_ms[nlev] : 1.5, 0.0, h->st_c ? 0.0 : 1e30};
+      if (h->st_c) GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));
+      h->aca_ev_used = 0;
+      auto stamp = [&](hipStream_t sx) -> int {               // record the next timing event on sx
+        if (h->aca_ev_used == h->aca_ev.size()) {
+          hipEvent_t e;
+          GH_HIP(hipEventCreate(&e));
+          h->aca_ev.push_back(e);
+        }
+        GH_HIP(hipEventRecord(h->aca_ev[h->aca_ev_used++], sx));
+        return GH_OK;
+      };
+      h->aca_items.clear();
+      // (the fused launch was enqueued above, between two stamps on st)
+      for (const Item& it : items) {
+        int q = 0;
+        for (int w = 1; w < 3; ++w) if (load[w] < load[q]) q = w;
+        load[q] += it.cost;
+        GH_CHECK(stamp(qs[q]));
+        if (it.level >= 0) GH_CHECK(enqueue_level(it.level, rcap0, qs[q])); else GH_CHECK(leaf_stage(qs[q]));
+        GH_CHECK(stamp(qs[q]));
+        h->aca_items.push_back(it.level);
       }
+      if (h->st_c) { GH_HIP(hipEventRecord(h->ev_c, h->st_c)); GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0)); }
+    } else {
+      for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
+      static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
+      if (!leaves_after) GH_CHECK(leaf_stage(h->st_b));
     }
     GH_HIP(hipEventRecord(h->ev_b, h->st_b));
     GH_HIP(hipStreamWaitEvent(st, h->ev_b, 0));
     for (int l = 0; l < nlev; ++l) GH_CHECK(fetch_level(l, st));
     GH_HIP(hipStreamSynchronize(st));
+    if (h->aca_timed) {                                 // durations for the next compute()'s schedule
+      h->aca_ms.assign(nlev + 2, 0.0);
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, h->aca_fused_ev[0], h->aca_fused_ev[1]) == hipSuccess) h->aca_ms[nlev] = ms;
+      for (size_t q = 0; q < h->aca_items.size() && 2 * q + 1 < h->aca_ev_used; ++q) {
+        if (hipEventElapsedTime(&ms, h->aca_ev[2 * q], h->aca_ev[2 * q + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const int lv = h->aca_items[q];
+        h->aca_ms[lv >= 0 ? lv : nlev + 1] = ms;
+      }
+      h->aca_timed = false;
+    }
     for (int l = 0; l < nlev; ++l) { GH_CHECK(settle_level(l)); rank_of_level(l); }
   } else {
     for (int l = 0; l < nlev; ++l) {
