@@ -528,16 +528,15 @@ __device__ __forceinline__ void panel_tile_gemm(double* sm, double* C, long ldc,
 
 __global__ __launch_bounds__(256) void panel_server_kernel(PanelArgs p) {
   __shared__ double s[GH_POTF2_S_DOUBLES];
-  __shared__ double inv16[GH_POTF2_INV_DOUBLES];
-  __shared__ double rdiag[128];
+  __shared__ double dscr[GH_POTF2_D_DOUBLES];
   __shared__ int fail_at;
   __builtin_amdgcn_s_setprio(3);
   if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   for (int j = 0; j < p.nblk; ++j) {
     if (j > 0 && !panel_wait(p.flags, PF_DIAG + j)) return;
-    const bool ok = gh_potf2::potf2_body<32>(p.A + (long)j * 128 * p.ld + (long)j * 128, p.ld, p.dinv + (long)j * 128 * 128,
-                                         p.info, p.base + (long long)j * 128, s, inv16, rdiag, &fail_at);
+    const bool ok = gh_potf2::potf2_body(p.A + (long)j * 128 * p.ld + (long)j * 128, p.ld, p.dinv + (long)j * 128 * 128,
+                                         p.info, p.base + (long long)j * 128, s, dscr, &fail_at);
     if (!ok) {                                        // (uniform) not positive definite: release everybody
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(p.flags + PF_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -23,50 +23,52 @@
 // inverse) took 553 us per block and was half of compute() at N = 16384; it is kept in
 // gh_chol.hip (`potf2_inv_kernel`) as the A/B validation arm (GEORGE_AMD_POTF2=simple).
 #include <stdlib.h>
+#include <string.h>
 #include "gh_potf2_body.h"
-
-#define T 128
-#define IP 17
+#include "gh_potf2_body_v1.h"
 
 // blockIdx.x selects the block of a batch (stride_a / stride_d doubles apart; 0 for the single
 // diagonal block of the dense factorisation): the HODLR leaves are factored and inverted this way.
-__global__ __launch_bounds__(256) void potf2_inv_mfma_kernel(double* A, long lda, double* dinv,
+// 75 KB of LDS: two workgroups per CU in a batched launch, and room beside a 64-KB SYRK workgroup.
+__global__ __launch_bounds__(256, 2) void potf2_inv_mfma_kernel(double* A, long lda, double* dinv,
                                                              long long* info, long long base,
                                                              long stride_a, long stride_d) {
   A += (long)blockIdx.x * stride_a;
   dinv += (long)blockIdx.x * stride_d;
-  __shared__ double s[T * (T + 1) / 2];
-  __shared__ double inv16[8 * 16 * IP];
-  __shared__ double rdiag[T];                   // 1 / L_jj, written as the pivots are taken
+  __shared__ double s[GH_POTF2_S_DOUBLES];
+  __shared__ double dscr[GH_POTF2_D_DOUBLES];   // the eight 16x16 diagonal inverses, packed
   __shared__ int fail_at;
-  (void)gh_potf2::potf2_body<32>(A, lda, dinv, info, base, s, inv16, rdiag, &fail_at);
+  (void)gh_potf2::potf2_body(A, lda, dinv, info, base, s, dscr, &fail_at);
 }
-// batched form (HODLR leaves): 75 KB of LDS, two workgroups per CU
-__global__ __launch_bounds__(256) void potf2_inv_mfma_batched_kernel(double* A, long lda, double* dinv,
-                                                                     long long* info, long stride_a, long stride_d) {
+// the first form of the kernel (GEORGE_AMD_POTF2=v1): 82 us per block against the 2x-3x shorter second form
+__global__ __launch_bounds__(256) void potf2_inv_mfma_v1_kernel(double* A, long lda, double* dinv,
+                                                                long long* info, long long base,
+                                                                long stride_a, long stride_d) {
   A += (long)blockIdx.x * stride_a;
   dinv += (long)blockIdx.x * stride_d;
-  __shared__ double s[T * (T + 1) / 2];
-  __shared__ double scr[GH_POTF2_INV_DOUBLES_NARROW];
-  __shared__ double rdiag[T];
+  __shared__ double s[GH_POTF2V1_S_DOUBLES];
+  __shared__ double scr[GH_POTF2V1_INV_DOUBLES_NARROW];
+  __shared__ double rdiag[128];                 // 1 / L_jj, written as the pivots are taken
   __shared__ int fail_at;
-  (void)gh_potf2::potf2_body<16>(A, lda, dinv, info, 0LL, s, scr, rdiag, &fail_at);
+  (void)gh_potf2_v1::potf2_body<16>(A, lda, dinv, info, base, s, scr, rdiag, &fail_at);
+}
+static bool potf2_v1() {
+  static const bool v1 = [] { const char* e = getenv("GEORGE_AMD_POTF2"); return e != nullptr && strcmp(e, "v1") == 0; }();
+  return v1;
 }
 
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
                             int nbatch, hipStream_t st) {
   if (nbatch <= 0) return GH_OK;
-  static const bool wide = getenv("GEORGE_AMD_POTF2_BATCH_WIDE") != nullptr;      // A/B: the 83-KB kernel, one workgroup per CU
-  if (wide) hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, dinv, info, 0LL,
-                               (long)stride_a, (long)stride_d);
-  else hipLaunchKernelGGL(potf2_inv_mfma_batched_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, dinv, info,
-                          (long)stride_a, (long)stride_d);
+  hipLaunchKernelGGL(potf2_v1() ? potf2_inv_mfma_v1_kernel : potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st,
+                     A, (long)lda, dinv, info, 0LL, (long)stride_a, (long)stride_d);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
 
 int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, long long base, hipStream_t st) {
-  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info, base, 0L, 0L);
+  hipLaunchKernelGGL(potf2_v1() ? potf2_inv_mfma_v1_kernel : potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info,
+                     base, 0L, 0L);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }

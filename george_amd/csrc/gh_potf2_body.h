@@ -1,17 +1,59 @@
-// gh_potf2_body.h -- the 128x128 Cholesky + inverse of gh_potf2.hip as a device function, so that the
-// fused panel kernel (gh_gemm.hip, panel_server_kernel) can run it from a persistent workgroup.
-// See gh_potf2.hip for the description of the algorithm.
+// gh_potf2_body.h -- the 128x128 Cholesky + inverse of gh_potf2.hip as a device function (second form;
+// the first one, 82 us per block, is gh_potf2_body_v1.h and stays selectable: GEORGE_AMD_POTF2=v1).
+//
+// Where the 82 us of the first form went (scripts/dev/potf2_phases.hip, profiles/r02/potf2_phases_v1.txt):
+// 8 x 3.3 us for the one-wavefront 16x16 diagonal steps, 7 x 2.2 us for row substitution + tile column
+// + their barriers, 6.5 us for the eight 16x16 inverses, 19.4 us for the doubling products (two
+// barrier-separated products per chunk through an LDS scratch), 14 us of HBM load / store phases run
+// to completion one after the other.  This form removes whole phases instead of tuning them:
+//
+//  * the 16x16 diagonal step produces the block's INVERSE in the same instruction stream: lanes
+//    0-15 hold the rows of the block, lanes 16-31 the columns of D^-1, and the recurrence
+//    `v[j] *= 1/sqrt(d);  v[k] -= v[j] * L_kj` is the Cholesky column step for the former and forward
+//    substitution for the latter, with the SAME broadcast multipliers L_kj.  No separate inverse
+//    phase, and the rows below become X = A D^-T on the matrix pipe instead of a 16-deep dependent
+//    substitution per thread;
+//  * one barrier per 16-column step instead of three: every wavefront recomputes the X^T tiles it
+//    needs (4 MFMAs each) straight into MFMA operand registers -- the f64 16x16x4 result of
+//    X^T = D^-1 A^T has exactly the lane layout both operands of C -= X X^T want, if the k index of
+//    that product is taken as (lane >> 4) + 4 r -- and wavefront 0 runs the critical chain
+//    (X of the next tile row, next diagonal tile, next diagonal step) on its own while wavefronts
+//    1-3 update everything else;
+//  * 1/sqrt(d) from v_rsq_f64 and ONE third-order step (4 dependent operations instead of 12), the
+//    chain interleaved by hand with the independent updates of the previous column;
+//  * the doubling products X = -B^-1 (C A^-1) chained through registers the same way (the result
+//    tile column of C A^-1 is the B operand of the second product): no scratch, one barrier between
+//    reading C and overwriting it;
+//  * HBM phases overlapped: all loads of a pass in flight at once and only the lower triangle
+//    fetched; the zeros above the diagonals are stored by wavefronts 1-3 while wavefront 0 does the
+//    first diagonal step; the factor is stored without waiting (phase 2 runs under the stores).
 #pragma once
 #include "gh_common.h"
+#include <type_traits>
 
 #ifndef GH_POTF2_BODY_H_
 #define GH_POTF2_BODY_H_
+// phase time stamps for scripts/dev/potf2_phases.hip; nothing in the library build
+#ifndef GH_POTF2_STAMP
+#define GH_POTF2_STAMP(k)
+#endif
+#ifndef GH_POTF2_STAMP2
+#define GH_POTF2_STAMP2(k)
+#endif
+
+#define GH_POTF2_S_DOUBLES (128 * 129 / 2)      // packed lower triangle of the block
+#define GH_POTF2_D_DOUBLES (8 * 136 + 64 + 136) // packed lower triangles of the eight 16x16 diagonal inverses, 64 spare slots, a dummy tile
+
 namespace gh_potf2 {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-#define T 128
-#define IP 17                                   // pitch of the 16x16 diagonal-inverse scratch
-#define PK(i, j) ((((i) * ((i) + 1)) >> 1) + (j))   // packed lower-triangular index, j <= i
+// offset of row i in the packed row-major lower triangle
+__device__ __forceinline__ int rowbase(int i) { return (i * (i + 1)) >> 1; }
+// the same without a 32-bit integer multiply (quarter rate) in the lane-dependent part: u < 16 is the
+// lane's offset inside a 16-row tile, rbu = rowbase16(u), t the (wave-uniform) tile row:
+// rowbase(16 t + u) = rowbase(u) + t (16 u + 8) + 128 t^2
+__device__ __forceinline__ int rowbase16(int u) { return __mul24(u, u + 1) >> 1; }
+__device__ __forceinline__ int rowbase_t(int t, int u, int rbu) { return rbu + __mul24(16 * u + 8, t) + 128 * t * t; }
 
 // value of `v` in lane `src` (a compile-time constant after unrolling), delivered through SGPRs
 __device__ __forceinline__ double bcast_lane(double v, int src) {
@@ -19,265 +61,514 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ v4d mma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-// ---------------------------------------------------------------- MFMA tile helper
-// one 16x16 tile:  acc += A(16 x 4*nkk) * B(4*nkk x 16), operands fetched by functors A(i, k) and
-// B(k, j);  lane map: A operand lane l <- A(l & 15, 4kk + (l >> 4)),
-//                     B operand lane l <- B(4kk + (l >> 4), l & 15),
-//                     acc[r] <-> C((l >> 4) + 4r, l & 15).
-// All operand fetches of a tile (at most NK k-steps) are issued BEFORE the dependent MFMA chain:
-// the phase-2 operands come from HBM/L2 (`dinv`), and one exposed load latency per k-step is what
-// made the first MFMA version 180 us.  Loads are unconditional (the k index is clamped, surplus
-// MFMAs are skipped by a wave-uniform test): a per-element load predicate makes hipcc wait per
-// element.
-template <int NK, typename FA, typename FB>
-__device__ __forceinline__ v4d tile_mma(v4d acc, int kk0, int kk1, FA fa, FB fb, int lane) {
-  const int fr = lane & 15, fk = lane >> 4;
-  double a[NK], b[NK];
-#pragma unroll
-  for (int q = 0; q < NK; ++q) {
-    const int kk = (kk0 + q < kk1) ? kk0 + q : kk1 - 1;
-    a[q] = fa(fr, 4 * kk + fk);
-    b[q] = fb(4 * kk + fk, fr);
-  }
-#pragma unroll
-  for (int q = 0; q < NK; ++q)
-    if (kk0 + q < kk1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
-  return acc;
+#define GH_SB() __builtin_amdgcn_sched_barrier(0)
+
+// tile slot e = ui (ui + 1) / 2 - 1 + uj (ui = 1..6, uj <= ui) of the 27 tiles a step updates below its diagonal tile
+__host__ __device__ constexpr int slot_ui(int e) { int ui = 1; while ((ui + 1) * (ui + 2) / 2 - 1 <= e) ++ui; return e < 0 ? 1 : ui; }
+__host__ __device__ constexpr int slot_uj(int e) { return e < 0 ? 0 : e - (slot_ui(e) * (slot_ui(e) + 1) / 2 - 1); }
+
+// The sixteen column steps of the register-resident 16x16 diagonal step (see potf2_body, phase 1 (a)).
+// v[k]: row `lane & 15` of the block; w[k]: column `lane & 15` of its inverse (e_i on entry).
+// No pivot test in here: a non-positive (or NaN) pivot makes 1/sqrt NaN and poisons every later
+// column, so L(15,15) > 0 afterwards says that all sixteen were fine.
+// MODE (scripts/dev/diag_probe.hip only): 2 = without the DPP updates, 4 = without the 1/sqrt chains.
+#define GH_DPP_UPD(acc, src, mul, k) \
+  asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul))
+#define GH_UPDK(j, k) do { if ((k) > (j)) { GH_DPP_UPD(v[k], v[j], v[j], k); GH_DPP_UPD(w[k], v[j], w[j], k); } } while (0)
+#define GH_COL(j) do { \
+    double y_; \
+    if (!(MODE & 4)) { \
+      double d_; \
+      asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #j " row_mask:0xf bank_mask:0xf" : "=v"(d_) : "v"(v[j])); \
+      /* 1/sqrt(d): v_rsq_f64 seed y0 (relative error e ~ 2^-23 or better) and ONE third-order step     */ \
+      /* y0 (1 + e + 3/2 e^2), e = (1 - d y0^2) / 2: error O(e^3) < 2^-60; with e2 = 2 e = 1 - d y0^2 the */ \
+      /* bracket is 1 + e2 (1/2 + 3/8 e2): rsq + 4 dependent operations                                  */ \
+      const double y0_ = __builtin_amdgcn_rsq(d_); \
+      const double e2_ = fma(-(d_ * y0_), y0_, 1.0); \
+      y_ = fma(y0_ * e2_, fma(0.375, e2_, 0.5), y0_); \
+    } else { y_ = 0.99; } \
+    v[j] *= y_; w[j] *= y_; \
+    asm volatile("s_nop 1" ::: "memory");          /* VALU write -> DPP read of v[j]: two wait states */ \
+    GH_POTF2_STAMP2(48 + 2 * (j)); \
+    if (!(MODE & 2)) { \
+    GH_UPDK(j, 1); GH_UPDK(j, 2); GH_UPDK(j, 3); GH_UPDK(j, 4); GH_UPDK(j, 5); GH_UPDK(j, 6); GH_UPDK(j, 7); GH_UPDK(j, 8); \
+    GH_UPDK(j, 9); GH_UPDK(j, 10); GH_UPDK(j, 11); GH_UPDK(j, 12); GH_UPDK(j, 13); GH_UPDK(j, 14); GH_UPDK(j, 15); } \
+    GH_POTF2_STAMP2(49 + 2 * (j)); \
+  } while (0)
+template <int MODE = 0>
+__device__ __forceinline__ void diag16(double (&v)[16], double (&w)[16]) {
+  GH_COL(0); GH_COL(1); GH_COL(2); GH_COL(3); GH_COL(4); GH_COL(5); GH_COL(6); GH_COL(7);
+  GH_COL(8); GH_COL(9); GH_COL(10); GH_COL(11); GH_COL(12); GH_COL(13); GH_COL(14); GH_COL(15);
 }
+#undef GH_COL
+#undef GH_UPDK
+#undef GH_DPP_UPD
 
-
-#define GH_POTF2_S_DOUBLES (128 * 129 / 2)
-#define GH_POTF2_INV_DOUBLES (8 * 16 * 17)
-#define GH_POTF2_INV_DOUBLES_NARROW (64 * 16)
-// s: T(T+1)/2 doubles, inv16: 8*16*IP doubles, rdiag: T doubles, fail_at_p: one int -- all LDS.
+// s: GH_POTF2_S_DOUBLES, dscr: GH_POTF2_D_DOUBLES doubles, fail_at_p: one int -- all LDS.
 // Returns false when the block is not positive definite (then *info is set) or an earlier one was not.
-// CWMAX: widest column chunk of the doubling products (32: scratch 64 x 32 doubles; 16: 64 x 16, two more
-// barrier pairs per block, but 75 instead of 83 KB of LDS -- TWO workgroups per CU for batched launches).
-template <int CWMAX = 32>
 __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, long long* info, long long base,
-                                           double* s, double* inv16, double* rdiag, int* fail_at_p) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                           double* s, double* dscr, int* fail_at_p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (an SGPR: everything derived from it is scalar)
+  const int fr = lane & 15, fq = lane >> 4;     // MFMA operand row / k sub-index of this lane
+  const int rbfr = rowbase16(fr);
+  int uq[4], rbuq[4];                           // fq + 4 r: row of MFMA result register r inside a tile
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { uq[r] = fq + 4 * r; rbuq[r] = rowbase16(uq[r]); }
   // latency-bound chain of dependent steps that, under look-ahead, shares its CU with wavefronts
   // of the trailing SYRK issuing 64 MFMAs back to back: take the instruction arbiter's top priority
   __builtin_amdgcn_s_setprio(3);
-  if (*info != 0) return false;                 // uniform: an earlier block already failed
+  GH_POTF2_STAMP(0);
+  const long long info_in = *info;              // (looked at after the loads have been issued)
   if (tid == 0) (*fail_at_p) = -1;
-  // block -> packed LDS image; 16 unconditional loads in flight per thread (a load under the
-  // `j <= i` predicate is waited for one at a time: 22 % of the kernel in the first version)
-  {
-    const int j = tid & 127, ih = tid >> 7;
-#pragma unroll
-    for (int q0 = 0; q0 < 64; q0 += 16) {
-      double v[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = A[(long)(ih + 2 * (q0 + q)) * lda + j];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int i = ih + 2 * (q0 + q);
-        if (j <= i) s[PK(i, j)] = v[q];
-      }
-    }
-  }
-  __syncthreads();
-
   // ================================================================ phase 1: Cholesky
-  // (a) diagonal block jb: ONE wavefront, register-resident: lane i (mod 16) holds row i of the
-  //     block in 16 VGPR pairs, a column's pivot and multipliers travel by v_readlane (SGPR
-  //     broadcast), the j/k loops are fully unrolled so every register index is static.  (The
-  //     first MFMA version did this through volatile LDS round trips: ~1100 cycles per column.)
+  // (a) diagonal block jb by wavefront 0, register-resident.  Lane i (of every 16-lane row: the
+  //     four rows work redundantly) holds row i of the block in v[0..15] AND column i of the block's
+  //     inverse in w[0..15] (starts as e_i).  Column step j:  v[j] *= 1/sqrt(d_j), w[j] *= 1/sqrt(d_j),
+  //     then for k > j:  v[k] -= L_kj v[j]  (Cholesky)  and  w[k] -= L_kj w[j]  (forward substitution),
+  //     L_kj = lane k's v[j] delivered INSIDE the FMA by DPP row_newbcast (gfx90a+; the only DPP form
+  //     64-bit operations take): one v_fmac_f64_dpp per update.  The first form of this step moved
+  //     L_kj through SGPRs: two v_readlane + the SGPR-read hazard + the FMA = 22 cycles per update
+  //     against 5-6 (scripts/dev/valu_probe.hip), 3.1 us per diagonal step of which this is the rest.
+  //     Everything here is issue-bound (a dependent f64 FMA issues every 4.9 cycles, an independent
+  //     one every 4.4), so the order of independent work does not matter.
+  int bad = -1;                                 // (wavefront 0) first non-positive pivot of the block
   auto diag_factor = [&](int jb) {
     const int c0 = 16 * jb;
     const int i = lane & 15;
-    double a[16];
+    const int rbi = rowbase_t(jb, i, rowbase16(i)) + c0;
+    double v[16], w[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = (k <= i) ? s[PK(c0 + i, c0 + k)] : 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      double d = bcast_lane(a[j], j);
-      if (!(d > 0.0)) {                         // also catches NaN (uniform: d is a broadcast)
-        if (lane == 0 && (*fail_at_p) < 0) (*fail_at_p) = c0 + j;
-        d = 1.0;
-      }
-      // sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 seed (~2^-23) + two Newton steps and a final
-      // correction each: half the dependent chain of sqrt() followed by a division
-      double y = __builtin_amdgcn_rsq(d);
-      const double hd = 0.5 * d;
-      y = fma(y, fma(-hd * y, y, 0.5), y);
-      y = fma(y, fma(-hd * y, y, 0.5), y);
-      double ajj = d * y;
-      ajj = fma(0.5 * y, fma(-ajj, ajj, d), ajj);
-      const double inv = fma(fma(-ajj, y, 1.0), y, y);
-      if (lane == 0) rdiag[c0 + j] = inv;
-      a[j] = (i == j) ? ajj : a[j] * inv;
-#pragma unroll
-      for (int k = j + 1; k < 16; ++k) {
-        const double lkj = bcast_lane(a[j], k);
-        a[k] -= a[j] * lkj;                     // meaningful for i >= k; other lanes' values are never stored
-      }
+    for (int k = 0; k < 16; ++k) {
+      const double a = s[rbi + (k < i ? k : i)];
+      v[k] = (k <= i) ? a : 0.0;
+      w[k] = (k == i) ? 1.0 : 0.0;
     }
+    diag16(v, w);
+    // Results to LDS from the first 16-lane row by UNCONDITIONAL stores (32 predicated ones, each with
+    // its exec-mask branch and a mask reloaded from a spilled SGPR, were 2460 cycles of this step):
+    //   L row i, k = 15 .. 0 to s[row i][min(k, i)]: what lane i does not own (k > i, garbage) lands on
+    //     its own diagonal slot BEFORE the diagonal itself is stored (one wavefront's LDS stores keep
+    //     their order);
+    //   D^-1 column i, r = 0 .. 15 to (max(r, i), i): the rows above the diagonal (exact zeros) land
+    //     on slot (i, i) before w[i] does.
     if (lane < 16) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k <= i) s[PK(c0 + i, c0 + k)] = a[k];
+      for (int k = 15; k >= 0; --k) s[rbi + (k < i ? k : i)] = v[k];
+      const int rbi16 = rowbase16(i), db = 136 * jb + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dscr[db + (rowbase(r) > rbi16 ? rowbase(r) : rbi16)] = w[r];
+    }
+    // all sixteen pivots positive?  (see diag16)  If not -- rare -- the first bad one is the first
+    // diagonal entry of the stored block that is not a positive number.
+    if (((__builtin_amdgcn_ballot_w64(v[15] > 0.0) >> 15) & 1ull) == 0ull && bad < 0) {
+      const double dg = s[rbi + i];
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(!(dg > 0.0)) & 0xffffull;
+      bad = c0 + (m ? (int)__builtin_ctzll(m) : 15);
     }
   };
-  // (c) one 16x16 tile of the trailing update for step jb: C(ti,tj) -= P_ti P_tj^T, K = 16
-  auto update_tile = [&](int jb, int ti, int tj) {                // ti >= tj > jb (absolute tile indices)
-    const int c0 = 16 * jb, R0 = 16 * ti, C0 = 16 * tj;
-    const int cc = C0 + (lane & 15);
+  // D^-1 of step jb as the A operand of X^T = D^-1 A^T:  lane <- D^-1(fr, 4 kk + fq)
+  auto dinv_operand = [&](int jb, double (&dv)[4]) {
+    const int b = 136 * jb + rbfr;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kk + fq;
+      const double x = dscr[b + (k < fr ? k : fr)];
+      dv[kk] = (k <= fr) ? x : 0.0;
+    }
+  };
+  // X^T of tile row t for step jb (X = A[t][jb] D^-T, the final L[t][jb]): lane holds
+  // X(fr, fq + 4 q), q = 0..3 -- the operand layout of BOTH sides of C -= X X^T with k = fq + 4 q
+  auto xt_tile = [&](int t, int jb, const double (&dv)[4]) -> v4d {
+    const int b = rowbase_t(t, fr, rbfr) + 16 * jb + fq;
+    double bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) bv[kk] = s[b + 4 * kk];
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = mma(dv[kk], bv[kk], acc);
+    return acc;
+  };
+  auto store_x = [&](int t, int jb, v4d x) {
+    const int b = rowbase_t(t, fr, rbfr) + 16 * jb + fq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[b + 4 * q] = x[q];
+  };
+  // C(ti, tj) -= X_ti X_tj^T, tj <= ti
+  auto upd_tile = [&](int ti, int tj, v4d xi, v4d xj) {
+    const int cc = 16 * tj + fr;
     v4d acc;
+    int idx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = R0 + (lane >> 4) + 4 * r;
-      acc[r] = (cc <= rr) ? s[PK(rr, cc)] : 0.0;
+      const int rr = 16 * ti + fq + 4 * r;
+      idx[r] = rowbase_t(ti, uq[r], rbuq[r]) + cc;   // (cc > rr on a diagonal tile: a valid address of the next row, read and dropped)
+      acc[r] = s[idx[r]];
     }
-    acc = tile_mma<4>(acc, 0, 4,
-                      [&](int i, int k) { return -s[PK(R0 + i, c0 + k)]; },
-                      [&](int k, int j) { return s[PK(C0 + j, c0 + k)]; }, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = mma(-xi[q], xj[q], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = R0 + (lane >> 4) + 4 * r;
-      if (cc <= rr) s[PK(rr, cc)] = acc[r];
+      const int rr = 16 * ti + fq + 4 * r;
+      if (ti != tj || cc <= rr) s[idx[r]] = acc[r];
     }
   };
-  // Software pipeline over the 16-column steps: the trailing update of step jb first brings tile
-  // column jb+1 up to date (all wavefronts), then wavefront 0 factors diagonal block jb+1 WHILE
-  // wavefronts 1-3 finish the rest of the update -- the one-wavefront diagonal step (a fifth of
-  // this kernel) no longer idles the other three.
-  if (wave == 0) diag_factor(0);
-  __syncthreads();
-  for (int jb = 0; jb < 7; ++jb) {
-    const int c0 = 16 * jb;
-    // (b) panel rows below the diagonal block: solve x D^T = a, one row per thread
-    {
-      const int r = c0 + 16 + tid;
-      if (r < T) {
-        double x[16];
+
+  // Zeros above the diagonal.  The store phases below write whole 64-column half rows (value or zero), so
+  // what is left is the quadrant rows 0..63 x columns 64..127 of the factor tile and of L^-1: eight
+  // chunks of eight rows, one per step, by wavefronts 1-3 (fire-and-forget 16-byte stores where the
+  // addresses allow; all 130 KB of the first version at once kept them at the store queue for 4 us).
+  const bool wide_ok = ((((unsigned long long)A | (unsigned long long)dinv) & 15ull) == 0) && ((lda & 1) == 0);
+  auto zero_chunk = [&](int W, int c) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 z2 = {0.0, 0.0};
+    const int pr = lane & 31, sub = lane >> 5;  // column pair, row of the pair of rows
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = s[PK(r, c0 + k)];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          double v0 = x[k], v1 = 0.0;             // two partial sums: half the dependent FMA chain
-#pragma unroll
-          for (int m = 0; m + 1 < k; m += 2) {
-            v0 -= x[m] * s[PK(c0 + k, c0 + m)];
-            v1 -= x[m + 1] * s[PK(c0 + k, c0 + m + 1)];
-          }
-          if (k & 1) v0 -= x[k - 1] * s[PK(c0 + k, c0 + k - 1)];
-          x[k] = (v0 + v1) * rdiag[c0 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s[PK(r, c0 + k)] = x[k];
-      }
+    for (int it = 0; it < 2; ++it) {
+      if (it == 1 && W != 1) continue;          // rows 6, 7 of the chunk: wavefront 1 again
+      const int i = 8 * c + (it == 0 ? 2 * (W - 1) : 6) + sub;
+      double* const pa = A + (long)i * lda + 64 + 2 * pr;
+      double* const pd = dinv + i * 128 + 64 + 2 * pr;
+      if (wide_ok) { *(d2*)pa = z2; *(d2*)pd = z2; }
+      else { pa[0] = 0.0; pa[1] = 0.0; pd[0] = 0.0; pd[1] = 0.0; }
     }
-    __syncthreads();
-    // (c1) tile column jb+1
-    for (int ti = jb + 1 + wave; ti < 8; ti += 4) update_tile(jb, ti, jb + 1);
-    __syncthreads();
-    // (a) of step jb+1  ||  (c2) the tiles right of column jb+1
-    if (wave == 0) {
-      diag_factor(jb + 1);
-    } else {
-      const int m = 6 - jb;                       // tile rows/cols right of column jb+1
-      const int ntiles = m * (m + 1) / 2;
-      for (int e = wave - 1; e < ntiles; e += 3) {
-        int ti = 0, acc_t = 0;
-        while (acc_t + ti + 1 <= e) { acc_t += ti + 1; ++ti; }
-        update_tile(jb, jb + 2 + ti, jb + 2 + (e - acc_t));
+  };
+  double* const dump = dscr + 8 * 136 + lane;   // 64 spare slots: where a lane's store that must not happen goes
+  // byte addressing relative to s for the worker passes: element (16 t + u, c) of the packed triangle is at
+  // 8 rowbase16(u) + (128 u + 64) t + 8 (128 t^2 + c)  -- lane constants, one v_mad_u32_u24, a scalar
+  char* const sb = (char*)s;
+  const int dummy_off = (int)((char*)(dscr + 8 * 136 + 64) - sb);       // a 16x16 packed tile nobody reads
+  const int c1fr = 128 * fr + 64, rbfq = 8 * (rbfr + fq);               // row fr, column fq (+ 4 kk)
+  int c1q[4], rbq[4];                                                   // row fq + 4 r, column fr
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { c1q[r] = 128 * uq[r] + 64; rbq[r] = 8 * (rbuq[r] + fr); }
+  // One pass of a worker wavefront W = 1, 2, 3 (a compile-time constant: three straight-line copies, no
+  // branch inside, so that the scheduler can run the LDS traffic of one tile under the MFMAs of another
+  // -- with a guard per tile the stores of a tile waited for its four dependent MFMAs before the loads
+  // of the next were issued: 3.7 us for a pass whose 64 MFMAs take 1.7).  Tiles that do not exist in
+  // this pass (rows past the end) are computed on re-read data and stored to the spare slots.
+  v4d x[7];
+  auto worker_pass = [&](auto Wc, int jb) {
+    constexpr int W = decltype(Wc)::value;
+    auto block = [&](auto NXc, auto NTc) {
+      constexpr int NX = decltype(NXc)::value, NT = decltype(NTc)::value;   // X tiles, tile slots computed in this pass
+      // On this chip the f64 MFMA runs at the rate of the vector f64 FMA and a wavefront issues nothing
+      // else to the vector unit while one executes (64.5 cycles each; hand-pipelining LDS traffic and
+      // address arithmetic between the MFMAs changed nothing: 137 cycles per MFMA either way).  So the
+      // cost of a pass is 64 MFMAs PLUS every other vector instruction, and what is left to do is to
+      // have few of those: addresses as one v_mad_u32_u24 + one add from per-lane constants, tiles
+      // that do not exist in this pass (rows past the end) redirected by a SCALAR select to a 16x16
+      // dummy tile instead of per-store v_cndmask, X negated once per tile row instead of per MFMA.
+      // (1) X^T of the tile rows below jb; the X tiles of the previous step go to their place as
+      //     L[.][jb-1] first (x[u] is still tile row jb+u of step jb-1)
+      double dv[4];
+      dinv_operand(jb, dv);
+      if (jb > 0) {
+#pragma unroll
+        for (int u = 0; u < (NX == 7 ? 7 : NX + 1); ++u) {      // (the previous pass had one tile row more)
+          const int t = jb + u;
+          const bool mine = t < 8 && t % 3 == W - 1;                    // (scalar)
+          const int o = mine ? __mul24(c1fr, t) + 8 * (128 * t * t + 16 * (jb - 1)) : dummy_off;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *(double*)(sb + o + rbfq + 32 * q) = x[u][q];
+        }
       }
+      double bv[NX][4];                         // all operand loads first, then the MFMAs back to back
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int t = jb + 1 + u < 8 ? jb + 1 + u : 7;
+        const int o = __mul24(c1fr, t) + rbfq + 8 * (128 * t * t + 16 * jb);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bv[u][kk] = *(const double*)(sb + o + 32 * kk);
+      }
+      GH_SB();
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = mma(dv[kk], bv[u][kk], acc);
+        x[u] = acc;
+      }
+      v4d nx[7];
+#pragma unroll
+      for (int u = 1; u < 7; ++u) nx[u] = -x[u];
+      // (2) this wavefront's nine tile slots e = 3 n + W - 1 of the 27 below the diagonal tile
+      //     (tile (jb+1+ui, jb+1+uj), e = ui (ui + 1) / 2 - 1 + uj, ui = 1..6, uj <= ui)
+      //     Software-pipelined by hand, pinned by sched_barrier: the LDS reads of tile n+1 are issued before
+      //     the MFMAs of tile n (a read issued after them is waited for in full: ~150 cycles per tile),
+      //     the stores of tile n come after the MFMAs of tile n+1 have been issued (no s_nop 15 for the result).
+      v4d acc[NT];
+      int o[NT][4];
+#pragma unroll
+      for (int n = -1; n < NT + 1; ++n) {
+        if (n + 1 < NT) {                        // addresses and loads of tile n+1
+          const int e = 3 * (n + 1) + W - 1, ui = slot_ui(e), uj = slot_uj(e);
+          const bool exists = jb + 1 + ui < 8;
+          const int ti = jb + 1 + ui, tj = jb + 1 + uj;
+          const int so = exists ? 8 * (128 * ti * ti + 16 * tj) : dummy_off;   // (scalar)
+          const int tm = exists ? ti : 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[n + 1][r] = __mul24(c1q[r], tm) + rbq[r] + so;
+            acc[n + 1][r] = *(const double*)(sb + o[n + 1][r]);
+          }
+        }
+        GH_SB();
+        if (n >= 0 && n < NT) {                 // MFMAs of tile n
+          const int e = 3 * n + W - 1, ui = slot_ui(e), uj = slot_uj(e);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[n] = mma(nx[ui][q], x[uj][q], acc[n]);
+        }
+        GH_SB();
+        if (n >= 1) {                           // stores of tile n-1
+          const int e = 3 * (n - 1) + W - 1, ui = slot_ui(e), uj = slot_uj(e);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (ui == uj) *(double*)((fr <= uq[r]) ? sb + o[n - 1][r] : (char*)dump) = acc[n - 1][r];   // diagonal tile: lower part only
+            else *(double*)(sb + o[n - 1][r]) = acc[n - 1][r];
+          }
+        }
+        GH_SB();
+      }
+    };
+    // (the seven X tiles and nine slots of the first two passes; five and five from then on: rows jb+6.. are past the end)
+    if (jb >= 0) {
+      if (jb < 2) block(std::integral_constant<int, 7>(), std::integral_constant<int, 9>());
+      else block(std::integral_constant<int, 5>(), std::integral_constant<int, 5>());
+    }
+    zero_chunk(W, jb + 1);
+    return true;
+  };
+  // One barrier per 16-column step.  Pass jb = -1 is the first diagonal step alone; for jb >= 0, between
+  // two barriers:
+  //   wavefront 0:    X of tile row jb+1, diagonal tile jb+1, diagonal step jb+1 (-> D^-1 of jb+1)
+  //   wavefronts 1-3: store the X tiles of the PREVIOUS step (the final L[.][jb-1]: the tiles they
+  //                   replace were still being read by the others then), X^T of all tile rows below jb
+  //                   (recomputed by each wavefront: no exchange), their third of the tile updates.
+  // (The step loop is NOT unrolled -- unrolled, the masks and addresses of eight diagonal steps and 77
+  // tile updates are hoisted and live across the whole kernel, 334 VGPRs, and the code no longer fits
+  // the instruction cache.  x[u] is tile row jb+1+u.)
+  // ---------------------------------------------------------------- block -> packed LDS image
+  // Before (and, for wavefronts 1-3, beside) the first diagonal step -- NOT inside the step loop, whose
+  // invariant-code motion would compute the 59 load addresses ahead of it and keep them, in scratch.
+  // Wavefront 0: the first diagonal tile (lane i: row i) into its place in s; it then starts pass -1.
+  // Wavefronts 1-3: the rest of the lower triangle in 64-column half rows: (row i, columns 0..63) for
+  // i = 16..127, (row i, columns 64..127) for i = 64..127 -- 176 half rows, 59 per wavefront, ALL loads
+  // in flight before the first is waited for.  The column index is clamped to the diagonal (the
+  // surplus lanes re-read a cache line that is fetched anyway).
+  if (wave == 0) {
+    const int i = lane & 15;
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = A[(long)i * lda + (k < i ? k : i)];
+    if (info_in != 0) return false;             // uniform over the workgroup: an earlier block already failed
+#pragma unroll
+    for (int k = 15; k >= 0; --k) s[rowbase16(i) + (k < i ? k : i)] = t[k];
+  } else {
+    double v[59];
+#pragma unroll
+    for (int m = 0; m < 59; ++m) {
+      const int q = (wave - 1) + 3 * m;         // (scalar)
+      const int i = q < 112 ? 16 + q : (q < 176 ? q - 48 : 127), j = (q < 112 ? 0 : 64) + lane;
+      v[m] = *(const double*)((const char*)(A + (long)i * lda) + (unsigned)(j < i ? j : i) * 8u);
+    }
+    if (info_in != 0) return false;
+#pragma unroll
+    for (int m = 0; m < 59; ++m) {
+      const int q = (wave - 1) + 3 * m;
+      const int i = q < 112 ? 16 + q : (q < 176 ? q - 48 : 127), j = (q < 112 ? 0 : 64) + lane;
+      *((q < 176 && j <= i) ? &s[rowbase(i) + j] : dump) = v[m];
+    }
+  }
+#pragma unroll 1
+  for (int jb = -1; jb < 7; ++jb) {
+    GH_POTF2_STAMP(10 + 4 * (jb + 1));
+    if (wave == 0) {
+      if (jb >= 0) {
+        double dv[4];
+        dinv_operand(jb, dv);
+        const v4d x1 = xt_tile(jb + 1, jb, dv);
+        upd_tile(jb + 1, jb + 1, x1, x1);
+      }
+      GH_POTF2_STAMP(11 + 4 * (jb + 1));
+      diag_factor(jb + 1);
+      GH_POTF2_STAMP(12 + 4 * (jb + 1));
+    } else if (wave == 1) {
+      if (!worker_pass(std::integral_constant<int, 1>(), jb)) return false;
+    } else if (wave == 2) {
+      if (!worker_pass(std::integral_constant<int, 2>(), jb)) return false;
+    } else {
+      if (!worker_pass(std::integral_constant<int, 3>(), jb)) return false;
     }
     __syncthreads();
   }
-  if ((*fail_at_p) >= 0) {                             // (all threads see it: barrier above)
+  if (wave == 2) store_x(7, 6, x[0]);           // 1 + 7 % 3; step 6 left tile row 7 in x[0]
+  if (tid == 0) (*fail_at_p) = bad;
+  __syncthreads();
+  GH_POTF2_STAMP(2);
+  if ((*fail_at_p) >= 0) {
     if (tid == 0) *info = base + (*fail_at_p) + 1;
     return false;
   }
-  // factor back to HBM, strict upper triangle of the tile zeroed
-  for (int idx = tid; idx < T * T; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    A[(long)i * lda + j] = (j <= i) ? s[PK(i, j)] : 0.0;
+  // factor -> HBM: the half rows that hold part of the lower triangle, value or zero (no per-store
+  // predicate); nothing waits for these stores
+  {
+    // (a pointer the optimiser cannot relate to the one of the load phase: otherwise the 32 load
+    // addresses are kept for these stores across the whole step loop, in scratch)
+    double* Ast = A;
+    asm volatile("" : "+s"(Ast));
+    const int j = tid & 127, ih = wave >> 1;      // (ih scalar: the row addresses are SGPR arithmetic)
+#pragma unroll
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+      if (q0 < 32 && (wave & 1)) continue;
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = ih + 2 * (q0 + q);
+        v[q] = s[(ih + q0 + q) * (2 * (q0 + q) + 1) + (j < i ? j : i)];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = ih + 2 * (q0 + q);
+        Ast[(long)i * lda + j] = (j <= i) ? v[q] : 0.0;
+      }
+    }
   }
+  __syncthreads();                                // every thread has the factor in registers: s is free
+  GH_POTF2_STAMP(3);
 
   // ================================================================ phase 2: L^-1, in place in LDS
-  // (the factor is already in HBM; `s` is free to become L^-1, `inv16` is the scratch for C A^-1)
-  // (a) the eight 16x16 diagonal inverses; wavefront w takes blocks 2w and 2w+1.
-  //     Registers again: lane r (mod 16) holds ROW r of the block (a[]) and COLUMN r of its
-  //     inverse (x[]); x_i = -(sum_{k<i} L_ik x_k) / L_ii with L_ik broadcast from lane i.
-  __syncthreads();                                // (the write-back above still reads s)
-  for (int bb = 0; bb < 2; ++bb) {
-    const int bI = 2 * wave + bb, d0 = 16 * bI;
-    const int c = lane & 15;
-    double a[16], x[16];
+  // (a) the eight 16x16 diagonal inverses exist already: into the diagonal tiles of s
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = (k <= c) ? s[PK(d0 + c, d0 + k)] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const double rd = rdiag[d0 + i];
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < i; ++k) acc += bcast_lane(a[k], i) * x[k];      // x[k] = 0 for k < c
-      x[i] = (i < c) ? 0.0 : ((i == c) ? rd : -acc * rd);
-    }
-    if (lane < 16) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (i >= c) s[PK(d0 + i, d0 + c)] = x[i];
-    }
+  for (int e = tid; e < 8 * 256; e += 256) {
+    const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    if (c <= r) s[rowbase_t(b, r, rowbase16(r)) + 16 * b + c] = dscr[136 * b + rowbase16(r) + c];
   }
   __syncthreads();
+  GH_POTF2_STAMP(4);
   // (b) doubling: blocks of size sz = 16, 32, 64.  Pair p: P0 = 2 p sz,
   //     A^-1 = s[P0 : P0+sz, P0 : P0+sz], B^-1 = s[P0+sz : P0+2sz, P0+sz : P0+2sz] (both lower
   //     triangular, already inverted), C = L[P0+sz : P0+2sz, P0 : P0+sz] (still the factor)
-  //     ->  C is overwritten by  X = -B^-1 (C A^-1).  Columns go in chunks of <= 32 (the scratch
-  //     holds 64 x 32 doubles), left to right: chunk c of T = C A^-1 needs the columns >= c of C
-  //     only (A^-1 is lower triangular), so overwriting the chunks already done is safe.
-  //     Operands of the first version came from HBM (`dinv`): 20 % of the kernel.
-  auto tri = [&](int r, int c) { return s[PK(r > c ? r : c, r > c ? c : r)]; };   // (valid address for any r, c)
-  double* scr = inv16;
-  for (int sz = 16; sz <= 64; sz *= 2) {
-    const int tps = sz / 16;                      // tiles per side of a block
-    const int cw = sz < CWMAX ? sz : CWMAX, tpc = cw / 16;   // chunk width, tile columns per chunk
-    const int npair = 64 / sz;
-    for (int c0 = 0; c0 < sz; c0 += cw) {
-      const int njobs = npair * tps * tpc;
-      // T[:, chunk] = C A^-1[:, chunk]   (k >= column: A^-1 lower triangular)
-      for (int e = wave; e < njobs; e += 4) {
-        const int p = e / (tps * tpc), rem = e % (tps * tpc), ti = rem / tpc, tj = rem % tpc;
-        const int P0 = 2 * p * sz, col = c0 + 16 * tj;          // column offset inside the block
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = tile_mma<16>(acc, col / 4, sz / 4,
-                           [&](int i, int k) { return s[PK(P0 + sz + 16 * ti + i, P0 + k)]; },
-                           [&](int k, int j) { const double v = tri(P0 + k, P0 + col + j); return k >= col + j ? v : 0.0; }, lane);
+  //     ->  C is overwritten by  X = -B^-1 (C A^-1).  Job = (pair, 16-column tile column tj): always
+  //     four jobs, one per wavefront.  T(:, tj) = C A^-1(:, tj) lands in MFMA result registers
+  //     T(fq + 4 r + 16 kt, fr), which IS the B operand of the second product with k = fq + 4 r.
+  //     One barrier between the last read of C and its overwriting, one after.
+  // (one instantiation per level: with the level a loop variable, the trip counts of the inner loops become
+  //  constants only after the outer loop has been unrolled, too late for the register promotion of the
+  //  operand buffers -- they stay in scratch memory)
+  auto level = [&](auto LVc) {
+    constexpr int lv = decltype(LVc)::value;
+    constexpr int sz = 16 << lv, tps = 1 << lv;   // tiles per side of a block
+    const int p = wave / tps, tj = wave % tps;
+    const int P0 = 2 * p * sz, Q0 = P0 + sz;
+    v4d T[4], X[4];
+    // B operands of the first product: A^-1(16 kt + u, 16 tj + fr), u = 4 kk + fq, for EVERY kt (zero
+    // above the diagonal -- tiles kt < tj whole; no wave-dependent branch: the level is one basic block
+    // and the loads of one product run under the MFMAs of another)
+    double bop[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          scr[(p * sz + 16 * ti + (lane >> 4) + 4 * r) * cw + 16 * tj + (lane & 15)] = acc[r];
-      }
-      __syncthreads();
-      // X[:, chunk] = -B^-1 T[:, chunk]   (k <= row: B^-1 lower triangular)
-      for (int e = wave; e < njobs; e += 4) {
-        const int p = e / (tps * tpc), rem = e % (tps * tpc), ti = rem / tpc, tj = rem % tpc;
-        const int P0 = 2 * p * sz;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = tile_mma<16>(acc, 0, 4 * (ti + 1),
-                           [&](int i, int k) { const double v = tri(P0 + sz + 16 * ti + i, P0 + sz + k); return k <= 16 * ti + i ? -v : 0.0; },
-                           [&](int k, int j) { return scr[(p * sz + k) * cw + 16 * tj + j]; }, lane);
+    for (int kt = 0; kt < tps; ++kt) {
+      const bool lower = kt > tj, ondiag = kt == tj;              // (scalar)
+      const int tt = (P0 >> 4) + (lower ? kt : tj);               // a stored tile row whatever kt is
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          s[PK(P0 + sz + 16 * ti + (lane >> 4) + 4 * r, P0 + c0 + 16 * tj + (lane & 15))] = acc[r];
+      for (int kk = 0; kk < 4; ++kk) {
+        const int u = 4 * kk + fq;
+        const int uu = lower ? u : (u > fr ? u : fr), cc = lower ? fr : (u > fr ? fr : u);
+        const double b = s[rowbase_t(tt, uu, rowbase16(uu)) + P0 + 16 * tj + cc];
+        bop[kt][kk] = (lower || (ondiag && u >= fr)) ? b : 0.0;
       }
-      __syncthreads();
+    }
+    // The operands of tile row ti+1 are loaded BEFORE the MFMAs of tile row ti are issued (sched_barrier
+    // pins that): a load issued after them is waited for in full, once per tile.
+    // (flat double-buffers indexed by constants after unrolling: a sub-array passed by reference to a
+    //  lambda is not scalarised and ends up in scratch memory)
+    double av[32];
+    auto load_c = [&](int ti, int slot) {                        // C(16 ti + fr, 16 kt + 4 kk + fq)
+      const int ra = rowbase_t((Q0 >> 4) + ti, fr, rbfr) + P0 + fq;
+#pragma unroll
+      for (int kt = 0; kt < tps; ++kt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) av[16 * slot + 4 * kt + kk] = s[ra + 16 * kt + 4 * kk];
+    };
+    load_c(0, 0);
+#pragma unroll
+    for (int ti = 0; ti < tps; ++ti) {
+      if (ti + 1 < tps) load_c(ti + 1, (ti + 1) & 1);
+      GH_SB();
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < tps; ++kt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = mma(av[16 * (ti & 1) + 4 * kt + kk], bop[kt][kk], acc);
+      T[ti] = -acc;                                              // (the sign of X = -B^-1 T)
+      GH_SB();
+    }
+    // second product: A operand B^-1(16 ti + fr, 16 kt + fq + 4 r), zero above the diagonal
+    double bi[32];
+    auto load_b = [&](int ti, int slot) {
+      const int rbq = rowbase_t((Q0 >> 4) + ti, fr, rbfr) + Q0;
+#pragma unroll
+      for (int kt = 0; kt < tps; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt < ti) {
+            bi[16 * slot + 4 * kt + r] = s[rbq + 16 * kt + uq[r]];
+          } else if (kt == ti) {
+            const double b = s[rbq + 16 * kt + (uq[r] < fr ? uq[r] : fr)];
+            bi[16 * slot + 4 * kt + r] = (uq[r] <= fr) ? b : 0.0;
+          }
+        }
+    };
+    load_b(0, 0);
+#pragma unroll
+    for (int ti = 0; ti < tps; ++ti) {
+      if (ti + 1 < tps) load_b(ti + 1, (ti + 1) & 1);
+      GH_SB();
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt <= ti; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mma(bi[16 * (ti & 1) + 4 * kt + r], T[kt][r], acc);
+      X[ti] = acc;
+      GH_SB();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < tps; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        s[rowbase_t((Q0 >> 4) + ti, uq[r], rbuq[r]) + P0 + 16 * tj + fr] = X[ti][r];
+    }
+    __syncthreads();
+  };
+  level(std::integral_constant<int, 0>());
+  level(std::integral_constant<int, 1>());
+  level(std::integral_constant<int, 2>());
+  GH_POTF2_STAMP(5);
+  // (c) L^-1 to HBM, likewise
+  {
+    const int j = tid & 127, ih = wave >> 1;      // (ih scalar: the row addresses are SGPR arithmetic)
+#pragma unroll
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+      if (q0 < 32 && (wave & 1)) continue;
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = ih + 2 * (q0 + q);
+        v[q] = s[(ih + q0 + q) * (2 * (q0 + q) + 1) + (j < i ? j : i)];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = ih + 2 * (q0 + q);
+        dinv[i * 128 + j] = (j <= i) ? v[q] : 0.0;
+      }
     }
   }
-  // (c) L^-1 to HBM, zeros above the diagonal
-  for (int idx = tid; idx < T * T; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    dinv[idx] = (j <= i) ? s[PK(i, j)] : 0.0;
-  }
+  GH_POTF2_STAMP(6);
   return true;
 }
-#undef PK
-#undef T
-#undef IP
+#undef GH_SB
 }  // namespace gh_potf2
 #endif
