@@ -722,6 +722,97 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_dma64(GemmDev g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K = 128, whole K resident: the two GEMMs of every link of the panel chain (rows <- rows L_jj^-T,
+// in place, and the update of the panel's other columns) have K = 128 and a grid far below the chip.
+// In gemm_f64_mfma_dma64 they took 16-18 us for 3.4-6.9 us of MFMA: eight K steps, each of them
+// waiting for a DMA that was issued one step earlier (~1.5 us of L2 latency per step).  Here all eight
+// 16-deep K chunks of both operands are requested AT ONCE into eight LDS buffers (64..144 KB of the
+// CU's 160 KB) and chunk c is waited for by count: s_waitcnt vmcnt((7 - c) * IPC), one barrier, its
+// MFMAs -- one memory latency for the whole tile instead of eight.
+// Tile (16 MI WM) x (16 NJ WN), WM x WN = 4 wavefronts of (16 MI) x (16 NJ); k-major operands, same
+// DMA + swizzle scheme as above.  <2,2,2,2>: 64 x 64;  <1,4,1,2>: 16 x 128 for the in-place call
+// (a workgroup owns whole rows, see above).
+template <int WM, int WN, int MI, int NJ>
+__global__ __launch_bounds__(256) void gemm_f64_mfma_k128(GemmDev g) {
+  constexpr int TR = 16 * MI * WM, TC = 16 * NJ * WN;
+  constexpr int IA = (TR / 8 + 3) / 4, IB = (TC / 8 + 3) / 4, IPC = IA + IB;   // DMA instructions per chunk per wavefront
+  __shared__ __attribute__((aligned(1024))) double sA[8][TR * BK];
+  __shared__ __attribute__((aligned(1024))) double sB[8][TC * BK];
+  const int tm = (int)(blockIdx.x / g.tiles_n), tn = (int)(blockIdx.x % g.tiles_n);
+  if (g.lower && (long)tn * TC > (long)tm * TR + TR - 1) return;         // (uniform) tile strictly above the diagonal
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  const long row0 = (long)tm * TR, col0 = (long)tn * TC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fk = lane >> 4;
+  double* cbase = g.C + (row0 + wm * 16 * MI + fk) * g.ldc + col0 + wn * 16 * NJ + fr;
+  v4d acc[MI][NJ];
+  if (g.preload) {                              // (before the DMAs: older in the vmcnt order)
+    const double rho = (g.beta == g.alpha) ? 1.0 : -1.0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j][r] = rho * cbase[(long)(i * 16 + 4 * r) * g.ldc + j * 16];
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  // every wavefront issues IA + IB instructions per chunk (a tile with fewer 8-row groups than
+  // wavefronts has some moved twice: the counts must agree for the vmcnt arithmetic)
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) {
+#pragma unroll
+    for (int q = 0; q < IA; ++q) {
+      const int idx = (wave + 4 * q) % (TR / 8), r = idx * 8 + (lane >> 3);
+      const double* ga = g.A + (row0 + r) * g.lda + kc * BK + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+      __builtin_amdgcn_global_load_lds((gh_glb_void*)ga, (gh_lds_void*)(sA[kc] + idx * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < IB; ++q) {
+      const int idx = (wave + 4 * q) % (TC / 8), r = idx * 8 + (lane >> 3);
+      const double* gb = g.B + (col0 + r) * g.ldb + kc * BK + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+      __builtin_amdgcn_global_load_lds((gh_glb_void*)gb, (gh_lds_void*)(sB[kc] + idx * 128), 16, 0, 0);
+    }
+  }
+  const int sw = (fr >> 1) & 7;
+  int offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+  const int rowA = (wm * 16 * MI + fr) * BK, rowB = (wn * 16 * NJ + fr) * BK;
+#define GH_K128_CHUNK(kc)                                                                              \
+  do {                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((7 - (kc)) * IPC) : "memory");                            \
+    __syncthreads();                                                                                   \
+    double a[4][MI], b[4][NJ];                                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                 \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) a[kk][i] = sA[kc][rowA + i * 16 * BK + offk[kk]]; \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) b[kk][j] = sB[kc][rowB + j * 16 * BK + offk[kk]]; \
+    }                                                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                   \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                 \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);    \
+  } while (0)
+  GH_K128_CHUNK(0); GH_K128_CHUNK(1); GH_K128_CHUNK(2); GH_K128_CHUNK(3);
+  GH_K128_CHUNK(4); GH_K128_CHUNK(5); GH_K128_CHUNK(6); GH_K128_CHUNK(7);
+#undef GH_K128_CHUNK
+  const double alpha = g.alpha, beta = g.preload ? 0.0 : g.beta;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        double* c = cbase + (long)(i * 16 + 4 * r) * g.ldc + j * 16;
+        *c = (beta == 0.0) ? alpha * acc[i][j][r] : fma(beta, *c, alpha * acc[i][j][r]);
+      }
+}
+
 // Plain-VALU kernel with identical semantics: validation arm for the MFMA lane maps
 // (GEORGE_AMD_NO_MFMA=1) -- each thread owns an 8x8 micro-tile of the 128x128 C tile.
 template <bool A_KM, bool B_KM>
@@ -817,7 +908,34 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     else         hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, false>), grid, block, 0, st, g);         \
   } while (0)
   static const bool no_small = getenv("GEORGE_AMD_GEMM_NO_SMALL") != nullptr;
+  static const bool no_k128 = getenv("GEORGE_AMD_GEMM_NO_K128") != nullptr;       // A/B: the K-loop kernels for K = 128 too
   const bool inplace = (const double*)h.C == h.A || (const double*)h.C == h.B;
+  if (dma && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small && !no_k128 &&
+      (!inplace || ((const double*)h.C == h.A && (const double*)h.C != h.B && h.N == 128 && !h.lower))) {
+    GemmDev q = g;
+    if (inplace) {                      // whole rows per workgroup: 16 x 128 tiles
+      q.tiles_m = (int)(h.M / 16); q.tiles_n = 1;
+      q.nblk = q.tiles_m;
+      hipLaunchKernelGGL((gemm_f64_mfma_k128<1, 4, 1, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
+    } else {                            // 64 x 64 or 32 x 32 tiles (of a lower-triangular C: those that touch the triangle)
+      static const int tile = [] { const char* e = getenv("GEORGE_AMD_K128_TILE"); return e ? atoi(e) : 64; }();
+      if (tile == 32) {
+        q.tiles_m = (int)(h.M / 32); q.tiles_n = (int)(h.N / 32);
+        q.nblk = (long)q.tiles_m * q.tiles_n;
+        hipLaunchKernelGGL((gemm_f64_mfma_k128<2, 2, 1, 1>), dim3((unsigned)q.nblk), block, 0, st, q);
+      } else if (tile == 6432) {
+        q.tiles_m = (int)(h.M / 64); q.tiles_n = (int)(h.N / 32);
+        q.nblk = (long)q.tiles_m * q.tiles_n;
+        hipLaunchKernelGGL((gemm_f64_mfma_k128<4, 1, 1, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
+      } else {
+        q.tiles_m = (int)(h.M / 64); q.tiles_n = (int)(h.N / 64);
+        q.nblk = (long)q.tiles_m * q.tiles_n;
+        hipLaunchKernelGGL((gemm_f64_mfma_k128<2, 2, 2, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
+      }
+    }
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
   if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small &&
       (!inplace || (h.N == 128 && !h.lower))) {
     // sub-chip launch: 64-row tiles, 2-4x the workgroups (see gemm_f64_mfma_dma64)
