@@ -177,7 +177,7 @@ def hodlr_level_ranks(ranks):
     return out
 
 
-def hodlr_report(n, local_rank, steps=5, warmup=1, cpu_n=32768):
+def hodlr_report(n, local_rank, steps=10, warmup=3, cpu_n=32768):
     """BASELINE config C4 for the N = 1 line: time, per-level ranks, footprint roofline, CPU sample."""
     job = HodlrJob(n, local_rank)
     elapsed, ll = run_timed(job, steps, warmup, lambda: None)
@@ -473,11 +473,11 @@ def main():
                 out["public_api"] = public_api_report(args.n, local_rank)
                 if args.n != 16384:
                     j2 = DenseJob(16384, args.nb, local_rank, profile=False)
-                    e2, ll2 = run_timed(j2, 3, 1, lambda: None)
+                    e2, ll2 = run_timed(j2, 5, 2, lambda: None)
                     j2.close()
                     out["config"]["also_configs1_N16384"] = {
-                        "seconds_per_step": e2 / 3, "value_tflops": flops_alg(16384) / (e2 / 3) * 1e-12,
-                        "frac_of_fp64_mfma_peak": flops_alg(16384) / (e2 / 3) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
+                        "seconds_per_step": e2 / 5, "value_tflops": flops_alg(16384) / (e2 / 5) * 1e-12,
+                        "frac_of_fp64_mfma_peak": flops_alg(16384) / (e2 / 5) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
                         "log_likelihood": ll2}
                     g2 = golden_ll(16384)
                     if g2 is not None:

@@ -728,8 +728,12 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_dma64(GemmDev g) {
 // In gemm_f64_mfma_dma64 they took 16-18 us for 3.4-6.9 us of MFMA: eight K steps, each of them
 // waiting for a DMA that was issued one step earlier (~1.5 us of L2 latency per step).  Here all eight
 // 16-deep K chunks of both operands are requested AT ONCE into eight LDS buffers (64..144 KB of the
-// CU's 160 KB) and chunk c is waited for by count: s_waitcnt vmcnt((7 - c) * IPC), one barrier, its
-// MFMAs -- one memory latency for the whole tile instead of eight.
+// CU's 160 KB): one memory latency for the whole tile instead of eight.  (The code waits for chunk c
+// by count, s_waitcnt vmcnt((7 - c) * IPC); as compiled, hipcc's LDS-DMA tracking puts a vmcnt(0) in
+// front of the first barrier, so the MFMAs start when the last chunk has landed -- reading the
+// fragments through inline asm would lift that, for ~1 us per launch.  C requested behind the DMAs and
+// added in the epilogue instead of starting the accumulators from it: measured, no gain, and the
+// sums are then no longer bit-identical to the other GEMM kernels'.)
 // Tile (16 MI WM) x (16 NJ WN), WM x WN = 4 wavefronts of (16 MI) x (16 NJ); k-major operands, same
 // DMA + swizzle scheme as above.  <2,2,2,2>: 64 x 64;  <1,4,1,2>: 16 x 128 for the in-place call
 // (a workgroup owns whole rows, see above).
