@@ -149,3 +149,29 @@ def test_potrf_reports_failing_pivot():
     N.check(N.lib.gh_dev_potrf_block(a.data_ptr(), n, n, dinv.data_ptr(), info.data_ptr(), 1000, None))
     torch.cuda.synchronize()
     assert int(info.item()) == 1000 + 201          # LAPACK dpotrf-style 1-based index
+
+
+@pytest.mark.parametrize("p", [0, 5, 15, 16, 31, 100, 127, 128, 143, 255])
+@pytest.mark.parametrize("bad", ["negative", "nan"])
+def test_potrf_failing_pivot_index_matches_lapack(p, bad):
+    """The second 128x128 kernel has no pivot test inside its column steps: a bad pivot poisons what
+    follows and the first non-positive diagonal entry of the stored 16x16 block is looked for afterwards
+    (gh_potf2_body.h).  The index it reports must still be LAPACK's, wherever the pivot sits in a
+    16-column step, a 128-block or the panel."""
+    import torch
+    from scipy.linalg import lapack
+    from george_amd import _native as N
+    rng = np.random.RandomState(3)
+    n = 256
+    G = rng.randn(n, n)
+    A = G @ G.T + n * np.eye(n)
+    A[p, p] = -1.0e6 if bad == "negative" else np.nan
+    _, info_ref = lapack.dpotrf(A, lower=1)
+    if bad == "negative":
+        assert info_ref == p + 1
+    a = _dev(A)
+    dinv = _dev(np.zeros((2, 128, 128)))
+    info = torch.zeros(1, dtype=torch.int64, device="cuda")
+    N.check(N.lib.gh_dev_potrf_block(a.data_ptr(), n, n, dinv.data_ptr(), info.data_ptr(), 0, None))
+    torch.cuda.synchronize()
+    assert int(info.item()) == p + 1

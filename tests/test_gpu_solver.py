@@ -534,3 +534,24 @@ def test_full_size_c5_properties():
         p = p0.copy(); p[i] -= eps; gp.set_parameter_vector(p); fm = gp.log_likelihood(y)
         assert abs((fp - fm) / (2 * eps) - g[i]) <= 1e-5 * max(1.0, abs(g[i])), (i, (fp - fm) / (2 * eps), g[i])
     gp.set_parameter_vector(p0)
+
+
+def test_first_potf2_form_agrees():
+    """GEORGE_AMD_POTF2=v1 selects the first MFMA form of the 128x128 Cholesky + inverse kernel (82 us
+    against 33): same factorisation to rounding, on repeated computes with one handle too."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "for n in (1000, 4096, 9000):\n"
+            "    job = bench.DenseJob(n, 0, 0, profile=False)\n"
+            "    print(' '.join(repr(float(job.step())) for _ in range(2)))\n"
+            "    job.close()\n") % root
+    outs = []
+    for env in ({}, {"GEORGE_AMD_POTF2": "v1"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-3:]])
+    for a, b in zip(outs[0], outs[1]):
+        assert a[0] == a[1] and b[0] == b[1]                              # each arm repeatable
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0])
