@@ -19,6 +19,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include "gh_common.h"
 
 #define T 128                 // tile edge
@@ -470,6 +471,7 @@ struct gh_chol {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;             // high-priority panel stream (look-ahead)
   hipStream_t st3 = nullptr;             // second panel stream: rows-below TRSM beside the potf2 chain
+  bool shared_streams = false;           // st, st2, st3, st4, st_mask belong to the process (gh_shared_streams): not destroyed here
   hipStream_t st4 = nullptr;             // third panel stream: in-panel rows >= j+2 (everything off the potf2 chain)
   hipEvent_t ev_diag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_p1[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -518,18 +520,58 @@ struct gh_chol {
     for (auto& e : ev_diag) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_p1) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_b) if (e) (void)hipEventDestroy(e);
-    if (st4) (void)hipStreamDestroy(st4);
-    if (st3) (void)hipStreamDestroy(st3);
-    if (st_mask) (void)hipStreamDestroy(st_mask);
+    if (st4 && !shared_streams) (void)hipStreamDestroy(st4);
+    if (st3 && !shared_streams) (void)hipStreamDestroy(st3);
+    if (st_mask && !shared_streams) (void)hipStreamDestroy(st_mask);
     if (st_crit) (void)hipStreamDestroy(st_crit);
     if (st_sa) (void)hipStreamDestroy(st_sa);
     if (st_sb) (void)hipStreamDestroy(st_sb);
 
 
-    if (st2) (void)hipStreamDestroy(st2);
-    if (st) (void)hipStreamDestroy(st);
+    if (st2 && !shared_streams) (void)hipStreamDestroy(st2);
+    if (st && !shared_streams) (void)hipStreamDestroy(st);
   }
 };
+
+// ---- the process-wide streams (see gh_common.h)
+#include <map>
+#include <mutex>
+namespace {
+struct SharedStreams { hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr}; bool made = false; std::map<int, hipStream_t> masked; };
+std::mutex g_ss_mu;
+std::map<int, SharedStreams> g_ss;
+}
+bool gh_shared_streams(int device, hipStream_t q[4]) {
+  std::lock_guard<std::mutex> lk(g_ss_mu);
+  SharedStreams& ss = g_ss[device];
+  if (!ss.made) {
+    ss.made = true;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipStreamCreate(&ss.q[0]) != hipSuccess) { ss.q[0] = nullptr; (void)hipGetLastError(); }
+    int lo = 0, hi = 0;                    // numerically lowest value = highest priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int i = 1; i < 4 && ss.q[0]; ++i)
+      if (hipStreamCreateWithPriority(&ss.q[i], hipStreamNonBlocking, hi) != hipSuccess) { ss.q[i] = nullptr; (void)hipGetLastError(); break; }
+  }
+  for (int i = 0; i < 4; ++i) q[i] = ss.q[i];
+  return ss.q[0] != nullptr;
+}
+hipStream_t gh_shared_masked_stream(int device, int reserve_cus) {
+  std::lock_guard<std::mutex> lk(g_ss_mu);
+  SharedStreams& ss = g_ss[device];
+  auto it = ss.masked.find(reserve_cus);
+  if (it != ss.masked.end()) return it->second;
+  hipStream_t st = nullptr;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 2 * reserve_cus) {
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0u);
+    for (int c = reserve_cus; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+    if (hipExtStreamCreateWithCUMask(&st, words, mask.data()) != hipSuccess) { st = nullptr; (void)hipGetLastError(); }
+  }
+  ss.masked[reserve_cus] = st;             // (a failed creation is not retried)
+  return st;
+}
 
 static int set_device(gh_chol* s) {
   if (gh_device_count() <= 0) { gh_set_error("no HIP device available: the george_amd solver needs an MI355X"); return GH_ERR_HIP; }
@@ -547,29 +589,63 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   if (s->opts.nb % T) { delete s; gh_set_error("nb must be a multiple of 128"); return GH_ERR_BAD_ARG; }
   int rc = set_device(s);
   if (rc != GH_OK) { delete s; return rc; }
-  if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  static const bool private_streams = getenv("GEORGE_AMD_PRIVATE_STREAMS") != nullptr;
+  hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (!private_streams && gh_shared_streams(s->opts.device, shq)) {
+    s->shared_streams = true;
+    s->st = shq[0];
+  } else if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
   if (s->opts.lookahead) {
     int lo = 0, hi = 0;                    // numerically lowest value = highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi) != hipSuccess) { s->st2 = nullptr; (void)hipGetLastError(); }
+    if (s->shared_streams) s->st2 = shq[1];
+    else if (hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi) != hipSuccess) { s->st2 = nullptr; (void)hipGetLastError(); }
     for (auto& e : s->ev_sync)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete s; gh_set_error("hipEventCreate failed"); return GH_ERR_HIP; }
     if (s->st2) {
-      bool ok = hipStreamCreateWithPriority(&s->st3, hipStreamNonBlocking, hi) == hipSuccess &&
+      if (s->shared_streams) s->st3 = shq[2];
+      bool ok = (s->shared_streams ? s->st3 != nullptr : hipStreamCreateWithPriority(&s->st3, hipStreamNonBlocking, hi) == hipSuccess) &&
                 hipEventCreateWithFlags(&s->ev_aux, hipEventDisableTiming) == hipSuccess;
       for (auto& e : s->ev_diag) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-      if (!ok) { (void)hipGetLastError(); if (s->st3) (void)hipStreamDestroy(s->st3); s->st3 = nullptr; }
+      if (!ok) { (void)hipGetLastError(); if (s->st3 && !s->shared_streams) (void)hipStreamDestroy(s->st3); s->st3 = nullptr; }
       if (s->st3) {
-        bool ok4 = hipStreamCreateWithPriority(&s->st4, hipStreamNonBlocking, hi) == hipSuccess &&
+        if (s->shared_streams) s->st4 = shq[3];
+        bool ok4 = (s->shared_streams ? s->st4 != nullptr : hipStreamCreateWithPriority(&s->st4, hipStreamNonBlocking, hi) == hipSuccess) &&
                    hipEventCreateWithFlags(&s->ev_aux2, hipEventDisableTiming) == hipSuccess;
         for (auto& e : s->ev_p1) ok4 = ok4 && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto& e : s->ev_b) ok4 = ok4 && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        if (!ok4) { (void)hipGetLastError(); if (s->st4) (void)hipStreamDestroy(s->st4); s->st4 = nullptr; }
+        if (!ok4) { (void)hipGetLastError(); if (s->st4 && !s->shared_streams) (void)hipStreamDestroy(s->st4); s->st4 = nullptr; }
       }
     }
   }
   if (hipMalloc((void**)&s->d_info, sizeof(long long)) != hipSuccess) { delete s; gh_set_error("hipMalloc failed"); return GH_ERR_HIP; }
   *out = s;
+  return GH_OK;
+}
+// Which of the handle's streams really run side by side?  HIP maps streams onto a few hardware queues
+// and two streams on one queue serialise.  out[i * 6 + j] (i < j) = milliseconds for a 300-us spin
+// kernel on stream i and one on stream j launched together (0.3 = concurrent, 0.6 = one queue);
+// streams: 0 the caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked trailing.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+extern "C" int gh_debug_stream_overlap(gh_chol* s, double* out, int n) {
+  if (!s || !out || n < 36) { gh_set_error("bad argument"); return GH_ERR_BAD_ARG; }
+  int rc = set_device(s);
+  if (rc != GH_OK) return rc;
+  hipStream_t q[6] = {nullptr, s->st, s->st2, s->st3, s->st4, s->st_mask};
+  for (int i = 0; i < 36; ++i) out[i] = 0.0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i + 1; j < 6; ++j) {
+      if ((i > 0 && !q[i]) || !q[j]) { out[i * 6 + j] = -1.0; continue; }
+      GH_HIP(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, q[i], 30000LL);
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, q[j], 30000LL);
+      GH_HIP(hipDeviceSynchronize());
+      out[i * 6 + j] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
   return GH_OK;
 }
 extern "C" void gh_chol_destroy(gh_chol* s) {
@@ -842,13 +918,13 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEve
 // short) costs the SYRK 12 %, the same as leaving out 32 (every engine one short), so 32 it is:
 // 12.5 % of the chip, about the panel's share of the flops at N = 16384 (9 %).  Larger matrices
 // hide the chain behind the SYRK anyway and keep all 256 CUs.  The masked stream takes ~1 s to
-// create (ROCm 7.2), once per handle.  GEORGE_AMD_RESERVE_CUS=0 disables, =<n> forces n CUs.
+// create (ROCm 7.2): once per process (gh_shared_masked_stream).  GEORGE_AMD_RESERVE_CUS=0 disables, =<n> forces n CUs.
 static hipStream_t trailing_stream(gh_chol* s) {
   int want = s->np < 24576 ? 32 : 0;
   if (const char* e = getenv("GEORGE_AMD_RESERVE_CUS")) want = atoi(e);
   if (want <= 0 || want >= 128) return s->st;
   if (s->mask_reserved != want) {
-    if (s->st_mask) { (void)hipStreamSynchronize(s->st_mask); (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr; }
+    if (s->st_mask) { (void)hipStreamSynchronize(s->st_mask); if (!s->shared_streams) (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr; }
     if (s->st_crit) { (void)hipStreamSynchronize(s->st_crit); (void)hipStreamDestroy(s->st_crit); s->st_crit = nullptr; }
     if (s->st_sa) { (void)hipStreamSynchronize(s->st_sa); (void)hipStreamDestroy(s->st_sa); s->st_sa = nullptr; }
     if (s->st_sb) { (void)hipStreamSynchronize(s->st_sb); (void)hipStreamDestroy(s->st_sb); s->st_sb = nullptr; }
@@ -858,7 +934,8 @@ static hipStream_t trailing_stream(gh_chol* s) {
       const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
       std::vector<uint32_t> mask(words, 0u);
       for (int c = want; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-      if (hipExtStreamCreateWithCUMask(&s->st_mask, words, mask.data()) != hipSuccess) { s->st_mask = nullptr; (void)hipGetLastError(); }
+      if (s->shared_streams) s->st_mask = gh_shared_masked_stream(s->opts.device, want);
+      else if (hipExtStreamCreateWithCUMask(&s->st_mask, words, mask.data()) != hipSuccess) { s->st_mask = nullptr; (void)hipGetLastError(); }
       // Exclusive mode (GEORGE_AMD_PANEL_EXCLUSIVE): the potf2 chain gets the reserved CUs to ITSELF
       // (a stream masked to exactly those), and the rows-below TRSM -- throughput work -- joins the
       // trailing update on the others; without it the high-priority panel streams are unmasked and
@@ -878,7 +955,7 @@ static hipStream_t trailing_stream(gh_chol* s) {
       }
     }
     if (s->st_mask && !s->ev_xfer && hipEventCreateWithFlags(&s->ev_xfer, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError(); (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr;
+      (void)hipGetLastError(); if (!s->shared_streams) (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr;
     }
   }
   return s->st_mask ? s->st_mask : s->st;
@@ -964,7 +1041,12 @@ static int factor_lookahead(gh_chol* s) {
 // larger of the two per step; with d > 1 the chain runs up to d panels ahead during the SYRK-bound
 // early steps and spends that lead in the chain-bound late ones.
 static int factor_lookahead_deep(gh_chol* s, int depth) {
-  hipStream_t sm = trailing_stream(s), sn = s->st4;
+  // depth 1 (the default): the only work of the "near" stream is the rows below the diagonal block of
+  // U(j, j+1), and the first thing that needs them is the rows-below TRSM of panel j+1 on st3 -- so it
+  // goes to st3 itself: one hardware queue less.  (The process degrades by 20-40 % at N <= 16384 once
+  // eight queues are in use -- null stream + this handle's + the application's; scripts/dev/queue_pattern.py.)
+  static const bool own_near = getenv("GEORGE_AMD_NEAR_STREAM") != nullptr;        // A/B: the fourth stream also at depth 1
+  hipStream_t sm = trailing_stream(s), sn = (depth == 1 && !own_near && s->st3) ? s->st3 : s->st4;
   // the potf2 chain on CUs of its own where the trailing update leaves some out (small matrices)
   hipStream_t sp = (sm != s->st && s->st_crit) ? s->st_crit : s->st2;
   double* A = s->A.d();

@@ -123,4 +123,12 @@ struct GhGemm {
   bool khi_row;                   // k ends at row0 + 128            (A lower-triangular: A(m,k) = 0 for k > m)
 };
 int gh_launch_gemm(const GhGemm& g, hipStream_t st);
+// Process-wide streams of a device, shared by every solver handle (gh_chol.hip): q[0] main (blocking,
+// normal priority), q[1..3] non-blocking high-priority.  nullptr where creation failed.  Never destroyed.
+// Why shared: HIP maps streams onto a few hardware queues; every further handle with streams of its
+// own moved the others' onto different queues and a dense compute() at N <= 16384 ran 20-40 % slower
+// with a second handle (or two application streams) alive (scripts/dev/queue_pattern.py) -- and a
+// CU-masked stream takes ~1 s to create.  GEORGE_AMD_PRIVATE_STREAMS restores per-handle streams.
+bool gh_shared_streams(int device, hipStream_t q[4]);
+hipStream_t gh_shared_masked_stream(int device, int reserve_cus);
 bool gh_use_mfma();               // false when GEORGE_AMD_NO_MFMA=1 (VALU validation path)

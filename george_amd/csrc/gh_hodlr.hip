@@ -858,6 +858,7 @@ struct HLevel {
 struct gh_hodlr {
   gh_hodlr_opts opts;
   hipStream_t st = nullptr;
+  bool shared_streams = false;   // st, st_b, st_c belong to the process (gh_shared_streams, gh_common.h): not destroyed here
   hipStream_t st_b = nullptr;    // second stream: ACA of the one-workgroup-per-node levels beside the clustered ones
   hipEvent_t ev_b = nullptr;
   hipStream_t st_c = nullptr;    // third stream: the leaf stage, beside both ACA streams
@@ -888,12 +889,12 @@ struct gh_hodlr {
   ~gh_hodlr() {
     for (auto* l : levels) delete l;
     if (ev_b) (void)hipEventDestroy(ev_b);
-    if (st_b) (void)hipStreamDestroy(st_b);
+    if (st_b && !shared_streams) (void)hipStreamDestroy(st_b);
     if (ev_c) (void)hipEventDestroy(ev_c);
-    if (st_c) (void)hipStreamDestroy(st_c);
+    if (st_c && !shared_streams) (void)hipStreamDestroy(st_c);
     for (auto& e : aca_ev) (void)hipEventDestroy(e);
     for (auto& e : aca_fused_ev) if (e) (void)hipEventDestroy(e);
-    if (st) (void)hipStreamDestroy(st);
+    if (st && !shared_streams) (void)hipStreamDestroy(st);
   }
   int64_t tree_n = -1;
   int tree_min = -1;
@@ -911,7 +912,13 @@ extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
   if (h->opts.min_size < 1) h->opts.min_size = 1;
   if (h->opts.max_rank < 0) h->opts.max_rank = 0;              // 0: as much as the tolerance asks for, up to RANK_CAP
   if (h->opts.max_rank > RANK_CAP) h->opts.max_rank = RANK_CAP;
-  if (hipSetDevice(h->opts.device) != hipSuccess || hipStreamCreate(&h->st) != hipSuccess) {
+  if (hipSetDevice(h->opts.device) != hipSuccess) { delete h; gh_set_error("cannot initialise HIP device %d", opts ? opts->device : 0); return GH_ERR_HIP; }
+  static const bool private_streams = getenv("GEORGE_AMD_PRIVATE_STREAMS") != nullptr;
+  hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (!private_streams && gh_shared_streams(h->opts.device, shq) && shq[2] && shq[3]) {
+    h->shared_streams = true;                 // the process-wide streams: main, and two side streams for compute()
+    h->st = shq[0];
+  } else if (hipStreamCreate(&h->st) != hipSuccess) {
     delete h; gh_set_error("cannot initialise HIP device %d", opts ? opts->device : 0); return GH_ERR_HIP;
   }
   *out = h;
@@ -1220,7 +1227,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   static const bool aca_serial = getenv("GEORGE_AMD_HODLR_SERIAL_LEVELS") != nullptr;
   const bool concurrent = !aca_serial && nlev > 1 && (double)n * rcap0 * sizeof(double) * nlev <= 12.0 * (1u << 30);
   if (concurrent && !h->st_b) {
-    if (hipStreamCreateWithFlags(&h->st_b, hipStreamNonBlocking) != hipSuccess ||
+    hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (h->shared_streams && gh_shared_streams(h->opts.device, shq)) h->st_b = shq[2];
+    if ((!h->shared_streams && hipStreamCreateWithFlags(&h->st_b, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_b = nullptr; }
   }
   struct AcaLevel { GhPooledBuf Tcm, idx, sync, part; int G = 1, rcap = 0; int flags[2] = {0, 0}; };
@@ -1422,7 +1431,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // durations MEASURED in the previous compute() of this handle (HIP events; a default guess the
       // first time): ranks, and with them the cost profile, hardly move inside an optimiser loop.
       if (!h->st_c) {
-        if (hipStreamCreateWithFlags(&h->st_c, hipStreamNonBlocking) != hipSuccess ||
+        hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (h->shared_streams && gh_shared_streams(h->opts.device, shq)) h->st_c = shq[3];
+        if ((!h->shared_streams && hipStreamCreateWithFlags(&h->st_c, hipStreamNonBlocking) != hipSuccess) ||
             hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_c = nullptr; }
       }
       static const bool leaves_after0 = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;

@@ -103,6 +103,10 @@ int gh_microbench_mfma_f64(double* tflops_out);
  * 2 = v_mfma_f64_4x4x4_4b, 3 = v_mfma_f64_16x16x4 with register staging; returns the previous
  * setting. */
 int gh_debug_set_mfma(int mode);
+/* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
+ * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
+ * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */
+int gh_debug_stream_overlap(gh_chol* s, double* out, int n);
 int gh_microbench_hbm_copy(double* gbps_out);
 /* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
  * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
