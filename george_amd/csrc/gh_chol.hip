@@ -541,12 +541,19 @@ struct SharedStreams { hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr}; 
 std::mutex g_ss_mu;
 std::map<int, SharedStreams> g_ss;
 }
+static void* ss_pad_word() { static void* p = nullptr; if (!p && hipMalloc(&p, 64) != hipSuccess) p = nullptr; return p; }
 bool gh_shared_streams(int device, hipStream_t q[4]) {
   std::lock_guard<std::mutex> lk(g_ss_mu);
   SharedStreams& ss = g_ss[device];
   if (!ss.made) {
     ss.made = true;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (const char* e = getenv("GEORGE_AMD_STREAM_PAD")) {         // experiment: shift the hardware-queue binding of what follows
+      for (int i = 0; i < atoi(e); ++i) {
+        hipStream_t d = nullptr;
+        if (hipStreamCreateWithFlags(&d, hipStreamNonBlocking) == hipSuccess) { (void)hipMemsetAsync(ss_pad_word(), 0, 4, d); (void)hipStreamSynchronize(d); }
+      }
+    }
     if (hipStreamCreate(&ss.q[0]) != hipSuccess) { ss.q[0] = nullptr; (void)hipGetLastError(); }
     int lo = 0, hi = 0;                    // numerically lowest value = highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
