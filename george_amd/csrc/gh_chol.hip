@@ -674,9 +674,15 @@ extern "C" int gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out) {
 static inline double* blk(double* A, int64_t ld, int64_t r, int64_t c) { return A + r * ld + c; }
 
 // C = A * B^T (alpha=1,beta=0) or C -= A * B^T helpers on k-major operands
+// (set by factor(): the K = 128 GEMMs of the chain hold 128-144 KiB of LDS per workgroup -- a whole CU.  Below
+//  Np = 24576 the trailing SYRK leaves 32 CUs out and they run there; above it every CU carries two SYRK
+//  workgroups and a chain workgroup that needs a CU to itself waits for one to drain while the dispatcher
+//  holds it empty: N = 65536 went from 1.407 to 1.433 s.  There they keep the 32-KiB K-loop kernel.)
+static thread_local bool t_gemm_small_lds = false;
 static int gemm_nt(hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, bool lower) {
   GhGemm g{};
+  g.small_lds = t_gemm_small_lds;
   g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.alpha = alpha; g.beta = beta; g.a_km = true; g.b_km = true; g.lower = lower;
   return gh_launch_gemm(g, st);
@@ -1168,6 +1174,9 @@ static int lookahead_depth(const gh_chol* s) {
 }
 
 static int factor(gh_chol* s) {
+  static const bool k128_always = getenv("GEORGE_AMD_K128_ALWAYS") != nullptr;          // A/B
+  struct Guard { bool prev; Guard(bool v) : prev(t_gemm_small_lds) { t_gemm_small_lds = v; } ~Guard() { t_gemm_small_lds = prev; } }
+      guard(!k128_always && s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
   if (s->opts.lookahead && s->st2) {
     const int d = lookahead_depth(s);
     if (d >= 1 && s->st4) return factor_lookahead_deep(s, d);

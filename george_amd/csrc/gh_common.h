@@ -121,6 +121,7 @@ struct GhGemm {
   bool klo_max;                   // k starts at max(row0, col0) of the tile (operands lower-triangular in k)
   bool khi_col;                   // k ends at col0 + 128            (B lower-triangular: B(n,k) = 0 for k > n)
   bool khi_row;                   // k ends at row0 + 128            (A lower-triangular: A(m,k) = 0 for k > m)
+  bool small_lds;                 // keep to <= 32 KiB of LDS per workgroup: the launch runs beside a SYRK that owns every CU
 };
 int gh_launch_gemm(const GhGemm& g, hipStream_t st);
 // Process-wide streams of a device, shared by every solver handle (gh_chol.hip): q[0] main (blocking,

@@ -914,7 +914,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   static const bool no_small = getenv("GEORGE_AMD_GEMM_NO_SMALL") != nullptr;
   static const bool no_k128 = getenv("GEORGE_AMD_GEMM_NO_K128") != nullptr;       // A/B: the K-loop kernels for K = 128 too
   const bool inplace = (const double*)h.C == h.A || (const double*)h.C == h.B;
-  if (dma && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small && !no_k128 &&
+  if (dma && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small && !no_k128 && !h.small_lds &&
       (!inplace || ((const double*)h.C == h.A && (const double*)h.C != h.B && h.N == 128 && !h.lower))) {
     GemmDev q = g;
     if (inplace) {                      // whole rows per workgroup: 16 x 128 tiles
