@@ -1,27 +1,25 @@
 // gh_potf2.hip -- the critical-path kernel of the blocked factorisation: one workgroup takes a
 // 128x128 diagonal block to its Cholesky factor L AND to L^-1 (which turns every TRSM of the
-// solver into an MFMA GEMM).
+// solver into an MFMA GEMM).  Also the leaf kernel of the HODLR solver (batched: blockIdx.x).
 //
 // The lower triangle of the block lives in LDS in PACKED row-major form (128*129/2 doubles =
-// 64.5 KiB; 82.5 KiB with the scratch below).  Packing is what lets this kernel be PLACED beside
-// the trailing SYRK during look-ahead: a SYRK workgroup holds 64 KiB of LDS, so a CU with one SYRK
-// workgroup still has room for this one, whereas the first, unpacked 129-KiB tile had to wait for
-// a whole CU to drain (1.7 ms average under SYRK).  Placed is not the same as fast: beside SYRK
-// wavefronts the kernel runs 4x slower (LDS queue contention), which is why small matrices keep
-// 32 CUs free of SYRK work (gh_chol.hip, trailing_stream).
-//   phase 1  blocked right-looking Cholesky, 16-column steps:
-//            (a) 16x16 diagonal block, unblocked, by ONE wavefront (no workgroup barriers),
-//            (b) rows below: x D^T = a by per-row substitution, one thread per row, registers,
-//            (c) trailing update on the matrix pipe: 16x16 tiles, v_mfma_f64_16x16x4_f64.
-//   phase 2  L^-1 by recursive doubling: the eight 16x16 diagonal inverses (wave-parallel
-//            substitution), then blocks of 16 -> 32 -> 64:  X = -B^-1 (C A^-1), every product a
-//            set of 16x16 MFMA tile jobs spread over the four wavefronts.  L^-1 overwrites the
-//            factor in LDS block by block (the factor itself has gone to HBM by then) and is
-//            written to `dinv` once at the end.
+// 64.5 KiB; 76 KiB with the eight packed 16x16 diagonal inverses and the spare slots).  Packing is
+// what lets this kernel be PLACED beside the trailing SYRK during look-ahead: a SYRK workgroup holds
+// 64 KiB of LDS, so a CU with one SYRK workgroup still has room for this one, whereas the first,
+// unpacked 129-KiB tile had to wait for a whole CU to drain (1.7 ms average under SYRK).  Placed is
+// not the same as fast: beside SYRK wavefronts the kernel runs several times slower, which is why
+// small matrices keep 32 CUs free of SYRK work (gh_chol.hip, trailing_stream).
 //
-// The first version of this kernel (scalar rank-1 updates, 3 barriers per column, column-wise
-// inverse) took 553 us per block and was half of compute() at N = 16384; it is kept in
-// gh_chol.hip (`potf2_inv_kernel`) as the A/B validation arm (GEORGE_AMD_POTF2=simple).
+// The algorithm is in the body headers:
+//   gh_potf2_body.h     second form, 33 us per block -- DPP-broadcast diagonal step that yields the
+//                       16x16 inverses for free, one barrier per 16-column step with X^T tiles recomputed
+//                       into MFMA operand registers, register-chained doubling products (the default);
+//   gh_potf2_body_v1.h  first MFMA form, 82 us (GEORGE_AMD_POTF2=v1): one-wavefront diagonal step by
+//                       v_readlane broadcasts, per-row substitution, tile updates, separate 16x16
+//                       inverses, doubling through an LDS scratch.
+// The very first version (scalar rank-1 updates, 3 barriers per column, column-wise inverse) took
+// 553 us per block and was half of compute() at N = 16384; it is kept in gh_chol.hip
+// (`potf2_inv_kernel`) as the validation arm GEORGE_AMD_POTF2=simple.
 #include <stdlib.h>
 #include <string.h>
 #include "gh_potf2_body.h"
