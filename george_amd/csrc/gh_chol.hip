@@ -729,10 +729,13 @@ static int trsm_right(hipStream_t st, const double* L11, int64_t ld11, const dou
 
 extern "C" int gh_dev_potrf_block(double* a, int64_t lda, int64_t n, double* dinv, int64_t* info_dev, int64_t base_index, void* stream) {
   if (n % T) { gh_set_error("potrf_block: n must be a multiple of 128"); return GH_ERR_BAD_ARG; }
+  // (tile operations of the multi-GPU driver run beside trailing updates that own every CU: small-LDS GEMMs, see t_gemm_small_lds)
+  struct Guard { bool prev; Guard() : prev(t_gemm_small_lds) { t_gemm_small_lds = true; } ~Guard() { t_gemm_small_lds = prev; } } guard;
   return potrf_block((hipStream_t)stream, a, lda, n, dinv, (long long*)info_dev, base_index);
 }
 extern "C" int gh_dev_trsm_right(const double* l11, int64_t ld11, const double* dinv, double* a21, int64_t lda, int64_t m, int64_t n, void* stream) {
   if (n % T || m % T) { gh_set_error("trsm_right: sizes must be multiples of 128"); return GH_ERR_BAD_ARG; }
+  struct Guard { bool prev; Guard() : prev(t_gemm_small_lds) { t_gemm_small_lds = true; } ~Guard() { t_gemm_small_lds = prev; } } guard;
   return trsm_right((hipStream_t)stream, l11, ld11, dinv, a21, lda, m, n);
 }
 extern "C" int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* dinv, int64_t n,
