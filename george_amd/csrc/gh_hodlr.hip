@@ -448,6 +448,9 @@ __global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* n
   const LvlNode nd = nodes[blockIdx.x];
   const int rk = ranks[blockIdx.x];
   const long tot = (long)nd.size * R;
+  // (element index split as (row, k), k fastest: the WRITES of a row's R columns are what must be
+  //  coalesced -- with one thread per row and coalesced reads of the column-major Tcm the eleven
+  //  launches took 558 instead of 185 us)
   for (long e = (long)blockIdx.y * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.y * blockDim.x) {
     const int r = (int)(e / R), k = (int)(e % R);
     const long i = nd.start + r;
@@ -858,6 +861,8 @@ struct HLevel {
 struct gh_hodlr {
   gh_hodlr_opts opts;
   hipStream_t st = nullptr;
+  GhBuf d_gather;                   // (fetch of every level's ranks / flags in one copy)
+  int* h_gather = nullptr; size_t h_gather_cap = 0;      // pinned
   bool shared_streams = false;   // st, st_b, st_c belong to the process (gh_shared_streams, gh_common.h): not destroyed here
   hipStream_t st_b = nullptr;    // second stream: ACA of the one-workgroup-per-node levels beside the clustered ones
   hipEvent_t ev_b = nullptr;
@@ -888,6 +893,7 @@ struct gh_hodlr {
   GhBuf ld_all, flags;           // log|det| of every factored block of a compute(); [0] Gauss-Jordan failure, [2..3] leaf info
   ~gh_hodlr() {
     for (auto* l : levels) delete l;
+    if (h_gather) (void)hipHostFree(h_gather);
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (st_b && !shared_streams) (void)hipStreamDestroy(st_b);
     if (ev_c) (void)hipEventDestroy(ev_c);
@@ -940,6 +946,15 @@ static int upload(GhBuf& buf, const std::vector<Tv>& v, hipStream_t st) {
   GH_CHECK(buf.ensure(std::max<size_t>(v.size(), 1) * sizeof(Tv)));
   if (!v.empty()) GH_HIP(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice, st));
   return GH_OK;
+}
+
+// Ranks and failure flags of ALL levels into one staging buffer, for ONE device-to-host copy: as 22 small
+// copies into pageable memory (two per level) they took 22 us each, back to back, with the GPU idle --
+// 0.5 of the 6.7 ms of a C4 compute().
+struct GatherItem { const int* src; int count, dst; };
+__global__ void hodlr_gather_kernel(const GatherItem* items, int* out) {
+  const GatherItem it = items[blockIdx.x];
+  for (int i = threadIdx.x; i < it.count; i += blockDim.x) out[it.dst + i] = it.src[i];
 }
 
 // mtiles: 32-row tiles of a job handled by ONE workgroup (the update passes: 4, i.e. a whole 128-row
@@ -1477,8 +1492,39 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     }
     GH_HIP(hipEventRecord(h->ev_b, h->st_b));
     GH_HIP(hipStreamWaitEvent(st, h->ev_b, 0));
-    for (int l = 0; l < nlev; ++l) GH_CHECK(fetch_level(l, st));
-    GH_HIP(hipStreamSynchronize(st));
+    {
+      // one gather launch + one copy into pinned memory for the ranks and the two failure flags of every level
+      std::vector<GatherItem> items;
+      int tot = 0;
+      for (int l = 0; l < nlev; ++l) {
+        HLevel* L = h->levels[l];
+        const int nn = (int)L->node_ids.size();
+        items.push_back({(const int*)L->d_ranks.p, nn, tot}); tot += nn;
+        items.push_back({(const int*)((unsigned*)al[l].sync.p + nn) + nn, 2, tot}); tot += 2;
+      }
+      // (pinned host memory, read by the kernel in place: the item table needs no copy of its own)
+      const size_t need = (size_t)tot + 4 + items.size() * (sizeof(GatherItem) / sizeof(int));
+      if (need > h->h_gather_cap) {
+        if (h->h_gather) (void)hipHostFree(h->h_gather);
+        h->h_gather = nullptr; h->h_gather_cap = 0;
+        GH_HIP(hipHostMalloc((void**)&h->h_gather, need * 2 * sizeof(int), hipHostMallocDefault));
+        h->h_gather_cap = need * 2;
+      }
+      GatherItem* const h_items = (GatherItem*)(h->h_gather + ((tot + 3) / 4) * 4);       // (16-byte aligned, behind the results)
+      memcpy(h_items, items.data(), items.size() * sizeof(GatherItem));
+      GH_CHECK(h->d_gather.ensure((size_t)tot * sizeof(int)));
+      hipLaunchKernelGGL(hodlr_gather_kernel, dim3((unsigned)items.size()), dim3(256), 0, st, (const GatherItem*)h_items, (int*)h->d_gather.p);
+      GH_HIP(hipGetLastError());
+      GH_HIP(hipMemcpyAsync(h->h_gather, h->d_gather.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, st));
+      GH_HIP(hipStreamSynchronize(st));
+      int at = 0;
+      for (int l = 0; l < nlev; ++l) {
+        HLevel* L = h->levels[l];
+        const int nn = (int)L->node_ids.size();
+        L->ranks.assign(h->h_gather + at, h->h_gather + at + nn); at += nn;
+        al[l].flags[0] = h->h_gather[at]; al[l].flags[1] = h->h_gather[at + 1]; at += 2;
+      }
+    }
     if (h->aca_timed) {                                 // durations for the next compute()'s schedule
       h->aca_ms.assign(nlev + 2, 0.0);
       float ms = 0;
