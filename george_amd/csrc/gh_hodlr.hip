@@ -866,6 +866,8 @@ struct gh_hodlr {
   bool shared_streams = false;   // st, st_b, st_c belong to the process (gh_shared_streams, gh_common.h): not destroyed here
   hipStream_t st_b = nullptr;    // second stream: ACA of the one-workgroup-per-node levels beside the clustered ones
   hipEvent_t ev_b = nullptr;
+  hipStream_t st_d = nullptr;    // fourth queue (the process-wide chain stream): one more independent ACA chain at a time
+  hipEvent_t ev_d = nullptr;
   hipStream_t st_c = nullptr;    // third stream: the leaf stage, beside both ACA streams
   hipEvent_t ev_c = nullptr;
   std::vector<hipEvent_t> aca_ev;        // timing stamps of the side items of the last compute(), two per item
@@ -897,6 +899,7 @@ struct gh_hodlr {
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (st_b && !shared_streams) (void)hipStreamDestroy(st_b);
     if (ev_c) (void)hipEventDestroy(ev_c);
+    if (ev_d) (void)hipEventDestroy(ev_d);
     if (st_c && !shared_streams) (void)hipStreamDestroy(st_c);
     for (auto& e : aca_ev) (void)hipEventDestroy(e);
     for (auto& e : aca_fused_ev) if (e) (void)hipEventDestroy(e);
@@ -938,6 +941,7 @@ extern "C" void gh_hodlr_destroy(gh_hodlr* h) {
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->st_b) (void)hipStreamSynchronize(h->st_b);
   if (h->st_c) (void)hipStreamSynchronize(h->st_c);
+  if (h->st_d) (void)hipStreamSynchronize(h->st_d);
   delete h;
 }
 
@@ -1451,6 +1455,12 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         if ((!h->shared_streams && hipStreamCreateWithFlags(&h->st_c, hipStreamNonBlocking) != hipSuccess) ||
             hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_c = nullptr; }
       }
+      static const int nqueues = getenv("GEORGE_AMD_HODLR_QUEUES") ? atoi(getenv("GEORGE_AMD_HODLR_QUEUES")) : 4;
+      if (!h->st_d && nqueues >= 4 && h->shared_streams && h->st_c) {
+        hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (gh_shared_streams(h->opts.device, shq) && shq[1] && hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming) == hipSuccess) h->st_d = shq[1];
+        else (void)hipGetLastError();
+      }
       static const bool leaves_after0 = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
       std::vector<int> ones = single;
       for (int l = 0; l < nlev; ++l) if (gmax[l] == 1) ones.push_back(l);
@@ -1460,9 +1470,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       for (int l : ones) items.push_back({l, have && h->aca_ms[l] > 0 ? h->aca_ms[l] : 1.0});
       if (!leaves_after0) items.push_back({-1, have && h->aca_ms[nlev + 1] > 0 ? h->aca_ms[nlev + 1] : 1.2});
       std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
-      hipStream_t qs[3] = {st, h->st_b, h->st_c ? h->st_c : h->st_b};
-      double load[3] = {have && h->aca_ms[nlev] > 0 ? h->aca_ms[nlev] : 1.5, 0.0, h->st_c ? 0.0 : 1e30};
+      hipStream_t qs[4] = {st, h->st_b, h->st_c ? h->st_c : h->st_b, h->st_d ? h->st_d : h->st_b};
+      double load[4] = {have && h->aca_ms[nlev] > 0 ? h->aca_ms[nlev] : 1.5, 0.0, h->st_c ? 0.0 : 1e30, h->st_d ? 0.0 : 1e30};
       if (h->st_c) GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));
+      if (h->st_d) GH_HIP(hipStreamWaitEvent(h->st_d, h->ev_b, 0));
       h->aca_ev_used = 0;
       auto stamp = [&](hipStream_t sx) -> int {               // record the next timing event on sx
         if (h->aca_ev_used == h->aca_ev.size()) {
@@ -1477,7 +1488,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // (the fused launch was enqueued above, between two stamps on st)
       for (const Item& it : items) {
         int q = 0;
-        for (int w = 1; w < 3; ++w) if (load[w] < load[q]) q = w;
+        for (int w = 1; w < 4; ++w) if (load[w] < load[q]) q = w;
         load[q] += it.cost;
         GH_CHECK(stamp(qs[q]));
         if (it.level >= 0) GH_CHECK(enqueue_level(it.level, rcap0, qs[q])); else GH_CHECK(leaf_stage(qs[q]));
@@ -1485,6 +1496,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         h->aca_items.push_back(it.level);
       }
       if (h->st_c) { GH_HIP(hipEventRecord(h->ev_c, h->st_c)); GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0)); }
+      if (h->st_d) { GH_HIP(hipEventRecord(h->ev_d, h->st_d)); GH_HIP(hipStreamWaitEvent(st, h->ev_d, 0)); }
     } else {
       for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
       static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
