@@ -764,7 +764,9 @@ extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, doub
 // at 1024: the fewer hand-overs between the streams the better), 128 and 256 nowhere.
 static int64_t panel_width(const gh_chol* s) {
   if (s->opts.nb > 0) return s->opts.nb;
-  return (s->np >= 12288 || s->np <= 4096) ? 1024 : 512;
+  // (swept again after the second 128x128 kernel and the K = 128 GEMM, N = 2048 .. 20480, nb = 256 .. 2048:
+  //  1024 wins or ties everywhere -- 512 used to win between 4096 and 12288, when a chain link cost twice as much)
+  return 1024;
 }
 
 // The panel with ONLY the potf2 chain on the critical stream.  Step j of the 128-column blocks:
