@@ -961,6 +961,62 @@ __global__ void hodlr_gather_kernel(const GatherItem* items, int* out) {
   for (int i = threadIdx.x; i < it.count; i += blockDim.x) out[it.dst + i] = it.src[i];
 }
 
+// X_leaf <- K_leaf^-1 X_leaf for every leaf, in place, ONE workgroup per leaf: the leaf's rows of X (<= 128 x
+// 16 CT columns) are staged in LDS once, K_leaf^-1 (a 128 x 128 slot, identity- or zero-padded) streams through
+// the A operand straight from HBM, the 128 x 16 CT result goes back over the rows it came from.  The generic tile
+// kernel took this as 16384 workgroups of one 32 x 64 tile each into a scratch copy (every U row staged four times,
+// every K^-1 slab twice) plus a copy back: 505 + 57 us of the C4 sweep for 0.6 GB of traffic.
+// Wavefront w: row tiles 2w, 2w+1 (16 rows each) x all CT column tiles.
+template <int CT>
+__global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ Kinv,
+                                                               double* __restrict__ X, long ldx, long xcol0, int C) {
+  constexpr int XP = 16 * CT + 1;
+  __shared__ double Xs[128 * XP];
+  typedef double la_v4d __attribute__((ext_vector_type(4)));
+  const MMJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  double* const xb = X + (long)job.b_row * ldx + xcol0;
+  for (int e = tid; e < 128 * 16 * CT; e += 256) {
+    const int r = e / (16 * CT), c = e % (16 * CT);
+    Xs[r * XP + c] = (r < job.m && c < C) ? xb[(long)r * ldx + c] : 0.0;
+  }
+  __syncthreads();
+  la_v4d acc[2][CT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[i][j] = (la_v4d){0.0, 0.0, 0.0, 0.0};
+  const double* const ka = Kinv + job.a_off + (long)(32 * wave + fr) * 128 + fk;
+#pragma unroll 1
+  for (int k0 = 0; k0 < 32; k0 += 8) {
+    double a[8][2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a[q][0] = ka[4 * (k0 + q)]; a[q][1] = ka[16 * 128 + 4 * (k0 + q)]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double* const bp = Xs + (4 * (k0 + q) + fk) * XP + fr;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const double b = bp[16 * j];
+        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b, acc[1][j], 0, 0, 0);
+      }
+    }
+  }
+  // f64 MFMA C/D map: row = (lane >> 4) + 4 reg, col = lane & 15
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 32 * wave + 16 * i + fk + 4 * r;
+      if (row >= job.m) continue;
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+        if (16 * j + fr < C) xb[(long)row * ldx + 16 * j + fr] = acc[i][j][r];
+    }
+}
+
 // mtiles: 32-row tiles of a job handled by ONE workgroup (the update passes: 4, i.e. a whole 128-row
 // chunk -- 8192 workgroups of one tiny tile each spent their 50 us on being dispatched)
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
@@ -1026,6 +1082,19 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
     hipLaunchKernelGGL(hodlr_mv_leaf_kernel, dim3((unsigned)h->leaves.size()), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p,
                        h->leaf_inv.d(), (long)h->leaf_pitch, X, ldx, xcol0, C);
     GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
+  static const bool no_leaf_apply = getenv("GEORGE_AMD_HODLR_NO_LEAF_APPLY") != nullptr;
+  if (!no_leaf_apply && h->leaf_pitch == 128 && h->max_leaf <= 128) {
+    // one workgroup per leaf, in place; column passes of <= 128 (80 where that covers the rest: less LDS, fewer MFMAs)
+    for (int cp = 0; cp < C;) {
+      const int cw = std::min(128, C - cp);
+      const unsigned nl = (unsigned)h->leaves.size();
+      if (cw <= 80) hipLaunchKernelGGL(hodlr_leaf_apply_kernel<5>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0 + cp, cw);
+      else hipLaunchKernelGGL(hodlr_leaf_apply_kernel<8>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0 + cp, cw);
+      GH_HIP(hipGetLastError());
+      cp += cw;
+    }
     return GH_OK;
   }
   for (int cp = 0; cp < C; cp += h->cpass) {
