@@ -961,6 +961,28 @@ __global__ void hodlr_gather_kernel(const GatherItem* items, int* out) {
   for (int i = threadIdx.x; i < it.count; i += blockDim.x) out[it.dst + i] = it.src[i];
 }
 
+// rows [0, nrows) x columns [0, 16 ct) of a row-major block into LDS (pitch xp), zero where row >= nrows or
+// column >= C; eight independent loads in flight per thread (a rolled load-store loop waits for every load in turn:
+// 40 round trips per workgroup)
+__device__ __forceinline__ void hodlr_stage_rows(double* Xs, int xp, const double* src, long ld, int nrows, int C, int ct) {
+  const int w = 16 * ct, tot = 128 * w;
+  for (int e0 = threadIdx.x; e0 < tot; e0 += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + 256 * q, r = e / w, c = e - r * w;
+      const bool ok = e < tot && r < nrows && c < C;
+      v[q] = src[ok ? (long)r * ld + c : 0];
+      if (!ok) v[q] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + 256 * q, r = e / w, c = e - r * w;
+      if (e < tot) Xs[r * xp + c] = v[q];
+    }
+  }
+}
+
 // X_leaf <- K_leaf^-1 X_leaf for every leaf, in place, ONE workgroup per leaf: the leaf's rows of X (<= 128 x
 // 16 CT columns) are staged in LDS once, K_leaf^-1 (a 128 x 128 slot, identity- or zero-padded) streams through
 // the A operand straight from HBM, the 128 x 16 CT result goes back over the rows it came from.  The generic tile
@@ -977,10 +999,8 @@ __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   double* const xb = X + (long)job.b_row * ldx + xcol0;
-  for (int e = tid; e < 128 * 16 * CT; e += 256) {
-    const int r = e / (16 * CT), c = e % (16 * CT);
-    Xs[r * XP + c] = (r < job.m && c < C) ? xb[(long)r * ldx + c] : 0.0;
-  }
+  const int ct = (C + 15) >> 4;                   // column tiles that hold anything (uniform)
+  hodlr_stage_rows(Xs, XP, xb, ldx, job.m, C, ct);
   __syncthreads();
   la_v4d acc[2][CT];
 #pragma unroll
@@ -998,6 +1018,7 @@ __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __re
       const double* const bp = Xs + (4 * (k0 + q) + fk) * XP + fr;
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
+        if (j >= ct) continue;
         const double b = bp[16 * j];
         acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b, acc[0][j], 0, 0, 0);
         acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b, acc[1][j], 0, 0, 0);
@@ -1017,10 +1038,83 @@ __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __re
     }
 }
 
+// The per-chunk products V_l^T U of the factorisation sweep (R <= 16 columns of V, <= 128 rows of a chunk, C <= 16 CT
+// columns of U), ONE workgroup per chunk in the manner of hodlr_leaf_apply_kernel: the chunk's rows of U staged in
+// LDS once, V^T as the A operand straight from HBM (row k of the result = column k of V), the K = 128 rows split
+// over the four wavefronts and their partial tiles added in a fixed order (bitwise repeatable).
+//   O[(o_row + k) * ldo + o_col0 + c] = sum_row A[a_off + k + row * R] * B[(b_row + row) * ldb + b_col0 + c]
+template <int CT>
+__global__ __launch_bounds__(256) void hodlr_red_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ A, int R,
+                                                        const double* __restrict__ B, long ldb, long b_col0,
+                                                        double* __restrict__ O, long ldo, long o_col0, int C) {
+  constexpr int XP = 16 * CT + 1;
+  __shared__ double Xs[128 * XP];
+  typedef double rk_v4d __attribute__((ext_vector_type(4)));
+  const MMJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const double* const bb = B + (long)job.b_row * ldb + b_col0;
+  const int ct = (C + 15) >> 4;                   // column tiles that hold anything (uniform)
+  hodlr_stage_rows(Xs, XP, bb, ldb, job.kd, C, ct);
+  // this wavefront's eight k steps of the A operand: V^T(fr, 4 kk + fk) = V(row, fr)
+  double a[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = 4 * (8 * wave + q) + fk;
+    a[q] = (fr < R && row < job.kd) ? A[job.a_off + (long)row * R + fr] : 0.0;
+  }
+  __syncthreads();
+  rk_v4d acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc[j] = (rk_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double* const bp = Xs + (4 * (8 * wave + q) + fk) * XP + fr;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+      if (j < ct) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bp[16 * j], acc[j], 0, 0, 0);
+  }
+  __syncthreads();                                // (Xs is free: the partial tiles of wavefronts 1-3 go there)
+  double* const part = Xs;                        // [3][CT][4][64]
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(((wave - 1) * CT + j) * 4 + r) * 64 + lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // f64 MFMA C/D map: row = (lane >> 4) + 4 reg, col = lane & 15
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = fk + 4 * r, c = 16 * j + fr;
+        if (k < R && c < C) {
+          const double v = ((acc[j][r] + part[((0 * CT + j) * 4 + r) * 64 + lane]) + part[((1 * CT + j) * 4 + r) * 64 + lane]) +
+                           part[((2 * CT + j) * 4 + r) * 64 + lane];
+          O[(long)(job.o_row + k) * ldo + o_col0 + c] = v;
+        }
+      }
+  }
+}
+static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
+                     const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1);
+static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* V, const double* B, long ldb, long b_col0,
+                      double* O, long ldo, long o_col0, int C) {
+  static const bool no_red = getenv("GEORGE_AMD_HODLR_NO_RED_KERNEL") != nullptr;
+  if (njobs <= 0 || C <= 0 || R <= 0) return GH_OK;
+  if (no_red || R > 16 || C > 128) return launch_mm(h, jobs, njobs, R, V, 1, R, B, ldb, b_col0, O, ldo, o_col0, C, false, 1);
+  if (C <= 80) hipLaunchKernelGGL(hodlr_red_kernel<5>, dim3(njobs), dim3(256), 0, h->st, jobs, V, R, B, ldb, b_col0, O, ldo, o_col0, C);
+  else hipLaunchKernelGGL(hodlr_red_kernel<8>, dim3(njobs), dim3(256), 0, h->st, jobs, V, R, B, ldb, b_col0, O, ldo, o_col0, C);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
 // mtiles: 32-row tiles of a job handled by ONE workgroup (the update passes: 4, i.e. a whole 128-row
 // chunk -- 8192 workgroups of one tiny tile each spent their 50 us on being dispatched)
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
-                     const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1) {
+                     const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles) {
   if (njobs <= 0 || C <= 0 || max_m <= 0) return GH_OK;
   MMArgs a;
   a.mtiles = mtiles;
@@ -1714,15 +1808,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     const int Call = L->off + R;
     const bool merged = !no_merge && Call <= h->cpass;
     if (merged) {
-      GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off, 1, R,
-                         h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call, false));
+      GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
+                          h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
       hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, Call, h->Tsum.d());
       GH_HIP(hipGetLastError());
       hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d() + L->off, (long)h->cpass, R, L->sinv.d());
       GH_HIP(hipGetLastError());
     } else {
-      GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off, 1, R,
-                         h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R, false));
+      GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
+                          h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R));
       hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
       GH_HIP(hipGetLastError());
       hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)h->cpass, R, L->sinv.d());
