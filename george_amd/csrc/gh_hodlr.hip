@@ -601,6 +601,81 @@ __global__ __launch_bounds__(256) void gj_inverse_kernel(double* base, const lon
   if (tid == 0) logdet[b] = ld;
 }
 
+// ---- the same inverse for SMALL matrices (n <= NMAX <= 32: the 2r x 2r Woodbury cores), one WAVEFRONT per
+// matrix, no barriers, no LDS: lane i holds row i in registers.  gj_inverse_kernel above is built for leaves
+// of up to 256 rows -- five workgroup barriers, a block-wide arg-max through LDS and a global write per
+// pivot: 3 us per pivot step, 91 us for the 30 x 30 core of the root node, 0.42 ms over the eleven levels
+// of C4.  Here a pivot step is a DPP row reduction for the pivot search (on the high words of |a|: as
+// unsigned integers they order like the doubles), 2 n v_readlane for the pivot row and n FMAs.
+// Rows are not swapped: pivot k is found among the rows not yet used and stays where it is (row p_k plays
+// row k of P A); (P A)^-1 = A^-1 P^T, so lane p_r ends with A^-1[r][p_c] in column register c.
+__device__ __forceinline__ double gj_bcast(double v, int src_lane) {         // src_lane: wave-uniform, not a constant
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned gj_row_max_u32(unsigned v) {            // max over the lane's 16-lane row, in every lane
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long* offs, const int* sizes, int nb,
+                                                       double* logdet, int* fail) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nb) return;                            // (the whole wavefront)
+  const int n = __builtin_amdgcn_readfirstlane(sizes[b]);
+  double* const M = base + offs[b];
+  const bool row = lane < n;
+  double m[NMAX];
+#pragma unroll
+  for (int c = 0; c < NMAX; ++c) m[c] = (row && c < n) ? M[(long)lane * n + c] : 0.0;
+  bool used = false, bad = false;
+  int myk = 0, pc[NMAX];
+  double ld = 0.0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    if (k < n && !bad) {                          // (uniform)
+      const bool cand = row && !used;
+      const unsigned key = cand ? (unsigned)__double2hiint(fabs(m[k])) : 0u;
+      const unsigned rm = gj_row_max_u32(key);
+      const unsigned mx = max((unsigned)__builtin_amdgcn_readlane((int)rm, 0), (unsigned)__builtin_amdgcn_readlane((int)rm, 16));   // n <= 32: two rows
+      const unsigned long long who = __builtin_amdgcn_ballot_w64(cand && key == mx);
+      const int p = (int)__builtin_ctzll(who | (1ull << 63));
+      const double pv = gj_bcast(m[k], p);
+      if (who == 0ull || !(fabs(pv) > 0.0)) { bad = true; }
+      else {
+        pc[k] = p;
+        if (lane == p) { used = true; myk = k; }
+        ld += log(fabs(pv));
+        const double rinv = 1.0 / pv;
+        const double f = m[k];
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) {
+          if (c != k && c < n) {
+            const double pr = gj_bcast(m[c], p) * rinv;
+            m[c] = (lane == p) ? pr : fma(-f, pr, m[c]);
+          }
+        }
+        m[k] = (lane == p) ? rinv : -f * rinv;
+      }
+    }
+  }
+  if (bad) {
+    if (lane == 0) { atomicExch(fail, b + 1); logdet[b] = 0.0; }
+    return;
+  }
+  if (row) {
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c)
+      if (c < n) M[(long)myk * n + pc[c]] = m[c];
+  }
+  if (lane == 0) logdet[b] = ld;
+}
+
 // =============================================================== batched small dense products
 // O(job rows, 0:C) (=|-=) A_job (m x kd) * B(job rows, 0:C); A element (r, k) at
 // A[a_off + r*a_rs + k*a_cs]; B row b_row+k at B[(b_row+k)*ldb + b_col0 + c].
@@ -1229,11 +1304,20 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
     GH_CHECK(upload(d_sizes, sizes, h->st));
     GH_CHECK(upload(d_sc, sc, h->st));
   }
+  int nmax = 0;
+  for (int v : sizes) nmax = std::max(nmax, v);
+  static const bool no_small = getenv("GEORGE_AMD_HODLR_NO_SMALL_GJ") != nullptr;
+  if (nmax <= 32 && !no_small) {                  // the Woodbury cores: one wavefront per matrix
+    const dim3 grid((unsigned)((nb + 3) / 4));
+    if (nmax <= 8) hipLaunchKernelGGL(gj_small_kernel<8>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p);
+    else if (nmax <= 16) hipLaunchKernelGGL(gj_small_kernel<16>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p);
+    else hipLaunchKernelGGL(gj_small_kernel<32>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
   GH_CHECK(d_sd.ensure(tot * sizeof(double)));
   GH_CHECK(d_si.ensure(tot * sizeof(int)));
   // dynamic LDS for the in-LDS path: the largest matrix of the batch if it fits (<= 144 KiB), else none
-  int nmax = 0;
-  for (int v : sizes) nmax = std::max(nmax, v);
   size_t lds_bytes = ((size_t)nmax * (nmax | 1) + nmax) * sizeof(double);
   if (lds_bytes > 144 * 1024 || getenv("GEORGE_AMD_HODLR_GJ_GLOBAL")) lds_bytes = 0;
   if (lds_bytes > 0) {
