@@ -1180,8 +1180,18 @@ static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const do
   static const bool no_red = getenv("GEORGE_AMD_HODLR_NO_RED_KERNEL") != nullptr;
   if (njobs <= 0 || C <= 0 || R <= 0) return GH_OK;
   if (no_red || R > 16 || C > 128) return launch_mm(h, jobs, njobs, R, V, 1, R, B, ldb, b_col0, O, ldo, o_col0, C, false, 1);
-  if (C <= 80) hipLaunchKernelGGL(hodlr_red_kernel<5>, dim3(njobs), dim3(256), 0, h->st, jobs, V, R, B, ldb, b_col0, O, ldo, o_col0, C);
-  else hipLaunchKernelGGL(hodlr_red_kernel<8>, dim3(njobs), dim3(256), 0, h->st, jobs, V, R, B, ldb, b_col0, O, ldo, o_col0, C);
+  // (one instantiation per number of 16-column tiles: the LDS image is 128 x (16 CT + 1) doubles, and with 17-50 KB
+  //  instead of 83 several workgroups share a CU at the shallow levels, whose U has few columns yet)
+#define GH_RED_LAUNCH(CT) hipLaunchKernelGGL(hodlr_red_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, V, R, B, ldb, b_col0, O, ldo, o_col0, C)
+  switch ((C + 15) / 16) {
+    case 1: GH_RED_LAUNCH(1); break;
+    case 2: GH_RED_LAUNCH(2); break;
+    case 3: GH_RED_LAUNCH(3); break;
+    case 4: GH_RED_LAUNCH(4); break;
+    case 5: GH_RED_LAUNCH(5); break;
+    default: GH_RED_LAUNCH(8); break;
+  }
+#undef GH_RED_LAUNCH
   GH_HIP(hipGetLastError());
   return GH_OK;
 }

@@ -12,7 +12,7 @@ if not aca:
 # ACA launches of one compute() start within a few ms of each other; computes are further apart
 groups = [[aca[0]]]
 for r in aca[1:]:
-    if r[0] - groups[-1][-1][0] < 4e6:
+    if r[0] - groups[-1][-1][0] < 2.5e6:
         groups[-1].append(r)
     else:
         groups.append([r])
