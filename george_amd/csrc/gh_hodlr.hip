@@ -1173,6 +1173,62 @@ __global__ __launch_bounds__(256) void hodlr_red_kernel(const MMJob* __restrict_
       }
   }
 }
+// The rank-R updates of the factorisation sweep, U[rows of a chunk, 0:C] -= U_l[rows, 0:R] * T[b_row : b_row+R, 0:C]
+// (R <= 16, <= 128 rows, C <= 16 CT), one workgroup per chunk without any LDS: the accumulators start from the
+// O tiles themselves (each lane's four rows x one column of a 16 x 16 tile, 128-byte row segments), K = R is
+// padded to 16 only (the tile kernel pads to 32 and stages both operands), operands straight from HBM / L2.
+//   O[(o_row + r) * ldo + c] -= sum_k A[a_off + r * a_rs + k] * B[(b_row + k) * ldb + c]
+template <int CT>
+__global__ __launch_bounds__(256) void hodlr_upd_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ A, long a_rs,
+                                                        const double* __restrict__ B, long ldb, double* __restrict__ O, long ldo, int C) {
+  typedef double uk_v4d __attribute__((ext_vector_type(4)));
+  const MMJob job = jobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int R = job.kd, nkk = (R + 3) >> 2, ct = (C + 15) >> 4;        // (uniform)
+  double a[2][4], b[4][CT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int row = 32 * wave + 16 * i + fr, k = 4 * kk + fk;
+      a[i][kk] = (row < job.m && k < R) ? -A[job.a_off + (long)row * a_rs + k] : 0.0;
+    }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int k = 4 * kk + fk, c = 16 * j + fr;
+      b[kk][j] = (k < R && c < C) ? B[(long)(job.b_row + k) * ldb + c] : 0.0;
+    }
+  double* const ob = O + (long)job.o_row * ldo;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (32 * wave + 16 * i >= job.m) continue;                         // (uniform)
+    uk_v4d acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * i + fk + 4 * r, c = 16 * j + fr;
+        acc[j][r] = (j < ct && row < job.m && c < C) ? ob[(long)row * ldo + c] : 0.0;
+      }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk >= nkk) continue;
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+        if (j < ct) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][kk], b[kk][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * i + fk + 4 * r, c = 16 * j + fr;
+        if (j < ct && row < job.m && c < C) ob[(long)row * ldo + c] = acc[j][r];
+      }
+  }
+}
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
                      const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1);
 static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* V, const double* B, long ldb, long b_col0,
@@ -1192,6 +1248,25 @@ static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const do
     default: GH_RED_LAUNCH(8); break;
   }
 #undef GH_RED_LAUNCH
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+static int launch_upd(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* A, long a_rs, const double* B, long ldb,
+                      double* O, long ldo, int C) {
+  static const bool no_upd = getenv("GEORGE_AMD_HODLR_NO_UPD_KERNEL") != nullptr;
+  if (njobs <= 0 || C <= 0 || R <= 0) return GH_OK;
+  if (no_upd || R > 16 || C > 128 || HCH > 128) return launch_mm(h, jobs, njobs, HCH, A, a_rs, 1, B, ldb, 0, O, ldo, 0, C, true, HCH / 32);
+#define GH_UPD_LAUNCH(CT) hipLaunchKernelGGL(hodlr_upd_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, A, a_rs, B, ldb, O, ldo, C)
+  switch ((C + 15) / 16) {
+    case 1: GH_UPD_LAUNCH(1); break;
+    case 2: GH_UPD_LAUNCH(2); break;
+    case 3: GH_UPD_LAUNCH(3); break;
+    case 4: GH_UPD_LAUNCH(4); break;
+    case 5: GH_UPD_LAUNCH(5); break;
+    default: GH_UPD_LAUNCH(8); break;
+  }
+#undef GH_UPD_LAUNCH
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
@@ -1930,8 +2005,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // (Tsum already holds V_l^T U[:, 0:off]: core product and update only)
       GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
                          h->Tsum.d(), h->cpass, 0, h->Tout.d(), h->cpass, 0, L->off, false));
-      GH_CHECK(launch_mm(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, HCH, h->UA.d() + L->off, Rtot, 1,
-                         h->Tout.d(), h->cpass, 0, h->UA.d(), Rtot, 0, L->off, true, HCH / 32));
+      GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
+                          h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
     } else {
       GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
     }
