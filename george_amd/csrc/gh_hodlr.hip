@@ -622,8 +622,11 @@ __device__ __forceinline__ unsigned gj_row_max_u32(unsigned v) {            // m
   return v;
 }
 template <int NMAX>
+// tsum != nullptr: the matrix is not read from `base` but built on the way in as the Woodbury core
+// S = [[I, V1^T U1], [V0^T U0, I]] (hodlr.h:229-232) from rows [2 R b, 2 R b + 2 R) x columns [0, R) of tsum
+// (pitch Cp) -- what hodlr_sbuild_kernel did in a launch of its own, eleven times per compute().
 __global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long* offs, const int* sizes, int nb,
-                                                       double* logdet, int* fail) {
+                                                       double* logdet, int* fail, const double* tsum, long Cp, int R) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= nb) return;                            // (the whole wavefront)
@@ -631,8 +634,21 @@ __global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long*
   double* const M = base + offs[b];
   const bool row = lane < n;
   double m[NMAX];
+  if (tsum) {
+    const double* const tr = tsum + ((long)b * n + lane) * Cp;
 #pragma unroll
-  for (int c = 0; c < NMAX; ++c) m[c] = (row && c < n) ? M[(long)lane * n + c] : 0.0;
+    for (int c = 0; c < NMAX; ++c) {
+      double v = (lane == c) ? 1.0 : 0.0;
+      if (row && c < n) {
+        if (lane < R && c >= R) v = tr[c - R];
+        else if (lane >= R && c < R) v = tr[c];
+      }
+      m[c] = (row && c < n) ? v : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) m[c] = (row && c < n) ? M[(long)lane * n + c] : 0.0;
+  }
   bool used = false, bad = false;
   int myk = 0, pc[NMAX];
   double ld = 0.0;
@@ -1373,8 +1389,10 @@ static int solve_all(gh_hodlr* h, double* X, long ldx, int C) {
 // enqueue only: logdet[b] of matrix b goes to d_logdet[b] (device), a singular block raises h->flags[0]
 // (tables: device copies of offs / sizes / scratch offsets kept by the caller; *tables_valid says they
 //  already hold this batch's values)
+// tsum / tsum_R: see gj_small_kernel (the caller then skips hodlr_sbuild_kernel)
 static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& offs, const std::vector<int>& sizes,
-                           double* d_logdet, GhBuf* const* tables = nullptr, bool tables_valid = false) {
+                           double* d_logdet, GhBuf* const* tables = nullptr, bool tables_valid = false,
+                           const double* tsum = nullptr, int tsum_R = 0) {
   const int nb = (int)sizes.size();
   if (nb == 0) return GH_OK;
   std::vector<long> sc(nb);
@@ -1394,11 +1412,15 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
   static const bool no_small = getenv("GEORGE_AMD_HODLR_NO_SMALL_GJ") != nullptr;
   if (nmax <= 32 && !no_small) {                  // the Woodbury cores: one wavefront per matrix
     const dim3 grid((unsigned)((nb + 3) / 4));
-    if (nmax <= 8) hipLaunchKernelGGL(gj_small_kernel<8>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p);
-    else if (nmax <= 16) hipLaunchKernelGGL(gj_small_kernel<16>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p);
-    else hipLaunchKernelGGL(gj_small_kernel<32>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p);
+    if (nmax <= 8) hipLaunchKernelGGL(gj_small_kernel<8>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
+    else if (nmax <= 16) hipLaunchKernelGGL(gj_small_kernel<16>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
+    else hipLaunchKernelGGL(gj_small_kernel<32>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
     GH_HIP(hipGetLastError());
     return GH_OK;
+  }
+  if (tsum) {                                     // (cores too big for the wavefront kernel: build them first)
+    hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nb), dim3(256), 0, h->st, tsum, (long)h->cpass, tsum_R, base);
+    GH_HIP(hipGetLastError());
   }
   GH_CHECK(d_sd.ensure(tot * sizeof(double)));
   GH_CHECK(d_si.ensure(tot * sizeof(int)));
@@ -1981,22 +2003,19 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
                           h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
       hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, Call, h->Tsum.d());
       GH_HIP(hipGetLastError());
-      hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d() + L->off, (long)h->cpass, R, L->sinv.d());
-      GH_HIP(hipGetLastError());
     } else {
       GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
                           h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R));
       hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
       GH_HIP(hipGetLastError());
-      hipLaunchKernelGGL(hodlr_sbuild_kernel, dim3(nn), dim3(256), 0, st, h->Tsum.d(), (long)h->cpass, R, L->sinv.d());
-      GH_HIP(hipGetLastError());
     }
+    const double* const core_src = h->Tsum.d() + (merged ? L->off : 0);      // V_l^T U[:, own columns]: the core is built from it inside the inverse
     std::vector<long> offs(nn);
     std::vector<int> sizes(nn, 2 * R);
     for (int q = 0; q < nn; ++q) offs[q] = (long)q * 4 * R * R;
     {
       GhBuf* const tabs[3] = {&L->d_gj_offs, &L->d_gj_sizes, &L->d_gj_sc};
-      GH_CHECK(batched_inverse(h, L->sinv.d(), offs, sizes, h->ld_all.d() + ld_at, tabs, L->gj_R == R));
+      GH_CHECK(batched_inverse(h, L->sinv.d(), offs, sizes, h->ld_all.d() + ld_at, tabs, L->gj_R == R, core_src, R));
       L->gj_R = R;
     }
     ld_at += nn;
