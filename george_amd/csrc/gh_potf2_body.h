@@ -7,26 +7,31 @@
 // barrier-separated products per chunk through an LDS scratch), 14 us of HBM load / store phases run
 // to completion one after the other.  This form removes whole phases instead of tuning them:
 //
-//  * the 16x16 diagonal step produces the block's INVERSE in the same instruction stream: lanes
-//    0-15 hold the rows of the block, lanes 16-31 the columns of D^-1, and the recurrence
-//    `v[j] *= 1/sqrt(d);  v[k] -= v[j] * L_kj` is the Cholesky column step for the former and forward
-//    substitution for the latter, with the SAME broadcast multipliers L_kj.  No separate inverse
-//    phase, and the rows below become X = A D^-T on the matrix pipe instead of a 16-deep dependent
-//    substitution per thread;
+//  * the 16x16 diagonal step produces the block's INVERSE in the same instruction stream: lane i
+//    (of every 16-lane row) holds row i of the block AND column i of D^-1, and the recurrence
+//    `v[j] *= 1/sqrt(d);  v[k] -= L_kj v[j]` is the Cholesky column step for the former and forward
+//    substitution for the latter, with the SAME multipliers L_kj -- broadcast INSIDE the FMA by DPP
+//    row_newbcast (v_fmac_f64_dpp), not through SGPRs (v_readlane + hazard + FMA: 22 cycles per
+//    update against 5).  No separate inverse phase, and the rows below become X = A D^-T on the
+//    matrix pipe instead of a 16-deep dependent substitution per thread;
 //  * one barrier per 16-column step instead of three: every wavefront recomputes the X^T tiles it
 //    needs (4 MFMAs each) straight into MFMA operand registers -- the f64 16x16x4 result of
 //    X^T = D^-1 A^T has exactly the lane layout both operands of C -= X X^T want, if the k index of
 //    that product is taken as (lane >> 4) + 4 r -- and wavefront 0 runs the critical chain
 //    (X of the next tile row, next diagonal tile, next diagonal step) on its own while wavefronts
-//    1-3 update everything else;
-//  * 1/sqrt(d) from v_rsq_f64 and ONE third-order step (4 dependent operations instead of 12), the
-//    chain interleaved by hand with the independent updates of the previous column;
+//    1-3 update everything else (straight-line code per wavefront, software-pipelined by hand);
+//  * 1/sqrt(d) from v_rsq_f64 and ONE third-order step (4 dependent operations instead of 12);
 //  * the doubling products X = -B^-1 (C A^-1) chained through registers the same way (the result
 //    tile column of C A^-1 is the B operand of the second product): no scratch, one barrier between
 //    reading C and overwriting it;
-//  * HBM phases overlapped: all loads of a pass in flight at once and only the lower triangle
-//    fetched; the zeros above the diagonals are stored by wavefronts 1-3 while wavefront 0 does the
-//    first diagonal step; the factor is stored without waiting (phase 2 runs under the stores).
+//  * HBM phases overlapped: wavefront 0 fetches the first diagonal tile itself and starts, the others
+//    fetch the rest of the lower triangle with all their loads in flight; the zeros of the upper-right
+//    quadrant are stored by wavefronts 1-3 a chunk per step; the factor is stored without waiting
+//    (phase 2 runs under the stores).
+// What the instructions cost on this chip (scripts/dev/valu_probe.hip): any instruction of a wavefront
+// issues every ~4.4 cycles, a dependent f64 FMA every 4.9 -- nothing to hide, only instructions to
+// remove -- and an f64 MFMA holds the SIMD for 64.5 cycles during which the wavefront issues no other
+// vector instruction.
 #pragma once
 #include "gh_common.h"
 #include <type_traits>
