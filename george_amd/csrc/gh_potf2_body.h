@@ -260,10 +260,10 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
     auto block = [&](auto NXc, auto NTc) {
       constexpr int NX = decltype(NXc)::value, NT = decltype(NTc)::value;   // X tiles, tile slots computed in this pass
       // On this chip the f64 MFMA runs at the rate of the vector f64 FMA and a wavefront issues nothing
-      // else to the vector unit while one executes (64.5 cycles each; hand-pipelining LDS traffic and
-      // address arithmetic between the MFMAs changed nothing: 137 cycles per MFMA either way).  So the
-      // cost of a pass is 64 MFMAs PLUS every other vector instruction, and what is left to do is to
-      // have few of those: addresses as one v_mad_u32_u24 + one add from per-lane constants, tiles
+      // else to the vector unit while one executes (64.5 cycles each; with ~640 other vector instructions
+      // in the pass, hand-pipelining the LDS traffic between the MFMAs alone changed nothing: 137 cycles
+      // per MFMA either way).  So the cost of a pass is its MFMAs PLUS every other vector instruction,
+      // and the first thing to do is to have few of those: addresses as one v_mad_u32_u24 + one add from per-lane constants, tiles
       // that do not exist in this pass (rows past the end) redirected by a SCALAR select to a 16x16
       // dummy tile instead of per-store v_cndmask, X negated once per tile row instead of per MFMA.
       // (1) X^T of the tile rows below jb; the X tiles of the previous step go to their place as
