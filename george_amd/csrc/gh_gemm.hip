@@ -730,8 +730,10 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_dma64(GemmDev g) {
 // 16-deep K chunks of both operands are requested AT ONCE into eight LDS buffers (64..144 KB of the
 // CU's 160 KB): one memory latency for the whole tile instead of eight.  (The code waits for chunk c
 // by count, s_waitcnt vmcnt((7 - c) * IPC); as compiled, hipcc's LDS-DMA tracking puts a vmcnt(0) in
-// front of the first barrier, so the MFMAs start when the last chunk has landed -- reading the
-// fragments through inline asm would lift that, for ~1 us per launch.  C requested behind the DMAs and
+// front of the first barrier, so the MFMAs start when the last chunk has landed.  Lifting that was tried
+// (raw s_barrier, fragment reads and the C preload as inline asm with their own waits: MFMAs of chunk 0
+// under the DMAs of chunks 1-7): bit-identical results, no gain -- 3.10 / 7.77 / 31.4 ms at N = 4096 /
+// 8192 / 16384 against 3.0 / 7.6 / 31.1.  C requested behind the DMAs and
 // added in the epilogue instead of starting the accumulators from it: measured, no gain, and the
 // sums are then no longer bit-identical to the other GEMM kernels'.)
 // Tile (16 MI WM) x (16 NJ WN), WM x WN = 4 wavefronts of (16 MI) x (16 NJ); k-major operands, same
