@@ -107,6 +107,7 @@ SIGNATURES = {
     "gh_chol_compute": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, C.POINTER(C.c_double)]),
     "gh_chol_info": (_i64, [_vp]),
     "gh_chol_size": (_i64, [_vp]),
+    "gh_chol_device_bytes": (_i64, [_vp]),
     "gh_chol_solve": (C.c_int, [_vp, _dp, _i64, _dp]),
     "gh_chol_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "gh_chol_apply_sqrt": (C.c_int, [_vp, _dp, _i64, _dp]),

@@ -665,6 +665,13 @@ extern "C" void gh_chol_destroy(gh_chol* s) {
 }
 extern "C" int64_t gh_chol_info(const gh_chol* s) { return s ? s->info : 0; }
 extern "C" int64_t gh_chol_size(const gh_chol* s) { return s ? s->n : 0; }
+extern "C" int64_t gh_chol_device_bytes(const gh_chol* s) {
+  if (!s) return 0;
+  size_t tot = 0;
+  for (const GhBuf* b : {&s->A, &s->dinv, &s->x, &s->yerr, &s->v0, &s->v1, &s->v2, &s->scal, &s->rhs, &s->work, &s->work2,
+                         &s->scratch, &s->chain, &s->pflags}) tot += b->p ? b->bytes : 0;
+  return (int64_t)tot;
+}
 extern "C" int gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out) {
   if (!s || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
   *out = s->prof;

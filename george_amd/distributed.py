@@ -817,13 +817,16 @@ class DistributedBasicSolver(object):
 
 class DistributedDenseJob(object):
     """bench.py helper: compute() + log_likelihood() of the headline config with device-resident
-    inputs, sharded over the launched ranks."""
+    inputs, sharded over the launched ranks.  ``kernel(name, amplitude)`` builds the kernel
+    (bench.make_kernel); ``ops`` replaces the HIP tile kernels (launcher self-test only)."""
 
-    def __init__(self, n, nb, local_rank, make_inputs):
+    def __init__(self, n, nb, local_rank, make_inputs, kernel=None, kernel_name="expsquared", ops=None):
         import george_amd.kernels as K
         x, yerr, y = make_inputs(n)
-        kernel = float(np.var(y)) * K.ExpSquaredKernel(1.0)
-        self.ops = HipTileOps(local_rank, kernel)
+        self._amp = float(np.var(y))
+        self._mk = kernel if kernel is not None else (lambda name, amp: float(amp) * K.ExpSquaredKernel(1.0))
+        spec = self._mk(kernel_name, self._amp)
+        self.ops = ops if ops is not None else HipTileOps(local_rank, spec)
         self.n, self.nb = n, (nb or (1024 if n >= 24576 else 512))
         self.chol = BlockCyclicCholesky(self.ops, n, self.nb)
         self.chol.profile = True
@@ -833,6 +836,17 @@ class DistributedDenseJob(object):
         ypad[:n] = y
         self.y = self.ops.to_device(ypad)
         self.ops.sync()
+
+    def set_kernel(self, kernel_name):
+        """Another kernel on the same block-cyclic workspace (bench.py: configs[2] after the headline)."""
+        spec = self._mk(kernel_name, self._amp)
+        if hasattr(self.ops, "set_kernel"):
+            self.ops.set_kernel(spec)
+        else:
+            self.ops.kernel = spec
+
+    def chol_grid(self):
+        return self.chol.Pr, self.chol.Pc
 
     def step(self):
         self.chol.build(self.x, self.yerr)

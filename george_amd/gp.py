@@ -160,6 +160,7 @@ class GP(ModelSet):
     # -- the hot path -------------------------------------------------------------
     def compute(self, x, yerr=0.0, **kwargs):
         """Build and factorise K(x, x) + diag(yerr^2 + exp(white_noise))  (gp.py:303-337)."""
+        self._obj_cache = None           # a gradient cached by the fused objective belongs to the OLD (x, yerr)
         self._x = np.ascontiguousarray(self.parse_samples(x), dtype=np.float64)
         # scalar yerr broadcasts over the points, anything else must have one entry per point
         if np.ndim(yerr) == 0 or (np.size(yerr) == 1 and len(self._x) != 1):
@@ -328,6 +329,11 @@ class GP(ModelSet):
             return np.inf
         if self.computed or not self._fused_capable():
             return -self.log_likelihood(y, quiet=quiet)
+        # eager gradient only while the caller keeps asking for it: two value-only evaluations in a
+        # row (a gradient-free optimiser, MCMC) switch it off again
+        self._nll_since_grad = getattr(self, "_nll_since_grad", 0) + 1
+        if self._nll_since_grad > 2:
+            self._grad_seen = False
         want_grad = getattr(self, "_grad_seen", False)
         ll, g = self._objective(y, want_grad, quiet)
         self._obj_cache = (np.array(vector, dtype=np.float64), np.array(y, dtype=np.float64), g) if want_grad else None
@@ -335,6 +341,7 @@ class GP(ModelSet):
 
     def grad_nll(self, vector, y, quiet=True):
         self._grad_seen = True
+        self._nll_since_grad = 0
         self.set_parameter_vector(vector)
         if not np.isfinite(self.log_prior()):
             return np.zeros(len(vector))

@@ -53,13 +53,16 @@ class BasicSolver(object):
     # times inside an optimiser loop -- so native handles (and the N x N device buffers they own)
     # are recycled through a small per-configuration pool instead of being hipMalloc'ed each time.
     # A handle keeps every buffer it ever grew (the factor, and after grad / get_inverse / predict up
-    # to three more N x N work arrays: ~100 GB at N = 65536), so a handle is TRIMMED to its factor
-    # before it is parked, at most _POOL_MAX handles are parked per option set and at most
-    # _POOL_MAX_BYTES of factor storage in total (larger ones are freed outright);
+    # to three more N x N work arrays: ~100 GB at N = 65536).  It is parked AS IT IS while the pool
+    # stays under _POOL_MAX_BYTES of device memory in total (an optimiser iterate drops its solver
+    # and the next one picks the same handle up: freeing the work arrays in between meant two or
+    # three hipFree + hipMalloc of 8 N^2 bytes per iterate -- the fused objective ran 2x slower than
+    # the separate calls in round 2's driver run); above that budget it is trimmed to its factor,
+    # and above it still it is destroyed.  At most _POOL_MAX handles are parked per option set;
     # ``BasicSolver.release_pool()`` empties the pool, and it is emptied at interpreter exit.
     _POOL = {}
     _POOL_MAX = 2
-    _POOL_MAX_BYTES = 48 << 30
+    _POOL_MAX_BYTES = 112 << 30
     # ``pickle`` of a computed solver carries the factor (reference behaviour, tests/test_pickle.py:21-36)
     # up to this many points (8 GB of packed lower triangle at 46340); beyond it the state drops the
     # factor and the solver comes back un-computed, like the reference's own native solver does
@@ -85,17 +88,22 @@ class BasicSolver(object):
 
     @staticmethod
     def _pooled_bytes():
-        return sum(8 * int(N.lib.gh_chol_size(h)) ** 2 for free in BasicSolver._POOL.values() for h in free)
+        return sum(int(N.lib.gh_chol_device_bytes(h)) for free in BasicSolver._POOL.values() for h in free)
 
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
             try:
                 free = BasicSolver._POOL.setdefault(self._pool_key(), [])
-                mine = 8 * int(N.lib.gh_chol_size(h)) ** 2
-                if len(free) < BasicSolver._POOL_MAX and BasicSolver._pooled_bytes() + mine <= BasicSolver._POOL_MAX_BYTES:
+                room = BasicSolver._POOL_MAX_BYTES - BasicSolver._pooled_bytes()
+                if len(free) < BasicSolver._POOL_MAX and int(N.lib.gh_chol_device_bytes(h)) <= room:
+                    free.append(h)                     # as it is: the next iterate re-uses the work arrays too
+                elif len(free) < BasicSolver._POOL_MAX:
                     N.lib.gh_chol_trim(h)              # keep the factor-sized buffers, drop the work arrays
-                    free.append(h)
+                    if int(N.lib.gh_chol_device_bytes(h)) <= room:
+                        free.append(h)
+                    else:
+                        N.lib.gh_chol_destroy(h)
                 else:
                     N.lib.gh_chol_destroy(h)
             except Exception:

@@ -172,6 +172,7 @@ int  gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32
                      const double* yerr, double* logdet_out);
 int64_t gh_chol_info(const gh_chol* s);     /* 1-based index of the failing pivot after GH_ERR_NOT_PD, else 0 */
 int64_t gh_chol_size(const gh_chol* s);
+int64_t gh_chol_device_bytes(const gh_chol* s);  /* HBM bytes the handle holds right now (factor + work arrays) */
 int  gh_chol_solve(gh_chol* s, const double* b, int64_t nrhs, double* out);   /* b, out: (n, nrhs) row-major; may alias */
 int  gh_chol_dot_solve(gh_chol* s, const double* y, double* out);
 int  gh_chol_apply_sqrt(gh_chol* s, const double* r, int64_t nrows, double* out); /* r, out: (nrows, n) */

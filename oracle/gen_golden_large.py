@@ -12,6 +12,9 @@ strided sample of ``alpha = K^-1 y`` for
   C3      N=65536  1-D Matern32                        (BASELINE configs[2])
   C5      N=32768  3-D Matern52 + Constant             (BASELINE configs[4]): + predict mean/var at
                                                        64 of the 4096 test points, + gradient
+  C4      N=262144 1-D ExpSquared, HODLRSolver(tol=1e-10, min_size=100, seed=42)
+                                                       (BASELINE configs[3]): the reference's own
+                                                       hodlr.h build (oracle/_ref/_hodlr), one core
 
 so that the ``-m gpu`` tests can compare the HIP path with the reference at the sizes the claims
 are made on without running minutes of LAPACK on the GPU box.
@@ -145,6 +148,33 @@ def dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=False, t=None, 
     return out
 
 
+def hodlr_case(george, kernel, x, yerr, y, tol=1e-10, min_size=100, seed=42):
+    """HODLRSolver.compute + GP.log_likelihood (hodlr.py:33-47, gp.py:333-335,396) through the reference's
+    unmodified hodlr.h (hodlr.h:75-103 compute, :237-254 apply_inverse) as built by oracle/Makefile."""
+    H = ref_loader.load_hodlr()
+    if H is None:
+        raise SystemExit("oracle/_ref/_hodlr is not built (make -C oracle)")
+    n = len(x)
+    x2 = np.ascontiguousarray(x.reshape(n, -1))
+    t0 = time.time()
+    h = H()
+    h.compute(kernel, x2, np.sqrt(yerr ** 2 + TINY), min_size, tol, seed)      # gp.py:330
+    t_fac = time.time() - t0
+    logdet = float(h.log_determinant)
+    alpha = np.asarray(h.apply_inverse(y)).reshape(-1)
+    q = float(h.dot_solve(y))
+    ll = -0.5 * (n * np.log(2 * np.pi) + logdet) - 0.5 * q
+    nodes = np.array(h.nodes(), dtype=np.int64).reshape(-1, 4)        # (level, start, size, rank), construction order
+    lv = {}
+    for level, _, _, r in nodes:
+        lv[int(level)] = max(lv.get(int(level), 0), int(r))
+    return {"n": n, "logdet": logdet, "loglike": float(ll), "quad": q, "quad_from_alpha": float(np.dot(y, alpha)),
+            "alpha_stride": max(n // 64, 1), "alpha": [float(v) for v in alpha[::max(n // 64, 1)]],
+            "tol": tol, "min_size": min_size, "seed": seed, "seconds_factor": t_fac,
+            "rank_per_level": [lv[k] for k in sorted(lv)], "n_internal_nodes": int(len(nodes)),
+            "factorisation": "reference hodlr.h (unmodified) against oracle/mini_eigen, one core"}
+
+
 def main():
     george = ref_loader.load_reference()
     if george is None:
@@ -154,6 +184,14 @@ def main():
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for name in want:
         t0 = time.time()
+        if name == "C4":
+            x, yerr, y = zoo.bench_data(262144)
+            res[name] = hodlr_case(george, np.var(y) * K.ExpSquaredKernel(1.0), x, yerr, y)
+            res[name]["seconds_total"] = time.time() - t0
+            res[name]["generator"] = "oracle/gen_golden_large.py (oracle/_ref/_hodlr: reference hodlr.h + kernel tree)"
+            print(name, {k: v for k, v in res[name].items() if k != "alpha"}, flush=True)
+            _save(res)
+            continue
         if name == "C5":
             x, yerr, y = zoo.bench_data(32768, ndim=3)
             kernel = K.Matern52Kernel(0.5, ndim=3) + K.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)

@@ -160,7 +160,40 @@ private:
   RefNode* solver_;
 };
 
+// Test hooks for oracle/mini_eigen itself (tests/test_oracle_hodlr.py checks these two routines against
+// SciPy / NumPy on random matrices: a pivot-order slip in the stand-in would move every HODLR golden).
+static Eigen::MatrixXd to_eigen(py::array_t<double, py::array::c_style | py::array::forcecast> a) {
+  if (a.ndim() != 2) throw std::invalid_argument("2-D array expected");
+  Eigen::MatrixXd m(a.shape(0), a.shape(1));
+  for (Eigen::Index i = 0; i < m.rows(); ++i)
+    for (Eigen::Index j = 0; j < m.cols(); ++j) m(i, j) = a.data()[i * m.cols() + j];
+  return m;
+}
+static py::array_t<double> from_eigen(const Eigen::MatrixXd& m) {
+  py::array_t<double> out({size_t(m.rows()), size_t(m.cols())});
+  for (Eigen::Index i = 0; i < m.rows(); ++i)
+    for (Eigen::Index j = 0; j < m.cols(); ++j) out.mutable_data()[i * m.cols() + j] = m(i, j);
+  return out;
+}
+static py::tuple mini_eigen_ldlt(py::array_t<double, py::array::c_style | py::array::forcecast> a,
+                                 py::array_t<double, py::array::c_style | py::array::forcecast> b) {
+  Eigen::LDLT<Eigen::MatrixXd> f;                       // as hodlr.h:24,227,242 uses it
+  f.compute(to_eigen(a));
+  Eigen::VectorXd d = f.vectorD();
+  std::vector<double> dv(size_t(d.rows()));
+  for (Eigen::Index i = 0; i < d.rows(); ++i) dv[size_t(i)] = d(i);
+  return py::make_tuple(dv, from_eigen(f.solve(to_eigen(b))));
+}
+static py::tuple mini_eigen_fullpivlu(py::array_t<double, py::array::c_style | py::array::forcecast> a,
+                                      py::array_t<double, py::array::c_style | py::array::forcecast> b) {
+  Eigen::FullPivLU<Eigen::MatrixXd> f;                  // as hodlr.h:23,233,250 uses it
+  f.compute(to_eigen(a));
+  return py::make_tuple(from_eigen(f.matrixLU()), int(f.rank()), from_eigen(f.solve(to_eigen(b))));
+}
+
 PYBIND11_MODULE(_hodlr, m) {
+  m.def("_mini_eigen_ldlt", &mini_eigen_ldlt);
+  m.def("_mini_eigen_fullpivlu", &mini_eigen_fullpivlu);
   py::class_<Solver> solver(m, "HODLRSolver");
   solver.def(py::init());
   solver.def_property_readonly("computed", &Solver::get_computed);

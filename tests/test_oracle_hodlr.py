@@ -120,3 +120,117 @@ def test_reference_hodlr_python_class_runs_on_the_build():
     gh.compute(x, yerr)
     assert np.allclose(gb.log_likelihood(y), gh.log_likelihood(y))
     assert np.allclose(gb.predict(y, x[:50], return_cov=False), gh.predict(y, x[:50], return_cov=False))
+
+
+# ------------------------------------------------------------------ oracle/mini_eigen against independent implementations
+def _np_ldlt_diag_pivot(A):
+    """Independent restatement of Eigen::LDLT (Eigen/src/Cholesky/LDLT.h, `ldlt_inplace<Lower>::unblocked`):
+    the factorisation is LEFT-looking -- step k updates column k only -- so the pivot search over
+    `mat.diagonal().tail(size - k)` sees the ORIGINAL diagonal entries of the rows not yet eliminated,
+    not the Schur complement's; the transposition swaps positions k and p.  D then is the diagonal of
+    the un-pivoted L D L^T of P A P^T, taken here from LAPACK's Cholesky (d_k = L_kk^2 for SPD A)."""
+    A = np.array(A, dtype=np.float64)
+    n = len(A)
+    diag = np.diag(A).copy()
+    perm = np.arange(n)
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(diag[k:])))
+        diag[[k, p]] = diag[[p, k]]
+        perm[[k, p]] = perm[[p, k]]
+    L = np.linalg.cholesky(A[np.ix_(perm, perm)])
+    return np.diag(L) ** 2
+
+
+def _np_lu_complete_pivot(A):
+    """Independent restatement of Eigen::FullPivLU: largest remaining |entry| (first in column-major
+    order) as pivot; returns diag(U) in elimination order."""
+    A = np.array(A, dtype=np.float64)
+    n = min(A.shape)
+    u = np.zeros(n)
+    for k in range(n):
+        sub = np.abs(A[k:, k:])
+        j, i = np.unravel_index(int(np.argmax(sub.T)), sub.T.shape)          # column-major first maximum
+        A[[k, k + i]] = A[[k + i, k]]
+        A[:, [k, k + j]] = A[:, [k + j, k]]
+        u[k] = A[k, k]
+        if u[k] == 0.0:
+            break
+        A[k + 1:, k] /= u[k]
+        A[k + 1:, k + 1:] -= np.outer(A[k + 1:, k], A[k, k + 1:])
+    return u
+
+
+def _mini_eigen():
+    if ref_loader.load_hodlr() is None:
+        pytest.skip("oracle/_ref/_hodlr not built")
+    import sys
+    return sys.modules["_george_ref_hodlr"]
+
+
+def test_mini_eigen_ldlt_against_scipy_and_numpy():
+    """hodlr.h:24,227,242 factor every leaf with Eigen::LDLT.  The stand-in's LDLT on 50 random SPD
+    matrices (leaf-like: kernel matrix + noise, and generic Wishart): D against an independent NumPy
+    restatement of the pivoting rule, sum log|D| against slogdet, solve against LAPACK (scipy cho_solve)."""
+    import scipy.linalg
+    M = _mini_eigen()
+    rng = np.random.RandomState(11)
+    for trial in range(50):
+        n = int(rng.randint(2, 90))
+        if trial % 2:
+            x = np.sort(rng.uniform(0, 3, n))
+            A = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2) + np.diag(rng.uniform(1e-4, 1e-1, n))
+        else:
+            G = rng.randn(n, n + 3)
+            A = G @ G.T + 1e-3 * np.eye(n)
+        B = rng.randn(n, 3)
+        d, X = M._mini_eigen_ldlt(A, B)
+        d = np.array(d)
+        assert np.all(d > 0)
+        np.testing.assert_allclose(d, _np_ldlt_diag_pivot(A), rtol=1e-7 * max(1.0, np.linalg.cond(A) * 1e-9), atol=0)
+        assert abs(np.sum(np.log(np.abs(d))) - np.linalg.slogdet(A)[1]) <= 1e-9 * n + 1e-9 * abs(np.linalg.slogdet(A)[1])
+        Xref = scipy.linalg.cho_solve(scipy.linalg.cho_factor(A), B)
+        assert np.abs(np.asarray(X) - Xref).max() <= 1e-12 * np.linalg.cond(A) * max(np.abs(Xref).max(), 1.0)
+        # scipy.linalg.ldl (Bunch-Kaufman, another pivoting rule): same determinant of the block diagonal
+        _, Dbk, _ = scipy.linalg.ldl(A)
+        assert abs(np.linalg.slogdet(Dbk)[1] - np.sum(np.log(d))) <= 1e-9 * n + 1e-9 * abs(np.sum(np.log(d)))
+
+
+def test_mini_eigen_fullpivlu_against_scipy_and_numpy():
+    """hodlr.h:23,233,250 factor every Woodbury core S with Eigen::FullPivLU.  The stand-in on 50 random
+    matrices shaped like S = [[I, A], [B, I]], generic ones and rank-deficient ones: diag(U) against an
+    independent NumPy complete-pivoting LU, sum log|u_ii| against slogdet, solve against scipy lu_solve,
+    rank() against numpy.linalg.matrix_rank."""
+    import scipy.linalg
+    M = _mini_eigen()
+    rng = np.random.RandomState(12)
+    for trial in range(50):
+        r = int(rng.randint(1, 30))
+        n = 2 * r
+        kind = trial % 3
+        if kind == 0:                                     # Woodbury-core shape (hodlr.h:229-232)
+            A = np.eye(n)
+            A[:r, r:] = 0.3 * rng.randn(r, r)
+            A[r:, :r] = 0.3 * rng.randn(r, r)
+        elif kind == 1:
+            A = rng.randn(n, n)
+        else:                                             # rank-deficient: rank() and the zeroed tail of solve()
+            A = rng.randn(n, max(r // 2, 1)) @ rng.randn(max(r // 2, 1), n)
+        B = rng.randn(n, 2)
+        LU, rank, X = M._mini_eigen_fullpivlu(A, B)
+        LU, X = np.asarray(LU), np.asarray(X)
+        u = np.diag(LU)
+        assert abs(abs(u[0]) - np.abs(A).max()) == 0.0
+        if kind < 2:
+            np.testing.assert_allclose(u, _np_lu_complete_pivot(A), rtol=1e-9, atol=1e-12)
+            assert rank == n
+            assert abs(np.sum(np.log(np.abs(u))) - np.linalg.slogdet(A)[1]) <= 1e-9 * n
+            Xref = scipy.linalg.lu_solve(scipy.linalg.lu_factor(A), B)
+            assert np.abs(X - Xref).max() <= 1e-11 * np.linalg.cond(A) * max(np.abs(Xref).max(), 1.0)
+        else:
+            assert rank == np.linalg.matrix_rank(A)
+            np.testing.assert_allclose(u[:rank], _np_lu_complete_pivot(A)[:rank], rtol=1e-7, atol=1e-12)
+            # solve() uses the leading rank() pivots and zeroes the rest: a least-norm-like solution of the
+            # consistent system A x = A x0
+            x0 = rng.randn(n, 1)
+            _, _, Xc = M._mini_eigen_fullpivlu(A, A @ x0)
+            assert np.abs(A @ np.asarray(Xc) - A @ x0).max() <= 1e-9 * max(np.abs(A @ x0).max(), 1.0)
