@@ -185,18 +185,22 @@ class HipTileOps(object):
         self.N.check(self.N.lib.gh_dev_trsv_lower(l.data_ptr(), l.stride(0), dinv.data_ptr(), n, w.data_ptr(), z.data_ptr(),
                                                   self._trsv_scratch.data_ptr(), self._st()))
         # the chain's time-out flag sits behind the block flags and is cleared by the next call:
-        # fold it into an accumulator on the same stream, read back once per sweep (check_trsv)
+        # fold it into an accumulator on the same stream, read back once per sweep (trsv_failed, all-reduced with the sum)
         if getattr(self, "_trsv_fail", None) is None:
             self._trsv_fail = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
         self._trsv_fail += self._trsv_scratch[n // 128:n // 128 + 1]
 
-    def check_trsv(self):
-        """Raise if a chained solve gave up waiting (its z would be garbage): the kernel sets the flag
-        after a 2 s stall."""
-        f = getattr(self, "_trsv_fail", None)
-        if f is not None and int(f.item()) != 0:
-            f.zero_()
-            raise RuntimeError("george_amd HIP backend failure: forward solve: a workgroup waited more than 2 s for its predecessor")
+    def trsv_failed(self):
+        """Device counter (1 element, int32) of chained solves that gave up waiting since the last
+        clear_trsv_failed() -- their z would be garbage: the kernel sets the flag after a 2 s stall.
+        BlockCyclicCholesky.dot_solve all-reduces it together with its sum so that every rank raises."""
+        if getattr(self, "_trsv_fail", None) is None:
+            self._trsv_fail = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
+        return self._trsv_fail
+
+    def clear_trsv_failed(self):
+        if getattr(self, "_trsv_fail", None) is not None:
+            self._trsv_fail.zero_()
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -579,11 +583,18 @@ class BlockCyclicCholesky(object):
                     self._bcast(zk, self.grank(kr, kc), self.col_groups[kc])
                 lk = self.lcol[k]
                 zloc[lk * nb:(lk + 1) * nb].copy_(zk)
+        # the chained solve's time-out flag travels WITH the sum: a stalled tile on one rank must raise on
+        # every rank (a rank that raised alone would leave the others waiting in the next collective)
+        fail = ops.trsv_failed() if hasattr(ops, "trsv_failed") else None
+        both = self.torch.cat([acc, fail.to(acc.dtype)]) if fail is not None else acc
         if self.live and self.world > 1:
-            self.dist.all_reduce(acc)
-        if hasattr(ops, "check_trsv"):
-            ops.check_trsv()
-        return float(acc.item())
+            self.dist.all_reduce(both)
+        vals = both.tolist()
+        if fail is not None and vals[1] != 0.0:
+            ops.clear_trsv_failed()
+            raise RuntimeError("george_amd HIP backend failure: forward solve: a workgroup waited more than 2 s for its "
+                               "predecessor (on %d tile solves across the group)" % int(vals[1]))
+        return float(vals[0])
 
 
     # -- K^-1 B, L^-1 B, r @ L^T on the sharded factor ------------------------------------------------
@@ -715,7 +726,8 @@ class DistributedBasicSolver(object):
             return BlockCyclicCholesky(self._ops, n, self.nb, lookahead=self._lookahead)
         import torch
         dev = self._device if self._device is not None else torch.cuda.current_device()
-        key = (n, self.nb, world, rank, dev, self._lookahead, id(dist.group.WORLD) if live else 0)
+        ndim = getattr(self.kernel, "ndim", None)           # (a parked workspace's tile ops are bound to an input dimension)
+        key = (n, self.nb, world, rank, dev, self._lookahead, id(dist.group.WORLD) if live else 0, ndim)
         if getattr(self, "_chol", None) is not None and self._key == key:
             chol = self._chol                           # recompute on the same solver object
         else:

@@ -311,6 +311,71 @@ def test_fused_objective_matches_separate_calls(fit_mean, fit_wn):
     assert calls == [False, True, True], calls
 
 
+def test_fused_objective_iterates_do_not_reallocate():
+    """An optimiser loop drops its solver at every iterate (gp.py:327); the pooled native handle must
+    come back WITH its work arrays (round 2 trimmed it on every drop: two or three hipFree + hipMalloc
+    of 8 N^2 bytes per iterate made the fused call 2x slower than the separate calls).  Iterates 3-5 of
+    nll_and_grad at N = 8192 must cost no more than compute + dot_solve + grad (+10 %), and the
+    handle's device footprint must not move between them."""
+    import time
+    from george_amd import _native as Nat
+    x, yerr, y = zoo.bench_data(8192, ndim=3)
+    kernel = kernels.Matern52Kernel(0.5, ndim=3) + kernels.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)
+    gp = GP(kernel)
+    sep = []
+    for rep in range(3):
+        gp.kernel.dirty = True
+        t0 = time.perf_counter()
+        gp.compute(x, yerr); gp.log_likelihood(y); gp.grad_log_likelihood(y)
+        sep.append(time.perf_counter() - t0)
+    p = gp.get_parameter_vector()
+    fused, foot = [], []
+    for it in range(5):
+        t0 = time.perf_counter()
+        v, g = gp.nll_and_grad(p + 1e-3 * (it + 1), y)
+        fused.append(time.perf_counter() - t0)
+        foot.append(int(Nat.lib.gh_chol_device_bytes(gp.solver._handle)))
+    assert len(set(foot[2:])) == 1, foot
+    assert sorted(fused[2:])[1] <= 1.10 * min(sep[1:]), (fused, sep)
+    # and the values are those of the separate calls at the last point
+    ref = GP(kernel)
+    ref.compute(x, yerr)
+    ref.set_parameter_vector(p + 5e-3)
+    assert abs(v + ref.log_likelihood(y)) <= 1e-12 * abs(v)
+    np.testing.assert_allclose(-g, ref.grad_log_likelihood(y), rtol=1e-10, atol=1e-10)
+
+
+def test_gradient_cache_is_dropped_by_compute():
+    """the gradient cached by the fused objective is keyed on (vector, y); compute() with
+    other inputs at the same vector must not serve the old one."""
+    x, yerr, y = zoo.bench_data(600)
+    gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+    gp.compute(x, yerr)
+    p = gp.get_parameter_vector() + 0.01
+    gp.grad_nll(p, y)
+    v, g_old = gp.nll_and_grad(p + 0.01, y)
+    gp.compute(x, 3.0 * yerr)                                              # same vector, other error bars
+    g_new = gp.grad_nll(p + 0.01, y)
+    ref = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+    ref.compute(x, 3.0 * yerr)
+    ref.set_parameter_vector(p + 0.01)
+    np.testing.assert_allclose(g_new, -ref.grad_log_likelihood(y), rtol=1e-10, atol=1e-10)
+    assert not np.allclose(g_new, g_old, rtol=1e-3)
+    # value-only evaluations switch the eager gradient off again (gradient-free optimisers, MCMC)
+    calls = []
+    real = BasicSolver.objective
+    def spy(self, *a, **k):
+        calls.append(k.get("want_grad", True))
+        return real(self, *a, **k)
+    BasicSolver.objective = spy
+    try:
+        for step in range(4):
+            gp.nll(p + 0.1 + 0.01 * step, y)
+    finally:
+        BasicSolver.objective = real
+    assert calls == [True, True, False, False], calls
+
+
 def test_objective_quiet_and_errors():
     k = kernels.CosineKernel(log_period=0.0)                               # singular without noise
     x = np.linspace(0, 3, 200)
@@ -336,7 +401,7 @@ def test_objective_quiet_and_errors():
         gp2.grad_log_likelihood(np.zeros((200, 2)), quiet=True)
 
 
-def test_handle_pool_is_trimmed_and_releasable():
+def test_handle_pool_is_budgeted_and_releasable():
     x, yerr, y = zoo.bench_data(1024)
     gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
     gp.compute(x, yerr)
@@ -351,6 +416,33 @@ def test_handle_pool_is_trimmed_and_releasable():
     gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
     gp.compute(x, yerr)
     assert gp.log_likelihood(y) == ll
+    # the byte budget: a handle is parked as it is while it fits, trimmed to its factor when only that
+    # fits, destroyed otherwise
+    from george_amd import _native as Nat
+    parked = lambda: [h for v in BasicSolver._POOL.values() for h in v]
+    old = BasicSolver._POOL_MAX_BYTES
+    try:
+        gp.grad_log_likelihood(y)
+        full = int(Nat.lib.gh_chol_device_bytes(gp.solver._handle))
+        assert full > 20 << 20                                             # factor 8 MB + two N x N work arrays
+        del gp
+        gc.collect()
+        assert len(parked()) == 1 and int(Nat.lib.gh_chol_device_bytes(parked()[0])) == full       # untrimmed
+        gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+        gp.compute(x, yerr)                                                # takes the parked handle
+        assert len(parked()) == 0
+        BasicSolver._POOL_MAX_BYTES = 12 << 20
+        del gp
+        gc.collect()
+        assert len(parked()) == 1 and int(Nat.lib.gh_chol_device_bytes(parked()[0])) <= 12 << 20   # trimmed
+        gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+        gp.compute(x, yerr)
+        BasicSolver._POOL_MAX_BYTES = 1 << 20
+        del gp
+        gc.collect()
+        assert len(parked()) == 0                                          # destroyed
+    finally:
+        BasicSolver._POOL_MAX_BYTES = old
 
 
 def test_fused_panel_arm_agrees():
