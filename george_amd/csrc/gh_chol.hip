@@ -474,15 +474,9 @@ struct gh_chol {
   bool shared_streams = false;           // st, st2, st3, st4, st_mask belong to the process (gh_shared_streams): not destroyed here
   hipStream_t st4 = nullptr;             // third panel stream: in-panel rows >= j+2 (everything off the potf2 chain)
   hipEvent_t ev_diag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_p1[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_b[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;
-  hipEvent_t ev_ub = nullptr;                  // deep look-ahead: rows below the next panel's diagonal block updated
   std::vector<hipEvent_t> ev_p, ev_w, ev_nf;   // deep look-ahead: panel j factored / W(j) done / U(j, j+2) done
   hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
-  hipStream_t st_crit = nullptr;         // exclusive mode: potf2 chain confined to the CUs st_mask leaves out
-  hipStream_t st_sa = nullptr;           // exclusive mode: rows-below TRSM on the SAME CUs as the trailing update
-  hipStream_t st_sb = nullptr;           // exclusive mode + inner split: in-panel rows >= j+2, same CUs again
 
 
   int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
@@ -493,7 +487,7 @@ struct gh_chol {
   bool computed = false;
   int64_t info = 0;
   double logdet = 0.0;
-  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain, pflags;
+  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
   long long* d_info = nullptr;
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
@@ -515,17 +509,11 @@ struct gh_chol {
     if (ev_xfer) (void)hipEventDestroy(ev_xfer);
     if (ev_aux) (void)hipEventDestroy(ev_aux);
     if (ev_aux2) (void)hipEventDestroy(ev_aux2);
-    if (ev_ub) (void)hipEventDestroy(ev_ub);
     for (auto* v : {&ev_p, &ev_w, &ev_nf}) for (auto e : *v) (void)hipEventDestroy(e);
     for (auto& e : ev_diag) if (e) (void)hipEventDestroy(e);
-    for (auto& e : ev_p1) if (e) (void)hipEventDestroy(e);
-    for (auto& e : ev_b) if (e) (void)hipEventDestroy(e);
     if (st4 && !shared_streams) (void)hipStreamDestroy(st4);
     if (st3 && !shared_streams) (void)hipStreamDestroy(st3);
     if (st_mask && !shared_streams) (void)hipStreamDestroy(st_mask);
-    if (st_crit) (void)hipStreamDestroy(st_crit);
-    if (st_sa) (void)hipStreamDestroy(st_sa);
-    if (st_sb) (void)hipStreamDestroy(st_sb);
 
 
     if (st2 && !shared_streams) (void)hipStreamDestroy(st2);
@@ -541,19 +529,12 @@ struct SharedStreams { hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr}; 
 std::mutex g_ss_mu;
 std::map<int, SharedStreams> g_ss;
 }
-static void* ss_pad_word() { static void* p = nullptr; if (!p && hipMalloc(&p, 64) != hipSuccess) p = nullptr; return p; }
 bool gh_shared_streams(int device, hipStream_t q[4]) {
   std::lock_guard<std::mutex> lk(g_ss_mu);
   SharedStreams& ss = g_ss[device];
   if (!ss.made) {
     ss.made = true;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (const char* e = getenv("GEORGE_AMD_STREAM_PAD")) {         // experiment: shift the hardware-queue binding of what follows
-      for (int i = 0; i < atoi(e); ++i) {
-        hipStream_t d = nullptr;
-        if (hipStreamCreateWithFlags(&d, hipStreamNonBlocking) == hipSuccess) { (void)hipMemsetAsync(ss_pad_word(), 0, 4, d); (void)hipStreamSynchronize(d); }
-      }
-    }
     if (hipStreamCreate(&ss.q[0]) != hipSuccess) { ss.q[0] = nullptr; (void)hipGetLastError(); }
     int lo = 0, hi = 0;                    // numerically lowest value = highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -619,8 +600,6 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
         if (s->shared_streams) s->st4 = shq[3];
         bool ok4 = (s->shared_streams ? s->st4 != nullptr : hipStreamCreateWithPriority(&s->st4, hipStreamNonBlocking, hi) == hipSuccess) &&
                    hipEventCreateWithFlags(&s->ev_aux2, hipEventDisableTiming) == hipSuccess;
-        for (auto& e : s->ev_p1) ok4 = ok4 && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        for (auto& e : s->ev_b) ok4 = ok4 && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok4) { (void)hipGetLastError(); if (s->st4 && !s->shared_streams) (void)hipStreamDestroy(s->st4); s->st4 = nullptr; }
       }
     }
@@ -669,7 +648,7 @@ extern "C" int64_t gh_chol_device_bytes(const gh_chol* s) {
   if (!s) return 0;
   size_t tot = 0;
   for (const GhBuf* b : {&s->A, &s->dinv, &s->x, &s->yerr, &s->v0, &s->v1, &s->v2, &s->scal, &s->rhs, &s->work, &s->work2,
-                         &s->scratch, &s->chain, &s->pflags}) tot += b->p ? b->bytes : 0;
+                         &s->scratch, &s->chain}) tot += b->p ? b->bytes : 0;
   return (int64_t)tot;
 }
 extern "C" int gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out) {
@@ -776,113 +755,20 @@ static int64_t panel_width(const gh_chol* s) {
   return 1024;
 }
 
-// The panel with ONLY the potf2 chain on the critical stream.  Step j of the 128-column blocks:
-//   st  (critical): potf2(j) -> row block j+1 alone: P1 = A[j+1, j] L_jj^-T, A[j+1, j+1] -= P1 P1^T
-//                   -> potf2(j+1) ...  (two one-tile launches between consecutive potf2 calls)
-//   sb  (st4)     : the in-panel rows >= j+2:  P2 = A[j+2.., j] L_jj^-T  and
-//                   A[j+2.., j+1..] -= P2 [P1; P2]^T   (full rectangle: the few strictly-upper tiles it
-//                   also writes are never read), beside potf2(j+1)
-//   sa  (st3)     : the rows BELOW the panel, column block j (as before)
-// Dependencies: sb's update needs P1 (ev_p1[j]); the critical TRSM of row block j+2 at step j+1
-// needs sb's update of step j (ev_b[j]); sa needs L[j, 0..j) final, which potf2(j)'s event covers
-// (the critical stream has waited for every ev_b before it).  With the whole TRSM + update of the
-// remaining panel rows on the critical stream (the previous arm, GEORGE_AMD_NO_PANEL_INNER_SPLIT)
-// a chain link cost potf2 + 2 launches of up to 84 workgroups; now potf2 + 2 launches of 2.
-static int panel_step_split(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
-  double* A = s->A.d();
-  const int64_t np = s->np, ld = np;
-  double* dinv = s->dinv.d() + (k0 / T) * T * T;
-  const int64_t m = np - (k0 + nb);
-  static const bool side_prio = getenv("GEORGE_AMD_PANEL_SIDE_PRIO") != nullptr;   // side streams: unmasked high priority
-  const bool excl = s->st_crit && st == s->st_crit && !side_prio;
-  hipStream_t sa = excl ? s->st_sa : s->st3, sb = excl ? s->st_sb : s->st4;
-  double* Ak = blk(A, ld, k0, k0);
-  double* B = blk(A, ld, k0 + nb, k0);
-  GH_HIP(hipEventRecord(s->ev_aux, st));
-  if (m > 0) GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
-  GH_HIP(hipStreamWaitEvent(sb, s->ev_aux, 0));
-  for (int64_t j0 = 0; j0 < nb; j0 += T) {
-    const int j = (int)(j0 / T);
-    double* dj = dinv + j * T * T;
-    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
-    GH_HIP(hipEventRecord(s->ev_diag[j], st));
-    if (m > 0) {
-      GH_HIP(hipStreamWaitEvent(sa, s->ev_diag[j], 0));
-      double* Xj = B + j0;
-      if (j0 > 0) GH_CHECK(gemm_nt(sa, Xj, ld, B, ld, Ak + j0 * ld, ld, m, T, j0, -1.0, 1.0, false));
-      GH_CHECK(gemm_nt(sa, Xj, ld, Xj, ld, dj, T, m, T, T, 1.0, 0.0, false));
-    }
-    const int64_t rem = nb - (j0 + T);
-    if (rem <= 0) break;
-    if (j > 0) GH_HIP(hipStreamWaitEvent(st, s->ev_b[j - 1], 0));         // A[j+1, j] carries step j-1's update
-    double* P1 = blk(Ak, ld, j0 + T, j0);
-    GH_CHECK(gemm_nt(st, P1, ld, P1, ld, dj, T, T, T, T, 1.0, 0.0, false));
-    GH_HIP(hipEventRecord(s->ev_p1[j], st));
-    GH_CHECK(gemm_nt(st, blk(Ak, ld, j0 + T, j0 + T), ld, P1, ld, P1, ld, T, T, T, -1.0, 1.0, true));
-    const int64_t rem2 = rem - T;
-    if (rem2 > 0) {
-      GH_HIP(hipStreamWaitEvent(sb, s->ev_diag[j], 0));
-      double* P2 = blk(Ak, ld, j0 + 2 * T, j0);
-      GH_CHECK(gemm_nt(sb, P2, ld, P2, ld, dj, T, rem2, T, T, 1.0, 0.0, false));
-      GH_HIP(hipStreamWaitEvent(sb, s->ev_p1[j], 0));
-      GH_CHECK(gemm_nt(sb, blk(Ak, ld, j0 + 2 * T, j0 + T), ld, P2, ld, P1, ld, rem2, rem, T, -1.0, 1.0, false));
-    }
-    GH_HIP(hipEventRecord(s->ev_b[j], sb));
-  }
-  if (m > 0) {
-    GH_HIP(hipEventRecord(s->ev_aux, sa));
-    GH_HIP(hipStreamWaitEvent(st, s->ev_aux, 0));
-  }
-  GH_HIP(hipEventRecord(s->ev_aux2, sb));
-  GH_HIP(hipStreamWaitEvent(st, s->ev_aux2, 0));
-  return GH_OK;
-}
-
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
-// gh_gemm.hip: the whole panel as two persistent flag-driven launches
-int gh_launch_panel_fused(double* A, int64_t ld, int64_t np, int64_t k0, int64_t nb, double* dinv, long long* info,
-                          unsigned* flags, hipStream_t sc, hipStream_t si, hipStream_t sw);
-
-// rows_ready (optional): the rows BELOW the nb x nb diagonal block are up to date only once this event
-// has fired (deep look-ahead updates them on another stream); the diagonal block itself is ready.
-static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEvent_t rows_ready = nullptr) {
+static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   double* A = s->A.d();
   const int64_t np = s->np, ld = np;
   double* dinv = s->dinv.d() + (k0 / T) * T * T;
   const int64_t m = np - (k0 + nb);
   static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
-  static const bool no_inner0 = getenv("GEORGE_AMD_NO_PANEL_INNER_SPLIT") != nullptr;
-  const bool on_panel_stream = (st == s->st2) || (s->st_crit && st == s->st_crit);
-  static const bool inner = getenv("GEORGE_AMD_PANEL_INNER_SPLIT") != nullptr;     // measured slower (cross-stream waits): off
-  (void)no_inner0;
-  if (inner && s->st4 && on_panel_stream && (st == s->st2 || s->st_sb) && nb / T <= 8 && nb > T && !no_split && !use_simple_potf2())
-    return panel_step_split(s, st, k0, nb);
-  // A/B arm GEORGE_AMD_PANEL_FUSED: the whole panel as two persistent flag-driven launches (gh_gemm.hip,
-  // panel_server_kernel / panel_worker_kernel).  Correct (bit-level agreement with the launch chain) but
-  // not faster: 1.32 vs 1.11 ms at N = 1024, 37.2 vs 35.1 ms at N = 16384 -- between two potf2 calls the
-  // two 128^3 products of ONE workgroup (30 us) and two release/acquire hand-overs replace two launches
-  // of 2-112 workgroups (27 us + gaps), and potf2 itself (80 of the ~120 us link) is unchanged.
-  static const int fused = getenv("GEORGE_AMD_PANEL_FUSED") ? atoi(getenv("GEORGE_AMD_PANEL_FUSED")) : 0;
-  if (fused && s->st3 && on_panel_stream && nb / T <= 8 && !use_simple_potf2() && np - k0 <= 24576) {
-    // server (potf2 chain) on the chain stream, workers (every row block of the column strip) on the side stream
-    GH_CHECK(s->pflags.ensure(64 * sizeof(unsigned)));
-    GH_HIP(hipMemsetAsync(s->pflags.p, 0, 64 * sizeof(unsigned), st));
-    GH_HIP(hipEventRecord(s->ev_aux, st));
-    GH_HIP(hipStreamWaitEvent(s->st3, s->ev_aux, 0));
-    if (rows_ready) GH_HIP(hipStreamWaitEvent(s->st3, rows_ready, 0));
-    // (Tried: server and in-panel workers on streams masked to the CUs the trailing update leaves out, so
-    //  that potf2 never shares a CU -- every second compute() on a handle then failed with a non-positive
-    //  pivot in the second panel, with or without host synchronisations at the panel's end and with an
-    //  agent acquire at the top of both kernels; cause not found.  Not kept.)
-    GH_CHECK(gh_launch_panel_fused(A, ld, np, k0, nb, dinv, s->d_info, (unsigned*)s->pflags.p, st, s->st3, s->st3));
-    GH_HIP(hipEventRecord(s->ev_aux, s->st3));
-    GH_HIP(hipStreamWaitEvent(st, s->ev_aux, 0));
-    return GH_OK;
-  }
+  const bool on_panel_stream = (st == s->st2);
+  // (Retired arms, all measured and slower, sources under scripts/dev/arms/: only row block j+1 on the chain and the
+  //  other in-panel rows on a third stream; the chain on CUs of its own; only the potf2 launches on reserved CUs; the
+  //  whole panel as two persistent flag-driven launches.  DESIGN.md section 4, "Where N < 24k stands".)
   if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
     if (m > 0) {
-      if (rows_ready) GH_HIP(hipStreamWaitEvent(st, rows_ready, 0));
       GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
     }
     return GH_OK;
@@ -890,24 +776,15 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEve
   // Look-ahead panels: the potf2 chain of the diagonal block stays on `st`; the TRSM of the rows
   // below runs on a second panel stream, column block j as soon as L_jj^-1 exists, so that only
   // the last block's TRSM is left when the chain ends (instead of all nb/128 of them).
-  static const bool side_masked = getenv("GEORGE_AMD_PANEL_SIDE_MASKED") != nullptr;   // A/B: rows-below TRSM on the SYRK's CUs, normal priority
-  hipStream_t sa = (s->st_crit && st == s->st_crit && side_masked) ? s->st_sa : s->st3;
+  hipStream_t sa = s->st3;
   double* Ak = blk(A, ld, k0, k0);
   double* B = blk(A, ld, k0 + nb, k0);
   GH_HIP(hipEventRecord(s->ev_aux, st));
   GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
-  if (rows_ready) GH_HIP(hipStreamWaitEvent(sa, rows_ready, 0));
-  // A/B arm GEORGE_AMD_POTF2_EXCL: ONLY the potf2 launches go to the stream masked to the CUs the
-  // trailing update leaves out (a potf2 workgroup beside SYRK wavefronts takes 130-150 us instead of
-  // 80); the GEMMs of the chain stay where they are.  Costs two cross-stream hand-overs per 128 columns.
-  static const bool potf2_excl = getenv("GEORGE_AMD_POTF2_EXCL") != nullptr;
-  hipStream_t sq = (potf2_excl && s->st_crit && st != s->st_crit) ? s->st_crit : st;
-  if (sq != st) GH_HIP(hipStreamWaitEvent(sq, s->ev_aux, 0));
   for (int64_t j0 = 0; j0 < nb; j0 += T) {
     double* dj = dinv + (j0 / T) * T * T;
-    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, sq));
-    GH_HIP(hipEventRecord(s->ev_diag[j0 / T], sq));
-    if (sq != st) GH_HIP(hipStreamWaitEvent(st, s->ev_diag[j0 / T], 0));
+    GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
+    GH_HIP(hipEventRecord(s->ev_diag[j0 / T], st));
     GH_HIP(hipStreamWaitEvent(sa, s->ev_diag[j0 / T], 0));
     double* Xj = B + j0;
     if (j0 > 0) GH_CHECK(gemm_nt(sa, Xj, ld, B, ld, Ak + j0 * ld, ld, m, T, j0, -1.0, 1.0, false));
@@ -917,7 +794,6 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, hipEve
       double* P = blk(Ak, ld, j0 + T, j0);
       GH_CHECK(gemm_nt(st, P, ld, P, ld, dj, T, rem, T, T, 1.0, 0.0, false));
       GH_CHECK(gemm_nt(st, blk(Ak, ld, j0 + T, j0 + T), ld, P, ld, P, ld, rem, rem, T, -1.0, 1.0, true));
-      if (sq != st) { GH_HIP(hipEventRecord(s->ev_p1[j0 / T], st)); GH_HIP(hipStreamWaitEvent(sq, s->ev_p1[j0 / T], 0)); }
     }
   }
   GH_HIP(hipEventRecord(s->ev_aux, sa));
@@ -950,9 +826,6 @@ static hipStream_t trailing_stream(gh_chol* s) {
   if (want <= 0 || want >= 128) return s->st;
   if (s->mask_reserved != want) {
     if (s->st_mask) { (void)hipStreamSynchronize(s->st_mask); if (!s->shared_streams) (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr; }
-    if (s->st_crit) { (void)hipStreamSynchronize(s->st_crit); (void)hipStreamDestroy(s->st_crit); s->st_crit = nullptr; }
-    if (s->st_sa) { (void)hipStreamSynchronize(s->st_sa); (void)hipStreamDestroy(s->st_sa); s->st_sa = nullptr; }
-    if (s->st_sb) { (void)hipStreamSynchronize(s->st_sb); (void)hipStreamDestroy(s->st_sb); s->st_sb = nullptr; }
     s->mask_reserved = want;                                       // (a failed creation is not retried)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->opts.device) == hipSuccess && prop.multiProcessorCount > 2 * want) {
@@ -961,95 +834,12 @@ static hipStream_t trailing_stream(gh_chol* s) {
       for (int c = want; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
       if (s->shared_streams) s->st_mask = gh_shared_masked_stream(s->opts.device, want);
       else if (hipExtStreamCreateWithCUMask(&s->st_mask, words, mask.data()) != hipSuccess) { s->st_mask = nullptr; (void)hipGetLastError(); }
-      // Exclusive mode (GEORGE_AMD_PANEL_EXCLUSIVE): the potf2 chain gets the reserved CUs to ITSELF
-      // (a stream masked to exactly those), and the rows-below TRSM -- throughput work -- joins the
-      // trailing update on the others; without it the high-priority panel streams are unmasked and
-      // their workgroups may still land beside SYRK wavefronts.
-      static const bool exclusive = (getenv("GEORGE_AMD_PANEL_EXCLUSIVE") && atoi(getenv("GEORGE_AMD_PANEL_EXCLUSIVE")) != 0) ||
-                                    getenv("GEORGE_AMD_POTF2_EXCL") != nullptr;
-      if (s->st_mask && exclusive && s->st3) {
-        std::vector<uint32_t> inv(words, 0u);
-        for (int c = 0; c < want; ++c) inv[c / 32] |= (1u << (c % 32));
-        if (hipExtStreamCreateWithCUMask(&s->st_crit, words, inv.data()) != hipSuccess) { s->st_crit = nullptr; (void)hipGetLastError(); }
-        if (s->st_crit && hipExtStreamCreateWithCUMask(&s->st_sa, words, mask.data()) != hipSuccess) {
-          (void)hipGetLastError(); (void)hipStreamDestroy(s->st_crit); s->st_crit = nullptr; s->st_sa = nullptr;
-        }
-        if (s->st_crit && s->st4 && hipExtStreamCreateWithCUMask(&s->st_sb, words, mask.data()) != hipSuccess) { s->st_sb = nullptr; (void)hipGetLastError(); }
-
-
-      }
     }
     if (s->st_mask && !s->ev_xfer && hipEventCreateWithFlags(&s->ev_xfer, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError(); if (!s->shared_streams) (void)hipStreamDestroy(s->st_mask); s->st_mask = nullptr;
     }
   }
   return s->st_mask ? s->st_mask : s->st;
-}
-
-static int factor_lookahead(gh_chol* s) {
-  hipStream_t sm = trailing_stream(s);
-  hipStream_t sp = (sm != s->st && s->st_crit) ? s->st_crit : s->st2;
-  if (sm != s->st) {                                               // everything queued so far (the build) first
-    GH_HIP(hipEventRecord(s->ev_xfer, s->st));
-    GH_HIP(hipStreamWaitEvent(sm, s->ev_xfer, 0));
-  }
-  double* A = s->A.d();
-  const int64_t np = s->np, ld = np, NB = panel_width(s);
-  const bool prof = s->opts.profile != 0;
-  auto rec = [&](hipEvent_t e, hipStream_t st) -> int { GH_HIP(hipEventRecord(e, st)); return GH_OK; };
-  // panel 0
-  {
-    const int64_t nb0 = std::min<int64_t>(NB, np);
-    GH_HIP(hipEventRecord(s->ev_sync[0], sm));
-    GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));            // the matrix build (on sm) is complete
-    const long ep = prof ? s->next_ev() : -1;
-    if (ep >= 0) { GH_CHECK(rec(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
-    GH_CHECK(panel_step(s, sp, 0, nb0));
-    if (ep >= 0) GH_CHECK(rec(s->ev_pool[ep].b, sp));
-    GH_HIP(hipEventRecord(s->ev_sync[1], sp));
-  }
-  int flip = 1;                                                   // ev_sync[flip] = "panel k is factored"
-  for (int64_t k0 = 0; k0 < np; k0 += NB) {
-    const int64_t nb = std::min<int64_t>(NB, np - k0);
-    const int64_t k1 = k0 + nb;
-    GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[flip], 0));          // panel k done
-    if (k1 >= np) break;
-    const int64_t nb1 = std::min<int64_t>(NB, np - k1);
-    const int64_t k2 = k1 + nb1;
-    const double* P1 = blk(A, ld, k1, k0);                        // panel k rows [k1, np)
-    // (a) bring block column k+1 up to date, diagonal block and the rows below in ONE launch (the
-    //     strictly-upper tiles of the diagonal block are computed too: nobody reads them, and a
-    //     separate 10-36 tile `lower` launch costs more than those few tiles)
-    GH_CHECK(gemm_nt(sm, blk(A, ld, k1, k1), ld, P1, ld, P1, ld, np - k1, nb1, nb, -1.0, 1.0, false));
-    const int nxt = 3 - flip;                                     // alternate ev_sync[1] / ev_sync[2]
-    GH_HIP(hipEventRecord(s->ev_sync[0], sm));
-    GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
-    {
-      const long ep = prof ? s->next_ev() : -1;
-      if (ep >= 0) { GH_CHECK(rec(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
-      GH_CHECK(panel_step(s, sp, k1, nb1));
-      if (ep >= 0) GH_CHECK(rec(s->ev_pool[ep].b, sp));
-      GH_HIP(hipEventRecord(s->ev_sync[nxt], sp));
-    }
-    // (b) the rest of the trailing matrix, concurrently with panel k+1
-    const int64_t m2 = np - k2;
-    if (m2 > 0) {
-      const long et = prof ? s->next_ev() : -1;
-      if (et >= 0) { GH_CHECK(rec(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); }
-      const double* P2 = blk(A, ld, k2, k0);
-      GH_CHECK(gemm_nt(sm, blk(A, ld, k2, k2), ld, P2, ld, P2, ld, m2, m2, nb, -1.0, 1.0, true));
-      if (et >= 0) GH_CHECK(rec(s->ev_pool[et].b, sm));
-      const double tiles = (double)(m2 / T) * (m2 / T + 1) / 2.0;
-      s->prof.trailing_flops += tiles * 2.0 * T * T * (double)nb;
-      s->prof.n_trailing += 1;
-    }
-    flip = nxt;
-  }
-  if (sm != s->st) {                                               // hand back to the handle's stream
-    GH_HIP(hipEventRecord(s->ev_xfer, sm));
-    GH_HIP(hipStreamWaitEvent(s->st, s->ev_xfer, 0));
-  }
-  return GH_OK;
 }
 
 // Look-ahead of depth d.  After panel j is factored, its trailing update is issued per block column
@@ -1072,15 +862,12 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   // eight queues are in use -- null stream + this handle's + the application's; scripts/dev/queue_pattern.py.)
   static const bool own_near = getenv("GEORGE_AMD_NEAR_STREAM") != nullptr;        // A/B: the fourth stream also at depth 1
   hipStream_t sm = trailing_stream(s), sn = (depth == 1 && !own_near && s->st3) ? s->st3 : s->st4;
-  // the potf2 chain on CUs of its own where the trailing update leaves some out (small matrices)
-  hipStream_t sp = (sm != s->st && s->st_crit) ? s->st_crit : s->st2;
+  hipStream_t sp = s->st2;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);
   const int P = (int)((np + NB - 1) / NB);
-  // (measured at N = 16384, depth 1: whole block column on the chain 34.8 ms; diagonal block on the chain +
-  //  rows below on the near stream 35.6; the same with the chain on CUs of its own 48.5 -- the in-panel
-  //  GEMMs crawl on 32 CUs; all three kept selectable)
-  static const bool no_usplit = getenv("GEORGE_AMD_BCOL_SPLIT") == nullptr;
+  // (measured at N = 16384, depth 1: whole block column on the chain 34.8 ms; diagonal block on the chain + rows
+  //  below on the near stream 35.6; the same with the chain on CUs of its own 48.5 -- retired, scripts/dev/arms/)
   const bool prof = s->opts.profile != 0;
   while ((int)s->ev_p.size() < P) {
     hipEvent_t e[3];
@@ -1089,8 +876,6 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   }
   auto c0 = [&](int c) { return (int64_t)c * NB; };
   auto nbc = [&](int c) { return std::min<int64_t>(NB, np - c0(c)); };
-  bool rows_split = false;
-  if (!s->ev_ub) GH_HIP(hipEventCreateWithFlags(&s->ev_ub, hipEventDisableTiming));
   auto narrow = [&](hipStream_t st, int j, int c) -> int {         // U(j, c)
     const double* Pj = blk(A, ld, c0(c), c0(j));
     const long eu = prof ? s->next_ev() : -1;
@@ -1113,30 +898,16 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     {
       const long ep = prof ? s->next_ev() : -1;
       if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
-      GH_CHECK(panel_step(s, sp, c0(j), nbc(j), (j >= 1 && rows_split) ? s->ev_ub : nullptr));
+      GH_CHECK(panel_step(s, sp, c0(j), nbc(j)));
       if (ep >= 0) GH_HIP(hipEventRecord(s->ev_pool[ep].b, sp));
       GH_HIP(hipEventRecord(s->ev_p[j], sp));
     }
     if (j + 1 >= P) break;
-    // ---- U(j, j+1): only its diagonal block (nb x nb, lower tiles) is on the chain -- that is all the
-    // potf2 chain of panel j+1 needs; the rows below it go to the near stream and are awaited by the
-    // rows-below TRSM of panel j+1 (ev_ub).  As one launch on the chain it was 5.7 of the chain's 28 ms
-    // at N = 16384.
+    // ---- U(j, j+1): the whole block column on the chain stream (its diagonal block is what the potf2 chain of
+    // panel j+1 needs, the rows below it what that panel's rows-below TRSM needs)
     const hipEvent_t prev = (j >= 1) ? (depth >= 2 ? s->ev_nf[j - 1] : s->ev_w[j - 1]) : nullptr;
     if (prev) GH_HIP(hipStreamWaitEvent(sp, prev, 0));
-    rows_split = !no_usplit && np - c0(j + 1) > nbc(j + 1);
-    if (rows_split) {
-      const int64_t k1 = c0(j + 1), nb1 = nbc(j + 1);
-      const double* Pd = blk(A, ld, k1, c0(j));
-      GH_CHECK(gemm_nt(sp, blk(A, ld, k1, k1), ld, Pd, ld, Pd, ld, nb1, nb1, nbc(j), -1.0, 1.0, true));
-      GH_HIP(hipStreamWaitEvent(sn, s->ev_p[j], 0));
-      if (prev) GH_HIP(hipStreamWaitEvent(sn, prev, 0));
-      const double* Pb = blk(A, ld, k1 + nb1, c0(j));
-      GH_CHECK(gemm_nt(sn, blk(A, ld, k1 + nb1, k1), ld, Pb, ld, Pd, ld, np - (k1 + nb1), nb1, nbc(j), -1.0, 1.0, false));
-      GH_HIP(hipEventRecord(s->ev_ub, sn));
-    } else {
-      GH_CHECK(narrow(sp, j, j + 1));
-    }
+    GH_CHECK(narrow(sp, j, j + 1));
     // ---- U(j, j+2 .. j+d) on the near stream
     const int last_near = std::min(j + depth, P - 1);
     if (j + 2 <= last_near || (depth >= 2 && j + 2 <= P - 1)) GH_HIP(hipStreamWaitEvent(sn, s->ev_p[j], 0));
@@ -1177,7 +948,7 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
 
 static int lookahead_depth(const gh_chol* s) {
   static const int forced = getenv("GEORGE_AMD_LOOKAHEAD_DEPTH") ? atoi(getenv("GEORGE_AMD_LOOKAHEAD_DEPTH")) : -1;
-  if (forced >= 0) return forced;
+  if (forced >= 1) return forced;
   // depth 1 in this formulation (block column j+1 updated on the chain stream itself, the wide SYRK
   // alone on the main stream) beats the older scheme (block column on the main stream, depth "0") by
   // 7-12 % from N = 4096 to 16384 and is level with it above; deeper windows lose (size sweep in
@@ -1186,14 +957,9 @@ static int lookahead_depth(const gh_chol* s) {
 }
 
 static int factor(gh_chol* s) {
-  static const bool k128_always = getenv("GEORGE_AMD_K128_ALWAYS") != nullptr;          // A/B
   struct Guard { bool prev; Guard(bool v) : prev(t_gemm_small_lds) { t_gemm_small_lds = v; } ~Guard() { t_gemm_small_lds = prev; } }
-      guard(!k128_always && s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
-  if (s->opts.lookahead && s->st2) {
-    const int d = lookahead_depth(s);
-    if (d >= 1 && s->st4) return factor_lookahead_deep(s, d);
-    return factor_lookahead(s);
-  }
+      guard(s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
+  if (s->opts.lookahead && s->st2 && s->st3 && s->st4) return factor_lookahead_deep(s, lookahead_depth(s));
   hipStream_t st = s->st;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);

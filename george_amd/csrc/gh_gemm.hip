@@ -13,14 +13,12 @@
 // MFMAs (1024 matrix-pipe cycles) a wavefront needs 8 fragment reads, so the
 // kernel is MFMA-issue bound, not LDS bound.
 //
-// Two implementations of the operand path:
-//   gemm_f64_mfma_dma  (default)  global -> LDS by global_load_lds_dwordx4, XOR-swizzled image;
-//   gemm_f64_mfma      (A/B arm)  global -> VGPR -> LDS, rows padded to 18 doubles;
-// plus gemm_f64_valu, a plain-VALU kernel with the same semantics that cross-checks the MFMA
-// lane maps on the device.  GEORGE_AMD_MFMA_MODE / gh_debug_set_mfma select among them.
+// The operand path is gemm_f64_mfma_dma: global -> LDS by global_load_lds_dwordx4, XOR-swizzled image
+// (the register-staged predecessor and the 4x4x4-4b instruction form are retired: scripts/dev/arms/);
+// gemm_f64_valu is a plain-VALU kernel with the same semantics that cross-checks the MFMA lane maps
+// on the device (GEORGE_AMD_MFMA_MODE=0 / gh_debug_set_mfma(0)).
 #include <stdlib.h>
 #include "gh_common.h"
-#include "gh_potf2_body.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -167,106 +165,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDev& g, const v4d (&acc)
   }
 }
 
-// MM selects the matrix instruction (A/B measured on MI355X, scripts/gemm_ab.py):
-//   MM == 1: v_mfma_f64_16x16x4_f64   -- 52 TFLOP/s (K = 512) to 58 TFLOP/s (K = 1024) on the
-//            trailing-update shape in this kernel; the default.
-//   MM == 2: v_mfma_f64_4x4x4_4b_f64  -- a bare issue loop of it runs faster than a bare loop of
-//            the 16x16x4 form (66 vs 47 TFLOP/s with 8 accumulators), but inside this kernel its
-//            4x larger instruction count and the extra fragment reads leave it at 36 TFLOP/s.
-// The 4-block form builds the same 16x16x4 product from four instructions that share the B
-// fragment: lane 16k+4b+i of the A operand holds A[4n+i][k] for EVERY block b (a broadcast LDS
-// read), lane 16k+c of B holds B[k][c]; instruction n then yields rows 4n..4n+3 of the tile in
-// exactly the (row = 4n + lane>>4, col = lane&15) slot that element n of the 16x16x4 result
-// vector occupies, so accumulators and epilogue are shared.  (Lane maps probed on hardware:
-// scripts/probes/mfma444_probe.hip.)
-template <bool A_KM, bool B_KM, int MM>
-__global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmDev g) {
-  __shared__ double sA[2][BM * LS];
-  __shared__ double sB[2][BN * LS];
-  int tm, tn;
-  if (!tile_of(g, tm, tn)) return;       // (uniform per workgroup, before any barrier)
-  if (g.prio) __builtin_amdgcn_s_setprio(3);
-  const long row0 = (long)tm * BM, col0 = (long)tn * BN;
-  long kbeg, kend;
-  k_range(g, row0, col0, kbeg, kend);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-
-  v4d acc[4][4];
-  gemm_init_acc(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
-
-  const long nk = (kend - kbeg) / BK;
-  double2 ra[4], rb[4];
-  if (nk > 0) {
-    stage_load<A_KM>(g.A, g.lda, row0, kbeg, tid, ra);
-    stage_load<B_KM>(g.B, g.ldb, col0, kbeg, tid, rb);
-    stage_store<A_KM>(sA[0], tid, ra);
-    stage_store<B_KM>(sB[0], tid, rb);
-  }
-  __syncthreads();
-  for (long kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    // unconditional prefetch (the last iteration re-reads its own slab into the idle buffer):
-    // a branch here makes the compiler keep the staging registers in scratch memory
-    const long knext = kbeg + ((kt + 1 < nk) ? kt + 1 : kt) * BK;
-    stage_load<A_KM>(g.A, g.lda, row0, knext, tid, ra);
-    stage_load<B_KM>(g.B, g.ldb, col0, knext, tid, rb);
-    const double* pb = sB[cur] + (wn * 64 + fr) * LS + fk;
-    if (MM == 1) {
-      const double* pa = sA[cur] + (wm * 64 + fr) * LS + fk;
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = pa[i * 16 * LS + kk * 4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = pb[j * 16 * LS + kk * 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    } else {
-      const double* pa = sA[cur] + (wm * 64 + (lane & 3)) * LS + fk;     // row 4n + (lane&3), replicated over blocks
-      // 16 steps of (one 16-row A group x 4 k): fragments of step s+1 are fetched while the 16
-      // MFMAs of step s issue; sched_barrier keeps the compiler from hoisting every fragment of
-      // the slab at once (which spills: 64 live A doubles on top of the 128-VGPR accumulator).
-      // (two fragment sets selected by compile-time parity after full unrolling: no copies)
-      double fa[2][4], fb[2][4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fa[0][n] = pa[(n * 4) * LS];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[0][j] = pb[j * 16 * LS];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int kk = s >> 2, i = s & 3;
-        if (s + 1 < 16) {
-          const int kk1 = (s + 1) >> 2, i1 = (s + 1) & 3;
-#pragma unroll
-          for (int n = 0; n < 4; ++n) fa[(s + 1) & 1][n] = pa[(i1 * 16 + n * 4) * LS + kk1 * 4];
-          if (i1 == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[kk1 & 1][j] = pb[j * 16 * LS + kk1 * 4];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[i][j][n] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s & 1][n], fb[kk & 1][j], acc[i][j][n], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    stage_store<A_KM>(sA[cur ^ 1], tid, ra);
-    stage_store<B_KM>(sB[cur ^ 1], tid, rb);
-    __syncthreads();
-  }
-  gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
-}
-
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA kernel (the default for every layout): slabs go global -> LDS directly
 // (global_load_lds_dwordx4, 1 KiB per wavefront instruction), so there are no staging VGPRs and
@@ -397,198 +295,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
 }
 #undef GH_DMA_ISSUE
-
-// ---------------------------------------------------------------------------------------------
-// Fused panel: the whole factorisation of one outer panel (nb = nblk * 128 columns: potf2 chain,
-// in-panel TRSMs and updates, TRSM of all rows below) as TWO persistent launches that talk through
-// flags, instead of ~4 dependent launches per 128 columns:
-//   panel_server_kernel  (1 workgroup)   : for j: wait diag_ready[j] -> 128x128 Cholesky + inverse of
-//                                          A_jj (gh_potf2_body.h) -> publish dinv_ready[j]
-//   panel_worker_kernel  (1 per row block): row block r (128 rows), LEFT-looking over the column
-//                                          blocks j: wait diag_ready[j] (row block j final)
-//                                          -> T = A_rj - sum_{k<j} X_rk X_jk^T   (ready before L_jj^-1 is)
-//                                          -> wait dinv_ready[j] -> X_rj = T L_jj^-T (in place)
-//                                          -> in-panel rows: A_rr -= X_rj X_rj^T, and after j = r-1
-//                                             publish diag_ready[r].
-// Between two potf2 calls the critical path is then one 128^3 multiply, one 128^3 diagonal update and
-// two flag hand-overs instead of two kernel launches of up to 112 workgroups plus three launch gaps.
-// Hand-over protocol (placement-independent, /opt/skills/guides Guideline 16): producer -- plain
-// stores, every wave s_waitcnt vmcnt(0), barrier, lane 0: agent release fence, s_waitcnt vmcnt(0),
-// relaxed agent flag store; consumer -- lane 0 polls relaxed, then ONE agent acquire fence, barrier,
-// plain loads.  Deadlock freedom: a workgroup waits only for the server and for in-panel workers,
-// which have smaller block indices and are dispatched first (workers) or run on their own stream
-// (server); every wait is bounded (2 s) and raises flags[PF_ABORT].
-#define PF_DIAG 0          // flags[PF_DIAG + j]: row block j of the panel is final, A_jj is ready for potf2
-#define PF_DINV 8          // flags[PF_DINV + j]: L_jj and L_jj^-1 are in memory
-#define PF_ABORT 16
-struct PanelArgs {
-  double* A; long ld;       // top-left corner of the panel's diagonal block
-  double* dinv;             // nblk x 128 x 128
-  long long* info; long long base;
-  unsigned* flags;
-  int nblk;
-  int r0;                   // first row block of this worker launch (1: all rows; nblk: only the rows below the panel)
-};
-__device__ __forceinline__ void panel_publish(unsigned* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// returns false when the panel was aborted (not positive definite, or a time-out)
-__device__ __forceinline__ bool panel_wait(unsigned* flags, int which) {
-  __shared__ int ok;
-  if (threadIdx.x == 0) {
-    int good = 1;
-    const long long t0 = wall_clock64();
-    unsigned spins = 0;
-    while (__hip_atomic_load(flags + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 31u) == 0u) {
-        if (__hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { good = 0; break; }
-        if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(flags + PF_ABORT, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); good = 0; break; }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ok = good;
-  }
-  __syncthreads();
-  const bool r = ok != 0;
-  __syncthreads();                                   // (ok is reused by the next wait)
-  return r;
-}
-
-#define GH_DMA_ISSUE2(op, sbuf)                                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
-    __builtin_amdgcn_global_load_lds((gh_glb_void*)op.src[i_], (gh_lds_void*)((sbuf) + dst + i_ * 128), 16, 0, 0); \
-    op.src[i_] += op.step;                                                                            \
-  }
-// One 128x128 tile on the calling workgroup (256 threads): C = A B^T (accumulate == false; C may be A)
-// or C -= A B^T, A and B 128 x K row-major (k contiguous), K a multiple of 16.  Same slab pipeline as
-// gemm_f64_mfma_dma.  sm: 4 x 2048 doubles of LDS, 1 KiB aligned.
-__device__ __forceinline__ void panel_tile_gemm(double* sm, double* C, long ldc, const double* A, long lda,
-                                                const double* B, long ldb, long K, bool accumulate) {
-  double* sA0 = sm; double* sA1 = sm + 2048; double* sB0 = sm + 4096; double* sB1 = sm + 6144;
-  GemmDev g{};
-  g.C = C; g.ldc = ldc; g.alpha = accumulate ? -1.0 : 1.0; g.beta = accumulate ? 1.0 : 0.0; g.preload = accumulate ? 1 : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-  v4d acc[4][4];
-  const long nk = K / BK;
-  DmaOperand<true> oa, ob;
-  oa.init(A, lda, 0, 0, wave, lane, wm);
-  ob.init(B, ldb, 0, 0, wave, lane, wn);
-  const int dst = wave * 4 * 128;
-  if (nk > 0) { GH_DMA_ISSUE2(oa, sA0) GH_DMA_ISSUE2(ob, sB0) }
-  gemm_init_acc(g, acc, wm * 64, wn * 64, fr, fk);
-  __syncthreads();
-  for (long kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    const double* ca = cur ? sA1 : sA0;
-    const double* cb = cur ? sB1 : sB0;
-    double a[4][4], b[4][4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[kk][i] = oa.frag(ca, kk, i);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[kk][j] = ob.frag(cb, kk, j);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      if (cur) { GH_DMA_ISSUE2(oa, sA0) GH_DMA_ISSUE2(ob, sB0) }
-      else     { GH_DMA_ISSUE2(oa, sA1) GH_DMA_ISSUE2(ob, sB1) }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 1; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-  gemm_epilogue(g, acc, wm * 64, wn * 64, fr, fk);
-  // the tile is read again by this workgroup's next call (through the DMA path): stores done, then barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-#undef GH_DMA_ISSUE2
-
-__global__ __launch_bounds__(256) void panel_server_kernel(PanelArgs p) {
-  __shared__ double s[GH_POTF2_S_DOUBLES];
-  __shared__ double dscr[GH_POTF2_D_DOUBLES];
-  __shared__ int fail_at;
-  __builtin_amdgcn_s_setprio(3);
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-  for (int j = 0; j < p.nblk; ++j) {
-    if (j > 0 && !panel_wait(p.flags, PF_DIAG + j)) return;
-    const bool ok = gh_potf2::potf2_body(p.A + (long)j * 128 * p.ld + (long)j * 128, p.ld, p.dinv + (long)j * 128 * 128,
-                                         p.info, p.base + (long long)j * 128, s, dscr, &fail_at);
-    if (!ok) {                                        // (uniform) not positive definite: release everybody
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(p.flags + PF_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    panel_publish(p.flags + PF_DINV + j);
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void panel_worker_kernel(PanelArgs p) {
-  __shared__ __attribute__((aligned(1024))) double sm[8192];
-  const int r = blockIdx.x + p.r0;                     // row block of the panel column strip (0 = the first diagonal block)
-  const int jmax = r < p.nblk ? r : p.nblk;
-  if (r < p.nblk) __builtin_amdgcn_s_setprio(3);       // in-panel rows feed the potf2 chain
-  double* Ar = p.A + (long)r * 128 * p.ld;             // row block r, column 0 of the panel
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-  for (int j = 0; j < jmax; ++j) {
-    double* Arj = Ar + (long)j * 128;
-    if (j > 0) {
-      if (!panel_wait(p.flags, PF_DIAG + j)) return;
-      panel_tile_gemm(sm, Arj, p.ld, Ar, p.ld, p.A + (long)j * 128 * p.ld, p.ld, (long)j * 128, true);
-    }
-    if (!panel_wait(p.flags, PF_DINV + j)) return;
-    panel_tile_gemm(sm, Arj, p.ld, Arj, p.ld, p.dinv + (long)j * 128 * 128, 128, 128, false);
-    if (r < p.nblk) {
-      panel_tile_gemm(sm, Ar + (long)r * 128, p.ld, Arj, p.ld, Arj, p.ld, 128, true);
-      if (j == r - 1) panel_publish(p.flags + PF_DIAG + r);
-    }
-  }
-}
-
-// one outer panel at (k0, k0) of the np x np matrix A: server on `st`, workers on `sw`; flags: >= 32 unsigned
-// sc: stream of the server; si: of the in-panel workers (NOT sc: the server waits for them); sw: of the
-// workers of the rows below the panel (may be si)
-int gh_launch_panel_fused(double* A, int64_t ld, int64_t np, int64_t k0, int64_t nb, double* dinv, long long* info,
-                          unsigned* flags, hipStream_t sc, hipStream_t si, hipStream_t sw) {
-  PanelArgs p;
-  p.A = A + k0 * ld + k0; p.ld = (long)ld; p.dinv = dinv; p.info = info; p.base = (long long)k0; p.flags = flags;
-  p.nblk = (int)(nb / 128);
-  const int nrows = (int)((np - k0) / 128);
-  p.r0 = 1;
-  hipLaunchKernelGGL(panel_server_kernel, dim3(1), dim3(256), 0, sc, p);          // (first: it must find a CU with 84 KB of LDS free)
-  if (si != sw && p.nblk > 1) {
-    hipLaunchKernelGGL(panel_worker_kernel, dim3(p.nblk - 1), dim3(256), 0, si, p);
-    p.r0 = p.nblk;
-    if (nrows > p.nblk) hipLaunchKernelGGL(panel_worker_kernel, dim3(nrows - p.nblk), dim3(256), 0, sw, p);
-  } else if (nrows > 1) hipLaunchKernelGGL(panel_worker_kernel, dim3(nrows - 1), dim3(256), 0, sw, p);
-  GH_HIP(hipGetLastError());
-  return GH_OK;
-}
 
 // ---------------------------------------------------------------------------------------------
 // 64x64-tile variant for launches that cannot fill the chip anyway (the GEMMs inside the panel
@@ -865,23 +571,21 @@ __global__ __launch_bounds__(256) void gemm_f64_valu(GemmDev g) {
     }
 }
 
-// 0 = plain VALU (validation arm), 1 = v_mfma_f64_16x16x4 (default; the k-major x k-major case
-// takes the LDS-DMA kernel), 2 = v_mfma_f64_4x4x4_4b (correct, but 36 TFLOP/s in this kernel:
-// kept as an A/B arm), 3 = v_mfma_f64_16x16x4 with register staging everywhere (A/B arm)
+// 0 = plain VALU (validation arm: cross-checks the MFMA lane maps on the device), 1 = the LDS-DMA
+// v_mfma_f64_16x16x4 kernels (default).  GEORGE_AMD_NO_MFMA=1 / GEORGE_AMD_MFMA_MODE=0 / gh_debug_set_mfma(0).
 static int g_mfma = -1;
-static int mfma_raw_mode() {
+static int mfma_mode() {
   if (g_mfma < 0) {
     const char* e = getenv("GEORGE_AMD_MFMA_MODE");
-    g_mfma = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : 1;
+    g_mfma = (e && e[0] == '0') ? 0 : 1;
+    if (getenv("GEORGE_AMD_NO_MFMA")) g_mfma = 0;
   }
   return g_mfma;
 }
-static int mfma_mode() { return mfma_raw_mode() == 3 ? 1 : mfma_raw_mode(); }
-static bool dma_mode() { return mfma_raw_mode() == 1; }
 bool gh_use_mfma() { return mfma_mode() != 0; }
 extern "C" int gh_debug_set_mfma(int mode) {
-  const int prev = mfma_raw_mode();
-  g_mfma = (mode < 0 || mode > 3) ? 1 : mode;
+  const int prev = mfma_mode();
+  g_mfma = mode == 0 ? 0 : 1;
   return prev;
 }
 
@@ -900,13 +604,10 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);
   const int mode = mfma_mode();
-#define GH_GEMM_LAUNCH(AK, BKM)                                                                  \
-  do {                                                                                           \
-    if (mode == 2)      hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM, 2>), grid, block, 0, st, g);  \
-    else if (mode == 1) hipLaunchKernelGGL((gemm_f64_mfma<AK, BKM, 1>), grid, block, 0, st, g);  \
-    else                hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g);     \
-  } while (0)
-  const bool dma = mode == 1 && dma_mode() && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
+  // (operands the LDS-DMA path cannot take -- an odd leading dimension or a base that is not 16-byte aligned; none of
+  //  the solver's own calls -- go through the plain-VALU kernel)
+#define GH_GEMM_LAUNCH(AK, BKM) hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g)
+  const bool dma = mode == 1 && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
                    ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0;
 #define GH_DMA_LAUNCH(AK, BKM)                                                                            \
   do {                                                                                                   \
@@ -924,20 +625,10 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
       q.nblk = q.tiles_m;
       hipLaunchKernelGGL((gemm_f64_mfma_k128<1, 4, 1, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
     } else {                            // 64 x 64 or 32 x 32 tiles (of a lower-triangular C: those that touch the triangle)
-      static const int tile = [] { const char* e = getenv("GEORGE_AMD_K128_TILE"); return e ? atoi(e) : 64; }();
-      if (tile == 32) {
-        q.tiles_m = (int)(h.M / 32); q.tiles_n = (int)(h.N / 32);
-        q.nblk = (long)q.tiles_m * q.tiles_n;
-        hipLaunchKernelGGL((gemm_f64_mfma_k128<2, 2, 1, 1>), dim3((unsigned)q.nblk), block, 0, st, q);
-      } else if (tile == 6432) {
-        q.tiles_m = (int)(h.M / 64); q.tiles_n = (int)(h.N / 32);
-        q.nblk = (long)q.tiles_m * q.tiles_n;
-        hipLaunchKernelGGL((gemm_f64_mfma_k128<4, 1, 1, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
-      } else {
-        q.tiles_m = (int)(h.M / 64); q.tiles_n = (int)(h.N / 64);
-        q.nblk = (long)q.tiles_m * q.tiles_n;
-        hipLaunchKernelGGL((gemm_f64_mfma_k128<2, 2, 2, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
-      }
+      // (32 x 32 and 64 x 32 tiles were measured too: 64 x 64 wins)
+      q.tiles_m = (int)(h.M / 64); q.tiles_n = (int)(h.N / 64);
+      q.nblk = (long)q.tiles_m * q.tiles_n;
+      hipLaunchKernelGGL((gemm_f64_mfma_k128<2, 2, 2, 2>), dim3((unsigned)q.nblk), block, 0, st, q);
     }
     GH_HIP(hipGetLastError());
     return GH_OK;

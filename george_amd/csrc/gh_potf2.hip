@@ -10,20 +10,17 @@
 // not the same as fast: beside SYRK wavefronts the kernel runs several times slower, which is why
 // small matrices keep 32 CUs free of SYRK work (gh_chol.hip, trailing_stream).
 //
-// The algorithm is in the body headers:
-//   gh_potf2_body.h     second form, 33 us per block -- DPP-broadcast diagonal step that yields the
-//                       16x16 inverses for free, one barrier per 16-column step with X^T tiles recomputed
-//                       into MFMA operand registers, register-chained doubling products (the default);
-//   gh_potf2_body_v1.h  first MFMA form, 82 us (GEORGE_AMD_POTF2=v1): one-wavefront diagonal step by
-//                       v_readlane broadcasts, per-row substitution, tile updates, separate 16x16
-//                       inverses, doubling through an LDS scratch.
+// The algorithm is in gh_potf2_body.h: 33 us per block -- DPP-broadcast diagonal step that yields the
+// 16x16 inverses for free, one barrier per 16-column step with X^T tiles recomputed into MFMA operand
+// registers, register-chained doubling products.  (Its 82-us predecessor -- one-wavefront diagonal step
+// by v_readlane broadcasts, per-row substitution, separate 16x16 inverses, doubling through an LDS
+// scratch -- is retired: scripts/dev/arms/gh_potf2_body_v1.h.)
 // The very first version (scalar rank-1 updates, 3 barriers per column, column-wise inverse) took
 // 553 us per block and was half of compute() at N = 16384; it is kept in gh_chol.hip
 // (`potf2_inv_kernel`) as the validation arm GEORGE_AMD_POTF2=simple.
 #include <stdlib.h>
 #include <string.h>
 #include "gh_potf2_body.h"
-#include "gh_potf2_body_v1.h"
 
 // blockIdx.x selects the block of a batch (stride_a / stride_d doubles apart; 0 for the single
 // diagonal block of the dense factorisation): the HODLR leaves are factored and inverted this way.
@@ -38,34 +35,17 @@ __global__ __launch_bounds__(256, 2) void potf2_inv_mfma_kernel(double* A, long 
   __shared__ int fail_at;
   (void)gh_potf2::potf2_body(A, lda, dinv, info, base, s, dscr, &fail_at);
 }
-// the first form of the kernel (GEORGE_AMD_POTF2=v1): 82 us per block against the 2x-3x shorter second form
-__global__ __launch_bounds__(256) void potf2_inv_mfma_v1_kernel(double* A, long lda, double* dinv,
-                                                                long long* info, long long base,
-                                                                long stride_a, long stride_d) {
-  A += (long)blockIdx.x * stride_a;
-  dinv += (long)blockIdx.x * stride_d;
-  __shared__ double s[GH_POTF2V1_S_DOUBLES];
-  __shared__ double scr[GH_POTF2V1_INV_DOUBLES_NARROW];
-  __shared__ double rdiag[128];                 // 1 / L_jj, written as the pivots are taken
-  __shared__ int fail_at;
-  (void)gh_potf2_v1::potf2_body<16>(A, lda, dinv, info, base, s, scr, rdiag, &fail_at);
-}
-static bool potf2_v1() {
-  static const bool v1 = [] { const char* e = getenv("GEORGE_AMD_POTF2"); return e != nullptr && strcmp(e, "v1") == 0; }();
-  return v1;
-}
-
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
                             int nbatch, hipStream_t st) {
   if (nbatch <= 0) return GH_OK;
-  hipLaunchKernelGGL(potf2_v1() ? potf2_inv_mfma_v1_kernel : potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st,
+  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3((unsigned)nbatch), dim3(256), 0, st,
                      A, (long)lda, dinv, info, 0LL, (long)stride_a, (long)stride_d);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
 
 int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, long long base, hipStream_t st) {
-  hipLaunchKernelGGL(potf2_v1() ? potf2_inv_mfma_v1_kernel : potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info,
+  hipLaunchKernelGGL(potf2_inv_mfma_kernel, dim3(1), dim3(256), 0, st, A, (long)lda, dinv, info,
                      base, 0L, 0L);
   GH_HIP(hipGetLastError());
   return GH_OK;

@@ -1,3 +1,5 @@
+// RETIRED ARM (source snapshot, not built): the first MFMA form of the 128x128 Cholesky + inverse kernel, 82 us per block
+// against 33 us of gh_potf2_body.h (GEORGE_AMD_POTF2=v1 until round 3); phase table in DESIGN.md section 4.
 // gh_potf2_body.h -- the 128x128 Cholesky + inverse of gh_potf2.hip as a device function, so that the
 // fused panel kernel (gh_gemm.hip, panel_server_kernel) can run it from a persistent workgroup.
 // See gh_potf2.hip for the description of the algorithm.

@@ -41,7 +41,7 @@ def test_microbench_peaks():
           "mfma_f64_4x4x4: %.1f TF (%.1f cyc/instr)" % (o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12]))
 
 
-@pytest.mark.parametrize("mfma", [2, 1, 0])
+@pytest.mark.parametrize("mfma", [1, 0])
 @pytest.mark.parametrize("a_mm,b_nm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_layouts(mfma, a_mm, b_nm):
     from george_amd import _native as N
@@ -104,7 +104,7 @@ def test_gemm_lower_and_k_clipping():
     assert np.abs(o.cpu().numpy() - R @ L.T).max() < 1e-10
 
 
-@pytest.mark.parametrize("mfma", [2, 1, 0])
+@pytest.mark.parametrize("mfma", [1, 0])
 def test_potrf_block_and_trsm(mfma):
     import torch
     from george_amd import _native as N

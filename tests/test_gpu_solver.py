@@ -445,28 +445,6 @@ def test_handle_pool_is_budgeted_and_releasable():
         BasicSolver._POOL_MAX_BYTES = old
 
 
-def test_fused_panel_arm_agrees():
-    """GEORGE_AMD_PANEL_FUSED=1: the panel as two persistent flag-driven launches (server + workers,
-    release/acquire hand-overs).  Same arithmetic in the same order as the launch chain: same bits,
-    also on repeated factorisations with one handle."""
-    import subprocess, sys, os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r); import bench\n"
-            "for n in (1000, 4096, 9000):\n"
-            "    job = bench.DenseJob(n, 0, 0, profile=False)\n"
-            "    print(' '.join(repr(float(job.step())) for _ in range(3)))\n"
-            "    job.close()\n") % root
-    outs = []
-    for env in ({}, {"GEORGE_AMD_PANEL_FUSED": "1"}):
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.strip().splitlines()[-3:])
-    assert outs[0] == outs[1], outs
-    for line in outs[1]:
-        assert len(set(line.split())) == 1, line                         # repeatable
-
-
 def test_stepwise_trsv_arm_still_works():
     """GEORGE_AMD_TRSV_STEPS selects the one-launch-per-block-row solves (the fallback should the
     chained kernels' in-order dispatch assumption ever fail): keep it exercised."""
@@ -628,22 +606,23 @@ def test_full_size_c5_properties():
     gp.set_parameter_vector(p0)
 
 
-def test_first_potf2_form_agrees():
-    """GEORGE_AMD_POTF2=v1 selects the first MFMA form of the 128x128 Cholesky + inverse kernel (82 us
-    against 33): same factorisation to rounding, on repeated computes with one handle too."""
+def test_scalar_potf2_validation_arm_agrees():
+    """GEORGE_AMD_POTF2=simple selects the scalar 128x128 Cholesky + inverse kernel (the validation arm
+    of the MFMA form, as GEORGE_AMD_MFMA_MODE=0 is for the GEMMs): same factorisation to rounding, on
+    repeated computes with one handle too."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r); import bench\n"
-            "for n in (1000, 4096, 9000):\n"
+            "for n in (1000, 4096):\n"
             "    job = bench.DenseJob(n, 0, 0, profile=False)\n"
             "    print(' '.join(repr(float(job.step())) for _ in range(2)))\n"
             "    job.close()\n") % root
     outs = []
-    for env in ({}, {"GEORGE_AMD_POTF2": "v1"}):
+    for env in ({}, {"GEORGE_AMD_POTF2": "simple"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-3:]])
+        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-2:]])
     for a, b in zip(outs[0], outs[1]):
         assert a[0] == a[1] and b[0] == b[1]                              # each arm repeatable
         assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0])
