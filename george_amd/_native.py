@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgeorge_amd.so")
 
 GH_MAX_AXES, GH_MAX_NDIM, GH_MAX_PARAMS, GH_MAX_METRIC = 8, 16, 4, 36
 GH_MAX_NODES, GH_MAX_GRAD, GH_MAX_STACK = 64, 64, 8
-GH_OK, GH_ERR_NOT_PD, GH_ERR_BAD_ARG, GH_ERR_HIP, GH_ERR_NOT_COMPUTED, GH_ERR_DIM, GH_ERR_NOMEM = range(7)
+GH_OK, GH_ERR_NOT_PD, GH_ERR_BAD_ARG, GH_ERR_HIP, GH_ERR_NOT_COMPUTED, GH_ERR_DIM, GH_ERR_NOMEM, GH_ERR_RANK = range(8)
 GH_OP_LEAF, GH_OP_SUM, GH_OP_PRODUCT = 0, 1, 2
 
 
@@ -152,6 +152,11 @@ def last_error():
     return msg.decode("utf-8", "replace") if msg else ""
 
 
+class RankCeilingError(ValueError):
+    """HODLR: a block needs a rank above the solver's ceiling for the requested tolerance
+    (HODLRSolver.compute answers with the dense device solver instead where the matrix fits)."""
+
+
 def check(rc):
     """Map a status code to the exception the reference raises at the same place."""
     if rc == GH_OK:
@@ -167,6 +172,8 @@ def check(rc):
         raise RuntimeError("you must call 'compute' first")   # george::not_computed, exceptions.h:14-18
     if rc == GH_ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == GH_ERR_RANK:
+        raise RankCeilingError(msg)
     raise RuntimeError("george_amd HIP backend failure: " + msg)
 
 

@@ -1698,7 +1698,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         gh_set_error("HODLR: an off-diagonal block of level %d needs a rank above %d to reach tol = %g (%s); "
                      "the factorisation is not usable", l, a.rcap, h->opts.tol,
                      user_cap ? "opts.max_rank" : "the solver's ceiling: loosen tol, raise min_size or use the dense solver");
-        return GH_ERR_BAD_ARG;
+        return user_cap ? GH_ERR_BAD_ARG : GH_ERR_RANK;
       }
       GH_CHECK(enqueue_level(l, std::min(2 * a.rcap, RANK_CAP), st));
       GH_CHECK(fetch_level(l, st));

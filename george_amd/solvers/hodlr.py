@@ -6,6 +6,7 @@ over ``_hodlr.cpp`` / ``include/george/hodlr.h``): same constructor keywords
 ``NotImplementedError`` (hodlr.py:62-64), pickling drops the factor (:69-76).
 """
 import ctypes as C
+import warnings
 
 import numpy as np
 
@@ -18,10 +19,19 @@ __all__ = ["HODLRSolver"]
 
 class HODLRSolver(BasicSolver):
 
+    # hodlr.h:147 lets a block's rank grow to min(rows, cols); the level-batched ACA here stops at 1024
+    # columns.  A block that needs more (3-D inputs at tight tolerances: docs/user/solvers.rst:40-42) is
+    # not low-rank in any useful sense -- the reference then spends O(N r^2) on it -- and up to this many
+    # points the solver answers with the EXACT dense device factorisation instead (BasicSolver on the
+    # same GPU: every tolerance is met; ``dense_fallback`` is set and a warning is issued); beyond it,
+    # or when an explicit ``max_rank`` is too small, compute() raises ValueError.  Never a truncation.
+    DENSE_FALLBACK_MAX_N = 98304          # 8 N^2 = 77 GB of the 288 GB
+
     def __init__(self, kernel, min_size=100, tol=0.1, seed=42, device=0, max_rank=0):
         # max_rank = 0: ranks grow as far as ``tol`` asks (hodlr.h:147), up to the solver's ceiling of
-        # 1024; a block that needs more -- or more than an explicit ``max_rank`` -- raises ValueError
-        # instead of being truncated.
+        # 1024 (then: dense fallback, above); an explicit ``max_rank`` that is too small raises ValueError.
+        self.dense_fallback = False
+        self._dense = None
         self.min_size = min_size
         self.tol = tol
         self.seed = seed
@@ -61,13 +71,30 @@ class HODLRSolver(BasicSolver):
             self._handle = None
         h = self._ensure_handle()
         logdet = C.c_double(0.0)
-        N.check(N.lib.gh_hodlr_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        self.dense_fallback, self._dense = False, None
+        try:
+            N.check(N.lib.gh_hodlr_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        except N.RankCeilingError as e:
+            if len(x) > HODLRSolver.DENSE_FALLBACK_MAX_N:
+                raise
+            warnings.warn("HODLRSolver: %s -- answering with the dense device solver (exact)" % (e,), RuntimeWarning)
+            N.lib.gh_hodlr_destroy(self._handle)          # (frees the HODLR scratch before the N x N matrix is built)
+            self._handle = None
+            self._dense = BasicSolver(self.kernel, device=self._hopts["device"])
+            self._dense.compute(x, yerr)
+            self.dense_fallback = True
+            self._n = len(x)
+            self._log_det = self._dense.log_determinant
+            self.computed = True
+            return
         self._n = len(x)
         self._log_det = logdet.value
         self.computed = True
 
     def apply_inverse(self, y, in_place=False):
         # the reference's pybind/Eigen binding always returns a fresh array
+        if self._computed and self._dense is not None:
+            return self._dense.apply_inverse(y, in_place=False)
         h = self._need()
         y = np.asarray(y, dtype=np.float64)
         if y.shape[0] != self._n or y.ndim > 2:
@@ -80,6 +107,8 @@ class HODLRSolver(BasicSolver):
         return out
 
     def dot_solve(self, y):
+        if self._computed and self._dense is not None:
+            return self._dense.dot_solve(y)
         h = self._need()
         y = N.as_f64(y).reshape(-1)
         if len(y) != self._n:
@@ -92,12 +121,16 @@ class HODLRSolver(BasicSolver):
         raise NotImplementedError("apply_sqrt is not implemented for the HODLRSolver")
 
     def get_inverse(self):
+        if self._computed and self._dense is not None:
+            return self._dense.get_inverse()
         h = self._need()
         out = np.empty((self._n, self._n), dtype=np.float64)
         N.check(N.lib.gh_hodlr_get_inverse(h, N.ptr(out)))
         return out
 
     def ranks(self):
+        if self._computed and self._dense is not None:
+            return []                             # (no low-rank blocks: the dense factorisation answered)
         buf = (C.c_int32 * 65536)()
         cnt = C.c_int32(0)
         N.check(N.lib.gh_hodlr_ranks(self._need(), buf, 65536, C.byref(cnt)))
@@ -110,6 +143,7 @@ class HODLRSolver(BasicSolver):
         state["_dk"] = None
         state["_factor_state"] = None
         state["_computed"] = False
+        state["_dense"] = None
         return state
 
     def __setstate__(self, state):

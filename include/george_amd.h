@@ -47,7 +47,8 @@ enum {
   GH_ERR_HIP = 3,
   GH_ERR_NOT_COMPUTED = 4,
   GH_ERR_DIM = 5,
-  GH_ERR_NOMEM = 6
+  GH_ERR_NOMEM = 6,
+  GH_ERR_RANK = 7        /* HODLR: a block needs a rank above the solver's ceiling (1024) for the requested tol */
 };
 
 /* node operators */

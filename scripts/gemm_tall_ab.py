@@ -3,7 +3,8 @@ shapes of the factorisation's trailing updates: bit-identical results (same K or
 time per launch, TFLOP/s.   python scripts/gemm_tall_ab.py [quick]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from george_amd import _native as N
 
 

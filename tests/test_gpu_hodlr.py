@@ -109,9 +109,38 @@ def test_rank_grows_past_256_and_cap_is_loud():
         HODLRSolver(kernel, tol=1e-7, min_size=100, max_rank=64).compute(x, yerr)
     # a loose tolerance under the same cap is fine
     HODLRSolver(kernel, tol=0.1, min_size=100, max_rank=64).compute(x, yerr)
+    # a block that needs more than the ACA's 1024 columns (hodlr.h:147 allows min(rows, cols) = 3000 here): the
+    # solver answers with the exact dense device factorisation -- every tolerance is met -- and says so
     x2, yerr2, y2 = zoo.bench_data(6000, ndim=3)
-    with pytest.raises(ValueError):                                       # needs > 1024: the solver's ceiling
-        HODLRSolver(kernel, tol=1e-12, min_size=100).compute(x2, yerr2)
+    s2 = HODLRSolver(kernel, tol=1e-12, min_size=100)
+    with pytest.warns(RuntimeWarning):
+        s2.compute(x2, yerr2)
+    assert s2.computed and s2.dense_fallback and s2.ranks() == []
+    d = BasicSolver(kernel)
+    d.compute(x2, yerr2)
+    assert s2.log_determinant == d.log_determinant
+    assert np.array_equal(s2.apply_inverse(y2), d.apply_inverse(y2)) and s2.dot_solve(y2) == d.dot_solve(y2)
+    with pytest.raises(NotImplementedError):
+        s2.apply_sqrt(y2)                                                 # (hodlr.py:62-64 either way)
+    # the same solver object goes back to the HODLR path when the next problem is low-rank again
+    s2.tol = 1e-6
+    s2.compute(x, yerr)
+    assert not s2.dense_fallback and max(s2.ranks()) > 0
+    # through GP: log-likelihood against the dense solver
+    gp = GP(kernel, solver=HODLRSolver, tol=1e-12)
+    with pytest.warns(RuntimeWarning):
+        gp.compute(x2, yerr2)
+    gd = GP(kernel)
+    gd.compute(x2, yerr2)
+    assert gp.log_likelihood(y2) == gd.log_likelihood(y2)
+    # beyond the size where a dense matrix is reasonable, and with an explicit cap, it stays an error
+    old = HODLRSolver.DENSE_FALLBACK_MAX_N
+    HODLRSolver.DENSE_FALLBACK_MAX_N = 1000
+    try:
+        with pytest.raises(ValueError):
+            HODLRSolver(kernel, tol=1e-12, min_size=100).compute(x2, yerr2)
+    finally:
+        HODLRSolver.DENSE_FALLBACK_MAX_N = old
 
 
 def test_barrier_release_arms_agree():
