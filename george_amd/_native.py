@@ -50,6 +50,13 @@ class gh_hodlr_opts(C.Structure):
                 ("max_rank", C.c_int32), ("tol", C.c_double), ("reserved", C.c_int32 * 4)]
 
 
+class gh_mgpu_opts(C.Structure):
+    _fields_ = [("n_dev", C.c_int32), ("devices", C.c_int32 * 16), ("pr", C.c_int32), ("pc", C.c_int32),
+                ("nb", C.c_int32), ("transport", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+GH_MGPU_RCCL, GH_MGPU_COPY = 0, 1
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "george_amd: %s not found -- build the HIP extension first "
@@ -131,6 +138,13 @@ SIGNATURES = {
     "gh_hodlr_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "gh_hodlr_get_inverse": (C.c_int, [_vp, _dp]),
     "gh_hodlr_ranks": (C.c_int, [_vp, C.POINTER(C.c_int32), _i32, C.POINTER(C.c_int32)]),
+    "gh_mgpu_create": (C.c_int, [C.POINTER(gh_mgpu_opts), C.POINTER(_vp)]),
+    "gh_mgpu_destroy": (None, [_vp]),
+    "gh_mgpu_compute": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, C.POINTER(C.c_double)]),
+    "gh_mgpu_info": (_i64, [_vp]),
+    "gh_mgpu_grid": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gh_mgpu_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
+    "gh_mgpu_solve": (C.c_int, [_vp, _dp, _i64, _dp]),
     "gh_dev_kmat_block": (C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64, _i64, _i64, _i64, _dp, _i64, _vp]),
     "gh_dev_gemv": (C.c_int, [_dp, _i64, _i64, _i64, _i32, _dp, _dp, C.c_double, C.c_double, _vp]),
     "gh_dev_potrf_block": (C.c_int, [_dp, _i64, _i64, _dp, _dp, _i64, _vp]),
@@ -139,6 +153,7 @@ SIGNATURES = {
     "gh_dev_gemm": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _i32, _vp]),
     "gh_dev_logdet_accum": (C.c_int, [_dp, _i64, _i64, _dp, _vp]),
     "gh_dev_trsv_lower": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _dp, _vp, _vp]),
+    "gh_dev_trsv_lower_t": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _dp, _vp, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

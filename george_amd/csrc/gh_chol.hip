@@ -736,6 +736,18 @@ extern "C" int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* din
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
+extern "C" int gh_dev_trsv_lower_t(const double* l, int64_t ldl, const double* dinv, int64_t n,
+                                   const double* w, double* x, void* scratch, void* stream) {
+  if (n % T || n <= 0 || !scratch) { gh_set_error("trsv_lower_t: n must be a positive multiple of 128"); return GH_ERR_BAD_ARG; }
+  const int64_t nt = n / T;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* flags = (unsigned*)scratch;
+  GH_HIP(hipMemsetAsync(flags, 0, (size_t)(nt + 1) * sizeof(unsigned), st));
+  hipLaunchKernelGGL(trsv_bwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, st, l, (long)ldl, dinv, (int)nt, w, x,
+                     flags, (int*)(flags + nt));
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
 extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, double* out_dev, void* stream) {
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (long)lda, (long)n, out_dev, 1);
   GH_HIP(hipGetLastError());

@@ -4,5 +4,6 @@ plug into the *reference's own* ``george.GP(kernel, solver=...)`` unchanged."""
 from .trivial import TrivialSolver
 from .basic import BasicSolver
 from .hodlr import HODLRSolver
+from .multigpu import MultiGPUSolver
 
-__all__ = ["TrivialSolver", "BasicSolver", "HODLRSolver"]
+__all__ = ["TrivialSolver", "BasicSolver", "HODLRSolver", "MultiGPUSolver"]

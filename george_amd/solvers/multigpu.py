@@ -1,0 +1,153 @@
+"""``MultiGPUSolver`` -- the dense solver on several MI355X of ONE process, behind the C ABI.
+
+``GP(kernel, solver=MultiGPUSolver, devices=[0, 1, 2, 3, 4, 5, 6, 7])`` shards the factorisation of
+``BasicSolver`` (reference ``src/george/solvers/basic.py:51-102``) 2-D block-cyclically over the
+listed devices (``gh_mgpu_*``, george_amd/csrc/gh_mgpu.hip: one host thread per device, RCCL over
+xGMI).  Protocol: ``compute`` / ``log_determinant`` / ``computed`` / ``dot_solve`` /
+``apply_inverse``; ``get_inverse`` solves against the identity column by column (N right-hand sides:
+meant for small N), ``apply_sqrt`` is not offered (``NotImplementedError``, as the reference's HODLR
+solver does, hodlr.py:62-64).  The multi-PROCESS form (one rank per GPU under torch.distributed) is
+``george_amd.distributed.DistributedBasicSolver``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _native as N
+from ..program import DeviceKernel
+
+__all__ = ["MultiGPUSolver"]
+
+
+class MultiGPUSolver(object):
+
+    def __init__(self, kernel, devices=None, nb=0, grid=None, transport="rccl"):
+        self.kernel = kernel
+        if devices is None:
+            devices = list(range(max(int(N.lib.gh_device_count()), 1)))
+        self.devices = [int(d) for d in devices]
+        if not 1 <= len(self.devices) <= 16:
+            raise ValueError("devices must list 1..16 device ordinals")
+        if transport not in ("rccl", "copy"):
+            raise ValueError("transport must be 'rccl' or 'copy'")
+        self.nb = int(nb)
+        self.grid = tuple(grid) if grid is not None else (0, 0)
+        self.transport = transport
+        self._handle = None
+        self._dk = None
+        self._computed = False
+        self._log_det = None
+
+    @property
+    def computed(self):
+        return self._computed
+
+    @computed.setter
+    def computed(self, v):
+        self._computed = v
+
+    @property
+    def log_determinant(self):
+        return self._log_det
+
+    @log_determinant.setter
+    def log_determinant(self, v):
+        self._log_det = v
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            o = N.gh_mgpu_opts()
+            o.n_dev = len(self.devices)
+            for i, d in enumerate(self.devices):
+                o.devices[i] = d
+            o.pr, o.pc = int(self.grid[0]), int(self.grid[1])
+            o.nb = self.nb
+            o.transport = N.GH_MGPU_RCCL if self.transport == "rccl" else N.GH_MGPU_COPY
+            h = N._vp()
+            N.check(N.lib.gh_mgpu_create(C.byref(o), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                N.lib.gh_mgpu_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def grid_shape(self):
+        pr, pc, nb = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        N.check(N.lib.gh_mgpu_grid(self._ensure_handle(), C.byref(pr), C.byref(pc), C.byref(nb)))
+        return pr.value, pc.value, nb.value
+
+    def compute(self, x, yerr):
+        """basic.py:51-70.  ``yerr`` already contains the white noise (gp.py:330)."""
+        x = N.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError("x must be (nsamples, ndim)")
+        yerr = N.as_f64(np.zeros(len(x)) + yerr)
+        self._computed = False
+        self._dk = DeviceKernel(self.kernel)
+        if x.shape[1] != self._dk.ndim:
+            raise RuntimeError("dimension mismatch")
+        h = self._ensure_handle()
+        logdet = C.c_double(0.0)
+        N.check(N.lib.gh_mgpu_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        self._n = len(x)
+        self.log_determinant = logdet.value
+        self.computed = True
+
+    def _need(self):
+        if not self._computed or self._handle is None:
+            raise RuntimeError("you must call 'compute' first")
+        return self._handle
+
+    def apply_inverse(self, y, in_place=False):
+        """basic.py:72-87: ``y`` is (n,) or (n, nrhs)."""
+        h = self._need()
+        yin = y
+        y = np.asarray(y, dtype=np.float64)
+        if y.ndim < 1 or y.ndim > 2 or y.shape[0] != self._n:
+            raise ValueError("dimension mismatch")
+        yc = np.ascontiguousarray(y)
+        nrhs = 1 if yc.ndim == 1 else yc.shape[1]
+        out = np.empty_like(yc)
+        if nrhs > 0:
+            N.check(N.lib.gh_mgpu_solve(h, N.ptr(yc), nrhs, N.ptr(out)))
+        if in_place and isinstance(yin, np.ndarray) and yin.dtype == np.float64:
+            try:
+                yin[...] = out
+                return yin
+            except (ValueError, TypeError):
+                pass
+        return out
+
+    def dot_solve(self, y):
+        """basic.py:89-102."""
+        h = self._need()
+        y = N.as_f64(y).reshape(-1)
+        if len(y) != self._n:
+            raise ValueError("dimension mismatch")
+        out = C.c_double(0.0)
+        N.check(N.lib.gh_mgpu_dot_solve(h, N.ptr(y), C.byref(out)))
+        return out.value
+
+    def get_inverse(self):
+        """basic.py:116-121 (N right-hand sides through the sharded factor: small N only)."""
+        return self.apply_inverse(np.eye(self._n))
+
+    def apply_sqrt(self, r):
+        raise NotImplementedError("apply_sqrt is not implemented for the MultiGPUSolver")
+
+    # pickling drops the (device-resident, sharded) factor, as the reference's native solver does (hodlr.py:69-76)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handle"] = None
+        state["_dk"] = None
+        state["_computed"] = False
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)

@@ -253,6 +253,40 @@ int  gh_hodlr_dot_solve(gh_hodlr* h, const double* y, double* out);
 int  gh_hodlr_get_inverse(gh_hodlr* h, double* out /* n*n */);
 int  gh_hodlr_ranks(const gh_hodlr* h, int32_t* ranks_out, int32_t max_out, int32_t* n_out);
 
+/* --------------------------------------------------- dense solver on several GPUs
+ * The BasicSolver protocol of /root/reference/src/george/solvers/basic.py:51-102 (compute, log-determinant,
+ * dot_solve, apply_inverse) for ONE process that owns several MI355X: 2-D block-cyclic tiles (tile (I, J)
+ * on rank (I mod pr) * pc + (J mod pc)), one host thread and one stream per device, panels moved with RCCL
+ * over xGMI (grouped ncclSend / ncclRecv on the communicator of ncclCommInitAll; librccl is dlopen'ed at the
+ * first create).  The reference has nothing here: it is single-process, single-host (gp.py:327).  The
+ * multi-PROCESS form of the same algorithm (one rank per GPU under torch.distributed; what bench.py
+ * --gpus N runs) is george_amd/distributed.py.  get_inverse / apply_sqrt / predict: not offered on this
+ * handle (K^-1 is N x N on the host: use gh_mgpu_solve on the columns that are needed). */
+typedef struct gh_mgpu gh_mgpu;
+enum {
+  GH_MGPU_RCCL = 0,      /* RCCL point-to-point over xGMI; one rank per physical device                      */
+  GH_MGPU_COPY = 1       /* peer copies behind events; the same device may be listed several times ("virtual
+                            devices": exercises the n_dev-rank ownership and ordering logic on one GPU)     */
+};
+typedef struct gh_mgpu_opts {
+  int32_t n_dev;             /* 1..16 */
+  int32_t devices[16];       /* HIP device ordinals, rank i runs on devices[i] */
+  int32_t pr, pc;            /* process grid, pr * pc == n_dev; 0, 0: as square as n_dev allows (1x2, 2x2, 2x4) */
+  int32_t nb;                /* tile edge, multiple of 128; 0: 1024 from N = 24576 up, else 512 */
+  int32_t transport;         /* GH_MGPU_RCCL | GH_MGPU_COPY */
+  int32_t reserved[4];
+} gh_mgpu_opts;
+int  gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out);      /* communicators + an all-reduce self-check */
+void gh_mgpu_destroy(gh_mgpu* h);
+/* basic.py:51-70 on the grid: every rank builds its own tiles from (kernel, x, yerr) -- host pointers --
+ * and the factor stays sharded; GH_ERR_NOT_PD + gh_mgpu_info() as gh_chol_compute */
+int  gh_mgpu_compute(gh_mgpu* h, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                     const double* yerr, double* logdet_out);
+int64_t gh_mgpu_info(const gh_mgpu* h);
+int  gh_mgpu_grid(const gh_mgpu* h, int32_t* pr, int32_t* pc, int32_t* nb);
+int  gh_mgpu_dot_solve(gh_mgpu* h, const double* y, double* out);                     /* basic.py:89-102 */
+int  gh_mgpu_solve(gh_mgpu* h, const double* b, int64_t nrhs, double* out);           /* basic.py:72-87; (n, nrhs) row-major, may alias */
+
 /* ------------------------------------------- device-level tile operations
  * Building blocks of the blocked factorisation on DEVICE pointers and an
  * explicit hipStream_t (passed as void*; NULL = default stream).  Used by the
@@ -272,6 +306,10 @@ int gh_dev_gemv(const double* a, int64_t lda, int64_t m, int64_t n, int32_t tran
  * (n/128 + 1) * 4 bytes of device memory, zeroed here.  w is read only. */
 int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* dinv, int64_t n,
                       const double* w, double* z, void* scratch, void* stream);
+/* x = L^-T w for the same block (trsv_bwd_chain); same scratch; w is read only.  After either call
+ * ((int32_t*)scratch)[n/128] != 0 means a workgroup gave up waiting for its predecessor (2 s). */
+int gh_dev_trsv_lower_t(const double* l, int64_t ldl, const double* dinv, int64_t n,
+                        const double* w, double* x, void* scratch, void* stream);
 /* in-place lower Cholesky of the n x n block `a`; dinv receives the inverses of
  * its 128x128 diagonal blocks, (n/128) x 128 x 128; *info_dev (device int64) is
  * set to base_index + failing pivot (1-based) when not positive definite. */

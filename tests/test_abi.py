@@ -34,6 +34,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(N.gh_chol_opts) == 8 * 4
     assert ctypes.sizeof(N.gh_chol_profile) == 11 * 8
     assert ctypes.sizeof(N.gh_hodlr_opts) == 4 * 4 + 8 + 4 * 4
+    assert ctypes.sizeof(N.gh_mgpu_opts) == (1 + 16 + 2 + 1 + 1 + 4) * 4
 
 
 def test_program_validation_runs_without_gpu():
@@ -49,6 +50,33 @@ def test_program_validation_runs_without_gpu():
         program.flatten(object())                          # "invalid kernel", parser.h:16
     with pytest.raises(ValueError):
         K.ExpSquaredKernel(1.0, ndim=2) + K.ExpSquaredKernel(1.0, ndim=3)   # dimension mismatch at build time
+
+
+def test_multi_gpu_entry_points_declared_and_validated():
+    """the sharded dense solver sits behind the C ABI (gh_mgpu_*).  Argument validation is
+    host code and runs without a GPU: bad device counts / grids are GH_ERR_BAD_ARG (ValueError), and with
+    no device visible creation fails loudly (RuntimeError), never a silent single-GPU or CPU path."""
+    from george_amd import _native as N, MultiGPUSolver
+    for name in ("gh_mgpu_create", "gh_mgpu_destroy", "gh_mgpu_compute", "gh_mgpu_info", "gh_mgpu_grid",
+                 "gh_mgpu_dot_solve", "gh_mgpu_solve", "gh_dev_trsv_lower_t"):
+        assert name in N.SIGNATURES and hasattr(N.lib, name)
+    o = N.gh_mgpu_opts()
+    h = N._vp()
+    o.n_dev = 0
+    with pytest.raises(ValueError):
+        N.check(N.lib.gh_mgpu_create(ctypes.byref(o), ctypes.byref(h)))
+    o.n_dev, o.nb = 2, 100
+    with pytest.raises(ValueError):
+        N.check(N.lib.gh_mgpu_create(ctypes.byref(o), ctypes.byref(h)))
+    with pytest.raises(ValueError):
+        MultiGPUSolver(None, devices=[], transport="rccl")
+    with pytest.raises(ValueError):
+        MultiGPUSolver(None, devices=[0], transport="smoke signals")
+    import george_amd
+    if george_amd.device_count() == 0:
+        o.n_dev, o.nb = 1, 0
+        with pytest.raises(RuntimeError):
+            N.check(N.lib.gh_mgpu_create(ctypes.byref(o), ctypes.byref(h)))
 
 
 def test_fails_loudly_without_gpu():
