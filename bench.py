@@ -120,6 +120,15 @@ class DenseJob(object):
         self.N.check(self.N.lib.gh_chol_get_profile(self.h, C.byref(p)))
         return p
 
+    def update_intervals(self):
+        """(start ms, end ms, flops) of every trailing-update launch of the last step (HIP events, each pair on the
+        stream its launch went to; times from the start of that step's compute())"""
+        cnt = C.c_int32(0)
+        self.N.check(self.N.lib.gh_chol_get_update_intervals(self.h, None, 0, C.byref(cnt)))
+        buf = np.zeros((max(cnt.value, 1), 3))
+        self.N.check(self.N.lib.gh_chol_get_update_intervals(self.h, self.N.ptr(buf), cnt.value, C.byref(cnt)))
+        return buf[:cnt.value]
+
     def close(self):
         self.N.lib.gh_chol_destroy(self.h)
 
@@ -423,6 +432,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl == RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: every rank uses device 0 (with --backend gloo: exercises the N>1 path on a 1-GPU box)")
+    ap.add_argument("--dump-intervals", default="", help="write the per-launch (start, end, flops) list behind the roofline "
+                    "object to this JSON file (committed under profiles/: the union-based fraction is reproducible from it)")
     ap.add_argument("--kernel", default="expsquared", choices=sorted(KERNEL_NAMES),
                     help="expsquared = north-star target / configs[1]; matern32 = configs[2] (C3, checked against "
                          "tests/golden/large.json[C3] at N=65536)")
@@ -623,6 +634,27 @@ def main():
                         "algorithmic_flops_per_launch": p.trailing_flops / p.n_trailing,
                     }
                 out["roofline"].update(pmc_traffic(args.n))
+                # the launches behind `achieved`, so that the union can be re-derived from the line itself (and from
+                # profiles/<round>/update_intervals_N<n>.json, written by --dump-intervals)
+                iv = job.update_intervals()
+                if len(iv):
+                    order = np.argsort(iv[:, 0])
+                    tot, lo, hi = 0.0, iv[order[0], 0], iv[order[0], 1]
+                    for q in order[1:]:
+                        if iv[q, 0] > hi:
+                            tot, lo, hi = tot + hi - lo, iv[q, 0], iv[q, 1]
+                        elif iv[q, 1] > hi:
+                            hi = iv[q, 1]
+                    tot += hi - lo
+                    out["roofline"]["launch_intervals"] = {
+                        "unit": "ms from the start of the last step's compute(); [start, end, algorithmic GFLOP] per launch",
+                        "launches": [[round(float(a), 3), round(float(b), 3), round(float(f) * 1e-9, 1)] for a, b, f in iv],
+                        "union_ms_recomputed": tot, "sum_gflop": float(iv[:, 2].sum() * 1e-9)}
+                    if args.dump_intervals:
+                        with open(args.dump_intervals, "w") as f:
+                            json.dump({"n": args.n, "nb": args.nb, "ms_update_union": union, "update_flops": p.update_flops,
+                                       "achieved_tflops": p.update_flops / (union * 1e-3) * 1e-12 if union > 0 else None,
+                                       "launches_start_end_ms_flops": iv.tolist()}, f)
             out["phases_ms"] = {"total_compute": p.ms_total, "kernel_matrix_build": p.ms_build,
                                 "panel_factor_trsm": p.ms_panel, "trailing_syrk": p.ms_trailing,
                                 "forward_solve": p.ms_solve}

@@ -131,6 +131,7 @@ SIGNATURES = {
     "gh_chol_trim": (None, [_vp]),
     "gh_chol_release_buffers": (None, [_vp]),
     "gh_chol_get_profile": (C.c_int, [_vp, C.POINTER(gh_chol_profile)]),
+    "gh_chol_get_update_intervals": (C.c_int, [_vp, _dp, _i32, C.POINTER(C.c_int32)]),
     "gh_hodlr_create": (C.c_int, [C.POINTER(gh_hodlr_opts), C.POINTER(_vp)]),
     "gh_hodlr_destroy": (None, [_vp]),
     "gh_hodlr_compute": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, C.POINTER(C.c_double)]),

@@ -493,6 +493,8 @@ struct gh_chol {
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
   std::vector<size_t> ev_trailing, ev_panel, ev_update;   // ev_update: EVERY trailing-update launch (wide SYRKs and block-column GEMMs)
+  std::vector<double> ev_update_flops;                    // algorithmic flops of each ev_update launch
+  std::vector<double> upd_intervals;                      // last compute(): (start ms, end ms, flops) per trailing-update launch
   // returns an index into ev_pool (the vector may grow, so never keep pointers), or -1
   long next_ev() {
     if (ev_used == ev_pool.size()) {
@@ -650,6 +652,14 @@ extern "C" int64_t gh_chol_device_bytes(const gh_chol* s) {
   for (const GhBuf* b : {&s->A, &s->dinv, &s->x, &s->yerr, &s->v0, &s->v1, &s->v2, &s->scal, &s->rhs, &s->work, &s->work2,
                          &s->scratch, &s->chain}) tot += b->p ? b->bytes : 0;
   return (int64_t)tot;
+}
+extern "C" int gh_chol_get_update_intervals(const gh_chol* s, double* out, int32_t max_launches, int32_t* n_out) {
+  if (!s || !n_out || (max_launches > 0 && !out)) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  const int32_t have = (int32_t)(s->upd_intervals.size() / 3);
+  *n_out = have;
+  for (int32_t i = 0; i < have && i < max_launches; ++i)
+    for (int q = 0; q < 3; ++q) out[3 * i + q] = s->upd_intervals[3 * (size_t)i + q];
+  return GH_OK;
 }
 extern "C" int gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out) {
   if (!s || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
@@ -897,7 +907,9 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     // (algorithmic flops of the block column: its lower part only -- the strictly-upper tiles of the
     //  diagonal block are computed for convenience and never read)
     const double tr = (double)(np - c0(c)) / T, tc = (double)nbc(c) / T;
-    s->prof.update_flops += (tr * tc - tc * (tc - 1.0) / 2.0) * 2.0 * T * T * (double)nbc(j);
+    const double fl = (tr * tc - tc * (tc - 1.0) / 2.0) * 2.0 * T * T * (double)nbc(j);
+    s->prof.update_flops += fl;
+    if (eu >= 0) s->ev_update_flops.push_back(fl);
     return GH_OK;
   };
   // everything queued so far (the build, on s->st) before any of the three streams starts
@@ -935,7 +947,10 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     if (cw <= P - 1) {
       const int64_t kw = c0(cw), m2 = np - kw;
       const long et = prof ? s->next_ev() : -1;
-      if (et >= 0) { GH_HIP(hipEventRecord(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); s->ev_update.push_back((size_t)et); }
+      if (et >= 0) {
+        GH_HIP(hipEventRecord(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); s->ev_update.push_back((size_t)et);
+        s->ev_update_flops.push_back((double)(m2 / T) * (m2 / T + 1) / 2.0 * 2.0 * T * T * (double)nbc(j));
+      }
       const double* P2 = blk(A, ld, kw, c0(j));
       GH_CHECK(gemm_nt(sm, blk(A, ld, kw, kw), ld, P2, ld, P2, ld, m2, m2, nbc(j), -1.0, 1.0, true));
       if (et >= 0) GH_HIP(hipEventRecord(s->ev_pool[et].b, sm));
@@ -1018,7 +1033,7 @@ static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n,
   GH_CHECK(s->scal.ensure(256 * sizeof(double)));      // [0] log-det, [1] quadratic form, [8..72) and [72..136) slice sums
   hipStream_t st = s->st;
   memset(&s->prof, 0, sizeof(s->prof));
-  s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear(); s->ev_update.clear();
+  s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear(); s->ev_update.clear(); s->ev_update_flops.clear();
   const bool prof = s->opts.profile != 0;
   c.e_all = prof ? s->next_ev() : -1;
   c.e_build = prof ? s->next_ev() : -1;
@@ -1045,11 +1060,15 @@ static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long 
     // chain stream) was running: union of their event intervals, measured from the start of compute()
     if (!s->ev_update.empty()) {
       std::vector<std::pair<float, float>> iv;
-      for (size_t i : s->ev_update) {
+      s->upd_intervals.clear();
+      for (size_t q = 0; q < s->ev_update.size(); ++q) {
+        const size_t i = s->ev_update[q];
         float a = 0, b = 0;
         GH_HIP(hipEventElapsedTime(&a, s->ev_pool[c.e_all].a, s->ev_pool[i].a));
         GH_HIP(hipEventElapsedTime(&b, s->ev_pool[c.e_all].a, s->ev_pool[i].b));
         iv.emplace_back(a, b);
+        s->upd_intervals.push_back(a); s->upd_intervals.push_back(b);
+        s->upd_intervals.push_back(q < s->ev_update_flops.size() ? s->ev_update_flops[q] : 0.0);
       }
       std::sort(iv.begin(), iv.end());
       double tot = 0.0;

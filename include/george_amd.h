@@ -230,6 +230,10 @@ typedef struct gh_chol_profile {
   double reserved[2];
 } gh_chol_profile;
 int  gh_chol_get_profile(const gh_chol* s, gh_chol_profile* out);
+/* per trailing-update launch of the last profiled compute(): (start ms, end ms, algorithmic flops), times from the
+ * start of compute() by HIP events on the stream each launch went to; *n_out = number of launches recorded.  The
+ * union of these intervals is gh_chol_profile.ms_update_union (bench.py's roofline: reproducible from them). */
+int  gh_chol_get_update_intervals(const gh_chol* s, double* out /* 3 * max_launches */, int32_t max_launches, int32_t* n_out);
 
 /* ------------------------------------------------------------ HODLR solver
  * Replaces HODLRSolver (src/george/solvers/hodlr.py:13-76), the pybind11

@@ -465,6 +465,49 @@ def test_stepwise_trsv_arm_still_works():
     assert abs(outs[0][1] - outs[1][1]) <= 1e-9 * abs(outs[0][1])
 
 
+def test_chained_solves_are_bit_stable_under_load():
+    """The flag-driven chained solves (trsv_fwd_chain / trsv_bwd_chain: one launch, workgroup b waits for the z_j of
+    its predecessors on agent-scope atomics ordered by s_waitcnt, no fences -- every log-likelihood goes through
+    them) repeated 150 times, first alone, then while a second thread keeps the chip full with factorisations of
+    another matrix on the SAME process-wide streams: every repetition must reproduce the first result bit for bit
+    (a stale flag or a missed hand-over shows up as a different sum), and a factor recomputed in between must too."""
+    import threading
+    x, yerr, y = zoo.bench_data(8192)
+    gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
+    gp.compute(x, yerr)
+    q0 = gp.solver.dot_solve(y)
+    a0 = gp.solver.apply_inverse(y)
+    for _ in range(50):
+        assert gp.solver.dot_solve(y) == q0
+    x2, yerr2, y2 = zoo.bench_data(6144)
+    other = GP(np.var(y2) * kernels.Matern32Kernel(1.0))
+    other.compute(x2, yerr2)
+    ld2 = other.solver.log_determinant
+    stop, bad = threading.Event(), []
+
+    def load():
+        while not stop.is_set():
+            other.kernel.dirty = True
+            other.compute(x2, yerr2)
+            if other.solver.log_determinant != ld2:
+                bad.append(other.solver.log_determinant)
+
+    t = threading.Thread(target=load)
+    t.start()
+    try:
+        for rep in range(100):
+            assert gp.solver.dot_solve(y) == q0, rep
+            if rep % 10 == 0:
+                assert np.array_equal(gp.solver.apply_inverse(y), a0), rep
+            if rep % 25 == 24:                                             # a fresh factor of the same matrix
+                gp.kernel.dirty = True
+                gp.compute(x, yerr)
+    finally:
+        stop.set()
+        t.join()
+    assert not bad, bad[:3]
+
+
 def test_tutorial_kernel_family():                                      # tests/test_tutorial.py
     rng = np.random.RandomState(1)
     x = np.sort(rng.uniform(0, 30, 50))
