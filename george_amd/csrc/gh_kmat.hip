@@ -283,21 +283,11 @@ struct KmatArgs {
   GhFast fast;             // affine single-leaf form (fast.ok) -> no interpreter, no node loads
 };
 
+// One 64 x 64 tile, any kernel expression, any position (edges, padding, diagonal).
 // FAST: the kernel has the affine single-leaf form (a.fast): no interpreter in the instantiation
 // (half the registers), passes unrolled so that several exp() chains are in flight per lane.
 template <bool FAST>
-__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
-  __shared__ double xr[KT * GH_MAX_NDIM];
-  __shared__ double xc[KT * GH_MAX_NDIM];
-  int ti, tj;
-  if (a.lower_only) {
-    // enumerate 128x128 tiles of the lower triangle (the granularity of the factorisation);
-    // blockIdx.y picks one of its four 64x64 sub-tiles, so diagonal 128-tiles are built in full
-    int TI, TJ;
-    tri_index(blockIdx.x, TI, TJ);
-    ti = TI * 2 + (blockIdx.y >> 1);
-    tj = TJ * 2 + (blockIdx.y & 1);
-  } else { ti = blockIdx.x / a.tiles_n; tj = blockIdx.x % a.tiles_n; }
+__device__ __forceinline__ void kmat_generic_tile(const KmatArgs& a, int ti, int tj, double* xr, double* xc) {
   const long r0 = (long)ti * KT, c0 = (long)tj * KT;
   const int nd = a.ndim;
   // stage the tile's points (coalesced: consecutive threads read consecutive doubles)
@@ -342,6 +332,83 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
     }
   }
 }
+__device__ __forceinline__ void kmat_tile_of(const KmatArgs& a, int& ti, int& tj) {
+  if (a.lower_only) {
+    // enumerate 128x128 tiles of the lower triangle (the granularity of the factorisation);
+    // blockIdx.y picks one of its four 64x64 sub-tiles, so diagonal 128-tiles are built in full
+    int TI, TJ;
+    tri_index(blockIdx.x, TI, TJ);
+    ti = TI * 2 + (blockIdx.y >> 1);
+    tj = TJ * 2 + (blockIdx.y & 1);
+  } else { ti = blockIdx.x / a.tiles_n; tj = blockIdx.x % a.tiles_n; }
+}
+template <bool FAST>
+__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
+  __shared__ double xr[KT * GH_MAX_NDIM];
+  __shared__ double xc[KT * GH_MAX_NDIM];
+  int ti, tj;
+  kmat_tile_of(a, ti, tj);
+  kmat_generic_tile<FAST>(a, ti, tj, xr, xc);
+}
+
+// Interior tiles of the stationary kernels a + b F(r^2) on ND <= 3 coordinates used as they come (axes =
+// 0 .. ND-1, isotropic or axis-aligned metric): the common case of the dense build (BASELINE configs C1-C5)
+// with everything the generic tile pays per ELEMENT taken out -- bounds and padding tests, the ordered
+// (x_min, x_max) evaluation (d * d is the same either way), the diagonal test, the run-time axis table and
+// dimension.  A lane keeps the coordinates of its two columns in registers and reads one row point per
+// pass from LDS.  r^2 and F are formed exactly as gh_fast_value forms them.  A tile that touches the
+// matrix edge, the padding or the global diagonal goes through kmat_generic_tile.  Counter-backed
+// motivation: the generic FAST kernel issues 63 vector instructions per element, 22 of them the exp
+// (profiles/r02/pmc_kmat_VALU_N32768.md): the build was VALU-bound at 38 % of the HBM write roofline.
+template <int KTYPE, int ND>
+__global__ __launch_bounds__(256) void kmat_interior_kernel(KmatArgs a) {
+  __shared__ double xr[KT * GH_MAX_NDIM];
+  __shared__ double xc[KT * GH_MAX_NDIM];
+  int ti, tj;
+  kmat_tile_of(a, ti, tj);
+  const long r0 = (long)ti * KT, c0 = (long)tj * KT;
+  const long gr0 = a.row0 + r0, gc0 = a.col0 + c0;
+  const bool interior = r0 + KT <= a.n1 && c0 + KT <= a.n2 && r0 + KT <= a.rows_p && c0 + KT <= a.cols_p &&
+                        (!a.sym || gr0 + KT <= gc0 || gc0 + KT <= gr0) && ((((size_t)a.out) | ((size_t)a.ldo * 8)) & 15) == 0;
+  if (!interior) { kmat_generic_tile<true>(a, ti, tj, xr, xc); return; }
+  for (int t = threadIdx.x; t < KT * ND; t += 256) xr[t] = a.x1[r0 * ND + t];
+  __syncthreads();
+  const int lc = (threadIdx.x & 31) * 2, lr = threadIdx.x >> 5;
+  double xa[ND], xb[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { xa[d] = a.x2[(c0 + lc) * ND + d]; xb[d] = a.x2[(c0 + lc + 1) * ND + d]; }
+  const GhFast& f = a.fast;
+  double* o = a.out + (r0 + lr) * a.ldo + c0 + lc;
+#pragma unroll 4
+  for (int pass = 0; pass < KT / 8; ++pass, o += 8 * a.ldo) {
+    const double* p1 = &xr[(lr + pass * 8) * ND];
+    double v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      double r2 = 0.0;
+      if (f.mtype == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) { const double dd = p1[d] - (e ? xb[d] : xa[d]); sum += dd * dd; }
+        r2 = sum * f.m[0];
+      } else {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) { const double dd = p1[d] - (e ? xb[d] : xa[d]); r2 += dd * dd * f.m[d]; }
+      }
+      double w;
+      if (KTYPE == GH_K_EXPSQUARED) w = exp(-0.5 * r2);
+      else if (KTYPE == GH_K_MATERN32) { const double r = sqrt(3.0 * r2); w = (1.0 + r) * exp(-r); }
+      else if (KTYPE == GH_K_MATERN52) { const double r = sqrt(5.0 * r2); w = (1 + r + 5.0 * r2 / 3.0) * exp(-r); }
+      else w = exp(-sqrt(r2));
+      {
+#pragma clang fp contract(off)          // two roundings, like gh_fast_value and the interpreter's * and + nodes
+        const double t = f.b * w;
+        v[e] = f.a + t;
+      }
+    }
+    *reinterpret_cast<double2*>(o) = make_double2(v[0], v[1]);
+  }
+}
 
 int gh_launch_kmat(const gh_kernel* k, const double* x1, int64_t n1, const double* x2, int64_t n2,
                    const double* yerr, double* out, int64_t ldo, int64_t rows_p, int64_t cols_p,
@@ -358,8 +425,29 @@ int gh_launch_kmat(const gh_kernel* k, const double* x1, int64_t n1, const doubl
   const long tm128 = (rows_p + 2 * KT - 1) / (2 * KT);
   long nblk = lower_only ? tm128 * (tm128 + 1) / 2 : tm * tn;
   if (nblk > 0x7fffffffL) { gh_set_error("kernel matrix too large"); return GH_ERR_BAD_ARG; }
-  if (a.fast.ok) hipLaunchKernelGGL(kmat_kernel<true>, dim3((unsigned)nblk, lower_only ? 4 : 1), dim3(256), 0, st, a);
-  else           hipLaunchKernelGGL(kmat_kernel<false>, dim3((unsigned)nblk, lower_only ? 4 : 1), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)nblk, lower_only ? 4 : 1), block(256);
+  // the specialised interior-tile kernel: a + b F(r^2), coordinates used as they come, ndim <= 3, x1 / x2 full arrays
+  static const bool no_interior = getenv("GEORGE_AMD_NO_KMAT_INTERIOR") != nullptr;
+  bool plain = a.fast.ok && !no_interior && k->ndim <= 3 && a.fast.naxes == k->ndim && (a.fast.mtype == 0 || a.fast.mtype == 1) &&
+               (a.fast.ktype == GH_K_EXPSQUARED || a.fast.ktype == GH_K_MATERN32 || a.fast.ktype == GH_K_MATERN52 || a.fast.ktype == GH_K_EXP);
+  for (int i = 0; plain && i < a.fast.naxes; ++i) if (a.fast.axes[i] != i) plain = false;
+  if (plain) {
+#define GH_KMAT_ND(KTYPE)                                                                                   \
+    do {                                                                                                    \
+      if (k->ndim == 1)      hipLaunchKernelGGL((kmat_interior_kernel<KTYPE, 1>), grid, block, 0, st, a);   \
+      else if (k->ndim == 2) hipLaunchKernelGGL((kmat_interior_kernel<KTYPE, 2>), grid, block, 0, st, a);   \
+      else                   hipLaunchKernelGGL((kmat_interior_kernel<KTYPE, 3>), grid, block, 0, st, a);   \
+    } while (0)
+    switch (a.fast.ktype) {
+      case GH_K_EXPSQUARED: GH_KMAT_ND(GH_K_EXPSQUARED); break;
+      case GH_K_MATERN32:   GH_KMAT_ND(GH_K_MATERN32); break;
+      case GH_K_MATERN52:   GH_KMAT_ND(GH_K_MATERN52); break;
+      default:              GH_KMAT_ND(GH_K_EXP); break;
+    }
+#undef GH_KMAT_ND
+  }
+  else if (a.fast.ok) hipLaunchKernelGGL(kmat_kernel<true>, grid, block, 0, st, a);
+  else                hipLaunchKernelGGL(kmat_kernel<false>, grid, block, 0, st, a);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }

@@ -52,6 +52,51 @@ def test_ragged_sizes_vs_oracle(name, kernel):
         kernel.thaw_all_parameters()
 
 
+@pytest.mark.parametrize("cls", [AK.ExpSquaredKernel, AK.Matern32Kernel, AK.Matern52Kernel, AK.ExpKernel])
+@pytest.mark.parametrize("ndim,metric", [(1, 0.7), (2, 1.9), (3, 0.5), (3, [1.0, 0.1, 10.0]), (2, [0.3, 2.0])])
+def test_interior_tile_kernel_vs_oracle(cls, ndim, metric):
+    """kmat_interior_kernel: the specialised 64x64 tiles of a + b F(r^2) on <= 3 plain coordinates, which only
+    matrices with at least one tile off the edge and off the diagonal reach -- symmetric, general and
+    offset builds at ragged sizes against the oracle, and against the generic tile path
+    (GEORGE_AMD_NO_KMAT_INTERIOR in a subprocess) to a few ulps."""
+    rng = np.random.RandomState(5 + ndim)
+    kernel = 0.8 * cls(metric, ndim=ndim) + 0.05
+    for n1, n2 in [(333, 200), (128, 192), (700, 65)]:
+        a, b = rng.uniform(0, 3, (n1, ndim)), rng.uniform(0, 3, (n2, ndim))
+        np.testing.assert_allclose(kernel.get_value(a, b), kernels_np.value_general(kernel, a, b), rtol=RTOL, atol=ATOL)
+        v = kernel.get_value(a)
+        np.testing.assert_allclose(v, kernels_np.value_symmetric(kernel, a), rtol=RTOL, atol=ATOL)
+        assert np.array_equal(v, v.T)
+    # the factorisation's own build (lower 128-tiles, yerr on the diagonal, identity padding): log-det vs NumPy
+    from george_amd import BasicSolver
+    x = np.sort(rng.uniform(0, 3, (900, ndim)), axis=0)
+    s = BasicSolver(kernel)
+    s.compute(x, 0.3 * np.ones(900))
+    Kd = kernels_np.value_symmetric(kernel, x) + 0.09 * np.eye(900)
+    assert abs(s.log_determinant - np.linalg.slogdet(Kd)[1]) <= 1e-9 * 900
+
+
+def test_interior_tile_kernel_matches_generic_path():
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np\n"
+            "import george_amd.kernels as K\n"
+            "rng = np.random.RandomState(3); x = rng.uniform(0, 3, (500, 3))\n"
+            "k = 0.8 * K.Matern52Kernel([1.0, 0.1, 10.0], ndim=3) + 0.05\n"
+            "np.save(sys.argv[1], k.get_value(x))\n") % root
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env in enumerate(({}, {"GEORGE_AMD_NO_KMAT_INTERIOR": "1"})):
+            e = dict(os.environ); e.update(env)
+            f = os.path.join(d, "v%d.npy" % i)
+            r = subprocess.run([sys.executable, "-c", code, f], env=e, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(np.load(f))
+    assert not np.array_equal(outs[0], np.zeros_like(outs[0]))
+    np.testing.assert_allclose(outs[0], outs[1], rtol=4e-16, atol=1e-17)
+
+
 def test_empty_and_bad_inputs():
     k = AK.ExpSquaredKernel(1.0, ndim=2)
     assert k.get_value(np.zeros((0, 2)), np.zeros((5, 2))).shape == (0, 5)
