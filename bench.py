@@ -308,6 +308,32 @@ def c5_report(local_rank, n=32768, m=4096):
     return res
 
 
+def mgpu_abi_report(local_rank, n=32768):
+    """The sharded solver behind the C ABI (gh_mgpu_*: host threads + RCCL) as a world of ONE on the leased GPU:
+    communicator creation, the all-reduce self-check and the block-cyclic driver end to end, against the
+    single-GPU solver on the same inputs.  (More than one physical device is the driver's 8-GPU tier.)"""
+    from george_amd import BasicSolver, MultiGPUSolver
+    x, yerr, y = make_inputs(n)
+    kernel = make_kernel("expsquared", np.var(y))
+    X, sig = x[:, None], np.sqrt(yerr ** 2 + 1.25e-12)
+    d = BasicSolver(kernel, device=local_rank)
+    d.compute(X, sig)
+    ll0 = -0.5 * (n * np.log(2 * np.pi) + d.log_determinant) - 0.5 * d.dot_solve(y)
+    s = MultiGPUSolver(kernel, devices=[local_rank], transport="rccl")
+    s.compute(X, sig)                                        # warm-up (buffers, communicator)
+    t0 = time.perf_counter()
+    s.compute(X, sig)
+    q = s.dot_solve(y)
+    sec = time.perf_counter() - t0
+    ll = -0.5 * (n * np.log(2 * np.pi) + s.log_determinant) - 0.5 * q
+    pr, pc, nb = s.grid_shape()
+    del s, d
+    return {"workload": "N=%d 1-D ExpSquared through gh_mgpu_create/compute/dot_solve, n_dev=1, transport RCCL" % n,
+            "seconds_per_step": sec, "value_tflops": flops_alg(n) / sec * 1e-12, "grid": "%dx%d" % (pr, pc), "nb": nb,
+            "log_likelihood": ll, "parity": {"n": n, "ll_gpu": ll, "ll_ref": ll0, "rel": abs(ll - ll0) / abs(ll0),
+                                             "ref": "single-GPU gh_chol_* on the same inputs (itself reference-pinned)"}}
+
+
 def public_api_report(n, local_rank, steps=2):
     """The headline work through the public facade: NumPy x, yerr, y -> GP.compute -> log_likelihood,
     host->device of the inputs included (SURVEY.md 8d's statement of the metric)."""
@@ -695,6 +721,11 @@ def main():
                 if "parity_cpu_sample" in out["config"]["also_C4"]:
                     parity["C4_hodlr_cpu_sample"] = out["config"]["also_C4"]["parity_cpu_sample"]
                 out["config"]["also_C5"] = c5_report(local_rank)
+                try:
+                    out["config"]["also_abi_multi_gpu_world_of_one"] = mgpu_abi_report(local_rank)
+                    parity["abi_multi_gpu_world_of_one"] = out["config"]["also_abi_multi_gpu_world_of_one"]["parity"]
+                except Exception as e:                               # (RCCL missing on the box: say so, keep the line)
+                    out["config"]["also_abi_multi_gpu_world_of_one"] = {"error": repr(e)}
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_n)
                 jp = DenseJob(args.cpu_n, args.nb, local_rank, profile=False)       # the GPU at the SAME N as the CPU sample

@@ -1,5 +1,6 @@
 // gh_mgpu.hip -- the dense GP solve on SEVERAL MI355X behind the C ABI: one process, one host thread
-// and one stream per device, 2-D block-cyclic tiles, panels moved with RCCL over xGMI.
+// and two streams per device (panel chain + transfers / trailing updates: one-panel look-ahead), 2-D
+// block-cyclic tiles, panels moved with RCCL over xGMI.
 //
 // Replaces, for a caller that binds include/george_amd.h directly, what BasicSolver.compute /
 // dot_solve / apply_inverse do on one host (reference src/george/solvers/basic.py:51-102) on `n_dev`
@@ -112,10 +113,14 @@ struct Group {                     // a process row, a process column, or the wo
 
 struct MRank {
   int rank = 0, dev = 0, pr = 0, pc = 0;
-  hipStream_t st = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipStream_t st = nullptr;        // trailing updates, build, sweeps
+  hipStream_t sp = nullptr;        // (high priority) the panel chain: potrf, TRSM and every transfer
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;        // GH_MGPU_COPY hand-shake (recorded on sp)
+  hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_bcol = nullptr;      // look-ahead: panel k is here / block column k+1 is up to date
+  hipStream_t su[2] = {nullptr, nullptr};                              // two more streams for the per-tile-column GEMMs of U(k): the tail of
+  hipEvent_t ev_fan = nullptr, ev_su[2] = {nullptr, nullptr};          // one launch overlaps the head of the next (fenced against st on both sides)
   gh_kernel kern;
-  GhBuf A, dinv, Lkk, wrow, colp, x, yerr, scal, zloc, xloc, va, vb, part, flags;
+  GhBuf A, dinv, Lkk, wrow[2], colp[2], x, yerr, scal, zloc, xloc, va, vb, part, flags;
   long long* d_info = nullptr;
   double* pin = nullptr;           // pinned host staging, 4 * nb doubles
   std::vector<int> rows, cols;     // global tile rows / columns this rank owns, ascending
@@ -145,12 +150,17 @@ struct gh_mgpu {
     for (auto& r : ranks) {
       (void)hipSetDevice(r.dev);
       if (r.st) (void)hipStreamSynchronize(r.st);
-      for (GhBuf* b : {&r.A, &r.dinv, &r.Lkk, &r.wrow, &r.colp, &r.x, &r.yerr, &r.scal, &r.zloc, &r.xloc, &r.va, &r.vb, &r.part, &r.flags}) b->release();
+      if (r.sp) (void)hipStreamSynchronize(r.sp);
+      for (GhBuf* b : {&r.A, &r.dinv, &r.Lkk, &r.wrow[0], &r.wrow[1], &r.colp[0], &r.colp[1], &r.x, &r.yerr, &r.scal, &r.zloc, &r.xloc, &r.va,
+                       &r.vb, &r.part, &r.flags}) b->release();
       if (r.kern.d_nodes) { (void)hipFree(r.kern.d_nodes); r.kern.d_nodes = nullptr; }
       if (r.d_info) (void)hipFree(r.d_info);
       if (r.pin) (void)hipHostFree(r.pin);
       if (r.ev_ready) (void)hipEventDestroy(r.ev_ready);
       if (r.ev_done) (void)hipEventDestroy(r.ev_done);
+      for (hipEvent_t e : {r.ev_panel[0], r.ev_panel[1], r.ev_bcol, r.ev_fan, r.ev_su[0], r.ev_su[1]}) if (e) (void)hipEventDestroy(e);
+      for (hipStream_t q : {r.su[0], r.su[1]}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+      if (r.sp) (void)hipStreamDestroy(r.sp);
       if (r.st) (void)hipStreamDestroy(r.st);
     }
     if (have_comms) for (int i = 0; i < W; ++i) (void)g_rccl.CommDestroy(comms[i]);
@@ -174,33 +184,33 @@ inline int local_index(const std::vector<int>& v, int g) {            // positio
 inline int first_at_least(const std::vector<int>& v, int g) { return (int)(std::lower_bound(v.begin(), v.end(), g) - v.begin()); }
 
 // ---- broadcast of `count` doubles at `buf` (same address role on every member) from global rank `root`
-int mg_bcast(gh_mgpu* h, MRank& r, Group& g, double* buf, size_t count, int root) {
+int mg_bcast(gh_mgpu* h, MRank& r, Group& g, double* buf, size_t count, int root, hipStream_t st) {
   if (g.members.size() <= 1 || count == 0) return GH_OK;
   if (h->opts.transport == GH_MGPU_RCCL) {
     MG_NCCL(g_rccl.GroupStart());
     if (r.rank == root) {
-      for (int p : g.members) if (p != root) MG_NCCL(g_rccl.Send(buf, count, ncclDouble, p, h->comms[r.rank], r.st));
+      for (int p : g.members) if (p != root) MG_NCCL(g_rccl.Send(buf, count, ncclDouble, p, h->comms[r.rank], st));
     } else {
-      MG_NCCL(g_rccl.Recv(buf, count, ncclDouble, root, h->comms[r.rank], r.st));
+      MG_NCCL(g_rccl.Recv(buf, count, ncclDouble, root, h->comms[r.rank], st));
     }
     MG_NCCL(g_rccl.GroupEnd());
     return GH_OK;
   }
   // peer copies: root publishes (pointer, "data ready" event); members pull; root waits for their "done" events
   if (r.rank == root) {
-    GH_HIP(hipEventRecord(r.ev_ready, r.st));
+    GH_HIP(hipEventRecord(r.ev_ready, st));
     g.src = buf; g.src_dev = r.dev; g.src_ready = r.ev_ready;
   }
   if (!g.bar.wait()) { gh_set_error("multi-GPU solve aborted (another rank failed)"); return GH_ERR_HIP; }
   if (r.rank != root) {
-    GH_HIP(hipStreamWaitEvent(r.st, g.src_ready, 0));
-    if (g.src_dev == r.dev) GH_HIP(hipMemcpyAsync(buf, g.src, count * sizeof(double), hipMemcpyDeviceToDevice, r.st));
-    else GH_HIP(hipMemcpyPeerAsync(buf, r.dev, g.src, g.src_dev, count * sizeof(double), r.st));
-    GH_HIP(hipEventRecord(r.ev_done, r.st));
+    GH_HIP(hipStreamWaitEvent(st, g.src_ready, 0));
+    if (g.src_dev == r.dev) GH_HIP(hipMemcpyAsync(buf, g.src, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    else GH_HIP(hipMemcpyPeerAsync(buf, r.dev, g.src, g.src_dev, count * sizeof(double), st));
+    GH_HIP(hipEventRecord(r.ev_done, st));
   }
   if (!g.bar.wait()) { gh_set_error("multi-GPU solve aborted (another rank failed)"); return GH_ERR_HIP; }
   if (r.rank == root)
-    for (int p : g.members) if (p != root) GH_HIP(hipStreamWaitEvent(r.st, h->ranks[p].ev_done, 0));
+    for (int p : g.members) if (p != root) GH_HIP(hipStreamWaitEvent(st, h->ranks[p].ev_done, 0));
   if (!g.bar.wait()) { gh_set_error("multi-GPU solve aborted (another rank failed)"); return GH_ERR_HIP; }   // (events and g.src are reused by the next call)
   return GH_OK;
 }
@@ -262,8 +272,10 @@ int rank_setup(gh_mgpu* h, MRank& r, const gh_kernel* k, const double* x, const 
   GH_CHECK(r.A.ensure(nlr * nb * nlc * nb * sizeof(double)));
   GH_CHECK(r.dinv.ensure((size_t)nt * (nb / T) * T * T * sizeof(double)));
   GH_CHECK(r.Lkk.ensure((size_t)nb * nb * sizeof(double)));
-  GH_CHECK(r.wrow.ensure(nlr * nb * nb * sizeof(double)));
-  GH_CHECK(r.colp.ensure(nlc * nb * nb * sizeof(double)));
+  for (int q = 0; q < 2; ++q) {                              // panel workspaces, double-buffered for the look-ahead
+    GH_CHECK(r.wrow[q].ensure(nlr * nb * nb * sizeof(double)));
+    GH_CHECK(r.colp[q].ensure(nlc * nb * nb * sizeof(double)));
+  }
   GH_CHECK(r.x.ensure((size_t)n * h->ndim * sizeof(double)));
   GH_CHECK(r.yerr.ensure((size_t)n * sizeof(double)));
   GH_CHECK(r.scal.ensure(64 * sizeof(double)));
@@ -283,6 +295,12 @@ int rank_setup(gh_mgpu* h, MRank& r, const gh_kernel* k, const double* x, const 
   return GH_OK;
 }
 
+// Right-looking factorisation with one-panel look-ahead on two streams per rank:
+//   sp (high priority): P(k) -- potrf, column TRSM and EVERY transfer of panel k;
+//   st                : U(k) -- first the tiles of block column k+1 (event ev_bcol: P(k+1) may start),
+//                       then the rest of the trailing update, which runs while P(k+1) is factored and travels.
+// Panel workspaces alternate by the parity of k: P(k+2) overwrites what U(k) read, and it is issued
+// only after the block-column part of U(k+1), which follows U(k) on st.
 int rank_factor(gh_mgpu* h, MRank& r) {
   const int64_t nb = h->nb, nt = h->nt;
   const int Pr = h->Pr, Pc = h->Pc;
@@ -296,58 +314,94 @@ int rank_factor(gh_mgpu* h, MRank& r) {
       if (j <= i)
         GH_CHECK(gh_dev_kmat_block(&r.kern, r.x.d(), h->n, (int32_t)h->ndim, r.yerr.d(), (int64_t)i * nb, nb, (int64_t)j * nb, nb,
                                    tile(i, j), ld, r.st));
-  // ---- factor
-  for (int k = 0; k < nt; ++k) {
+  // P(k) on stream sp into workspace `buf`
+  auto panel = [&](int k, int buf) -> int {
+    hipStream_t sp = r.sp;
     const int kr = k % Pr, kc = k % Pc;
     const bool in_col = (r.pc == kc);
     double* dk = r.dinv.d() + (long)k * (nb / T) * T * T;
+    double* wrow = r.wrow[buf].d();
+    double* colp = r.colp[buf].d();
     if (r.pr == kr && in_col) {
       double* akk = tile(k, k);
-      GH_CHECK(gh_dev_potrf_block(akk, ld, nb, dk, (int64_t*)r.d_info, (int64_t)k * nb, r.st));
-      GH_CHECK(gh_dev_logdet_accum(akk, ld, nb, r.scal.d(), r.st));
-      GH_CHECK(mg_copy2d(r.st, akk, ld, r.Lkk.d(), nb, nb, nb));
+      GH_CHECK(gh_dev_potrf_block(akk, ld, nb, dk, (int64_t*)r.d_info, (int64_t)k * nb, sp));
+      GH_CHECK(gh_dev_logdet_accum(akk, ld, nb, r.scal.d(), sp));
+      GH_CHECK(mg_copy2d(sp, akk, ld, r.Lkk.d(), nb, nb, nb));
     }
-    if (k == nt - 1) break;
+    if (k == nt - 1) return GH_OK;
     if (in_col && Pr > 1) {
       GH_CHECK(mg_group_start(h));
-      GH_CHECK(mg_bcast(h, r, h->colg[kc], r.Lkk.d(), (size_t)nb * nb, grank(h, kr, kc)));
-      GH_CHECK(mg_bcast(h, r, h->colg[kc], dk, (size_t)(nb / T) * T * T, grank(h, kr, kc)));
+      GH_CHECK(mg_bcast(h, r, h->colg[kc], r.Lkk.d(), (size_t)nb * nb, grank(h, kr, kc), sp));
+      GH_CHECK(mg_bcast(h, r, h->colg[kc], dk, (size_t)(nb / T) * T * T, grank(h, kr, kc), sp));
       GH_CHECK(mg_group_end(h));
     }
     const int li0 = first_at_least(r.rows, k + 1);
     const long m = (long)(nlr - li0) * nb;
     if (in_col && m > 0) {
-      double* panel = A + (long)li0 * nb * ld + (long)local_index(r.cols, k) * nb;
-      GH_CHECK(gh_dev_trsm_right(r.Lkk.d(), nb, dk, panel, ld, m, nb, r.st));
-      GH_CHECK(mg_copy2d(r.st, panel, ld, r.wrow.d(), nb, m, nb));
+      double* pan = A + (long)li0 * nb * ld + (long)local_index(r.cols, k) * nb;
+      GH_CHECK(gh_dev_trsm_right(r.Lkk.d(), nb, dk, pan, ld, m, nb, sp));
+      GH_CHECK(mg_copy2d(sp, pan, ld, wrow, nb, m, nb));
     }
-    if (Pc > 1 && m > 0) GH_CHECK(mg_bcast(h, r, h->rowg[r.pr], r.wrow.d(), (size_t)m * nb, grank(h, r.pr, kc)));
+    if (Pc > 1 && m > 0) GH_CHECK(mg_bcast(h, r, h->rowg[r.pr], wrow, (size_t)m * nb, grank(h, r.pr, kc), sp));
     // column panel: tile row j of the panel, for my tile columns j > k; held (after the row transfer) by process row j % Pr
     const int lc0 = first_at_least(r.cols, k + 1);
     GH_CHECK(mg_group_start(h));
     for (size_t lj = lc0; lj < r.cols.size(); ++lj) {
       const int j = r.cols[lj], src_pr = j % Pr;
-      double* pj = r.colp.d() + (long)lj * nb * nb;
+      double* pj = colp + (long)lj * nb * nb;
       if (r.pr == src_pr)
-        GH_HIP(hipMemcpyAsync(pj, r.wrow.d() + (long)(local_index(r.rows, j) - li0) * nb * nb, (size_t)nb * nb * sizeof(double),
-                              hipMemcpyDeviceToDevice, r.st));
-      if (Pr > 1) GH_CHECK(mg_bcast(h, r, h->colg[r.pc], pj, (size_t)nb * nb, grank(h, src_pr, r.pc)));
+        GH_HIP(hipMemcpyAsync(pj, wrow + (long)(local_index(r.rows, j) - li0) * nb * nb, (size_t)nb * nb * sizeof(double),
+                              hipMemcpyDeviceToDevice, sp));
+      if (Pr > 1) GH_CHECK(mg_bcast(h, r, h->colg[r.pc], pj, (size_t)nb * nb, grank(h, src_pr, r.pc), sp));
     }
     GH_CHECK(mg_group_end(h));
-    // U(k): my trailing tiles
-    for (size_t lj = lc0; lj < r.cols.size(); ++lj) {
+    return GH_OK;
+  };
+  // U(k) restricted to my tile columns with global index in [jlo, jhi], on stream st, from workspace `buf`
+  auto update = [&](int k, int buf, int jlo, int jhi) -> int {
+    const int li0 = first_at_least(r.rows, k + 1);
+    const size_t l0 = first_at_least(r.cols, jlo);
+    size_t l1 = l0;
+    while (l1 < r.cols.size() && r.cols[l1] <= jhi) ++l1;
+    const bool fan = l1 - l0 >= 3;                               // independent GEMMs dealt over st, su[0], su[1]
+    if (fan) {
+      GH_HIP(hipEventRecord(r.ev_fan, r.st));
+      for (hipStream_t q : r.su) GH_HIP(hipStreamWaitEvent(q, r.ev_fan, 0));
+    }
+    for (size_t lj = l0; lj < l1; ++lj) {
       const int j = r.cols[lj];
       const int ls = first_at_least(r.rows, j);
       if (ls >= nlr) continue;
-      GH_CHECK(gh_dev_gemm_nt(A + (long)ls * nb * ld + (long)lj * nb, ld, r.wrow.d() + (long)(ls - li0) * nb * nb, nb,
-                              r.colp.d() + (long)lj * nb * nb, nb, (long)(nlr - ls) * nb, nb, nb, 0, r.st));
+      const size_t q = fan ? (lj - l0) % 3 : 0;
+      GH_CHECK(gh_dev_gemm_nt(A + (long)ls * nb * ld + (long)lj * nb, ld, r.wrow[buf].d() + (long)(ls - li0) * nb * nb, nb,
+                              r.colp[buf].d() + (long)lj * nb * nb, nb, (long)(nlr - ls) * nb, nb, nb, 0, q == 0 ? r.st : r.su[q - 1]));
     }
+    if (fan)
+      for (int q = 0; q < 2; ++q) { GH_HIP(hipEventRecord(r.ev_su[q], r.su[q])); GH_HIP(hipStreamWaitEvent(r.st, r.ev_su[q], 0)); }
+    return GH_OK;
+  };
+  // ---- factor
+  GH_HIP(hipEventRecord(r.ev_bcol, r.st));                       // (the build is complete)
+  GH_HIP(hipStreamWaitEvent(r.sp, r.ev_bcol, 0));
+  GH_CHECK(panel(0, 0));
+  GH_HIP(hipEventRecord(r.ev_panel[0], r.sp));
+  for (int k = 0; k < nt; ++k) {
+    const int buf = k & 1;
+    GH_HIP(hipStreamWaitEvent(r.st, r.ev_panel[buf], 0));        // panel k is factored and here
+    if (k == nt - 1) break;
+    GH_CHECK(update(k, buf, k + 1, k + 1));                      // block column k+1 first
+    GH_HIP(hipEventRecord(r.ev_bcol, r.st));
+    GH_HIP(hipStreamWaitEvent(r.sp, r.ev_bcol, 0));
+    GH_CHECK(panel(k + 1, buf ^ 1));                             // P(k+1) beside the rest of U(k)
+    GH_HIP(hipEventRecord(r.ev_panel[buf ^ 1], r.sp));
+    GH_CHECK(update(k, buf, k + 2, (int)nt - 1));
   }
   long long info = 0;
   double ld_part = 0.0;
   GH_HIP(hipMemcpyAsync(&info, r.d_info, sizeof(long long), hipMemcpyDeviceToHost, r.st));
   GH_HIP(hipMemcpyAsync(&ld_part, r.scal.d(), sizeof(double), hipMemcpyDeviceToHost, r.st));
   GH_HIP(hipStreamSynchronize(r.st));
+  GH_HIP(hipStreamSynchronize(r.sp));
   r.info = info; r.logdet = ld_part;
   return GH_OK;
 }
@@ -479,9 +533,20 @@ extern "C" int gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out) {
     MRank& r = h->ranks[i];
     r.rank = i; r.dev = opts->devices[i]; r.pr = i / Pc; r.pc = i % Pc;
     h->rowg[r.pr].members.push_back(i); h->colg[r.pc].members.push_back(i); h->world.members.push_back(i);
+    int plo = 0, phi = 0;                                       // numerically lowest value = highest priority
+    if (hipSetDevice(r.dev) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
     if (hipSetDevice(r.dev) != hipSuccess || hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&r.sp, hipStreamNonBlocking, phi) != hipSuccess ||
         hipEventCreateWithFlags(&r.ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_panel[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_panel[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_bcol, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&r.su[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&r.su[1], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_fan, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_su[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_su[1], hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError(); delete h; gh_set_error("stream / event creation failed on device %d", opts->devices[i]); return GH_ERR_HIP;
     }
   }
