@@ -796,29 +796,13 @@ __global__ __launch_bounds__(256) void hodlr_mv_reduce_kernel(const MMJob* jobs,
     __syncthreads();
   }
 }
-// X(o_row + i, c) -= sum_k U(i, k) T(b_row + k, c);  U(i, k) at A[a_off + i * a_rs + k], i < m, k < kd <= 32.
-// sinv != nullptr: T = S^-1 Tsum is formed HERE for the rows this chunk needs (its half of the node's 2R rows:
-// T(b_row + k, c) = sum_j sinv[node][b_row % 2R + k][j] Tsum(node 2R + j, c), j ascending) instead of by a launch of
-// the tile kernel in between -- one launch fewer per level of every solve (11 per log-likelihood at C4).
+// X(o_row + i, c) -= sum_k U(i, k) T(b_row + k, c);  U(i, k) at A[a_off + i * a_rs + k], i < m, k < kd <= 32
 __global__ __launch_bounds__(128) void hodlr_mv_update_kernel(const MMJob* jobs, const double* A, long a_rs, const double* T, long Cp,
-                                                              double* X, long ldx, long xcol0, int C, const double* sinv, int R2) {
+                                                              double* X, long ldx, long xcol0, int C) {
   __shared__ double ts[32 * MV_C];
   const MMJob job = jobs[blockIdx.x];
   const int tid = threadIdx.x;
-  if (sinv) {
-    const int node = job.b_row / R2, r0 = job.b_row % R2;
-    const double* sv = sinv + (long)node * R2 * R2;
-    const double* tsum = T + (long)node * R2 * Cp;
-    for (int e = tid; e < job.kd * C; e += 128) {
-      const int k = e / C, c = e % C;
-      const double* srow = sv + (long)(r0 + k) * R2;
-      double acc = 0.0;
-      for (int j = 0; j < R2; ++j) acc += srow[j] * tsum[(long)j * Cp + c];
-      ts[k * MV_C + c] = acc;
-    }
-  } else {
-    for (int e = tid; e < job.kd * C; e += 128) ts[(e / C) * MV_C + (e % C)] = T[(long)(job.b_row + e / C) * Cp + (e % C)];
-  }
+  for (int e = tid; e < job.kd * C; e += 128) ts[(e / C) * MV_C + (e % C)] = T[(long)(job.b_row + e / C) * Cp + (e % C)];
   __syncthreads();
   if (tid >= job.m) return;
   double acc[MV_C];
@@ -1210,33 +1194,14 @@ __global__ __launch_bounds__(256) void hodlr_red_kernel(const MMJob* __restrict_
 // O tiles themselves (each lane's four rows x one column of a 16 x 16 tile, 128-byte row segments), K = R is
 // padded to 16 only (the tile kernel pads to 32 and stages both operands), operands straight from HBM / L2.
 //   O[(o_row + r) * ldo + c] -= sum_k A[a_off + r * a_rs + k] * B[(b_row + k) * ldb + c]
-// sinv != nullptr: B = S^-1 Tsum is formed here first, for the R rows of this chunk's half (into LDS, every
-// entry a dot product over j = 0 .. 2R-1 in ascending order), instead of by a launch of the tile kernel in
-// between (11 launches fewer per compute() at C4; each was 30-40 us of a latency-bound chain).
 template <int CT>
 __global__ __launch_bounds__(256) void hodlr_upd_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ A, long a_rs,
-                                                        const double* __restrict__ B, long ldb, double* __restrict__ O, long ldo, int C,
-                                                        const double* __restrict__ sinv, int R2) {
+                                                        const double* __restrict__ B, long ldb, double* __restrict__ O, long ldo, int C) {
   typedef double uk_v4d __attribute__((ext_vector_type(4)));
-  __shared__ double Ts[16 * (16 * CT + 1)];
-  constexpr int TP = 16 * CT + 1;
   const MMJob job = jobs[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   const int R = job.kd, nkk = (R + 3) >> 2, ct = (C + 15) >> 4;        // (uniform)
-  if (sinv) {
-    const int node = job.b_row / R2, r0 = job.b_row % R2;
-    const double* sv = sinv + (long)node * R2 * R2;
-    const double* tsum = B + (long)node * R2 * ldb;
-    for (int e = threadIdx.x; e < R * C; e += 256) {
-      const int k = e / C, c = e % C;
-      const double* srow = sv + (long)(r0 + k) * R2;
-      double acc = 0.0;
-      for (int j = 0; j < R2; ++j) acc += srow[j] * tsum[(long)j * ldb + c];
-      Ts[k * TP + c] = acc;
-    }
-    __syncthreads();
-  }
   double a[2][4], b[4][CT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1250,7 +1215,7 @@ __global__ __launch_bounds__(256) void hodlr_upd_kernel(const MMJob* __restrict_
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
       const int k = 4 * kk + fk, c = 16 * j + fr;
-      b[kk][j] = (k < R && c < C) ? (sinv ? Ts[k * TP + c] : B[(long)(job.b_row + k) * ldb + c]) : 0.0;
+      b[kk][j] = (k < R && c < C) ? B[(long)(job.b_row + k) * ldb + c] : 0.0;
     }
   double* const ob = O + (long)job.o_row * ldo;
 #pragma unroll
@@ -1303,16 +1268,12 @@ static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const do
   return GH_OK;
 }
 
-// sinv != nullptr: B is Tsum (row pitch ldb) and the core product S^-1 Tsum is formed inside the update kernel
 static int launch_upd(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* A, long a_rs, const double* B, long ldb,
-                      double* O, long ldo, int C, const double* sinv = nullptr) {
+                      double* O, long ldo, int C) {
   static const bool no_upd = getenv("GEORGE_AMD_HODLR_NO_UPD_KERNEL") != nullptr;
   if (njobs <= 0 || C <= 0 || R <= 0) return GH_OK;
-  if (no_upd || R > 16 || C > 128 || HCH > 128) {
-    if (sinv) { gh_set_error("internal: fused core product needs the per-chunk update kernel"); return GH_ERR_BAD_ARG; }
-    return launch_mm(h, jobs, njobs, HCH, A, a_rs, 1, B, ldb, 0, O, ldo, 0, C, true, HCH / 32);
-  }
-#define GH_UPD_LAUNCH(CT) hipLaunchKernelGGL(hodlr_upd_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, A, a_rs, B, ldb, O, ldo, C, sinv, 2 * R)
+  if (no_upd || R > 16 || C > 128 || HCH > 128) return launch_mm(h, jobs, njobs, HCH, A, a_rs, 1, B, ldb, 0, O, ldo, 0, C, true, HCH / 32);
+#define GH_UPD_LAUNCH(CT) hipLaunchKernelGGL(hodlr_upd_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, A, a_rs, B, ldb, O, ldo, C)
   switch ((C + 15) / 16) {
     case 1: GH_UPD_LAUNCH(1); break;
     case 2: GH_UPD_LAUNCH(2); break;
@@ -1356,17 +1317,9 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
                        h->P.d(), Cp, C);
     hipLaunchKernelGGL(hodlr_sum_narrow_kernel, dim3(nn, 2 * R), dim3(256), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, C, h->Tsum.d());
     GH_HIP(hipGetLastError());
-    static const bool no_fused_core = getenv("GEORGE_AMD_HODLR_NO_FUSED_CORE") != nullptr;
-    if (no_fused_core) {
-      GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
-                         h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, C, false));
-      hipLaunchKernelGGL(hodlr_mv_update_kernel, dim3(L->nchunks), dim3(128), 0, h->st, uj, Ub, u_rs, h->Tout.d(), Cp, X, ldx, xcol0, C,
-                         (const double*)nullptr, 2 * R);
-    } else {
-      // (the core product S^-1 Tsum is formed inside the update kernel, per chunk, for the rows it needs)
-      hipLaunchKernelGGL(hodlr_mv_update_kernel, dim3(L->nchunks), dim3(128), 0, h->st, uj, Ub, u_rs, h->Tsum.d(), Cp, X, ldx, xcol0, C,
-                         (const double*)L->sinv.d(), 2 * R);
-    }
+    GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
+                       h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, C, false));
+    hipLaunchKernelGGL(hodlr_mv_update_kernel, dim3(L->nchunks), dim3(128), 0, h->st, uj, Ub, u_rs, h->Tout.d(), Cp, X, ldx, xcol0, C);
     GH_HIP(hipGetLastError());
     return GH_OK;
   }
@@ -2069,17 +2022,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // apply this level's inverse to the U's of all shallower levels: columns [0, off)
     if (merged && L->off > 0) {
       // (Tsum already holds V_l^T U[:, 0:off]: core product and update only)
-      static const bool no_fused_core = getenv("GEORGE_AMD_HODLR_NO_FUSED_CORE") != nullptr || getenv("GEORGE_AMD_HODLR_NO_UPD_KERNEL") != nullptr;
-      if (no_fused_core || R > 16 || L->off > 128) {
-        GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
-                           h->Tsum.d(), h->cpass, 0, h->Tout.d(), h->cpass, 0, L->off, false));
-        GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
-                            h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
-      } else {
-        // (core product S^-1 (V^T U) inside the update kernel, per chunk)
-        GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
-                            h->Tsum.d(), h->cpass, h->UA.d(), Rtot, L->off, L->sinv.d()));
-      }
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
+                         h->Tsum.d(), h->cpass, 0, h->Tout.d(), h->cpass, 0, L->off, false));
+      GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
+                          h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
     } else {
       GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
     }
