@@ -443,6 +443,25 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
 }
 
 // B (rows of this level's nodes x R, row-major, ld = R) <- first rank columns of Tcm, zero padded
+// All levels in ONE launch (eleven launches of 10-38 us each at C4): workgroups [b0, b0 + nn * ny) belong to the
+// level described by a segment; inside it, workgroup (node, y) as in hodlr_compact_kernel below.
+struct CompactSeg { const double* Tcm; const LvlNode* nodes; const int* ranks; int R, ny; long off, offv, ldv; int b0, nblk; };
+__global__ void hodlr_compact_all_kernel(const CompactSeg* segs, int nseg, long N, double* UA, long ld, double* VA) {
+  int q = 0;
+  while (q + 1 < nseg && (int)blockIdx.x >= segs[q].b0 + segs[q].nblk) ++q;
+  const CompactSeg sg = segs[q];
+  const int local = (int)blockIdx.x - sg.b0, node = local / sg.ny, by = local % sg.ny;
+  const LvlNode nd = sg.nodes[node];
+  const int rk = sg.ranks[node], R = sg.R;
+  const long tot = (long)nd.size * R;
+  for (long e = (long)by * blockDim.x + threadIdx.x; e < tot; e += (long)sg.ny * blockDim.x) {
+    const int r = (int)(e / R), k = (int)(e % R);
+    const long i = nd.start + r;
+    const double v = (k < rk) ? sg.Tcm[(long)k * N + i] : 0.0;
+    UA[i * ld + sg.off + k] = v;
+    VA[i * sg.ldv + sg.offv + k] = v;
+  }
+}
 __global__ void hodlr_compact_kernel(const double* Tcm, long N, const LvlNode* nodes, const int* ranks,
                                      int R, double* UA, long ld, long off, double* VA, long ldv, long offv) {
   const LvlNode nd = nodes[blockIdx.x];
@@ -979,7 +998,7 @@ struct gh_hodlr {
   int cpass = CPASS;             // columns per apply pass = row pitch of P / Tsum / Tout / Y (>= the largest level rank)
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   GhBuf d_leaf_prod;
-  GhBuf d_aca_segs;
+  GhBuf d_aca_segs, d_compact_segs;
   GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (solves) and its column map
   long col_Rtot = -1;
   std::vector<int> col_sig;
@@ -1921,13 +1940,42 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   const long Rtot = std::max(h->Rtot, 1);
   GH_CHECK(h->UA.ensure((size_t)n * Rtot * sizeof(double)));
   GH_CHECK(h->VA.ensure((size_t)n * Rtot * sizeof(double)));
-  GH_HIP(hipMemsetAsync(h->UA.p, 0, (size_t)n * Rtot * sizeof(double), st));
-  GH_HIP(hipMemsetAsync(h->VA.p, 0, (size_t)n * Rtot * sizeof(double), st));
+  // UA / VA are written in full by the compaction when every level's nodes cover all n rows (a complete tree: level l
+  // has 2^l internal nodes -- the case of C4); only then can the two memsets (157 MB each at C4) be skipped
+  bool complete = true;
+  for (int l = 0; l < nlev; ++l) if (h->levels[l]->node_ids.size() != ((size_t)1 << l)) complete = false;
+  static const bool no_fused_compact = getenv("GEORGE_AMD_HODLR_NO_FUSED_COMPACT") != nullptr;
+  bool fused_compact = !no_fused_compact;
+  for (int l = 0; l < nlev; ++l) if (levelB[l]) fused_compact = false;
+  if (!(complete && fused_compact)) {
+    GH_HIP(hipMemsetAsync(h->UA.p, 0, (size_t)n * Rtot * sizeof(double), st));
+    GH_HIP(hipMemsetAsync(h->VA.p, 0, (size_t)n * Rtot * sizeof(double), st));
+  }
+  if (fused_compact) {
+    std::vector<CompactSeg> segs;
+    int b0 = 0;
+    for (int l = 0; l < nlev; ++l) {
+      HLevel* L = h->levels[l];
+      if (L->R == 0) continue;
+      const int nn = (int)L->node_ids.size(), ny = std::max(8, std::min(512, 2048 / nn));
+      segs.push_back({al[l].Tcm.d(), (const LvlNode*)L->d_nodes.p, (const int*)L->d_ranks.p, L->R, ny, (long)L->off, (long)n * L->off,
+                      (long)L->R, b0, nn * ny});
+      b0 += nn * ny;
+    }
+    if (b0 > 0) {
+      GH_CHECK(upload(h->d_compact_segs, segs, st));
+      hipLaunchKernelGGL(hodlr_compact_all_kernel, dim3((unsigned)b0), dim3(256), 0, st, (const CompactSeg*)h->d_compact_segs.p, (int)segs.size(),
+                         (long)n, h->UA.d(), (long)Rtot, h->VA.d());
+      GH_HIP(hipGetLastError());
+    }
+  }
   for (int l = 0; l < nlev; ++l) {
     HLevel* L = h->levels[l];
     if (L->R == 0) continue;
     const int R = L->R, nn = (int)L->node_ids.size();
-    if (levelB[l]) {
+    if (fused_compact) {
+      // (done above, all levels in one launch)
+    } else if (levelB[l]) {
       // (serial mode) scatter the compact level buffer into column block [off, off+R) of UA and VA
       GH_HIP(hipMemcpy2DAsync(h->UA.d() + L->off, Rtot * sizeof(double), levelB[l]->p, R * sizeof(double), R * sizeof(double), n, hipMemcpyDeviceToDevice, st));
       GH_HIP(hipMemcpyAsync(h->VA.d() + (long)n * L->off, levelB[l]->p, (size_t)n * R * sizeof(double), hipMemcpyDeviceToDevice, st));
