@@ -38,6 +38,7 @@ done
 python scripts/traffic_from_pmc.py "$(find $OUT/pmc_fetch -name '*.db' | head -1)" "$(find $OUT/pmc_write -name '*.db' | head -1)" 65536 1024 "$OUT/traffic_N65536.json"
 f=$(find "$OUT/trace16k" -name "*.db" | head -1); [ -n "$f" ] && python scripts/chain_stats.py "$f" > "$OUT/chain_stats_N16384.txt"
 f=$(find "$OUT/traceC4" -name "*.db" | head -1); [ -n "$f" ] && python scripts/hodlr_levels.py "$f" > "$OUT/hodlr_levels_C4.txt"
+f=$(find "$OUT/traceC4" -name "*.db" | head -1); [ -n "$f" ] && python scripts/dev/hodlr_timeline.py "$f" > "$OUT/hodlr_timeline_C4.txt"
 for f in trace64k trace16k traceC4 traceC5; do grep -h '^{' "$OUT/$f.log" | tail -1 >> "$OUT/bench_lines_under_rocprof.jsonl"; done
 cut -c1-260 "$OUT/bench_lines_under_rocprof.jsonl"
 cat "$OUT/traffic_N65536.json"; cat "$OUT/pmc_kmat_valu.md" | grep -i kmat | head; cat "$OUT/pmc_mfma.md" | grep "dmaILb1ELb1ELb1" | head -5
