@@ -400,7 +400,20 @@ def hodlr_main(args, local_rank):
         out["cpu_baseline"] = {"value": dt, "unit": "s", "cores": 1, "kind": "port",
                                "sample": "NumPy restatement of hodlr.h at N=%d (the reference's Eigen extension "
                                          "cannot be built here); loglike=%.10g" % (nc, llc)}
+    emit(out)
+
+
+def emit(out):
+    """Print THE line.  RCCL writes a version banner to C stdout at communicator creation ("RCCL version : ...",
+    five lines); through a pipe that stdio buffer is flushed at exit, i.e. AFTER Python's line.  Flush it first so
+    that the JSON line is the last thing on stdout."""
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out))
+    sys.stdout.flush()
 
 
 def relaunch(args):
@@ -568,6 +581,15 @@ def main():
             dist.all_reduce(t3, op=dist.ReduceOp.MAX)
             c3 = (float(t3.item()), ll3)
 
+    if world > 1:
+        # every rank's RCCL banner (C stdio) out BEFORE rank 0 prints the line, so that the line is last
+        import torch.distributed as dist
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        dist.barrier()
     if rank == 0:
         sec = elapsed / args.steps
         value = flops_alg(args.n) / sec * 1e-12
@@ -749,7 +771,7 @@ def main():
                 out["parity"]["ok"] = all(v["rel"] <= 1e-6 for v in parity.values() if isinstance(v, dict))
         if world > 1:
             out["timeline_rank0_ms"] = tline                     # panel / exchange / gather chain over the timed steps
-        print(json.dumps(out))
+        emit(out)
         c5 = out.get("config", {}).get("also_C5", {})
         if c5 and (not c5.get("fused_not_slower_than_separate_calls", True) or "flop_model_error" in c5):
             sys.stderr.write("bench.py: C5 CHECK FAILED: fused objective slower than the separate calls, or a rate above "
