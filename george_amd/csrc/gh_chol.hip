@@ -784,7 +784,7 @@ static int64_t panel_width(const gh_chol* s) {
 // issued yet -- A[k0 + nb :, k0 : k0 + nb] -= Pb Pd^T with Pb = rows >= k0 + nb and Pd = rows [k0, k0 + nb) of the
 // previous panel (K columns): it is issued here in 128-column strips on the rows-below stream, strip c right in
 // front of the TRSM of column block c that is its only consumer (see factor_lookahead_deep).
-struct PendingBcol { const double* Pb = nullptr; const double* Pd = nullptr; int64_t K = 0; hipEvent_t ready = nullptr; };
+struct PendingBcol { const double* Pb = nullptr; const double* Pd = nullptr; int64_t K = 0; hipEvent_t ready = nullptr; bool strips = false; };
 static bool panel_splits(const gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
   return s->st3 && st == s->st2 && s->np - (k0 + nb) > 0 && nb / T <= 8 && !no_split && !use_simple_potf2();
@@ -823,7 +823,7 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, const 
     double* dj = dinv + (j0 / T) * T * T;
     GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
     GH_HIP(hipEventRecord(s->ev_diag[j0 / T], st));
-    if (pend && pend->Pb) {                                  // strip j0 of the pending block-column update, beside potf2(j0)
+    if (pend && pend->Pb && pend->strips) {                  // strip j0 of the pending block-column update, beside potf2(j0)
       const long eu = prof ? s->next_ev() : -1;
       if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sa)); s->ev_update.push_back((size_t)eu); }
       GH_CHECK(gemm_nt(sa, B + j0, ld, pend->Pb, ld, pend->Pd + j0 * ld, ld, m, T, pend->K, -1.0, 1.0, false));
@@ -964,21 +964,42 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     // TRSM c (panel_step), beside the potf2 chain instead of in front of it.  (As ONE launch on a third stream that
     // the TRSMs then waited for, the split lost: 35.6 vs 34.8 ms at N = 16384, round 2's BCOL_SPLIT arm -- the rows
     // pipeline then was as long as chain + update.)  GEORGE_AMD_BCOL_STRIPS=0: whole block column on the chain.
-    static const bool strips = !(getenv("GEORGE_AMD_BCOL_STRIPS") && atoi(getenv("GEORGE_AMD_BCOL_STRIPS")) == 0);
-    if (strips && panel_splits(s, sp, c0(j + 1), nbc(j + 1))) {
+    // GEORGE_AMD_BCOL=0: whole block column on the chain (the default until round 3); =1 (default): rows below as ONE
+    // launch on the trailing stream -- the CU-masked one below Np = 24576, so that it does not flood the CUs kept free
+    // for the chain -- in front of W(j), the rows-below TRSM of panel j+1 waits for it; =2: rows below in 128-column
+    // strips on the rows-below stream, strip c in front of TRSM c (measured: a K = 1024 strip costs its ~70 us of
+    // K-loop latency whatever its width: 32.9 vs 30.9 ms at N = 16384, 8.44 vs 7.59 at 8192).
+    static const int bcol_mode = getenv("GEORGE_AMD_BCOL") ? atoi(getenv("GEORGE_AMD_BCOL")) : 1;
+    if (bcol_mode != 0 && panel_splits(s, sp, c0(j + 1), nbc(j + 1))) {
       const int64_t k1 = c0(j + 1), nb1 = nbc(j + 1);
       if (!s->ev_pre) GH_HIP(hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming));
-      GH_HIP(hipEventRecord(s->ev_pre, sp));
       const double* Pd = blk(A, ld, k1, c0(j));
-      const long eu = prof ? s->next_ev() : -1;
-      if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sp)); s->ev_update.push_back((size_t)eu); }
-      GH_CHECK(gemm_nt(sp, blk(A, ld, k1, k1), ld, Pd, ld, Pd, ld, nb1, nb1, nbc(j), -1.0, 1.0, true));
-      if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, sp));
-      const double tc = (double)nb1 / T;
-      const double fl = tc * (tc + 1.0) / 2.0 * 2.0 * T * T * (double)nbc(j);
-      s->prof.update_flops += fl;
-      if (eu >= 0) s->ev_update_flops.push_back(fl);
-      pend.Pb = blk(A, ld, k1 + nb1, c0(j)); pend.Pd = Pd; pend.K = nbc(j); pend.ready = s->ev_pre;
+      const double* Pb = blk(A, ld, k1 + nb1, c0(j));
+      if (bcol_mode == 2) GH_HIP(hipEventRecord(s->ev_pre, sp));
+      {
+        const long eu = prof ? s->next_ev() : -1;
+        if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sp)); s->ev_update.push_back((size_t)eu); }
+        GH_CHECK(gemm_nt(sp, blk(A, ld, k1, k1), ld, Pd, ld, Pd, ld, nb1, nb1, nbc(j), -1.0, 1.0, true));
+        if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, sp));
+        const double tc = (double)nb1 / T;
+        const double fl = tc * (tc + 1.0) / 2.0 * 2.0 * T * T * (double)nbc(j);
+        s->prof.update_flops += fl;
+        if (eu >= 0) s->ev_update_flops.push_back(fl);
+      }
+      pend.Pb = Pb; pend.Pd = Pd; pend.K = nbc(j); pend.ready = s->ev_pre; pend.strips = (bcol_mode == 2);
+      if (bcol_mode != 2) {
+        const int64_t mb = np - (k1 + nb1);
+        GH_HIP(hipStreamWaitEvent(sm, s->ev_p[j], 0));               // (at depth 1 W(j-1) precedes it on sm by stream order)
+        if (prev && depth >= 2) GH_HIP(hipStreamWaitEvent(sm, prev, 0));
+        const long eu = prof ? s->next_ev() : -1;
+        if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sm)); s->ev_update.push_back((size_t)eu); }
+        GH_CHECK(gemm_nt(sm, blk(A, ld, k1 + nb1, k1), ld, Pb, ld, Pd, ld, mb, nb1, nbc(j), -1.0, 1.0, false));
+        if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, sm));
+        const double fl = (double)(mb / T) * (double)(nb1 / T) * 2.0 * T * T * (double)nbc(j);
+        s->prof.update_flops += fl;
+        if (eu >= 0) s->ev_update_flops.push_back(fl);
+        GH_HIP(hipEventRecord(s->ev_pre, sm));
+      }
     } else {
       GH_CHECK(narrow(sp, j, j + 1));
     }
