@@ -475,7 +475,6 @@ struct gh_chol {
   hipStream_t st4 = nullptr;             // third panel stream: in-panel rows >= j+2 (everything off the potf2 chain)
   hipEvent_t ev_diag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;
-  hipEvent_t ev_pre = nullptr;                 // panel j complete and block column j+1's older updates done (strips of U(j, j+1))
   std::vector<hipEvent_t> ev_p, ev_w, ev_nf;   // deep look-ahead: panel j factored / W(j) done / U(j, j+2) done
   hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
 
@@ -512,7 +511,6 @@ struct gh_chol {
     if (ev_xfer) (void)hipEventDestroy(ev_xfer);
     if (ev_aux) (void)hipEventDestroy(ev_aux);
     if (ev_aux2) (void)hipEventDestroy(ev_aux2);
-    if (ev_pre) (void)hipEventDestroy(ev_pre);
     for (auto* v : {&ev_p, &ev_w, &ev_nf}) for (auto e : *v) (void)hipEventDestroy(e);
     for (auto& e : ev_diag) if (e) (void)hipEventDestroy(e);
     if (st4 && !shared_streams) (void)hipStreamDestroy(st4);
@@ -780,26 +778,17 @@ static int64_t panel_width(const gh_chol* s) {
 }
 
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
-// `pend` (optional): the update of THIS panel's rows below the diagonal block by the previous panel has not been
-// issued yet -- A[k0 + nb :, k0 : k0 + nb] -= Pb Pd^T with Pb = rows >= k0 + nb and Pd = rows [k0, k0 + nb) of the
-// previous panel (K columns): it is issued here in 128-column strips on the rows-below stream, strip c right in
-// front of the TRSM of column block c that is its only consumer (see factor_lookahead_deep).
-struct PendingBcol { const double* Pb = nullptr; const double* Pd = nullptr; int64_t K = 0; hipEvent_t ready = nullptr; bool strips = false; };
-static bool panel_splits(const gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
-  static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
-  return s->st3 && st == s->st2 && s->np - (k0 + nb) > 0 && nb / T <= 8 && !no_split && !use_simple_potf2();
-}
-static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, const PendingBcol* pend = nullptr) {
+static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   double* A = s->A.d();
   const int64_t np = s->np, ld = np;
   double* dinv = s->dinv.d() + (k0 / T) * T * T;
   const int64_t m = np - (k0 + nb);
-  const bool split = panel_splits(s, st, k0, nb);
+  static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
+  const bool on_panel_stream = (st == s->st2);
   // (Retired arms, all measured and slower, sources under scripts/dev/arms/: only row block j+1 on the chain and the
   //  other in-panel rows on a third stream; the chain on CUs of its own; only the potf2 launches on reserved CUs; the
   //  whole panel as two persistent flag-driven launches.  DESIGN.md section 4, "Where N < 24k stands".)
-  if (!split) {
-    if (pend && pend->Pb) { gh_set_error("internal: pending block-column update on a panel that does not split"); return GH_ERR_BAD_ARG; }
+  if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
     if (m > 0) {
       GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
@@ -812,26 +801,12 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb, const 
   hipStream_t sa = s->st3;
   double* Ak = blk(A, ld, k0, k0);
   double* B = blk(A, ld, k0 + nb, k0);
-  if (pend && pend->Pb) {
-    GH_HIP(hipStreamWaitEvent(sa, pend->ready, 0));          // previous panel complete, this column's older updates done
-  } else {
-    GH_HIP(hipEventRecord(s->ev_aux, st));
-    GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
-  }
-  const bool prof = s->opts.profile != 0;
+  GH_HIP(hipEventRecord(s->ev_aux, st));
+  GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
   for (int64_t j0 = 0; j0 < nb; j0 += T) {
     double* dj = dinv + (j0 / T) * T * T;
     GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
     GH_HIP(hipEventRecord(s->ev_diag[j0 / T], st));
-    if (pend && pend->Pb && pend->strips) {                  // strip j0 of the pending block-column update, beside potf2(j0)
-      const long eu = prof ? s->next_ev() : -1;
-      if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sa)); s->ev_update.push_back((size_t)eu); }
-      GH_CHECK(gemm_nt(sa, B + j0, ld, pend->Pb, ld, pend->Pd + j0 * ld, ld, m, T, pend->K, -1.0, 1.0, false));
-      if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, sa));
-      const double fl = (double)(m / T) * 2.0 * T * T * (double)pend->K;
-      s->prof.update_flops += fl;
-      if (eu >= 0) s->ev_update_flops.push_back(fl);
-    }
     GH_HIP(hipStreamWaitEvent(sa, s->ev_diag[j0 / T], 0));
     double* Xj = B + j0;
     if (j0 > 0) GH_CHECK(gemm_nt(sa, Xj, ld, B, ld, Ak + j0 * ld, ld, m, T, j0, -1.0, 1.0, false));
@@ -942,14 +917,12 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
   GH_HIP(hipStreamWaitEvent(sn, s->ev_sync[0], 0));
   if (sm != s->st) GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[0], 0));
-  PendingBcol pend;
   for (int j = 0; j < P; ++j) {
     // ---- chain: column j is complete once U(j-1, j) has run (issued at the end of the previous turn)
     {
       const long ep = prof ? s->next_ev() : -1;
       if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
-      GH_CHECK(panel_step(s, sp, c0(j), nbc(j), pend.Pb ? &pend : nullptr));
-      pend = PendingBcol();
+      GH_CHECK(panel_step(s, sp, c0(j), nbc(j)));
       if (ep >= 0) GH_HIP(hipEventRecord(s->ev_pool[ep].b, sp));
       GH_HIP(hipEventRecord(s->ev_p[j], sp));
     }
@@ -958,51 +931,7 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     // panel j+1 needs, the rows below it what that panel's rows-below TRSM needs)
     const hipEvent_t prev = (j >= 1) ? (depth >= 2 ? s->ev_nf[j - 1] : s->ev_w[j - 1]) : nullptr;
     if (prev) GH_HIP(hipStreamWaitEvent(sp, prev, 0));
-    // Only the DIAGONAL block of U(j, j+1) (nb x nb, lower tiles) has to be on the chain: it is all the potf2 chain
-    // of panel j+1 waits for.  The rows below it are needed by the rows-below TRSM of panel j+1, column block by
-    // column block -- so they are updated in 128-column strips on that TRSM's own stream, strip c right in front of
-    // TRSM c (panel_step), beside the potf2 chain instead of in front of it.  (As ONE launch on a third stream that
-    // the TRSMs then waited for, the split lost: 35.6 vs 34.8 ms at N = 16384, round 2's BCOL_SPLIT arm -- the rows
-    // pipeline then was as long as chain + update.)  GEORGE_AMD_BCOL_STRIPS=0: whole block column on the chain.
-    // GEORGE_AMD_BCOL=0: whole block column on the chain (the default until round 3); =1 (default): rows below as ONE
-    // launch on the trailing stream -- the CU-masked one below Np = 24576, so that it does not flood the CUs kept free
-    // for the chain -- in front of W(j), the rows-below TRSM of panel j+1 waits for it; =2: rows below in 128-column
-    // strips on the rows-below stream, strip c in front of TRSM c (measured: a K = 1024 strip costs its ~70 us of
-    // K-loop latency whatever its width: 32.9 vs 30.9 ms at N = 16384, 8.44 vs 7.59 at 8192).
-    static const int bcol_mode = getenv("GEORGE_AMD_BCOL") ? atoi(getenv("GEORGE_AMD_BCOL")) : 1;
-    if (bcol_mode != 0 && panel_splits(s, sp, c0(j + 1), nbc(j + 1))) {
-      const int64_t k1 = c0(j + 1), nb1 = nbc(j + 1);
-      if (!s->ev_pre) GH_HIP(hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming));
-      const double* Pd = blk(A, ld, k1, c0(j));
-      const double* Pb = blk(A, ld, k1 + nb1, c0(j));
-      if (bcol_mode == 2) GH_HIP(hipEventRecord(s->ev_pre, sp));
-      {
-        const long eu = prof ? s->next_ev() : -1;
-        if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sp)); s->ev_update.push_back((size_t)eu); }
-        GH_CHECK(gemm_nt(sp, blk(A, ld, k1, k1), ld, Pd, ld, Pd, ld, nb1, nb1, nbc(j), -1.0, 1.0, true));
-        if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, sp));
-        const double tc = (double)nb1 / T;
-        const double fl = tc * (tc + 1.0) / 2.0 * 2.0 * T * T * (double)nbc(j);
-        s->prof.update_flops += fl;
-        if (eu >= 0) s->ev_update_flops.push_back(fl);
-      }
-      pend.Pb = Pb; pend.Pd = Pd; pend.K = nbc(j); pend.ready = s->ev_pre; pend.strips = (bcol_mode == 2);
-      if (bcol_mode != 2) {
-        const int64_t mb = np - (k1 + nb1);
-        GH_HIP(hipStreamWaitEvent(sm, s->ev_p[j], 0));               // (at depth 1 W(j-1) precedes it on sm by stream order)
-        if (prev && depth >= 2) GH_HIP(hipStreamWaitEvent(sm, prev, 0));
-        const long eu = prof ? s->next_ev() : -1;
-        if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, sm)); s->ev_update.push_back((size_t)eu); }
-        GH_CHECK(gemm_nt(sm, blk(A, ld, k1 + nb1, k1), ld, Pb, ld, Pd, ld, mb, nb1, nbc(j), -1.0, 1.0, false));
-        if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, sm));
-        const double fl = (double)(mb / T) * (double)(nb1 / T) * 2.0 * T * T * (double)nbc(j);
-        s->prof.update_flops += fl;
-        if (eu >= 0) s->ev_update_flops.push_back(fl);
-        GH_HIP(hipEventRecord(s->ev_pre, sm));
-      }
-    } else {
-      GH_CHECK(narrow(sp, j, j + 1));
-    }
+    GH_CHECK(narrow(sp, j, j + 1));
     // ---- U(j, j+2 .. j+d) on the near stream
     const int last_near = std::min(j + depth, P - 1);
     if (j + 2 <= last_near || (depth >= 2 && j + 2 <= P - 1)) GH_HIP(hipStreamWaitEvent(sn, s->ev_p[j], 0));
