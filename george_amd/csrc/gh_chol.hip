@@ -125,12 +125,13 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double* A, long lda, 
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + 2.0 * v;
 }
 // out[0] = sum_i a[i] * b[i]
-__global__ __launch_bounds__(256) void dot_kernel(const double* a, const double* b, long n, double* out) {
+// (fail != nullptr: the chained solve's time-out flag travels with the result, out[2] = flag: one copy back instead of two)
+__global__ __launch_bounds__(256) void dot_kernel(const double* a, const double* b, long n, double* out, const int* fail) {
   __shared__ double sh[4];
   double v = 0.0;
   for (long i = threadIdx.x; i < n; i += 256) v += a[i] * b[i];
   v = block_sum_256(v, sh);
-  if (threadIdx.x == 0) out[0] = v;
+  if (threadIdx.x == 0) { out[0] = v; if (fail) out[2] = (double)*fail; }
 }
 
 // Two-stage versions for long vectors: `part[g]` = the g-th contiguous slice, then one workgroup adds
@@ -155,11 +156,12 @@ __global__ __launch_bounds__(256) void dot_part_kernel(const double* a, const do
   if (threadIdx.x == 0) part[blockIdx.x] = v;
 }
 // out[0] (+)= scale * sum_{g < m} part[g], m <= 64, added in index order by one lane
-__global__ void reduce_final_kernel(const double* part, int m, double scale, double* out, int accumulate) {
+__global__ void reduce_final_kernel(const double* part, int m, double scale, double* out, int accumulate, const int* fail) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double v = 0.0;
   for (int g = 0; g < m; ++g) v += part[g];
   out[0] = (accumulate ? out[0] : 0.0) + scale * v;
+  if (fail) out[2] = (double)*fail;
 }
 #define RED_SLICES 64
 static int launch_logdet(const double* A, long lda, long n, double* out, double* part, hipStream_t st) {
@@ -168,18 +170,18 @@ static int launch_logdet(const double* A, long lda, long n, double* out, double*
     hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out, 0);
   } else {
     hipLaunchKernelGGL(logdet_part_kernel, dim3(g), dim3(256), 0, st, A, lda, n, part);
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, part, g, 2.0, out, 0);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, part, g, 2.0, out, 0, (const int*)nullptr);
   }
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
-static int launch_dot(const double* a, const double* b, long n, double* out, double* part, hipStream_t st) {
+static int launch_dot(const double* a, const double* b, long n, double* out, double* part, hipStream_t st, const int* fail = nullptr) {
   const int g = (int)std::min<long>(RED_SLICES, (n + 4095) / 4096);
   if (g <= 1) {
-    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, a, b, n, out);
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, a, b, n, out, fail);
   } else {
     hipLaunchKernelGGL(dot_part_kernel, dim3(g), dim3(256), 0, st, a, b, n, part);
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, part, g, 1.0, out, 0);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, part, g, 1.0, out, 0, fail);
   }
   GH_HIP(hipGetLastError());
   return GH_OK;
@@ -488,7 +490,7 @@ struct gh_chol {
   int64_t info = 0;
   double logdet = 0.0;
   GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
-  long long* d_info = nullptr;
+  long long* d_info = nullptr;           // = (long long*)(scal + 2): the failure word lives beside the scalars (set in compute_enqueue)
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
@@ -506,7 +508,6 @@ struct gh_chol {
   }
   ~gh_chol() {
     for (auto& p : ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    if (d_info) (void)hipFree(d_info);
     for (auto& e : ev_sync) if (e) (void)hipEventDestroy(e);
     if (ev_xfer) (void)hipEventDestroy(ev_xfer);
     if (ev_aux) (void)hipEventDestroy(ev_aux);
@@ -606,7 +607,6 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
       }
     }
   }
-  if (hipMalloc((void**)&s->d_info, sizeof(long long)) != hipSuccess) { delete s; gh_set_error("hipMalloc failed"); return GH_ERR_HIP; }
   *out = s;
   return GH_OK;
 }
@@ -986,7 +986,9 @@ static int lookahead_depth(const gh_chol* s) {
 static int factor(gh_chol* s) {
   struct Guard { bool prev; Guard(bool v) : prev(t_gemm_small_lds) { t_gemm_small_lds = v; } ~Guard() { t_gemm_small_lds = prev; } }
       guard(s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
-  if (s->opts.lookahead && s->st2 && s->st3 && s->st4) return factor_lookahead_deep(s, lookahead_depth(s));
+  // (a matrix of ONE panel has nothing to look ahead to: on the main stream it saves the two cross-stream hand-overs,
+  //  ~35 us each -- a tenth of the step at N = 1024)
+  if (s->opts.lookahead && s->st2 && s->st3 && s->st4 && s->np > panel_width(s)) return factor_lookahead_deep(s, lookahead_depth(s));
   hipStream_t st = s->st;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);
@@ -1014,6 +1016,15 @@ static int factor(gh_chol* s) {
   return GH_OK;
 }
 
+// x, yerr into the handle's copies and the failure word cleared, ONE launch (device-resident inputs: as two copies
+// and a memset these were three runtime operations with 5-30 us between them -- a tenth of a step at N = 1024)
+__global__ void prep_inputs_kernel(const double* xs, long nx, const double* es, long ne, double* xd, double* ed, long long* info) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  for (long e = i; e < nx; e += stride) xd[e] = xs[e];
+  for (long e = i; e < ne; e += stride) ed[e] = es[e];
+  if (i == 0) *info = 0;
+}
+
 // Everything of compute() up to and including the log-det launch, enqueued on s->st without a
 // host synchronisation; compute_finish() reads the scalars back.
 struct ComputeCtx { long e_all = -1, e_build = -1; };
@@ -1038,9 +1049,17 @@ static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n,
   c.e_all = prof ? s->next_ev() : -1;
   c.e_build = prof ? s->next_ev() : -1;
   if (c.e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_all].a, st));
-  GH_CHECK(gh_to_device(s->x.d(), x, (size_t)n * ndim, st));
-  GH_CHECK(gh_to_device(s->yerr.d(), yerr, (size_t)n, st));
-  GH_HIP(hipMemsetAsync(s->d_info, 0, sizeof(long long), st));
+  s->d_info = (long long*)(s->scal.d() + 2);            // beside log-det [0] and quadratic form [1]: ONE copy brings them back
+  if (gh_is_device_ptr(x) && gh_is_device_ptr(yerr)) {
+    const long tot = (long)n * ndim;
+    hipLaunchKernelGGL(prep_inputs_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 1024)), dim3(256), 0, st,
+                       x, tot, yerr, (long)n, s->x.d(), s->yerr.d(), s->d_info);
+    GH_HIP(hipGetLastError());
+  } else {
+    GH_CHECK(gh_to_device(s->x.d(), x, (size_t)n * ndim, st));
+    GH_CHECK(gh_to_device(s->yerr.d(), yerr, (size_t)n, st));
+    GH_HIP(hipMemsetAsync(s->d_info, 0, sizeof(long long), st));
+  }
   if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].a, st));
   GH_CHECK(gh_launch_kmat(k, s->x.d(), n, s->x.d(), n, s->yerr.d(), s->A.d(), np, np, np, 0, 0, true, true, st));
   if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].b, st));
@@ -1098,12 +1117,12 @@ extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_
   ComputeCtx c;
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
   hipStream_t st = s->st;
-  double ld_host = 0.0;
-  long long info_host = 0;
-  GH_HIP(hipMemcpyAsync(&ld_host, s->scal.d(), sizeof(double), hipMemcpyDeviceToHost, st));
-  GH_HIP(hipMemcpyAsync(&info_host, s->d_info, sizeof(long long), hipMemcpyDeviceToHost, st));
+  double back[3] = {0.0, 0.0, 0.0};                     // [0] log-det, [1] (quadratic form), [2] the failure word's bits
+  GH_HIP(hipMemcpyAsync(back, s->scal.d(), 3 * sizeof(double), hipMemcpyDeviceToHost, st));
   GH_HIP(hipStreamSynchronize(st));
-  return compute_finish(s, c, ld_host, info_host, logdet_out);
+  long long info_host = 0;
+  memcpy(&info_host, &back[2], sizeof(long long));
+  return compute_finish(s, c, back[0], info_host, logdet_out);
 }
 
 static int need_computed(gh_chol* s) {
@@ -1175,18 +1194,23 @@ extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
   GH_CHECK(need_computed(s));
   if (!y || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
   // y^T K^-1 y = || L^-1 y ||^2 : one forward sweep (the reference does both, basic.py:102)
-  GH_CHECK(load_vec(s, s->v0, y));
+  static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;
+  // (the chained kernel only READS its right-hand side: a device-resident y of full padded length is used where it lies)
+  const bool direct = !stepwise && s->np == s->n && gh_is_device_ptr(y);
+  if (!direct) GH_CHECK(load_vec(s, s->v0, y));
   GH_CHECK(s->v1.ensure((size_t)s->np * sizeof(double)));
   const long e = s->opts.profile ? s->next_ev() : -1;
   if (e >= 0) GH_HIP(hipEventRecord(s->ev_pool[e].a, s->st));
-  GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d()));
-  GH_CHECK(launch_dot(s->v1.d(), s->v1.d(), (long)s->np, s->scal.d() + 1, s->scal.d() + 72, s->st));
+  GH_CHECK(trsv_forward(s, direct ? const_cast<double*>(y) : s->v0.d(), s->v1.d(), !stepwise));
+  const int* fail = stepwise ? nullptr : (const int*)((unsigned*)s->chain.p + s->np / T);
+  GH_CHECK(launch_dot(s->v1.d(), s->v1.d(), (long)s->np, s->scal.d() + 1, s->scal.d() + 72, s->st, fail));
   if (e >= 0) GH_HIP(hipEventRecord(s->ev_pool[e].b, s->st));
-  double v = 0.0;
-  GH_HIP(hipMemcpyAsync(&v, s->scal.d() + 1, sizeof(double), hipMemcpyDeviceToHost, s->st));
+  double back[3] = {0.0, 0.0, 0.0};                     // [0] quadratic form, [1] (failure word of compute()), [2] the chain's time-out flag
+  GH_HIP(hipMemcpyAsync(back, s->scal.d() + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, s->st));
   GH_HIP(hipStreamSynchronize(s->st));
   if (e >= 0) { float ms = 0; GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[e].a, s->ev_pool[e].b)); s->prof.ms_solve = ms; }
-  *out = v;
+  if (!stepwise && back[2] != 0.0) { gh_set_error("forward solve: a workgroup waited more than 2 s for its predecessor"); return GH_ERR_HIP; }
+  *out = back[0];
   return GH_OK;
 }
 
@@ -1417,8 +1441,10 @@ extern "C" int gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int6
   const bool want_alpha = grad || alpha || diagA;
   GH_CHECK(load_vec(s, s->v0, r));
   GH_CHECK(s->v1.ensure((size_t)np * sizeof(double)));
+  static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;
   GH_CHECK(trsv_forward(s, s->v0.d(), s->v1.d(), true));
-  GH_CHECK(launch_dot(s->v1.d(), s->v1.d(), (long)np, s->scal.d() + 1, s->scal.d() + 72, st));
+  GH_CHECK(launch_dot(s->v1.d(), s->v1.d(), (long)np, s->scal.d() + 1, s->scal.d() + 72, st,
+                      stepwise ? nullptr : (const int*)((const unsigned*)s->chain.p + nt)));           // -> scal[3]
   double* dgrad = nullptr;
   double* ddiag = nullptr;
   if (want_alpha) {
@@ -1435,23 +1461,19 @@ extern "C" int gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int6
     static const uint32_t none[GH_MAX_GRAD] = {0};
     GH_CHECK(gh_launch_kgrad_reduce(k, grad ? which : none, s->x.d(), n, s->v2.d(), s->work.d(), np, dgrad, ddiag, s->scratch, st));
   }
-  static const bool stepwise = getenv("GEORGE_AMD_TRSV_STEPS") != nullptr;
-  double host[2] = {0.0, 0.0};
-  long long info_host = 0;
-  int fail_f = 0, fail_b = 0;
-  GH_HIP(hipMemcpyAsync(host, s->scal.d(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-  GH_HIP(hipMemcpyAsync(&info_host, s->d_info, sizeof(long long), hipMemcpyDeviceToHost, st));
-  if (!stepwise) {
-    const unsigned* flags = (const unsigned*)s->chain.p;
-    GH_HIP(hipMemcpyAsync(&fail_f, flags + nt, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (want_alpha) GH_HIP(hipMemcpyAsync(&fail_b, flags + (nt + 1) + nt, sizeof(int), hipMemcpyDeviceToHost, st));
-  }
+  double host[4] = {0.0, 0.0, 0.0, 0.0};                // log-det, quadratic form, failure word (bits), forward chain's time-out flag
+  int fail_b = 0;
+  GH_HIP(hipMemcpyAsync(host, s->scal.d(), 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (!stepwise && want_alpha)
+    GH_HIP(hipMemcpyAsync(&fail_b, (const unsigned*)s->chain.p + (nt + 1) + nt, sizeof(int), hipMemcpyDeviceToHost, st));
   if (grad && k->size > 0) GH_CHECK(gh_from_device(grad, dgrad, (size_t)k->size, st));
   if (alpha) GH_CHECK(gh_from_device(alpha, s->v2.d(), (size_t)n, st));
   if (diagA) GH_CHECK(gh_from_device(diagA, ddiag, (size_t)n, st));
   GH_HIP(hipStreamSynchronize(st));
+  long long info_host = 0;
+  memcpy(&info_host, &host[2], sizeof(long long));
   GH_CHECK(compute_finish(s, c, host[0], info_host, logdet));
-  if (fail_f || fail_b) { gh_set_error("objective: a chained solve waited more than 2 s for its predecessor"); return GH_ERR_HIP; }
+  if ((!stepwise && host[3] != 0.0) || fail_b) { gh_set_error("objective: a chained solve waited more than 2 s for its predecessor"); return GH_ERR_HIP; }
   *quad = host[1];
   return GH_OK;
 }
