@@ -12,11 +12,11 @@ from . import _native                     # noqa: F401  (raises ImportError if t
 from . import kernels
 from .gp import GP
 from .metrics import Metric
-from .solvers import TrivialSolver, BasicSolver, HODLRSolver, MultiGPUSolver
+from .solvers import TrivialSolver, BasicSolver, HODLRSolver, MultiGPUSolver, MultiGPUHODLRSolver
 from .kernel_interface import KernelInterface
 
 __all__ = ["__version__", "kernels", "GP", "Metric", "TrivialSolver", "BasicSolver",
-           "HODLRSolver", "MultiGPUSolver", "KernelInterface"]
+           "HODLRSolver", "MultiGPUSolver", "MultiGPUHODLRSolver", "KernelInterface"]
 
 
 def device_count():

@@ -55,6 +55,11 @@ class gh_mgpu_opts(C.Structure):
                 ("nb", C.c_int32), ("transport", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
+class gh_hodlr_mgpu_opts(C.Structure):
+    _fields_ = [("n_dev", C.c_int32), ("devices", C.c_int32 * 16), ("min_size", C.c_int32), ("seed", C.c_int32),
+                ("max_rank", C.c_int32), ("tol", C.c_double), ("reserved", C.c_int32 * 4)]
+
+
 GH_MGPU_RCCL, GH_MGPU_COPY = 0, 1
 
 if not os.path.exists(LIB_PATH):
@@ -146,6 +151,13 @@ SIGNATURES = {
     "gh_mgpu_grid": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gh_mgpu_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "gh_mgpu_solve": (C.c_int, [_vp, _dp, _i64, _dp]),
+    "gh_hodlr_mgpu_create": (C.c_int, [C.POINTER(gh_hodlr_mgpu_opts), C.POINTER(_vp)]),
+    "gh_hodlr_mgpu_destroy": (None, [_vp]),
+    "gh_hodlr_mgpu_compute": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, C.POINTER(C.c_double)]),
+    "gh_hodlr_mgpu_solve": (C.c_int, [_vp, _dp, _i64, _dp]),
+    "gh_hodlr_mgpu_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
+    "gh_hodlr_mgpu_ranks": (C.c_int, [_vp, C.POINTER(C.c_int32), _i32, C.POINTER(C.c_int32)]),
+    "gh_hodlr_mgpu_rows": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gh_dev_kmat_block": (C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64, _i64, _i64, _i64, _dp, _i64, _vp]),
     "gh_dev_gemv": (C.c_int, [_dp, _i64, _i64, _i64, _i32, _dp, _dp, C.c_double, C.c_double, _vp]),
     "gh_dev_potrf_block": (C.c_int, [_dp, _i64, _i64, _dp, _dp, _i64, _vp]),

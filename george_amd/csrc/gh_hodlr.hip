@@ -37,8 +37,10 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <thread>
 #include <vector>
 #include "gh_common.h"
+#include "gh_threads.h"
 
 // gh_potf2.hip: batched 128x128 Cholesky + inverse of the factor (block b at A + b*stride_a)
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
@@ -49,7 +51,7 @@ int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* di
 #define RANK_CAP 1024    // hard ceiling on a block's ACA rank (scratch n x rank, 2 rank x 2 rank cores)
 
 // ------------------------------------------------------------------ device structs
-struct LvlNode { int start, half, size, pad; };
+struct LvlNode { int start, half, size, pad; };      // pad: added to the node's index where the ACA seeds its generator
 struct Chunk { int node, half, row0, nrows; };
 struct MMJob { long a_off; int b_row, o_row, m, kd; };
 struct LeafDesc { int start, size; long off; };
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   double norm = 0.0;
   const double tol2 = tol * tol;
   bool converged = false;
-  unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)node * 0x9E3779B97F4A7C15ull);
+  // (nodev.pad: index of the launch's first node in its tree level -- non-zero only for the sub-trees of a split tree)
+  unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)(node + nodev.pad) * 0x9E3779B97F4A7C15ull);
   __syncthreads();
   while (rank < max_rank) {
     // ---- choose a random unused row with a non-negligible residual (hodlr.h:159-191)
@@ -955,6 +958,8 @@ __global__ void hodlr_eye_kernel(double* p, long n) {
 // ================================================================================ host side
 struct HNode { int start, size, half, level, is_leaf; };
 struct HLevel {
+  int top_level = -1;
+  bool top = false;                 // pseudo-level of a sub-tree handle (HSub below): one node, the ancestor cut down to the local rows
   std::vector<int> node_ids;
   int R = 0, off = 0, nchunks = 0;
   GhPooledBuf d_nodes, d_chunks, d_crange, d_red_jobs, d_upd_jobs, d_smul_jobs, d_ranks, sinv;   // (one stream: h->st)
@@ -968,8 +973,29 @@ struct HLevel {
   long tab_Rtot = -1;
 };
 
+// A handle can be ONE SUB-TREE of a tree that is split over several devices (gh_hodlr_mgpu, end of this file): its
+// rows are rows [row0, row0 + n) of the whole problem, its tree is the sub-tree rooted at global level `depth`, and the
+// `depth` levels above it appear here as PSEUDO-LEVELS of one node each -- the ancestor at that level, cut down to the
+// local rows (which all lie in ONE of its halves).  Their low-rank factors are not computed here (the ACA of a top node
+// runs on one device; T[l] holds the local rows of its result), and whenever such a level is applied, the 2R x C sums
+// V^T X are completed over the devices below that ancestor (`allreduce`) between "sum" and "core product".  Everything
+// else -- tables, kernels, the order of the sweep -- is the single-device code.
+struct HSub {
+  int depth = 0;                    // 0: an ordinary handle
+  std::vector<int> half, R;         // [depth] the half of the level-l ancestor the local rows are in; the rank of global level l
+  std::vector<const double*> T;     // [depth] column-major n x R[l]: local rows of the ancestor's ACA factors (this device)
+  std::vector<int> seed_off;        // per local level: index of this sub-tree's first internal node in the global level
+  void* ctx = nullptr;
+  int (*allreduce)(void* ctx, int level, double* dT, int rows, int cols, long pitch, hipStream_t st) = nullptr;
+  int (*local_done)(void* ctx) = nullptr;      // the part of compute() that needs no other device has been enqueued and has finished
+  std::vector<double> ld_top;       // out: log|det| of the core of the level-l ancestor (every device below it computes the same)
+  std::vector<int> sig() const { std::vector<int> v{depth}; v.insert(v.end(), half.begin(), half.end()); v.insert(v.end(), seed_off.begin(), seed_off.end()); return v; }
+};
+
 struct gh_hodlr {
   gh_hodlr_opts opts;
+  HSub sub;
+  std::vector<int> tree_sub;        // sub.sig() the tree was built for
   hipStream_t st = nullptr;
   GhBuf d_gather;                   // (fetch of every level's ranks / flags in one copy)
   int* h_gather = nullptr; size_t h_gather_cap = 0;      // pinned
@@ -1336,20 +1362,25 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
                        h->P.d(), Cp, C);
     hipLaunchKernelGGL(hodlr_sum_narrow_kernel, dim3(nn, 2 * R), dim3(256), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, C, h->Tsum.d());
     GH_HIP(hipGetLastError());
+    if (L->top) GH_CHECK(h->sub.allreduce(h->sub.ctx, L->top_level, h->Tsum.d(), 2 * R, C, Cp, h->st));
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
                        h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, C, false));
     hipLaunchKernelGGL(hodlr_mv_update_kernel, dim3(L->nchunks), dim3(128), 0, h->st, uj, Ub, u_rs, h->Tout.d(), Cp, X, ldx, xcol0, C);
     GH_HIP(hipGetLastError());
     return GH_OK;
   }
-  for (int cp = 0; cp < C; cp += h->cpass) {
-    const int cw = std::min(h->cpass, C - cp);
+  // (a pseudo-level goes in passes of CPASS columns whatever this handle's own pass width: the devices below the
+  //  ancestor must agree on the number and the shape of the sums they complete together)
+  const int pw = L->top ? CPASS : h->cpass;
+  for (int cp = 0; cp < C; cp += pw) {
+    const int cw = std::min(pw, C - cp);
     const long Cp = h->cpass;
     // reduce: P[chunk] = V_chunk^T X_chunk
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, Vl, 1, R,
                        X, ldx, xcol0 + cp, h->P.d(), Cp, 0, cw, false));
     hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, h->st, h->P.d(), (const int*)L->d_crange.p, R, Cp, cw, h->Tsum.d());
     GH_HIP(hipGetLastError());
+    if (L->top) GH_CHECK(h->sub.allreduce(h->sub.ctx, L->top_level, h->Tsum.d(), 2 * R, cw, Cp, h->st));
     // core: Tout = S^-1 Tsum
     GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
                        h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, cw, false));
@@ -1477,9 +1508,13 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
 
   // ---- tree (hodlr.h:47-64), breadth first; kept from the previous compute() when n and min_size are the same
   const int min_size = h->opts.min_size;
-  if (h->tree_n != n || h->tree_min != min_size) {
+  const int l0 = h->sub.depth;                   // levels [0, l0) are the pseudo-levels of a sub-tree handle (HSub)
+  if (l0 > 0 && ((int)h->sub.half.size() != l0 || (int)h->sub.R.size() != l0 || (int)h->sub.T.size() != l0 || !h->sub.allreduce)) {
+    gh_set_error("HODLR: incomplete sub-tree description"); return GH_ERR_BAD_ARG;
+  }
+  if (h->tree_n != n || h->tree_min != min_size || h->tree_sub != h->sub.sig()) {
     h->reset_tree();
-    h->nodes.push_back({0, (int)n, (int)n / 2, 0, 0});
+    h->nodes.push_back({0, (int)n, (int)n / 2, l0, 0});
     for (size_t q = 0; q < h->nodes.size(); ++q) {
       HNode nd = h->nodes[q];
       if (nd.half >= min_size) {
@@ -1494,7 +1529,16 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         h->leaves.push_back({nd.start, nd.size, off});
       }
     }
-    h->tree_n = n; h->tree_min = min_size;
+    // pseudo-levels: the ancestor at level l, cut down to the local rows -- one of its halves is empty here
+    if ((int)h->levels.size() < l0) h->levels.resize(l0, nullptr);
+    for (int l = 0; l < l0; ++l) {
+      h->levels[l] = new HLevel();
+      h->levels[l]->top = true;
+      h->levels[l]->top_level = l;
+      h->levels[l]->node_ids.push_back((int)h->nodes.size());
+      h->nodes.push_back({0, (int)n, h->sub.half[l] == 0 ? (int)n : 0, l, 0});
+    }
+    h->tree_n = n; h->tree_min = min_size; h->tree_sub = h->sub.sig();
   }
   h->max_leaf = 0;
   for (auto& lf : h->leaves) h->max_leaf = std::max(h->max_leaf, lf.size);
@@ -1617,7 +1661,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   static const int aca_fence = getenv("GEORGE_AMD_HODLR_FENCE") ? 1 : 0;
   static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
   static const bool aca_serial = getenv("GEORGE_AMD_HODLR_SERIAL_LEVELS") != nullptr;
-  const bool concurrent = !aca_serial && nlev > 1 && (double)n * rcap0 * sizeof(double) * nlev <= 12.0 * (1u << 30);
+  const bool concurrent = !aca_serial && nlev - l0 > 1 && (double)n * rcap0 * sizeof(double) * (nlev - l0) <= 12.0 * (1u << 30);
   if (concurrent && !h->st_b) {
     hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
     if (h->shared_streams && gh_shared_streams(h->opts.device, shq)) h->st_b = shq[2];
@@ -1726,6 +1770,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   };
   auto rank_of_level = [&](int l) {
     HLevel* L = h->levels[l];
+    if (L->top) L->ranks.assign(1, h->sub.R[l]);         // (given: the ACA of the ancestor ran elsewhere)
     L->R = 0;
     for (int r : L->ranks) L->R = std::max(L->R, r);
     L->off = h->Rtot;
@@ -1752,9 +1797,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     HLevel* L = h->levels[l];
     const int nn = (int)L->node_ids.size();
     std::vector<LvlNode> ln(nn);
-    for (int q = 0; q < nn; ++q) { const HNode& nd = h->nodes[L->node_ids[q]]; ln[q] = {nd.start, nd.half, nd.size, 0}; }
+    const int seed_off = (l >= l0 && l - l0 < (int)h->sub.seed_off.size()) ? h->sub.seed_off[l - l0] : 0;
+    for (int q = 0; q < nn; ++q) { const HNode& nd = h->nodes[L->node_ids[q]]; ln[q] = {nd.start, nd.half, nd.size, seed_off}; }
     if (!L->nodes_up) { GH_CHECK(upload(L->d_nodes, ln, st)); L->nodes_up = true; }
     GH_CHECK(L->d_ranks.ensure(nn * sizeof(int)));
+    if (L->top) {                                        // no ACA here: its "rank" is the level's, the staged factors are zero-padded to it
+      GH_HIP(hipMemcpyAsync(L->d_ranks.p, &h->sub.R[l], sizeof(int), hipMemcpyHostToDevice, st));
+      al[l].G = 1;
+      continue;
+    }
     // cluster size: as many workgroups per node as keep the whole grid resident (nodes * G <= 256)
     // and leave every thread `ept` columns (GEORGE_AMD_HODLR_EPT; measured at C4: 2 -> 12.5 ms,
     // 4 -> 13.1, 8 -> 14.1, 16 -> 16.0: the step is bound by per-thread memory latency, not by the
@@ -1776,7 +1827,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // whose threads carry most columns).
     std::vector<int> cl;
     static const bool no_fused = getenv("GEORGE_AMD_HODLR_NO_FUSED_ACA") != nullptr;
-    for (int l = 0; l < nlev; ++l) if (al[l].G > 1) cl.push_back(l);
+    for (int l = l0; l < nlev; ++l) if (al[l].G > 1) cl.push_back(l);
     if (cl.size() >= 2 && !no_fused) {
       std::vector<int> gmax(nlev, 1), half(nlev, 1);
       int total = 0;
@@ -1836,7 +1887,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       }
       static const bool leaves_after0 = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
       std::vector<int> ones = single;
-      for (int l = 0; l < nlev; ++l) if (gmax[l] == 1) ones.push_back(l);
+      for (int l = l0; l < nlev; ++l) if (gmax[l] == 1) ones.push_back(l);
       struct Item { int level; double cost; };             // level -1: the leaf stage
       std::vector<Item> items;
       const bool have = (int)h->aca_ms.size() == nlev + 2;     // [0..nlev): levels, [nlev]: fused launch, [nlev+1]: leaf stage
@@ -1871,7 +1922,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       if (h->st_c) { GH_HIP(hipEventRecord(h->ev_c, h->st_c)); GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0)); }
       if (h->st_d) { GH_HIP(hipEventRecord(h->ev_d, h->st_d)); GH_HIP(hipStreamWaitEvent(st, h->ev_d, 0)); }
     } else {
-      for (int l = 0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
+      for (int l = l0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
       static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
       if (!leaves_after) GH_CHECK(leaf_stage(h->st_b));
     }
@@ -1881,7 +1932,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // one gather launch + one copy into pinned memory for the ranks and the two failure flags of every level
       std::vector<GatherItem> items;
       int tot = 0;
-      for (int l = 0; l < nlev; ++l) {
+      for (int l = l0; l < nlev; ++l) {
         HLevel* L = h->levels[l];
         const int nn = (int)L->node_ids.size();
         items.push_back({(const int*)L->d_ranks.p, nn, tot}); tot += nn;
@@ -1903,7 +1954,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       GH_HIP(hipMemcpyAsync(h->h_gather, h->d_gather.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, st));
       GH_HIP(hipStreamSynchronize(st));
       int at = 0;
-      for (int l = 0; l < nlev; ++l) {
+      for (int l = l0; l < nlev; ++l) {
         HLevel* L = h->levels[l];
         const int nn = (int)L->node_ids.size();
         L->ranks.assign(h->h_gather + at, h->h_gather + at + nn); at += nn;
@@ -1921,9 +1972,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       }
       h->aca_timed = false;
     }
-    for (int l = 0; l < nlev; ++l) { GH_CHECK(settle_level(l)); rank_of_level(l); }
+    for (int l = 0; l < nlev; ++l) { if (l >= l0) GH_CHECK(settle_level(l)); rank_of_level(l); }
   } else {
-    for (int l = 0; l < nlev; ++l) {
+    for (int l = 0; l < l0; ++l) rank_of_level(l);
+    for (int l = l0; l < nlev; ++l) {
       GH_CHECK(enqueue_level(l, rcap0, st));
       GH_CHECK(fetch_level(l, st));
       GH_HIP(hipStreamSynchronize(st));
@@ -1943,7 +1995,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // UA / VA are written in full by the compaction when every level's nodes cover all n rows (a complete tree: level l
   // has 2^l internal nodes -- the case of C4); only then can the two memsets (157 MB each at C4) be skipped
   bool complete = true;
-  for (int l = 0; l < nlev; ++l) if (h->levels[l]->node_ids.size() != ((size_t)1 << l)) complete = false;
+  for (int l = l0; l < nlev; ++l) if (h->levels[l]->node_ids.size() != ((size_t)1 << (l - l0))) complete = false;   // (a pseudo-level covers every local row)
   static const bool no_fused_compact = getenv("GEORGE_AMD_HODLR_NO_FUSED_COMPACT") != nullptr;
   bool fused_compact = !no_fused_compact;
   for (int l = 0; l < nlev; ++l) if (levelB[l]) fused_compact = false;
@@ -1958,7 +2010,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       HLevel* L = h->levels[l];
       if (L->R == 0) continue;
       const int nn = (int)L->node_ids.size(), ny = std::max(8, std::min(512, 2048 / nn));
-      segs.push_back({al[l].Tcm.d(), (const LvlNode*)L->d_nodes.p, (const int*)L->d_ranks.p, L->R, ny, (long)L->off, (long)n * L->off,
+      segs.push_back({L->top ? h->sub.T[l] : al[l].Tcm.d(), (const LvlNode*)L->d_nodes.p, (const int*)L->d_ranks.p, L->R, ny, (long)L->off, (long)n * L->off,
                       (long)L->R, b0, nn * ny});
       b0 += nn * ny;
     }
@@ -1982,7 +2034,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     } else {
       // every rank is known by now: the level's scratch goes straight into its column block (22 strided
       // device copies per compute() before)
-      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, std::max(8, std::min(512, 2048 / nn))), dim3(256), 0, st, al[l].Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
+      hipLaunchKernelGGL(hodlr_compact_kernel, dim3(nn, std::max(8, std::min(512, 2048 / nn))), dim3(256), 0, st, L->top ? h->sub.T[l] : al[l].Tcm.d(), (long)n, (const LvlNode*)L->d_nodes.p,
                          (const int*)L->d_ranks.p, R, h->UA.d(), (long)Rtot, (long)L->off, h->VA.d(), (long)R, (long)n * L->off);
       GH_HIP(hipGetLastError());
     }
@@ -2035,10 +2087,36 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
 
   // ---- factorisation sweep (hodlr.h:75-103, level-batched): leaves into every U, then levels bottom-up
   if (h->Rtot > 0) GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot));
+  std::vector<size_t> top_ld(l0, (size_t)-1);        // where in ld_all the core of pseudo-level l put its log|det|
+  bool local_done = (l0 == 0);
   for (int l = nlev - 1; l >= 0; --l) {
     HLevel* L = h->levels[l];
+    if (l < l0 && !local_done) {
+      // everything below needs the other devices: tell the owner of the split that this one has finished on its own
+      GH_HIP(hipStreamSynchronize(st));
+      local_done = true;
+      if (h->sub.local_done) GH_CHECK(h->sub.local_done(h->sub.ctx));
+    }
     if (L->R == 0) continue;
     const int R = L->R, nn = (int)L->node_ids.size();
+    if (L->top) {
+      // The ancestor's core: V^T U over its own columns, each device the rows it holds, completed over the devices below
+      // the ancestor; every one of them then inverts the same 2R x 2R matrix and updates its own rows of the shallower U's.
+      GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
+                          h->UA.d(), Rtot, L->off, h->P.d(), h->cpass, 0, R));
+      hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, R, h->Tsum.d());
+      GH_HIP(hipGetLastError());
+      GH_CHECK(h->sub.allreduce(h->sub.ctx, l, h->Tsum.d(), 2 * R, R, (long)h->cpass, st));
+      const std::vector<long> offs1(1, 0L);
+      const std::vector<int> sizes1(1, 2 * R);
+      GhBuf* const tabs[3] = {&L->d_gj_offs, &L->d_gj_sizes, &L->d_gj_sc};
+      GH_CHECK(batched_inverse(h, L->sinv.d(), offs1, sizes1, h->ld_all.d() + ld_at, tabs, L->gj_R == R, h->Tsum.d(), R));
+      L->gj_R = R;
+      top_ld[l] = ld_at;
+      ld_at += 1;
+      GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
+      continue;
+    }
     // S = I + [0, V1^T U1; V0^T U0, 0] with the CURRENT U of this level.  The products V_l^T U that the
     // core needs (columns [off, off + R)) and the ones that applying this level's inverse to the shallower
     // levels' U needs (columns [0, off)) read the same V_l chunks and neighbouring columns of the same U
@@ -2108,6 +2186,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   memcpy(&leaf_info, fl + 2, sizeof(long long));
   if (leaf_info != 0) { gh_set_error("HODLR: a leaf block is not positive definite"); return GH_ERR_NOT_PD; }
   if (fl[0] != 0) { gh_set_error("HODLR: singular block encountered (matrix %d of its batch)", fl[0] - 1); return GH_ERR_NOT_PD; }
+  // (a sub-tree handle reports the blocks it owns alone; the ancestors' cores, the same on every device below them,
+  //  are handed to the owner of the split separately)
+  h->sub.ld_top.assign(l0, 0.0);
+  for (int l = 0; l < l0; ++l) if (top_ld[l] != (size_t)-1) { h->sub.ld_top[l] = ld_host[top_ld[l]]; ld_host[top_ld[l]] = 0.0; }
   double logdet = 0.0;
   for (size_t i = 0; i < ld_at; ++i) logdet += ld_host[i];          // leaves first, then the cores bottom-up: fixed order
   h->logdet = logdet;
@@ -2167,5 +2249,396 @@ extern "C" int gh_hodlr_ranks(const gh_hodlr* h, int32_t* ranks_out, int32_t max
   for (auto* L : h->levels)
     for (int r : L->ranks) { if (ranks_out && cnt < max_out) ranks_out[cnt] = r; ++cnt; }
   *n_out = cnt < max_out ? cnt : max_out;
+  return GH_OK;
+}
+
+// ===================================================================== the tree split over several devices
+// gh_hodlr_mgpu_* (include/george_amd.h): the top log2(P) levels of the tree are shared, sub-tree p is an ordinary
+// gh_hodlr handle on devices[p] in sub-tree mode (HSub above).  One host thread per device; the threads meet at host
+// barriers, and the only data they exchange after the ancestors' factors have been dealt out are the 2R x C sums of the
+// top levels, through pinned host memory.
+namespace {
+std::mutex g_hm_dev_mu[16];          // one clustered (spin-waiting) ACA grid per PHYSICAL device at a time ("virtual devices")
+
+struct gh_hodlr_mgpu_impl;
+struct HmRank {
+  int p = 0, dev = 0;
+  gh_hodlr* h = nullptr;
+  gh_kernel kern;
+  GhBuf xg;                                   // all N points: only where the ACA of a top node runs
+  std::vector<GhBuf*> stage;                  // [depth] local rows of the ancestors' factors, column-major n x R_l
+  long row0 = 0, n = 0;
+  double* pin = nullptr;                      // pinned: [0, cap) this device's partial sums, [cap, 2 cap) the completed sums
+  size_t pin_cap = 0, pin_cnt = 0;
+  std::unique_lock<std::mutex> dev_lock;
+  int rc = GH_OK;
+  std::string err;
+  double ld = 0.0;
+  gh_hodlr_mgpu_impl* owner = nullptr;
+  std::vector<int> seed_off;
+};
+struct HmTop {                                // a node above the split
+  int level = 0, q = 0, start = 0, half = 0, size = 0;
+  int runner = 0;                             // the rank whose device runs its ACA
+  int first = 0, span = 1;                    // the ranks below it: [first, first + span)
+  int rank = 0;
+  GhBuf Tcm, packed;                          // on the runner's device: ACA scratch; the same rows dealt into one contiguous chunk per rank
+  std::vector<long> pack_off;
+  HostBarrier bar;
+};
+struct gh_hodlr_mgpu_impl {
+  gh_hodlr_mgpu_opts opts;
+  int P = 1, depth = 0;
+  std::vector<HmRank> ranks;
+  std::vector<std::vector<HmTop*>> top;       // [level][q]
+  HostBarrier world;
+  std::atomic<int> abort{0};
+  int64_t n = 0;
+  int ndim = 0;
+  bool computed = false;
+  double logdet = 0.0;
+  std::vector<int> all_ranks;
+  void clear_top() { for (auto& lv : top) for (auto* t : lv) { if (t) { (void)hipSetDevice(ranks[t->runner].dev); delete t; } } top.clear(); }
+};
+
+// out[k * n_m + i] = Tcm[k * N + row0 + i]: the rows of one device out of a node's column-major factors
+__global__ void hodlr_pack_rows_kernel(const double* Tcm, long N, long row0, long n_m, int r, double* out) {
+  const long tot = n_m * r;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const long k = e / n_m, i = e % n_m;
+    out[e] = Tcm[k * N + row0 + i];
+  }
+}
+
+// hodlr.h:136-221 for ONE node above the split, on this handle's device against all N points (x_dev).  Same kernel,
+// same cluster rule and same retry ladder as the levels of gh_hodlr_compute; nd.pad = the node's index in its level.
+int aca_top_node(gh_hodlr* h, gh_kernel* k, const double* x_dev, long N, int ndim, int level, LvlNode nd, GhBuf& Tcm, int* rank_out) {
+  hipStream_t st = h->st;
+  GhBuf d_node, d_rank, idx, sync, part;
+  GH_CHECK(d_node.ensure(sizeof(LvlNode)));
+  GH_CHECK(d_rank.ensure(sizeof(int)));
+  GH_HIP(hipMemcpyAsync(d_node.p, &nd, sizeof(LvlNode), hipMemcpyHostToDevice, st));
+  int G = 1;
+  if (!getenv("GEORGE_AMD_HODLR_NO_CLUSTER")) {
+    static const int ept = getenv("GEORGE_AMD_HODLR_EPT") ? std::max(1, atoi(getenv("GEORGE_AMD_HODLR_EPT"))) : 2;
+    while (G * 2 <= 256 && (long)(G * 2) * ACA_THREADS * ept <= nd.half) G *= 2;
+  }
+  static const int aca_fence = getenv("GEORGE_AMD_HODLR_FENCE") ? 1 : 0;
+  static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
+  const int pstride = 8 + 2 * ACA_MAXR;
+  const bool user_cap = h->opts.max_rank > 0;
+  int rc = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
+  GH_CHECK(idx.ensure((size_t)N * sizeof(int)));
+  GH_CHECK(sync.ensure(sizeof(unsigned) + sizeof(int) + 2 * sizeof(int)));
+  GH_CHECK(part.ensure((size_t)G * pstride * sizeof(double)));
+  for (;;) {
+    GH_CHECK(Tcm.ensure((size_t)N * rc * sizeof(double)));
+    GH_HIP(hipMemsetAsync(sync.p, 0, sizeof(unsigned) + sizeof(int) + 2 * sizeof(int), st));
+    unsigned* d_bars = (unsigned*)sync.p;
+    int* d_sel = (int*)(d_bars + 1);
+    int* d_fail = d_sel + 1;
+#define GH_ACA_LAUNCH(F)                                                                                               \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, \
+                       ndim, x_dev, (const LvlNode*)d_node.p, Tcm.d(), N, rc, (int*)idx.p, (int*)d_rank.p, h->opts.tol,  \
+                       (unsigned long long)(unsigned)h->opts.seed, level, G, d_bars, part.d(), pstride, d_sel, d_fail,   \
+                       aca_multi, aca_fence, d_fail + 1, (const AcaSeg*)nullptr, 0)
+    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+#undef GH_ACA_LAUNCH
+    GH_HIP(hipGetLastError());
+    int flags[2] = {0, 0};
+    GH_HIP(hipMemcpyAsync(flags, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(rank_out, d_rank.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    if (flags[0]) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", level); return GH_ERR_HIP; }
+    if (!flags[1]) return GH_OK;
+    if (user_cap || rc >= RANK_CAP) {
+      gh_set_error("HODLR: an off-diagonal block of level %d needs a rank above %d to reach tol = %g (%s); the factorisation is not usable",
+                   level, rc, h->opts.tol, user_cap ? "opts.max_rank" : "the solver's ceiling: loosen tol, raise min_size or use the dense solver");
+      return user_cap ? GH_ERR_BAD_ARG : GH_ERR_RANK;
+    }
+    rc = std::min(2 * rc, RANK_CAP);
+  }
+}
+
+// the 2R x C sums of a top level, completed over the ranks below the ancestor (HSub::allreduce)
+int hm_allreduce(void* ctx, int level, double* dT, int rows, int cols, long pitch, hipStream_t st) {
+  HmRank& r = *(HmRank*)ctx;
+  gh_hodlr_mgpu_impl* H = r.owner;
+  HmTop& t = *H->top[level][r.p >> (H->depth - level)];
+  const size_t cnt = (size_t)rows * cols;
+  if (cnt > r.pin_cap) {                      // (nobody reads this rank's buffer between two all-reduces)
+    if (r.pin) (void)hipHostFree(r.pin);
+    r.pin = nullptr; r.pin_cap = 0;
+    const size_t cap = std::max<size_t>(2 * cnt, 1 << 16);
+    GH_HIP(hipHostMalloc((void**)&r.pin, 2 * cap * sizeof(double), hipHostMallocDefault));
+    r.pin_cap = cap;
+  }
+  GH_HIP(hipMemcpy2DAsync(r.pin, cols * sizeof(double), dT, pitch * sizeof(double), cols * sizeof(double), rows, hipMemcpyDeviceToHost, st));
+  GH_HIP(hipStreamSynchronize(st));
+  r.pin_cnt = cnt;
+  if (!t.bar.wait()) { gh_set_error("aborted: another device failed"); return GH_ERR_HIP; }
+  double* sum = r.pin + r.pin_cap;
+  for (int m = t.first; m < t.first + t.span; ++m) {            // fixed order: every rank adds up the same numbers the same way
+    const HmRank& o = H->ranks[m];
+    if (o.pin_cnt != cnt) { gh_set_error("HODLR split: ranks %d and %d disagree on the shape of a level-%d sum", r.p, m, level); H->abort.store(1); return GH_ERR_HIP; }
+    if (m == t.first) memcpy(sum, o.pin, cnt * sizeof(double));
+    else for (size_t e = 0; e < cnt; ++e) sum[e] += o.pin[e];
+  }
+  if (!t.bar.wait()) { gh_set_error("aborted: another device failed"); return GH_ERR_HIP; }
+  GH_HIP(hipMemcpy2DAsync(dT, pitch * sizeof(double), sum, cols * sizeof(double), cols * sizeof(double), rows, hipMemcpyHostToDevice, st));
+  return GH_OK;
+}
+int hm_local_done(void* ctx) {
+  HmRank& r = *(HmRank*)ctx;
+  if (r.dev_lock.owns_lock()) r.dev_lock.unlock();
+  return GH_OK;
+}
+
+template <typename F>
+int hm_run(gh_hodlr_mgpu_impl* H, F fn) {
+  H->abort.store(0);
+  std::vector<std::thread> th;
+  for (int i = 0; i < H->P; ++i) {
+    th.emplace_back([H, i, &fn]() {
+      HmRank& r = H->ranks[i];
+      r.rc = GH_OK; r.err.clear();
+      if (hipSetDevice(r.dev) != hipSuccess) { r.rc = GH_ERR_HIP; r.err = "hipSetDevice failed"; H->abort.store(1); return; }
+      const int rc = fn(r);
+      if (r.dev_lock.owns_lock()) r.dev_lock.unlock();
+      if (rc != GH_OK) { r.rc = rc; r.err = gh_last_error(); H->abort.store(1); }
+    });
+  }
+  for (auto& t : th) t.join();
+  int first = GH_OK;
+  for (auto& r : H->ranks) {
+    if (r.rc == GH_OK) continue;
+    if (first == GH_OK || r.err.find("aborted") == std::string::npos) {       // (prefer a real message to "saw the abort flag")
+      first = r.rc;
+      gh_set_error("sub-tree %d (device %d): %s", r.p, r.dev, r.err.c_str());
+      if (r.err.find("aborted") == std::string::npos) break;
+    }
+  }
+  return first;
+}
+}  // namespace
+
+struct gh_hodlr_mgpu : gh_hodlr_mgpu_impl {};
+
+extern "C" void gh_hodlr_mgpu_destroy(gh_hodlr_mgpu* H) {
+  if (!H) return;
+  H->clear_top();
+  for (auto& r : H->ranks) {
+    (void)hipSetDevice(r.dev);
+    if (r.h) gh_hodlr_destroy(r.h);
+    for (auto* b : r.stage) delete b;
+    r.xg.release();
+    if (r.kern.d_nodes) { (void)hipFree(r.kern.d_nodes); r.kern.d_nodes = nullptr; }
+    if (r.pin) (void)hipHostFree(r.pin);
+  }
+  delete H;
+}
+
+extern "C" int gh_hodlr_mgpu_create(const gh_hodlr_mgpu_opts* opts, gh_hodlr_mgpu** out) {
+  if (!opts || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  const int P = opts->n_dev;
+  if (P < 1 || P > 16 || (P & (P - 1))) { gh_set_error("HODLR split: n_dev must be 1, 2, 4, 8 or 16 (got %d)", P); return GH_ERR_BAD_ARG; }
+  const int ndev = gh_device_count();
+  if (ndev <= 0) { gh_set_error("no HIP device available: the george_amd HODLR solver needs an MI355X"); return GH_ERR_HIP; }
+  bool dup = false;
+  for (int i = 0; i < P; ++i) {
+    if (opts->devices[i] < 0 || opts->devices[i] >= ndev) { gh_set_error("HODLR split: device %d does not exist (%d visible)", opts->devices[i], ndev); return GH_ERR_BAD_ARG; }
+    for (int j = 0; j < i; ++j) if (opts->devices[j] == opts->devices[i]) dup = true;
+  }
+  if (dup && getenv("GEORGE_AMD_PRIVATE_STREAMS")) {
+    gh_set_error("HODLR split: a device listed several times needs the process-wide streams (unset GEORGE_AMD_PRIVATE_STREAMS)"); return GH_ERR_BAD_ARG;
+  }
+  gh_hodlr_mgpu* H = new gh_hodlr_mgpu();
+  H->opts = *opts;
+  H->P = P;
+  for (H->depth = 0; (1 << H->depth) < P; ++H->depth) {}
+  H->ranks.resize(P);
+  H->world.n = P;
+  H->world.abort = &H->abort;
+  for (int i = 0; i < P; ++i) {
+    HmRank& r = H->ranks[i];
+    r.p = i; r.dev = opts->devices[i]; r.owner = H;
+    gh_hodlr_opts o;
+    memset(&o, 0, sizeof(o));
+    o.device = r.dev; o.min_size = opts->min_size; o.seed = opts->seed; o.max_rank = opts->max_rank; o.tol = opts->tol;
+    const int rc = gh_hodlr_create(&o, &r.h);
+    if (rc != GH_OK) { gh_hodlr_mgpu_destroy(H); return rc; }
+    for (int l = 0; l < H->depth; ++l) r.stage.push_back(new GhBuf());
+  }
+  *out = H;
+  return GH_OK;
+}
+
+extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                                     const double* yerr, double* logdet_out) {
+  if (!H || !k || !x || !yerr || n <= 0) { gh_set_error("bad argument to compute"); return GH_ERR_BAD_ARG; }
+  if (ndim != k->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
+  if (n > 0x3fffffffL) { gh_set_error("HODLR: n too large"); return GH_ERR_BAD_ARG; }
+  if (gh_is_device_ptr(x) || gh_is_device_ptr(yerr)) { gh_set_error("HODLR split: x and yerr must be host pointers"); return GH_ERR_BAD_ARG; }
+  H->computed = false;
+  H->n = n; H->ndim = ndim;
+  const int P = H->P, depth = H->depth, min_size = std::max(1, H->opts.min_size);
+  // ---- the tree above the split (hodlr.h:47-64) and the rows of every sub-tree
+  H->clear_top();
+  H->top.resize(depth);
+  struct Seg { int start, size; };
+  std::vector<Seg> cur(1, Seg{0, (int)n});
+  for (int l = 0; l < depth; ++l) {
+    std::vector<Seg> next;
+    for (int q = 0; q < (int)cur.size(); ++q) {
+      const int half = cur[q].size / 2;
+      if (half < min_size) {
+        gh_set_error("HODLR split: %lld points are too few for %d devices with min_size = %d (a node of level %d would be a leaf)",
+                     (long long)n, P, min_size, l);
+        H->clear_top();
+        return GH_ERR_BAD_ARG;
+      }
+      HmTop* t = new HmTop();
+      t->level = l; t->q = q; t->start = cur[q].start; t->half = half; t->size = cur[q].size;
+      t->span = P >> l; t->first = q * t->span; t->runner = t->first + (l % t->span);
+      t->bar.n = t->span; t->bar.abort = &H->abort;
+      H->top[l].push_back(t);
+      next.push_back({cur[q].start, half});
+      next.push_back({cur[q].start + half, cur[q].size - half});
+    }
+    cur.swap(next);
+  }
+  // internal nodes per level of every sub-tree: a node's random stream is keyed by its index in the GLOBAL level
+  std::vector<std::vector<int>> cnt(P);
+  size_t maxl = 0;
+  for (int p = 0; p < P; ++p) {
+    H->ranks[p].row0 = cur[p].start; H->ranks[p].n = cur[p].size;
+    std::vector<int> sizes(1, cur[p].size);
+    while (!sizes.empty()) {
+      std::vector<int> nx;
+      int internal = 0;
+      for (int sz : sizes) if (sz / 2 >= min_size) { ++internal; nx.push_back(sz / 2); nx.push_back(sz - sz / 2); }
+      if (internal == 0) break;
+      cnt[p].push_back(internal);
+      sizes.swap(nx);
+    }
+    maxl = std::max(maxl, cnt[p].size());
+  }
+  for (int p = 0; p < P; ++p) {
+    H->ranks[p].seed_off.assign(maxl, 0);
+    for (size_t l = 0; l < maxl; ++l)
+      for (int o = 0; o < p; ++o) if (l < cnt[o].size()) H->ranks[p].seed_off[l] += cnt[o][l];
+  }
+
+  const int rc = hm_run(H, [&](HmRank& r) -> int {
+    gh_hodlr* h = r.h;
+    hipStream_t st = h->st;
+    // a private copy of the kernel program on this device (a gh_kernel caches ONE device copy)
+    if (r.kern.d_nodes) { (void)hipFree(r.kern.d_nodes); r.kern.d_nodes = nullptr; }
+    r.kern.nodes = k->nodes; r.kern.ndim = k->ndim; r.kern.size = k->size; r.kern.fast = k->fast; r.kern.device = -1;
+    GH_CHECK(r.kern.upload());
+    // ---- the ACA of the top nodes this device runs
+    std::vector<HmTop*> mine;
+    for (auto& lv : H->top) for (auto* t : lv) if (t->runner == r.p) mine.push_back(t);
+    if (!mine.empty()) {
+      GH_CHECK(r.xg.ensure((size_t)n * ndim * sizeof(double)));
+      GH_CHECK(gh_to_device(r.xg.d(), x, (size_t)n * ndim, st));
+      std::lock_guard<std::mutex> lk(g_hm_dev_mu[r.dev & 15]);
+      for (HmTop* t : mine) {
+        GH_CHECK(aca_top_node(h, &r.kern, r.xg.d(), (long)n, ndim, t->level, LvlNode{t->start, t->half, t->size, t->q}, t->Tcm, &t->rank));
+        t->pack_off.assign(t->span, 0);
+        GH_CHECK(t->packed.ensure(std::max<size_t>((size_t)t->size * t->rank, 1) * sizeof(double)));
+        long off = 0;
+        for (int m = 0; m < t->span && t->rank > 0; ++m) {
+          const HmRank& o = H->ranks[t->first + m];
+          t->pack_off[m] = off;
+          const long tot = o.n * t->rank;
+          hipLaunchKernelGGL(hodlr_pack_rows_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 4096)), dim3(256), 0, st,
+                             t->Tcm.d(), (long)n, o.row0, o.n, t->rank, t->packed.d() + off);
+          off += tot;
+        }
+        GH_HIP(hipGetLastError());
+      }
+      GH_HIP(hipStreamSynchronize(st));
+    }
+    if (!H->world.wait()) { gh_set_error("aborted: another device failed"); return GH_ERR_HIP; }
+    // ---- every device pulls its rows of each ancestor's factors
+    HSub& sub = h->sub;
+    sub.depth = depth;
+    sub.half.assign(depth, 0); sub.R.assign(depth, 0); sub.T.assign(depth, nullptr);
+    sub.seed_off = r.seed_off;
+    sub.ctx = &r; sub.allreduce = hm_allreduce; sub.local_done = hm_local_done;
+    for (int l = 0; l < depth; ++l) {
+      int R = 0;
+      for (auto* t : H->top[l]) R = std::max(R, t->rank);
+      HmTop* t = H->top[l][r.p >> (depth - l)];
+      sub.R[l] = R;
+      sub.half[l] = (r.row0 >= t->start + t->half) ? 1 : 0;
+      GhBuf* sg = r.stage[l];
+      GH_CHECK(sg->ensure(std::max<size_t>((size_t)r.n * R, 1) * sizeof(double)));
+      sub.T[l] = sg->d();
+      if (R > t->rank) GH_HIP(hipMemsetAsync(sg->d() + (size_t)r.n * t->rank, 0, (size_t)r.n * (R - t->rank) * sizeof(double), st));
+      if (t->rank > 0) {
+        const double* src = t->packed.d() + t->pack_off[r.p - t->first];
+        const size_t bytes = (size_t)r.n * t->rank * sizeof(double);
+        const int sdev = H->ranks[t->runner].dev;
+        if (sdev == r.dev) GH_HIP(hipMemcpyAsync(sg->p, src, bytes, hipMemcpyDeviceToDevice, st));
+        else GH_HIP(hipMemcpyPeerAsync(sg->p, r.dev, src, sdev, bytes, st));
+      }
+    }
+    GH_HIP(hipStreamSynchronize(st));
+    if (!H->world.wait()) { gh_set_error("aborted: another device failed"); return GH_ERR_HIP; }
+    // ---- the sub-tree: the single-device code (released for the next sub-tree of this device once its own part is done)
+    r.dev_lock = std::unique_lock<std::mutex>(g_hm_dev_mu[r.dev & 15]);
+    return gh_hodlr_compute(h, &r.kern, x + r.row0 * ndim, r.n, ndim, yerr + r.row0, &r.ld);
+  });
+  if (rc != GH_OK) return rc;
+  // log|det|: the sub-trees' own blocks in tree order, then the ancestors' cores bottom-up (each from the first device below it)
+  double logdet = 0.0;
+  for (auto& r : H->ranks) logdet += r.ld;
+  for (int l = depth - 1; l >= 0; --l)
+    for (auto* t : H->top[l]) logdet += H->ranks[t->first].h->sub.ld_top[l];
+  H->logdet = logdet;
+  // ranks, level by level
+  H->all_ranks.clear();
+  for (int l = 0; l < depth; ++l) for (auto* t : H->top[l]) H->all_ranks.push_back(t->rank);
+  for (size_t l = depth;; ++l) {
+    bool any = false;
+    for (auto& r : H->ranks)
+      if (l < r.h->levels.size()) { any = true; for (int v : r.h->levels[l]->ranks) H->all_ranks.push_back(v); }
+    if (!any) break;
+  }
+  H->computed = true;
+  if (logdet_out) *logdet_out = logdet;
+  return GH_OK;
+}
+
+extern "C" int gh_hodlr_mgpu_solve(gh_hodlr_mgpu* H, const double* b, int64_t nrhs, double* out) {
+  if (!H) { gh_set_error("null solver"); return GH_ERR_BAD_ARG; }
+  if (!H->computed) { gh_set_error("you must call 'compute' first"); return GH_ERR_NOT_COMPUTED; }
+  if (!b || !out || nrhs <= 0) { gh_set_error("bad argument to solve"); return GH_ERR_BAD_ARG; }
+  if (gh_is_device_ptr(b) || gh_is_device_ptr(out)) { gh_set_error("HODLR split: b and out must be host pointers"); return GH_ERR_BAD_ARG; }
+  // (n, nrhs) row-major: the rows of a sub-tree are one contiguous slice
+  return hm_run(H, [&](HmRank& r) -> int { return gh_hodlr_solve(r.h, b + r.row0 * nrhs, nrhs, out + r.row0 * nrhs); });
+}
+extern "C" int gh_hodlr_mgpu_dot_solve(gh_hodlr_mgpu* H, const double* y, double* out) {
+  if (!H || !y || !out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  if (!H->computed) { gh_set_error("you must call 'compute' first"); return GH_ERR_NOT_COMPUTED; }
+  std::vector<double> a((size_t)H->n);
+  GH_CHECK(gh_hodlr_mgpu_solve(H, y, 1, a.data()));
+  double v = 0.0;
+  for (int64_t i = 0; i < H->n; ++i) v += y[i] * a[i];
+  *out = v;
+  return GH_OK;
+}
+extern "C" int gh_hodlr_mgpu_ranks(const gh_hodlr_mgpu* H, int32_t* ranks_out, int32_t max_out, int32_t* n_out) {
+  if (!H || !n_out) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  int cnt = 0;
+  for (int v : H->all_ranks) { if (ranks_out && cnt < max_out) ranks_out[cnt] = v; ++cnt; }
+  *n_out = cnt < max_out ? cnt : max_out;
+  return GH_OK;
+}
+extern "C" int gh_hodlr_mgpu_rows(const gh_hodlr_mgpu* H, int64_t* row0, int64_t* nrows) {
+  if (!H || !row0 || !nrows) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
+  for (int p = 0; p < H->P; ++p) { row0[p] = H->ranks[p].row0; nrows[p] = H->ranks[p].n; }
   return GH_OK;
 }

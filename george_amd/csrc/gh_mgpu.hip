@@ -37,6 +37,7 @@
 #include <mutex>
 #include <thread>
 #include "gh_common.h"
+#include "gh_threads.h"
 #include <rccl/rccl.h>            // types and enums only: every function is resolved with dlsym
 
 #define T GH_TILE
@@ -80,27 +81,6 @@ bool rccl_load() {
   g_rccl.ok = true;
   return true;
 }
-
-// A barrier of `n` host threads that gives up when the handle's abort flag goes up (a rank that
-// failed must not leave the others waiting for ever).
-struct HostBarrier {
-  std::mutex m;
-  std::condition_variable cv;
-  int n = 1, waiting = 0;
-  unsigned gen = 0;
-  std::atomic<int>* abort = nullptr;
-  bool wait() {
-    if (n <= 1) return !abort->load();
-    std::unique_lock<std::mutex> lk(m);
-    const unsigned g = gen;
-    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); return !abort->load(); }
-    while (gen == g) {
-      cv.wait_for(lk, std::chrono::milliseconds(20));
-      if (abort->load()) { cv.notify_all(); return false; }
-    }
-    return !abort->load();
-  }
-};
 
 struct Group {                     // a process row, a process column, or the world
   std::vector<int> members;        // global ranks, ascending

@@ -4,6 +4,6 @@ plug into the *reference's own* ``george.GP(kernel, solver=...)`` unchanged."""
 from .trivial import TrivialSolver
 from .basic import BasicSolver
 from .hodlr import HODLRSolver
-from .multigpu import MultiGPUSolver
+from .multigpu import MultiGPUSolver, MultiGPUHODLRSolver
 
-__all__ = ["TrivialSolver", "BasicSolver", "HODLRSolver", "MultiGPUSolver"]
+__all__ = ["TrivialSolver", "BasicSolver", "HODLRSolver", "MultiGPUSolver", "MultiGPUHODLRSolver"]

@@ -16,7 +16,7 @@ import numpy as np
 from .. import _native as N
 from ..program import DeviceKernel
 
-__all__ = ["MultiGPUSolver"]
+__all__ = ["MultiGPUSolver", "MultiGPUHODLRSolver"]
 
 
 class MultiGPUSolver(object):
@@ -151,3 +151,112 @@ class MultiGPUSolver(object):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+
+
+class MultiGPUHODLRSolver(MultiGPUSolver):
+    """The HODLR solver with its tree split over several MI355X of one process (``gh_hodlr_mgpu_*``,
+    george_amd/csrc/gh_hodlr.hip): the top log2(len(devices)) levels are shared, each device owns one
+    sub-tree.  Same keywords as ``HODLRSolver`` (reference ``src/george/solvers/hodlr.py:13-76``:
+    ``min_size=100, tol=0.1, seed=42``) plus ``devices``; same node-by-node random streams as the
+    single-GPU solver, so ranks and answers agree with it to rounding.  ``len(devices)`` must be a power
+    of two and ``N / len(devices) >= 2 * min_size``.  ``apply_sqrt`` raises ``NotImplementedError``
+    (hodlr.py:62-64); pickling drops the factor (:69-76)."""
+
+    def __init__(self, kernel, min_size=100, tol=0.1, seed=42, devices=None, max_rank=0):
+        super(MultiGPUHODLRSolver, self).__init__(kernel, devices=devices)
+        n = len(self.devices)
+        if n & (n - 1):
+            raise ValueError("the HODLR tree is split over 1, 2, 4, 8 or 16 devices (got %d)" % n)
+        self.min_size, self.tol, self.seed, self.max_rank = min_size, tol, seed, int(max_rank)
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            o = N.gh_hodlr_mgpu_opts()
+            o.n_dev = len(self.devices)
+            for i, d in enumerate(self.devices):
+                o.devices[i] = d
+            o.min_size, o.seed, o.max_rank, o.tol = int(self.min_size), int(self.seed), self.max_rank, float(self.tol)
+            h = N._vp()
+            N.check(N.lib.gh_hodlr_mgpu_create(C.byref(o), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                N.lib.gh_hodlr_mgpu_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def grid_shape(self):
+        raise NotImplementedError("the HODLR split has no process grid: see rows()")
+
+    def rows(self):
+        """[(first row, number of rows)] of every device's sub-tree (after compute())."""
+        n = len(self.devices)
+        r0, nr = (C.c_int64 * n)(), (C.c_int64 * n)()
+        N.check(N.lib.gh_hodlr_mgpu_rows(self._need(), r0, nr))
+        return [(int(r0[i]), int(nr[i])) for i in range(n)]
+
+    def ranks(self):
+        """ACA ranks of all internal nodes, level by level, left to right (as ``HODLRSolver.ranks()``)."""
+        h = self._need()
+        cap = 1 << 16
+        buf, cnt = (C.c_int32 * cap)(), C.c_int32(0)
+        N.check(N.lib.gh_hodlr_mgpu_ranks(h, buf, cap, C.byref(cnt)))
+        return [int(buf[i]) for i in range(cnt.value)]
+
+    def compute(self, x, yerr):
+        """hodlr.h:75-103 over the split tree.  ``yerr`` already contains the white noise (gp.py:330)."""
+        x = N.as_f64(x)
+        if x.ndim != 2:
+            raise ValueError("x must be (nsamples, ndim)")
+        yerr = N.as_f64(np.zeros(len(x)) + yerr)
+        self._computed = False
+        self._dk = DeviceKernel(self.kernel)
+        if x.shape[1] != self._dk.ndim:
+            raise RuntimeError("dimension mismatch")
+        if self._handle is not None:          # options may have been changed on the instance
+            N.lib.gh_hodlr_mgpu_destroy(self._handle)
+            self._handle = None
+        h = self._ensure_handle()
+        logdet = C.c_double(0.0)
+        N.check(N.lib.gh_hodlr_mgpu_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        self._n = len(x)
+        self.log_determinant = logdet.value
+        self.computed = True
+
+    def apply_inverse(self, y, in_place=False):
+        """hodlr.h:107-114: ``y`` is (n,) or (n, nrhs)."""
+        h = self._need()
+        yin = y
+        y = np.asarray(y, dtype=np.float64)
+        if y.ndim < 1 or y.ndim > 2 or y.shape[0] != self._n:
+            raise ValueError("dimension mismatch")
+        yc = np.ascontiguousarray(y)
+        nrhs = 1 if yc.ndim == 1 else yc.shape[1]
+        out = np.empty_like(yc)
+        if nrhs > 0:
+            N.check(N.lib.gh_hodlr_mgpu_solve(h, N.ptr(yc), nrhs, N.ptr(out)))
+        if in_place and isinstance(yin, np.ndarray) and yin.dtype == np.float64:
+            try:
+                yin[...] = out
+                return yin
+            except (ValueError, TypeError):
+                pass
+        return out
+
+    def dot_solve(self, y):
+        """hodlr.h:116-120."""
+        h = self._need()
+        y = N.as_f64(y).reshape(-1)
+        if len(y) != self._n:
+            raise ValueError("dimension mismatch")
+        out = C.c_double(0.0)
+        N.check(N.lib.gh_hodlr_mgpu_dot_solve(h, N.ptr(y), C.byref(out)))
+        return out.value
+
+    def apply_sqrt(self, r):
+        raise NotImplementedError("apply_sqrt is not implemented for the HODLRSolver")

@@ -291,6 +291,42 @@ int  gh_mgpu_grid(const gh_mgpu* h, int32_t* pr, int32_t* pc, int32_t* nb);
 int  gh_mgpu_dot_solve(gh_mgpu* h, const double* y, double* out);                     /* basic.py:89-102 */
 int  gh_mgpu_solve(gh_mgpu* h, const double* b, int64_t nrhs, double* out);           /* basic.py:72-87; (n, nrhs) row-major, may alias */
 
+/* --------------------------------------------------- HODLR solver, tree split over several GPUs
+ * hodlr::Node (include/george/hodlr.h:29-254) with the top log2(n_dev) levels of the tree shared and the
+ * n_dev sub-trees below them -- independent of each other (hodlr.h:75-103: a node's factorisation touches
+ * its own rows only) -- one per device.  ONE process, a host thread per device.  Per compute():
+ *   - the ACA of each of the n_dev - 1 top nodes runs on one device against the whole point set, and every
+ *     device pulls the rows it owns of each ancestor's factors (peer copies, N x r doubles per node in all);
+ *   - every device builds and factors its sub-tree (the single-GPU code on rows [row0, row0 + n_p)), carrying
+ *     the ancestors' U rows along as extra right-hand-side columns;
+ *   - a top node's 2r x 2r core needs V^T U summed over the devices below it: 2r x C doubles exchanged
+ *     through pinned host memory per level -- the only data-path exchange, also in every solve.
+ * Same node-by-node random streams as the single-GPU solver (a node's generator is keyed by its position
+ * in the global tree), so ranks and results agree with gh_hodlr_* to rounding.  n_dev must be a power of
+ * two and every top node internal (N / n_dev >= 2 min_size); x, yerr, b, y are HOST pointers.  The same
+ * device may be listed several times ("virtual devices": the split is then exercised on one GPU).
+ * The reference has nothing here (single process, single thread). */
+typedef struct gh_hodlr_mgpu gh_hodlr_mgpu;
+typedef struct gh_hodlr_mgpu_opts {
+  int32_t n_dev;             /* 1, 2, 4, 8 or 16 */
+  int32_t devices[16];       /* HIP device ordinals; sub-tree p (rows in tree order) lives on devices[p] */
+  int32_t min_size;          /* as gh_hodlr_opts */
+  int32_t seed;
+  int32_t max_rank;
+  double  tol;
+  int32_t reserved[4];
+} gh_hodlr_mgpu_opts;
+int  gh_hodlr_mgpu_create(const gh_hodlr_mgpu_opts* opts, gh_hodlr_mgpu** out);
+void gh_hodlr_mgpu_destroy(gh_hodlr_mgpu* h);
+int  gh_hodlr_mgpu_compute(gh_hodlr_mgpu* h, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
+                           const double* yerr, double* logdet_out);                          /* hodlr.h:75-103 */
+int  gh_hodlr_mgpu_solve(gh_hodlr_mgpu* h, const double* b, int64_t nrhs, double* out);      /* hodlr.h:107-114; (n, nrhs) row-major */
+int  gh_hodlr_mgpu_dot_solve(gh_hodlr_mgpu* h, const double* y, double* out);                /* hodlr.h:116-120 */
+/* ranks of all internal nodes, level by level, left to right (the order gh_hodlr_ranks uses) */
+int  gh_hodlr_mgpu_ranks(const gh_hodlr_mgpu* h, int32_t* ranks_out, int32_t max_out, int32_t* n_out);
+/* rows [row0[p], row0[p] + nrows[p]) live on devices[p]; arrays of n_dev entries (after compute()) */
+int  gh_hodlr_mgpu_rows(const gh_hodlr_mgpu* h, int64_t* row0, int64_t* nrows);
+
 /* ------------------------------------------- device-level tile operations
  * Building blocks of the blocked factorisation on DEVICE pointers and an
  * explicit hipStream_t (passed as void*; NULL = default stream).  Used by the

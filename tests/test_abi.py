@@ -35,6 +35,8 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(N.gh_chol_profile) == 11 * 8
     assert ctypes.sizeof(N.gh_hodlr_opts) == 4 * 4 + 8 + 4 * 4
     assert ctypes.sizeof(N.gh_mgpu_opts) == (1 + 16 + 2 + 1 + 1 + 4) * 4
+    assert ctypes.sizeof(N.gh_hodlr_mgpu_opts) == (1 + 16 + 3) * 4 + 8 + 4 * 4
+    assert N.gh_hodlr_mgpu_opts.tol.offset == 80
 
 
 def test_program_validation_runs_without_gpu():
@@ -77,6 +79,34 @@ def test_multi_gpu_entry_points_declared_and_validated():
         o.n_dev, o.nb = 1, 0
         with pytest.raises(RuntimeError):
             N.check(N.lib.gh_mgpu_create(ctypes.byref(o), ctypes.byref(h)))
+
+
+def test_hodlr_split_entry_points_declared_and_validated():
+    """the HODLR tree split over several devices sits behind the C ABI (gh_hodlr_mgpu_*).  Validation
+    is host code: device counts that are not a power of two are GH_ERR_BAD_ARG, and with no device visible
+    creation fails loudly."""
+    from george_amd import _native as N, MultiGPUHODLRSolver
+    for name in ("gh_hodlr_mgpu_create", "gh_hodlr_mgpu_destroy", "gh_hodlr_mgpu_compute", "gh_hodlr_mgpu_solve",
+                 "gh_hodlr_mgpu_dot_solve", "gh_hodlr_mgpu_ranks", "gh_hodlr_mgpu_rows"):
+        assert name in N.SIGNATURES and hasattr(N.lib, name)
+    o = N.gh_hodlr_mgpu_opts()
+    h = N._vp()
+    for bad in (0, 3, 6, 32):
+        o.n_dev = bad
+        with pytest.raises(ValueError):
+            N.check(N.lib.gh_hodlr_mgpu_create(ctypes.byref(o), ctypes.byref(h)))
+    with pytest.raises(ValueError):
+        MultiGPUHODLRSolver(None, devices=[0, 0, 0])
+    s = MultiGPUHODLRSolver(None, devices=[0, 0])
+    with pytest.raises(RuntimeError):
+        s.dot_solve(np.zeros(3))                           # "you must call 'compute' first"
+    with pytest.raises(NotImplementedError):
+        s.apply_sqrt(np.zeros(3))
+    import george_amd
+    if george_amd.device_count() == 0:
+        o.n_dev = 2
+        with pytest.raises(RuntimeError):
+            N.check(N.lib.gh_hodlr_mgpu_create(ctypes.byref(o), ctypes.byref(h)))
 
 
 def test_fails_loudly_without_gpu():
