@@ -344,6 +344,25 @@ def mgpu_abi_report(local_rank, n=32768):
                                              "ref": "single-GPU gh_chol_* on the same inputs (itself reference-pinned)"}}
 
 
+def multi_device_probe(timeout_s=240):
+    """scripts/abi_multi_device_probe.py in a child process with a time limit: the two several-devices-in-one-process
+    forms of the C ABI (gh_mgpu_*, gh_hodlr_mgpu_*) on every device this box shows -- real peer traffic when there is
+    more than one MI355X, the HODLR split on one GPU listed twice otherwise.  Never part of the timed region or of the
+    line's parity verdict: a failure here is reported in place, the headline stands."""
+    import subprocess
+    if os.environ.get("GEORGE_AMD_BENCH_NO_MULTI_PROBE"):
+        return {"skipped": "GEORGE_AMD_BENCH_NO_MULTI_PROBE"}
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "abi_multi_device_probe.py")]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": "no answer within %d s" % timeout_s}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "exit %d: %s" % (r.returncode, r.stderr.strip()[-400:])}
+    return json.loads(lines[-1])
+
+
 def public_api_report(n, local_rank, steps=2):
     """The headline work through the public facade: NumPy x, yerr, y -> GP.compute -> log_likelihood,
     host->device of the inputs included (SURVEY.md 8d's statement of the metric)."""
@@ -758,6 +777,7 @@ def main():
                     parity["abi_multi_gpu_world_of_one"] = out["config"]["also_abi_multi_gpu_world_of_one"]["parity"]
                 except Exception as e:                               # (RCCL missing on the box: say so, keep the line)
                     out["config"]["also_abi_multi_gpu_world_of_one"] = {"error": repr(e)}
+                out["config"]["also_abi_multi_device"] = multi_device_probe()
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_n)
                 jp = DenseJob(args.cpu_n, args.nb, local_rank, profile=False)       # the GPU at the SAME N as the CPU sample

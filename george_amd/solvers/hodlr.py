@@ -5,6 +5,7 @@ over ``_hodlr.cpp`` / ``include/george/hodlr.h``): same constructor keywords
 (``min_size=100, tol=0.1, seed=42``), same methods, ``apply_sqrt`` raises
 ``NotImplementedError`` (hodlr.py:62-64), pickling drops the factor (:69-76).
 """
+import atexit
 import ctypes as C
 import warnings
 
@@ -38,8 +39,23 @@ class HODLRSolver(BasicSolver):
         self._hopts = dict(device=int(device), max_rank=int(max_rank))
         super(HODLRSolver, self).__init__(kernel, device=device)
 
+    # A native handle keeps its tree, its per-level job tables on the device and the measured schedule of its
+    # last compute(): inside an optimiser loop (GP makes a NEW solver object per compute, gp.py:327) a fresh handle
+    # per iterate cost 3 of the 8.4 ms of a C4 step through this class.  Handles of dropped solvers are parked per
+    # option set (at most _HPOOL_MAX each) and picked up by the next solver with the same options.
+    _HPOOL = {}
+    _HPOOL_MAX = 2
+
+    def _hkey(self):
+        return (self._hopts["device"], int(self.min_size), int(self.seed), self._hopts["max_rank"], float(self.tol))
+
     def _ensure_handle(self):
         if self._handle is None:
+            self._handle_key = self._hkey()
+            free = HODLRSolver._HPOOL.get(self._handle_key)
+            if free:
+                self._handle = free.pop()
+                return self._handle
             o = N.gh_hodlr_opts()
             o.device, o.min_size, o.seed = self._hopts["device"], int(self.min_size), int(self.seed)
             o.max_rank, o.tol = self._hopts["max_rank"], float(self.tol)
@@ -48,14 +64,31 @@ class HODLRSolver(BasicSolver):
             self._handle = h
         return self._handle
 
-    def __del__(self):
-        h = getattr(self, "_handle", None)
+    def _park_handle(self):
+        h, self._handle = getattr(self, "_handle", None), None
         if h is not None and h.value:
             try:
-                N.lib.gh_hodlr_destroy(h)
+                free = HODLRSolver._HPOOL.setdefault(getattr(self, "_handle_key", None), [])
+                if getattr(self, "_handle_key", None) is not None and len(free) < HODLRSolver._HPOOL_MAX:
+                    free.append(h)
+                else:
+                    N.lib.gh_hodlr_destroy(h)
             except Exception:
                 pass
-            self._handle = None
+
+    def __del__(self):
+        self._park_handle()
+
+    @classmethod
+    def release_pool(cls):
+        """Destroy every parked native handle (frees their device memory)."""
+        for free in cls._HPOOL.values():
+            while free:
+                try:
+                    N.lib.gh_hodlr_destroy(free.pop())
+                except Exception:
+                    pass
+        cls._HPOOL.clear()
 
     def compute(self, x, yerr):
         x = N.as_f64(x)
@@ -66,9 +99,8 @@ class HODLRSolver(BasicSolver):
         self._dk = DeviceKernel(self.kernel)
         if x.shape[1] != self._dk.ndim:
             raise RuntimeError("dimension mismatch")
-        if self._handle is not None:          # options may have been changed on the instance
-            N.lib.gh_hodlr_destroy(self._handle)
-            self._handle = None
+        if self._handle is not None and getattr(self, "_handle_key", None) != self._hkey():
+            self._park_handle()               # options were changed on the instance
         h = self._ensure_handle()
         logdet = C.c_double(0.0)
         self.dense_fallback, self._dense = False, None
@@ -159,3 +191,6 @@ class HODLRSolver(BasicSolver):
     grad = None
     profile = None
     objective = None
+
+
+atexit.register(HODLRSolver.release_pool)

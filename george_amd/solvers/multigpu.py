@@ -218,9 +218,11 @@ class MultiGPUHODLRSolver(MultiGPUSolver):
         self._dk = DeviceKernel(self.kernel)
         if x.shape[1] != self._dk.ndim:
             raise RuntimeError("dimension mismatch")
-        if self._handle is not None:          # options may have been changed on the instance
-            N.lib.gh_hodlr_mgpu_destroy(self._handle)
+        key = (tuple(self.devices), int(self.min_size), int(self.seed), self.max_rank, float(self.tol))
+        if self._handle is not None and getattr(self, "_handle_key", None) != key:
+            N.lib.gh_hodlr_mgpu_destroy(self._handle)          # options were changed on the instance
             self._handle = None
+        self._handle_key = key
         h = self._ensure_handle()
         logdet = C.c_double(0.0)
         N.check(N.lib.gh_hodlr_mgpu_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
