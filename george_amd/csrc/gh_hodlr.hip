@@ -1498,6 +1498,11 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   GH_HIP(hipSetDevice(h->opts.device));
   GH_CHECK(k->upload());
   hipStream_t st = h->st;
+  static const bool dbg_phases = getenv("GEORGE_AMD_HODLR_SPLIT_DEBUG") != nullptr;
+  const auto dbg_t0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (dbg_phases) fprintf(stderr, "[hodlr %p] %s at %.2f ms\n", (void*)h, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
+  };
   h->computed = false;
   h->n = n; h->ndim = ndim;
   GH_CHECK(h->x.ensure((size_t)n * ndim * sizeof(double)));
@@ -1505,6 +1510,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   GH_CHECK(gh_to_device(h->x.d(), x, (size_t)n * ndim, st));
   GH_CHECK(gh_to_device(h->yerr.d(), yerr, (size_t)n, st));
   GH_CHECK(h->scal.ensure(64));
+  mark("inputs enqueued");
 
   // ---- tree (hodlr.h:47-64), breadth first; kept from the previous compute() when n and min_size are the same
   const int min_size = h->opts.min_size;
@@ -1975,10 +1981,13 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     for (int l = 0; l < nlev; ++l) { if (l >= l0) GH_CHECK(settle_level(l)); rank_of_level(l); }
   } else {
     for (int l = 0; l < l0; ++l) rank_of_level(l);
+    mark("serial ACA starts");
     for (int l = l0; l < nlev; ++l) {
       GH_CHECK(enqueue_level(l, rcap0, st));
+      if (dbg_phases) mark("  level enqueued");
       GH_CHECK(fetch_level(l, st));
       GH_HIP(hipStreamSynchronize(st));
+      if (dbg_phases) mark("  level synchronised");
       GH_CHECK(settle_level(l));
       GH_CHECK(compact_level(l));
     }
@@ -1987,6 +1996,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   GhPooledBuf idx;
   Tcm.release();
   idx.release();
+  mark("ACA done, ranks known");
 
   // ---- UA / VA (n x Rtot) and the per-level chunk / job tables
   const long Rtot = std::max(h->Rtot, 1);
@@ -2071,7 +2081,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(upload(L->d_smul_jobs, smul, st));
     L->tab_R = R; L->tab_off = L->off; L->tab_Rtot = Rtot;
   }
-  GH_HIP(hipStreamSynchronize(st));          // levelB buffers are freed when `cleanup` goes out of scope
+  mark("tables enqueued");
+  GH_HIP(hipStreamSynchronize(st));
+  mark("U, V assembled");
+  // The ACA scratch (n x 256 doubles per level: 6 GB at C4, 12 GB for a 524288-row sub-tree) goes back to the block
+  // cache NOW, not when compute() returns: in a split tree the next sub-tree of this device starts while this one waits
+  // for the others in its top levels, and found the cache empty -- tens of GB of hipMalloc / hipFree per compute(),
+  // stalls of 1.4-2.8 s at N = 2M over four sub-trees on one GPU.  (Nothing is queued on them any more: just synchronised.)
+  for (auto& a : al) { a.Tcm.release(); a.idx.release(); a.sync.release(); a.part.release(); }
+  for (auto*& b : levelB) { delete b; b = nullptr; }
   {
     size_t maxnodes = 1;
     for (auto* L : h->levels) maxnodes = std::max(maxnodes, L->node_ids.size() * (size_t)std::max(L->R, 1));
@@ -2084,6 +2102,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
 
   // ---- leaves (enqueued above, beside the ACA, when the levels run concurrently)
   if (!leaves_done) GH_CHECK(leaf_stage(st));
+  mark("work arrays, leaf stage enqueued");
 
   // ---- factorisation sweep (hodlr.h:75-103, level-batched): leaves into every U, then levels bottom-up
   if (h->Rtot > 0) GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot));
@@ -2093,7 +2112,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     HLevel* L = h->levels[l];
     if (l < l0 && !local_done) {
       // everything below needs the other devices: tell the owner of the split that this one has finished on its own
+      mark("local sweep enqueued");
       GH_HIP(hipStreamSynchronize(st));
+      mark("local sweep done");
       local_done = true;
       if (h->sub.local_done) GH_CHECK(h->sub.local_done(h->sub.ctx));
     }
@@ -2298,6 +2319,8 @@ struct gh_hodlr_mgpu_impl {
   bool computed = false;
   double logdet = 0.0;
   std::vector<int> all_ranks;
+  int64_t top_n = -1;                         // the top nodes in `top` were laid out for this many points / this min_size
+  int top_min = -1;
   void clear_top() { for (auto& lv : top) for (auto* t : lv) { if (t) { (void)hipSetDevice(ranks[t->runner].dev); delete t; } } top.clear(); }
 };
 
@@ -2314,7 +2337,7 @@ __global__ void hodlr_pack_rows_kernel(const double* Tcm, long N, long row0, lon
 // same cluster rule and same retry ladder as the levels of gh_hodlr_compute; nd.pad = the node's index in its level.
 int aca_top_node(gh_hodlr* h, gh_kernel* k, const double* x_dev, long N, int ndim, int level, LvlNode nd, GhBuf& Tcm, int* rank_out) {
   hipStream_t st = h->st;
-  GhBuf d_node, d_rank, idx, sync, part;
+  GhPooledBuf d_node, d_rank, idx, sync, part;       // (all used on st only, and the call ends synchronised)
   GH_CHECK(d_node.ensure(sizeof(LvlNode)));
   GH_CHECK(d_rank.ensure(sizeof(int)));
   GH_HIP(hipMemcpyAsync(d_node.p, &nd, sizeof(LvlNode), hipMemcpyHostToDevice, st));
@@ -2366,7 +2389,8 @@ int hm_allreduce(void* ctx, int level, double* dT, int rows, int cols, long pitc
   gh_hodlr_mgpu_impl* H = r.owner;
   HmTop& t = *H->top[level][r.p >> (H->depth - level)];
   const size_t cnt = (size_t)rows * cols;
-  if (cnt > r.pin_cap) {                      // (nobody reads this rank's buffer between two all-reduces)
+  if (cnt > r.pin_cap) {                      // (no other rank reads this one's buffer between two all-reduces; this rank's
+    GH_HIP(hipStreamSynchronize(st));          //  own copy of the previous sums back to the device may still be in flight)
     if (r.pin) (void)hipHostFree(r.pin);
     r.pin = nullptr; r.pin_cap = 0;
     const size_t cap = std::max<size_t>(2 * cnt, 1 << 16);
@@ -2483,8 +2507,10 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
   H->n = n; H->ndim = ndim;
   const int P = H->P, depth = H->depth, min_size = std::max(1, H->opts.min_size);
   // ---- the tree above the split (hodlr.h:47-64) and the rows of every sub-tree
-  H->clear_top();
-  H->top.resize(depth);
+  // (kept from one compute() to the next while n is the same: a top node holds 8 N rcap bytes of ACA scratch)
+  const bool keep_top = H->top_n == n && H->top_min == min_size && (int)H->top.size() == depth;
+  H->top_n = -1;
+  if (!keep_top) { H->clear_top(); H->top.resize(depth); }
   struct Seg { int start, size; };
   std::vector<Seg> cur(1, Seg{0, (int)n});
   for (int l = 0; l < depth; ++l) {
@@ -2497,11 +2523,13 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
         H->clear_top();
         return GH_ERR_BAD_ARG;
       }
-      HmTop* t = new HmTop();
-      t->level = l; t->q = q; t->start = cur[q].start; t->half = half; t->size = cur[q].size;
-      t->span = P >> l; t->first = q * t->span; t->runner = t->first + (l % t->span);
-      t->bar.n = t->span; t->bar.abort = &H->abort;
-      H->top[l].push_back(t);
+      if (!keep_top) {
+        HmTop* t = new HmTop();
+        t->level = l; t->q = q; t->start = cur[q].start; t->half = half; t->size = cur[q].size;
+        t->span = P >> l; t->first = q * t->span; t->runner = t->first + (l % t->span);
+        t->bar.n = t->span; t->bar.abort = &H->abort;
+        H->top[l].push_back(t);
+      }
       next.push_back({cur[q].start, half});
       next.push_back({cur[q].start + half, cur[q].size - half});
     }
@@ -2529,9 +2557,14 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
       for (int o = 0; o < p; ++o) if (l < cnt[o].size()) H->ranks[p].seed_off[l] += cnt[o][l];
   }
 
+  static const bool dbg = getenv("GEORGE_AMD_HODLR_SPLIT_DEBUG") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   const int rc = hm_run(H, [&](HmRank& r) -> int {
     gh_hodlr* h = r.h;
     hipStream_t st = h->st;
+    double tm[6] = {0, 0, 0, 0, 0, 0};
+    struct Report { bool on; int p; double* tm; ~Report() { if (on) fprintf(stderr, "[hodlr split] rank %d: top ACA done %.2f, met %.2f, rows pulled %.2f, met %.2f, lock %.2f, compute returned %.2f ms\n", p, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]); } } report{dbg, r.p, tm};
     // a private copy of the kernel program on this device (a gh_kernel caches ONE device copy)
     if (r.kern.d_nodes) { (void)hipFree(r.kern.d_nodes); r.kern.d_nodes = nullptr; }
     r.kern.nodes = k->nodes; r.kern.ndim = k->ndim; r.kern.size = k->size; r.kern.fast = k->fast; r.kern.device = -1;
@@ -2560,7 +2593,9 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
       }
       GH_HIP(hipStreamSynchronize(st));
     }
+    tm[0] = ms_since();
     if (!H->world.wait()) { gh_set_error("aborted: another device failed"); return GH_ERR_HIP; }
+    tm[1] = ms_since();
     // ---- every device pulls its rows of each ancestor's factors
     HSub& sub = h->sub;
     sub.depth = depth;
@@ -2586,10 +2621,15 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
       }
     }
     GH_HIP(hipStreamSynchronize(st));
+    tm[2] = ms_since();
     if (!H->world.wait()) { gh_set_error("aborted: another device failed"); return GH_ERR_HIP; }
+    tm[3] = ms_since();
     // ---- the sub-tree: the single-device code (released for the next sub-tree of this device once its own part is done)
     r.dev_lock = std::unique_lock<std::mutex>(g_hm_dev_mu[r.dev & 15]);
-    return gh_hodlr_compute(h, &r.kern, x + r.row0 * ndim, r.n, ndim, yerr + r.row0, &r.ld);
+    tm[4] = ms_since();
+    const int rcc = gh_hodlr_compute(h, &r.kern, x + r.row0 * ndim, r.n, ndim, yerr + r.row0, &r.ld);
+    tm[5] = ms_since();
+    return rcc;
   });
   if (rc != GH_OK) return rc;
   // log|det|: the sub-trees' own blocks in tree order, then the ancestors' cores bottom-up (each from the first device below it)
@@ -2608,6 +2648,7 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
     if (!any) break;
   }
   H->computed = true;
+  H->top_n = n; H->top_min = min_size;
   if (logdet_out) *logdet_out = logdet;
   return GH_OK;
 }

@@ -50,7 +50,7 @@ struct BlockCache {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks[16];      // per device, keyed by capacity
   size_t cached_bytes[16] = {0};
-  static constexpr size_t kMaxCached = (size_t)16 << 30;   // per device; beyond it blocks are really freed
+  static constexpr size_t kMaxCached = (size_t)48 << 30;   // per device (of 288 GB); beyond it blocks are really freed
 };
 BlockCache g_cache;
 }
