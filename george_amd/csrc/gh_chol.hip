@@ -228,15 +228,30 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* L, long ld, c
 }
 // The whole forward sweep L z = y as ONE launch: workgroup b owns block row b.  It walks the blocks
 // L[b, 0..b-1] left to right, folding each z_j into per-lane partial sums as soon as workgroup j
-// has published it (a flag per block row in HBM), then solves its own diagonal block with the
-// stored inverse and publishes z_b.  The step-per-launch version above costs a launch gap plus
-// two dependent 128x128 mat-vecs per block row (25-27 us, 14.3 ms at N = 65536 against 3.8 ms of
-// HBM time for the triangle); here a link of the chain is flag -> 128 FMAs per lane -> reduce ->
-// one mat-vec, and the L blocks of a row stream in ahead of the flags (the next block is loaded
-// into registers before the wait).  512 threads: wavefront w takes rows 16w..16w+15, a lane two
-// columns.  Deadlock freedom: workgroup b only waits for workgroups j < b, and a 1-D grid is
-// dispatched in blockIdx order, so whatever it waits for is resident or finished (the grid need
-// not fit the chip).  A wait that outlasts ~2 s raises *fail instead of hanging.
+// has published it, then solves its own diagonal block with the stored inverse and publishes z_b.
+// The step-per-launch version above costs a launch gap plus two dependent 128x128 mat-vecs per block
+// row (25-27 us, 14.3 ms at N = 65536 against 2.2 ms of HBM time for the triangle); here a link of the
+// chain is  z_j seen -> 128 FMAs per lane -> reduce -> one mat-vec -> store,  and the L blocks of a
+// row stream in ahead of the wait (the next block is loaded into registers before it).  512 threads:
+// wavefront w takes rows 16w..16w+15, a lane two columns.  Deadlock freedom: workgroup b only waits
+// for workgroups j < b, and a 1-D grid is dispatched in blockIdx order, so whatever it waits for is
+// resident or finished (the grid need not fit the chip).  A wait that outlasts ~2 s raises *fail
+// instead of hanging.
+//
+// z ITSELF IS THE MESSAGE (round 3; the flag-per-block-row predecessor, 10.7 us per link, is
+// scripts/dev/arms/trsv_chain_flags.hip.inc).  z is pre-filled with a sentinel (all bits set: a NaN no
+// arithmetic produces), workgroup j publishes its 128 values as agent-scope atomic stores (write-through
+// past its XCD's L2; no fences: a release/acquire pair costs an L2 write-back on one side and an
+// invalidate on the other at every link -- chain neighbours sit on different XCDs -- 16-29 us measured),
+// and a consumer's first wavefront polls those 128 values directly -- lane l its two -- until none is
+// the sentinel, then hands them to the other wavefronts through LDS.  Against the flag version a link
+// loses one L2 round trip (flag seen -> THEN z fetched), the producer's s_waitcnt + barrier + flag
+// store, the sixteen one-lane stores of a wavefront (now one 128-byte store from lanes 0-15) and 5/6 of
+// its cross-lane traffic: the 16 row sums of a wavefront are formed by a transposing butterfly (8 + 4 +
+// 2 + 1 exchanges inside a row of 16 lanes, then 2 across rows: 17 instead of 96), which leaves row q's
+// total in lane q; y is fetched before the loop (it was a dependent load on the critical path).
+// Measured: 3.4 us per link; the solve part of compute()+log_likelihood() 0.68 -> 0.22 ms at N = 8192,
+// apply_inverse(y) 9.0 -> 6.6 ms at N = 65536 (two sweeps over 17 GB: 5.2 TB/s, 0.65 of HBM; was 0.39).
 #define CHAIN_THREADS 512
 __device__ __forceinline__ double2 ld_coherent2(const double* p) {
   double2 v;
@@ -244,13 +259,49 @@ __device__ __forceinline__ double2 ld_coherent2(const double* p) {
   v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return v;
 }
-__global__ __launch_bounds__(CHAIN_THREADS) void trsv_fwd_chain(const double* L, long ld, const double* dinv,
-                                                                const double* y, double* z, unsigned* flags, int* fail) {
+#define CHAIN_SENTINEL 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ bool chain_ready(double v) { return (unsigned long long)__double_as_longlong(v) != CHAIN_SENTINEL; }
+// v[0..15] per lane -> returns, in lane l, the sum over all 64 lanes of v[l & 15]
+__device__ __forceinline__ double transpose_sum16(double (&v)[16], int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool up = (lane & 8) != 0;
+    const double keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+    v[i] = keep + __shfl_xor(send, 8, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool up = (lane & 4) != 0;
+    const double keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+    v[i] = keep + __shfl_xor(send, 4, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool up = (lane & 2) != 0;
+    const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+    v[i] = keep + __shfl_xor(send, 2, 64);
+  }
+  {
+    const bool up = (lane & 1) != 0;
+    const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + __shfl_xor(send, 1, 64);
+  }
+  double t = v[0];
+  t += __shfl_xor(t, 16, 64);
+  t += __shfl_xor(t, 32, 64);
+  return t;
+}
+__global__ __launch_bounds__(CHAIN_THREADS) void trsv_fwd_chain_direct(const double* L, long ld, const double* dinv,
+                                                                       const double* y, double* z, int* fail) {
+  __shared__ double zs[2][T];
   __shared__ double ws[T];
+  __shared__ int gave_up;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long row0 = (long)b * T + wave * 16;
   double acc[16];
   double2 dv[16], blk[16];
+  if (tid == 0) gave_up = 0;
+  const double yv = y[row0 + (lane & 15)];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     acc[q] = 0.0;
@@ -260,25 +311,39 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_fwd_chain(const double* L,
 #pragma unroll
     for (int q = 0; q < 16; ++q) blk[q] = *reinterpret_cast<const double2*>(L + (row0 + q) * ld + 2 * lane);
   }
+  __syncthreads();
   for (int j = 0; j < b; ++j) {
-    if (tid == 0) {
-      // ONE poller per workgroup, and the further a workgroup is from the front of the chain the
-      // more patiently it polls: with every wavefront of every waiting workgroup spinning on the
-      // same flag the L2 atomics queue was the critical path (29 ms at N = 65536)
+    if (wave == 0) {
+      // The further from the front of the chain, the more patiently: a waiting workgroup first probes ONE value with one
+      // lane (one request; every waiting workgroup hammering all 128 was the L2 queue as the critical path), and only the
+      // next two in line poll the whole block at once.
       const int dist = b - j;
       const long long t0 = wall_clock64();
       unsigned spins = 0;
-      while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);   // 0 .. 8k cycles
-        if ((++spins & 63u) == 0u) {
-          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // somebody gave up
-          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); break; }       // 100 MHz ticks: 2 s
+      bool ok = true;
+      if (dist > 2) {
+        while (!chain_ready(__hip_atomic_load(z + (long)j * T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);   // 0 .. 8k cycles
+          if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+            if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }   // 100 MHz ticks: 2 s
+          }
         }
       }
+      double2 zj = ld_coherent2(z + (long)j * T + 2 * lane);
+      while (ok && !__all(chain_ready(zj.x) && chain_ready(zj.y))) {
+        if ((++spins & 1023u) == 0u) {
+          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }
+        }
+        zj = ld_coherent2(z + (long)j * T + 2 * lane);
+      }
+      if (!ok && lane == 0) gave_up = 1;
+      *reinterpret_cast<double2*>(&zs[j & 1][2 * lane]) = zj;
     }
     __syncthreads();
-    asm volatile("" ::: "memory");                         // (compiler only: nothing below moves above the wait)
-    const double2 zj = ld_coherent2(z + (long)j * T + 2 * lane);
+    if (gave_up) break;
+    const double2 zj = *reinterpret_cast<const double2*>(&zs[j & 1][2 * lane]);
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] += blk[q].x * zj.x + blk[q].y * zj.y;
     if (j + 1 < b) {
@@ -287,26 +352,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_fwd_chain(const double* L,
         blk[q] = *reinterpret_cast<const double2*>(L + (row0 + q) * ld + (long)(j + 1) * T + 2 * lane);
     }
   }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const double v = wave_sum(acc[q]);
-    if (lane == 0) ws[wave * 16 + q] = y[row0 + q] - v;
-  }
+  // (after a time-out the values published are garbage but NOT the sentinel: the workgroups behind come through, the
+  //  host sees *fail)
+  const double tot = transpose_sum16(acc, lane);
+  if (lane < 16) ws[wave * 16 + lane] = yv - tot;
   __syncthreads();
   const double wx = ws[2 * lane], wy = ws[2 * lane + 1];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const double v = wave_sum(dv[q].x * wx + dv[q].y * wy);
-    if (lane == 0) __hip_atomic_store(z + row0 + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // No fences: z and the flag travel as agent-scope atomics (write-through past this XCD's L2,
-  // read past the reader's), and s_waitcnt makes every z store complete before the flag is
-  // issued.  A release/acquire pair instead costs an L2 write-back on this side and an L2
-  // invalidate on the other at every link of the chain (chain neighbours sit on different XCDs):
-  // 16-29 us per link measured, against the ~5 us of the work itself.
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int q = 0; q < 16; ++q) acc[q] = dv[q].x * wx + dv[q].y * wy;
+  double v = transpose_sum16(acc, lane);
+  if (!chain_ready(v)) v = __longlong_as_double(0x7FF8000000000000LL);      // (a NaN with every bit set must not look unpublished)
+  if (lane < 16) __hip_atomic_store(z + row0 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Backward step j of L^T x = z.  x_j = L_jj^-T w_j; columns c < j0: w[c] -= sum_r L[j0+r][c] x_j[r].
@@ -338,22 +394,29 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* L, long ld, c
   if (tid < T) w[col0 + tid] -= part[0][tid] + part[1][tid];
 }
 
-// The backward sweep L^T x = z as one chained launch, the mirror image of trsv_fwd_chain: the
+// The backward sweep L^T x = z as one chained launch, the mirror image of trsv_fwd_chain_direct: the
 // chain runs from the LAST block to the first, so workgroup w owns block column b = nt-1-w (its
 // predecessors in the chain then have smaller workgroup indices and are dispatched first).
 //   x_b = L_bb^-T ( z_b - sum_{j>b} L_jb^T x_j )
 // Wavefront v takes rows 16v..16v+15 of every block L_jb (row segments of 1 KiB, a lane two
 // columns), accumulates its lane's two columns of L_jb^T x_j over all j, and the eight wavefront
 // partials meet in LDS once, before the diagonal solve (same scheme again with L_bb^-1).
-__global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain(const double* L, long ld, const double* dinv, int nt,
-                                                                const double* zin, double* x, unsigned* flags, int* fail) {
+// x itself is the message, as in trsv_fwd_chain_direct: x pre-filled with the sentinel, the first wavefront of a
+// consumer polls the 128 values of x_j and hands them on through LDS (they used to be sixteen broadcast loads from
+// L2 per wavefront, after the flag had been seen).
+__global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain_direct(const double* L, long ld, const double* dinv, int nt,
+                                                                       const double* zin, double* x, int* fail) {
   __shared__ double red[8][T];
   __shared__ double wv[T];
+  __shared__ double xs[2][T];
+  __shared__ int gave_up;
   const int w = blockIdx.x, b = nt - 1 - w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long col0 = (long)b * T + 2 * lane;
   double2 acc = make_double2(0.0, 0.0);
   double2 dv[16], blk[16];
+  if (tid == 0) gave_up = 0;
+  const double zv = tid < T ? zin[(long)b * T + tid] : 0.0;
 #pragma unroll
   for (int q = 0; q < 16; ++q)
     dv[q] = *reinterpret_cast<const double2*>(dinv + (long)b * T * T + (wave * 16 + q) * T + 2 * lane);
@@ -362,28 +425,38 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain(const double* L,
     for (int q = 0; q < 16; ++q)
       blk[q] = *reinterpret_cast<const double2*>(L + ((long)(nt - 1) * T + wave * 16 + q) * ld + col0);
   }
+  __syncthreads();
   for (int j = nt - 1; j > b; --j) {
-    if (tid == 0) {
+    if (wave == 0) {
       const int dist = j - b;
       const long long t0 = wall_clock64();
       unsigned spins = 0;
-      while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);
-        if ((++spins & 63u) == 0u) {
-          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); break; }
+      bool ok = true;
+      if (dist > 2) {
+        while (!chain_ready(__hip_atomic_load(x + (long)j * T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);
+          if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+            if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }
+          }
         }
       }
+      double2 xj = ld_coherent2(x + (long)j * T + 2 * lane);
+      while (ok && !__all(chain_ready(xj.x) && chain_ready(xj.y))) {
+        if ((++spins & 1023u) == 0u) {
+          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }
+        }
+        xj = ld_coherent2(x + (long)j * T + 2 * lane);
+      }
+      if (!ok && lane == 0) gave_up = 1;
+      *reinterpret_cast<double2*>(&xs[j & 1][2 * lane]) = xj;
     }
     __syncthreads();
-    asm volatile("" ::: "memory");
-    // x_j[16 wave + q]: the same address for every lane of the wavefront (one broadcast load each)
-    double xr[16];
+    if (gave_up) break;
+    const double* xw = &xs[j & 1][wave * 16];              // x_j[16 wave + q]: LDS broadcast reads
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      xr[q] = __hip_atomic_load(x + (long)j * T + wave * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { acc.x += blk[q].x * xr[q]; acc.y += blk[q].y * xr[q]; }
+    for (int q = 0; q < 16; ++q) { const double xr = xw[q]; acc.x += blk[q].x * xr; acc.y += blk[q].y * xr; }
     if (j - 1 > b) {
 #pragma unroll
       for (int q = 0; q < 16; ++q)
@@ -397,7 +470,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain(const double* L,
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += red[q][tid];
-    wv[tid] = zin[(long)b * T + tid] - v;
+    wv[tid] = zv - v;
   }
   __syncthreads();
   acc = make_double2(0.0, 0.0);                         // x_b[c] = sum_r dinv_b[r][c] w[r]
@@ -411,11 +484,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain(const double* L,
     double v = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v += red[q][tid];
+    if (!chain_ready(v)) v = __longlong_as_double(0x7FF8000000000000LL);
     __hip_atomic_store(x + (long)b * T + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ========================================================= predict reductions
@@ -723,6 +794,25 @@ static int trsm_right(hipStream_t st, const double* L11, int64_t ld11, const dou
   return GH_OK;
 }
 
+// z = L^-1 w as one chained launch; flags[nt] = the time-out flag (cleared here; the words before it are no longer
+// used: the flag-per-block-row kernels are retired, scripts/dev/arms/trsv_chain_flags.hip.inc).  w is read only and
+// must not be z (z is pre-filled with the sentinel).
+static int launch_trsv_fwd_chain(const double* L, long ld, const double* dinv, int64_t nt, const double* w, double* z,
+                                 unsigned* flags, hipStream_t st) {
+  GH_HIP(hipMemsetAsync(flags + nt, 0, sizeof(unsigned), st));
+  GH_HIP(hipMemsetAsync(z, 0xFF, (size_t)nt * T * sizeof(double), st));
+  hipLaunchKernelGGL(trsv_fwd_chain_direct, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, st, L, ld, dinv, w, z, (int*)(flags + nt));
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+static int launch_trsv_bwd_chain(const double* L, long ld, const double* dinv, int64_t nt, const double* w, double* x,
+                                 unsigned* flags, hipStream_t st) {
+  GH_HIP(hipMemsetAsync(flags + nt, 0, sizeof(unsigned), st));
+  GH_HIP(hipMemsetAsync(x, 0xFF, (size_t)nt * T * sizeof(double), st));
+  hipLaunchKernelGGL(trsv_bwd_chain_direct, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, st, L, ld, dinv, (int)nt, w, x, (int*)(flags + nt));
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
 extern "C" int gh_dev_potrf_block(double* a, int64_t lda, int64_t n, double* dinv, int64_t* info_dev, int64_t base_index, void* stream) {
   if (n % T) { gh_set_error("potrf_block: n must be a multiple of 128"); return GH_ERR_BAD_ARG; }
   // (tile operations of the multi-GPU driver run beside trailing updates that own every CU: small-LDS GEMMs, see t_gemm_small_lds)
@@ -738,25 +828,15 @@ extern "C" int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* din
                                  const double* w, double* z, void* scratch, void* stream) {
   if (n % T || n <= 0 || !scratch) { gh_set_error("trsv_lower: n must be a positive multiple of 128"); return GH_ERR_BAD_ARG; }
   const int64_t nt = n / T;
-  hipStream_t st = (hipStream_t)stream;
-  unsigned* flags = (unsigned*)scratch;
-  GH_HIP(hipMemsetAsync(flags, 0, (size_t)(nt + 1) * sizeof(unsigned), st));
-  hipLaunchKernelGGL(trsv_fwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, st, l, (long)ldl, dinv, w, z,
-                     flags, (int*)(flags + nt));
-  GH_HIP(hipGetLastError());
-  return GH_OK;
+  if (w == z) { gh_set_error("trsv_lower: w and z must not be the same array"); return GH_ERR_BAD_ARG; }
+  return launch_trsv_fwd_chain(l, (long)ldl, dinv, nt, w, z, (unsigned*)scratch, (hipStream_t)stream);
 }
 extern "C" int gh_dev_trsv_lower_t(const double* l, int64_t ldl, const double* dinv, int64_t n,
                                    const double* w, double* x, void* scratch, void* stream) {
   if (n % T || n <= 0 || !scratch) { gh_set_error("trsv_lower_t: n must be a positive multiple of 128"); return GH_ERR_BAD_ARG; }
   const int64_t nt = n / T;
-  hipStream_t st = (hipStream_t)stream;
-  unsigned* flags = (unsigned*)scratch;
-  GH_HIP(hipMemsetAsync(flags, 0, (size_t)(nt + 1) * sizeof(unsigned), st));
-  hipLaunchKernelGGL(trsv_bwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, st, l, (long)ldl, dinv, (int)nt, w, x,
-                     flags, (int*)(flags + nt));
-  GH_HIP(hipGetLastError());
-  return GH_OK;
+  if (w == x) { gh_set_error("trsv_lower_t: w and x must not be the same array"); return GH_ERR_BAD_ARG; }
+  return launch_trsv_bwd_chain(l, (long)ldl, dinv, nt, w, x, (unsigned*)scratch, (hipStream_t)stream);
 }
 extern "C" int gh_dev_logdet_accum(const double* a, int64_t lda, int64_t n, double* out_dev, void* stream) {
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (long)lda, (long)n, out_dev, 1);
@@ -1145,11 +1225,8 @@ static int trsv_forward(gh_chol* s, double* w, double* z, bool defer = false) {
   if (!stepwise) {
     // forward and backward sweeps keep separate flag sets, [0, nt] and [nt + 1, 2 nt + 1]
     GH_CHECK(s->chain.ensure((size_t)(2 * nt + 2) * sizeof(unsigned)));
-    GH_HIP(hipMemsetAsync(s->chain.p, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
     unsigned* flags = (unsigned*)s->chain.p;
-    hipLaunchKernelGGL(trsv_fwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, s->st,
-                       s->A.d(), (long)s->np, s->dinv.d(), w, z, flags, (int*)(flags + nt));
-    GH_HIP(hipGetLastError());
+    GH_CHECK(launch_trsv_fwd_chain(s->A.d(), (long)s->np, s->dinv.d(), nt, w, z, flags, s->st));
     if (defer) return GH_OK;
     int failed = 0;
     GH_HIP(hipMemcpyAsync(&failed, flags + nt, sizeof(int), hipMemcpyDeviceToHost, s->st));
@@ -1171,10 +1248,7 @@ static int trsv_backward(gh_chol* s, double* w, double* x, bool defer = false) {
   if (!stepwise) {
     GH_CHECK(s->chain.ensure((size_t)(2 * nt + 2) * sizeof(unsigned)));
     unsigned* flags = (unsigned*)s->chain.p + (nt + 1);
-    GH_HIP(hipMemsetAsync(flags, 0, (size_t)(nt + 1) * sizeof(unsigned), s->st));
-    hipLaunchKernelGGL(trsv_bwd_chain, dim3((unsigned)nt), dim3(CHAIN_THREADS), 0, s->st,
-                       s->A.d(), (long)s->np, s->dinv.d(), (int)nt, w, x, flags, (int*)(flags + nt));
-    GH_HIP(hipGetLastError());
+    GH_CHECK(launch_trsv_bwd_chain(s->A.d(), (long)s->np, s->dinv.d(), nt, w, x, flags, s->st));
     if (defer) return GH_OK;
     int failed = 0;
     GH_HIP(hipMemcpyAsync(&failed, flags + nt, sizeof(int), hipMemcpyDeviceToHost, s->st));

@@ -342,7 +342,7 @@ int gh_dev_kmat_block(gh_kernel* k, const double* x, int64_t n, int32_t ndim, co
 int gh_dev_gemv(const double* a, int64_t lda, int64_t m, int64_t n, int32_t trans,
                 const double* x, double* y, double alpha, double beta, void* stream);
 /* z = L^-1 w for the n x n lower-triangular block `l` factored by gh_dev_potrf_block (`dinv` = its
- * diagonal-block inverses): one chained launch (gh_chol.hip, trsv_fwd_chain).  `scratch` needs
+ * diagonal-block inverses): one chained launch (gh_chol.hip, trsv_fwd_chain_direct; w and z must be different arrays).  `scratch` needs
  * (n/128 + 1) * 4 bytes of device memory, zeroed here.  w is read only. */
 int gh_dev_trsv_lower(const double* l, int64_t ldl, const double* dinv, int64_t n,
                       const double* w, double* z, void* scratch, void* stream);

@@ -466,11 +466,11 @@ def test_stepwise_trsv_arm_still_works():
 
 
 def test_chained_solves_are_bit_stable_under_load():
-    """The flag-driven chained solves (trsv_fwd_chain / trsv_bwd_chain: one launch, workgroup b waits for the z_j of
-    its predecessors on agent-scope atomics ordered by s_waitcnt, no fences -- every log-likelihood goes through
-    them) repeated 150 times, first alone, then while a second thread keeps the chip full with factorisations of
+    """The chained solves (trsv_fwd_chain_direct / trsv_bwd_chain_direct: one launch, workgroup b waits for the z_j of
+    its predecessors by polling the values themselves -- sentinel-filled output, agent-scope atomics, no fences --
+    and every log-likelihood goes through them) repeated 150 times, first alone, then while a second thread keeps the chip full with factorisations of
     another matrix on the SAME process-wide streams: every repetition must reproduce the first result bit for bit
-    (a stale flag or a missed hand-over shows up as a different sum), and a factor recomputed in between must too."""
+    (a stale value or a missed hand-over shows up as a different sum), and a factor recomputed in between must too."""
     import threading
     x, yerr, y = zoo.bench_data(8192)
     gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0))
@@ -604,8 +604,8 @@ def test_full_size_c3_properties():
 
 @pytest.mark.parametrize("n", [130, 1000, 5000, 20000])
 def test_chained_forward_solve_repeatable(n):
-    """The forward sweep is ONE launch whose workgroups hand z blocks to each other through flags
-    (gh_chol.hip, trsv_fwd_chain): hammer it -- 25 sweeps per size must give the same bits, and
+    """The forward sweep is ONE launch whose workgroups hand z blocks to each other through HBM
+    (gh_chol.hip, trsv_fwd_chain_direct): hammer it -- 25 sweeps per size must give the same bits, and
     r^T K^-1 r must agree with the full solve r . apply_inverse(r) (forward + backward sweeps)."""
     x, yerr, y = zoo.bench_data(n)
     s = BasicSolver(np.var(y) * kernels.Matern32Kernel(1.0))
