@@ -1,5 +1,5 @@
 // gh_potf2_body.h -- the 128x128 Cholesky + inverse of gh_potf2.hip as a device function (second form;
-// the first one, 82 us per block, is gh_potf2_body_v1.h and stays selectable: GEORGE_AMD_POTF2=v1).
+// the first one, 82 us per block, is retired: scripts/dev/arms/gh_potf2_body_v1.h).
 //
 // Where the 82 us of the first form went (scripts/dev/potf2_phases.hip, profiles/r02/potf2_phases_v1.txt):
 // 8 x 3.3 us for the one-wavefront 16x16 diagonal steps, 7 x 2.2 us for row substitution + tile column
