@@ -609,6 +609,7 @@ bool gh_shared_streams(int device, hipStream_t q[4]) {
   if (!ss.made) {
     ss.made = true;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    gh_prime_device(device);
     if (hipStreamCreate(&ss.q[0]) != hipSuccess) { ss.q[0] = nullptr; (void)hipGetLastError(); }
     int lo = 0, hi = 0;                    // numerically lowest value = highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -656,7 +657,10 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   if (!private_streams && gh_shared_streams(s->opts.device, shq)) {
     s->shared_streams = true;
     s->st = shq[0];
-  } else if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  } else {
+    gh_prime_device(s->opts.device);
+    if (hipStreamCreate(&s->st) != hipSuccess) { delete s; gh_set_error("hipStreamCreate failed"); return GH_ERR_HIP; }
+  }
   if (s->opts.lookahead) {
     int lo = 0, hi = 0;                    // numerically lowest value = highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);

@@ -131,5 +131,14 @@ int gh_launch_gemm(const GhGemm& g, hipStream_t st);
 // with a second handle (or two application streams) alive (scripts/dev/queue_pattern.py) -- and a
 // CU-masked stream takes ~1 s to create.  GEORGE_AMD_PRIVATE_STREAMS restores per-handle streams.
 bool gh_shared_streams(int device, hipStream_t q[4]);
+// Once per device and process, BEFORE the library creates its first stream there: one empty kernel on the null stream
+// and a device synchronisation.  Measured (scripts/dev/no_torch_step.py, stream_order_probe.py): when this library's
+// streams are the first thing a process creates on the device -- any george user who does not import torch first -- the
+// panel chain of every mid-size factorisation runs at half speed (N = 8192: 13.0 instead of 7.0 ms per
+// compute()+log_likelihood(), N = 4096 4.5 instead of 2.7, N = 16384 40 instead of 30); once the null stream has had a
+// launch first (what `torch.zeros(1, device="cuda")` happens to do) it does not.  The pairwise overlap of the streams
+// is the same in both cases (gh_debug_stream_overlap), so it is not queue sharing; which hardware queue the runtime
+// hands out first is not visible from here.  GEORGE_AMD_NO_NULL_PRIME=1 skips it (A/B).
+void gh_prime_device(int device);
 hipStream_t gh_shared_masked_stream(int device, int reserve_cus);
 bool gh_use_mfma();               // false when GEORGE_AMD_NO_MFMA=1 (VALU validation path)

@@ -1063,7 +1063,7 @@ extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
   if (!private_streams && gh_shared_streams(h->opts.device, shq) && shq[2] && shq[3]) {
     h->shared_streams = true;                 // the process-wide streams: main, and two side streams for compute()
     h->st = shq[0];
-  } else if (hipStreamCreate(&h->st) != hipSuccess) {
+  } else if ((gh_prime_device(h->opts.device), hipStreamCreate(&h->st)) != hipSuccess) {
     delete h; gh_set_error("cannot initialise HIP device %d", opts ? opts->device : 0); return GH_ERR_HIP;
   }
   *out = h;

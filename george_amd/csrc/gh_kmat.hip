@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <math.h>
 #include "gh_common.h"
+#include <mutex>
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
@@ -32,6 +33,24 @@ extern "C" int gh_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+__global__ void gh_prime_kernel() {}
+void gh_prime_device(int device) {
+  static std::mutex mu;
+  static bool done[64] = {false};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 64 || done[device]) return;
+  done[device] = true;
+  if (getenv("GEORGE_AMD_NO_NULL_PRIME")) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (hipSetDevice(device) == hipSuccess) {
+    hipLaunchKernelGGL(gh_prime_kernel, dim3(1), dim3(64), 0, (hipStream_t)nullptr);
+    (void)hipDeviceSynchronize();
+  }
+  (void)hipGetLastError();
+  (void)hipSetDevice(cur);
 }
 
 bool gh_is_device_ptr(const void* p) {

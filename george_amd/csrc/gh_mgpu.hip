@@ -515,6 +515,7 @@ extern "C" int gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out) {
     h->rowg[r.pr].members.push_back(i); h->colg[r.pc].members.push_back(i); h->world.members.push_back(i);
     int plo = 0, phi = 0;                                       // numerically lowest value = highest priority
     if (hipSetDevice(r.dev) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+    gh_prime_device(r.dev);                  // (gh_common.h: the null stream must have seen a launch before the first stream is made)
     if (hipSetDevice(r.dev) != hipSuccess || hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&r.sp, hipStreamNonBlocking, phi) != hipSuccess ||
         hipEventCreateWithFlags(&r.ev_ready, hipEventDisableTiming) != hipSuccess ||

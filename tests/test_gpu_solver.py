@@ -669,3 +669,37 @@ def test_scalar_potf2_validation_arm_agrees():
     for a, b in zip(outs[0], outs[1]):
         assert a[0] == a[1] and b[0] == b[1]                              # each arm repeatable
         assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0])
+
+
+def test_process_without_torch_runs_at_the_benchmarked_speed():
+    """A george user's process never imports torch.  The library's streams are then the first thing created on the
+    device, and before gh_prime_device (gh_common.h) the panel chain of every mid-size factorisation ran at half speed
+    in such a process (N = 8192: 13.0 instead of 7.0 ms).  Runs scripts/dev/no_torch_step.py in a child process with
+    and without the priming launch: same log-likelihood as here, torch really absent, and the primed run not slower
+    than the unprimed one (a generous bound: the effect is 1.8x where it exists)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "dev", "no_torch_step.py")
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, script, "8192"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-400:]
+        m = re.search(r"N=\s*8192 GP.compute\+log_likelihood ([0-9.]+) ms \(torch imported: (\w+)\)\s+ll ([-0-9.e+]+)", r.stdout)
+        assert m, r.stdout
+        return float(m.group(1)), m.group(2), float(m.group(3))
+
+    ms, torch_in, ll = run({})
+    assert torch_in == "False"
+    x, yerr, y = zoo.bench_data(8192)
+    gp = GP(float(np.var(y)) * kernels.ExpSquaredKernel(1.0))
+    gp.compute(x, yerr)
+    assert abs(ll - gp.log_likelihood(y)) <= 1e-9 * abs(ll)
+    ms_unprimed, _, ll2 = run({"GEORGE_AMD_NO_NULL_PRIME": "1"})
+    assert ll2 == ll
+    assert ms <= 1.15 * ms_unprimed, (ms, ms_unprimed)
+    assert ms <= 11.0, ms                                  # (7.0-7.4 ms on an MI355X; 13 ms is the failure this guards against)
