@@ -2421,6 +2421,8 @@ int hm_local_done(void* ctx) {
 template <typename F>
 int hm_run(gh_hodlr_mgpu_impl* H, F fn) {
   H->abort.store(0);
+  H->world.reset();
+  for (auto& lv : H->top) for (auto* t : lv) t->bar.reset();
   std::vector<std::thread> th;
   for (int i = 0; i < H->P; ++i) {
     th.emplace_back([H, i, &fn]() {

@@ -215,6 +215,11 @@ int mg_copy2d(hipStream_t st, const double* in, long ldi, double* out, long ldo,
 template <typename F>
 int mg_run(gh_mgpu* h, F fn) {
   h->abort.store(0);
+  // (a run that was aborted -- a matrix that is not positive definite, say -- leaves the arrival count of the barrier it
+  //  died in behind: the test of the NOT_PD path re-uses its handle)
+  h->world.bar.reset();
+  for (auto& g : h->rowg) g.bar.reset();
+  for (auto& g : h->colg) g.bar.reset();
   std::vector<std::thread> th;
   for (int i = 0; i < h->W; ++i) {
     th.emplace_back([h, i, &fn]() {

@@ -26,4 +26,6 @@ struct HostBarrier {
     }
     return !abort->load();
   }
+  // before a new run of the threads: an aborted run leaves the arrival count of the barrier it died in behind
+  void reset() { std::lock_guard<std::mutex> lk(m); waiting = 0; }
 };

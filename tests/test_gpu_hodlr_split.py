@@ -112,3 +112,25 @@ def test_split_in_gp_and_errors():
         s.compute(np.zeros((len(x), 2)), yerr)             # dimension mismatch
     with pytest.raises(RuntimeError):
         s.dot_solve(y)                                     # not computed
+
+
+def test_split_failure_on_one_device_is_reported_and_the_handle_recovers():
+    """A leaf that is not positive definite on ONE sub-tree (forty copies of one point, no noise on them): its rank fails inside its own
+    part while the other one already waits in the top level's exchange -- the abort flag must release it, the error must
+    be the failing rank's, and the same solver must then factor a healthy matrix (barrier counts and top nodes of the
+    aborted run are not carried over)."""
+    kernel, x, yerr, y, kw = HCONF["C4_4096"]
+    bad = x.copy()
+    bad[3000:3040] = bad[3000]                              # a singular block inside sub-tree 1 of 2
+    s = MultiGPUHODLRSolver(kernel, devices=[0, 0], **kw)
+    noise = yerr.copy()
+    noise[3000:3040] = 0.0
+    with pytest.raises((np.linalg.LinAlgError, ValueError)) as e:
+        s.compute(bad[:, None], noise)
+    assert "sub-tree 1" in str(e.value) and "positive definite" in str(e.value)
+    assert not s.computed
+    ref = HODLRSolver(kernel, **kw)
+    ref.compute(x[:, None], yerr)
+    for _ in range(2):
+        s.compute(x[:, None], yerr)
+        _agree(s, ref, y)
