@@ -1294,12 +1294,14 @@ extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
 
 // B (np x rp, row-major, zero padded) <- L^-1 B  (forward) and optionally L^-T (backward)
 // Two-level blocking: 128-row steps (multiplication by the stored diagonal inverse + a small
-// update) inside super-blocks of SB tiles, then ONE K = 128*SB update of everything below (above)
+// update) inside super-blocks of SB = 8 tiles, then ONE K = 128*SB update of everything below (above)
 // the super-block -- the right-hand side is swept N/(128*SB) times instead of N/128 times.
 // `tri`: B is the identity being overwritten by L^-1 (forward only): block row j is non-zero in
 // columns [0, (j+1)*128) only, so every product is clipped to those columns.
-#define SB 4
 static int trsm_multi(gh_chol* s, double* B, int64_t rp, bool forward, bool backward, bool tri = false) {
+  // (tiles per super-block; measured at N = 32768 with 4096 right-hand sides, both sweeps: 2 -> 167 ms, 4 -> 158.5,
+  //  8 -> 151.6, 16 -> 149.5; no difference at N = 8192.  GEORGE_AMD_TRSM_SB overrides)
+  static const int64_t SB = getenv("GEORGE_AMD_TRSM_SB") ? std::max(1, atoi(getenv("GEORGE_AMD_TRSM_SB"))) : 8;
   const int64_t np = s->np, nt = np / T;
   const double* L = s->A.d();
   auto mm = [&](double* Cp, const double* Ap, int64_t lda, bool a_km, const double* Bp, int64_t M, int64_t N, int64_t K,
