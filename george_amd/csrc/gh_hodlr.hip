@@ -1024,7 +1024,7 @@ struct gh_hodlr {
   int cpass = CPASS;             // columns per apply pass = row pitch of P / Tsum / Tout / Y (>= the largest level rank)
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   GhBuf d_leaf_prod;
-  GhBuf d_aca_segs, d_compact_segs;
+  GhBuf d_aca_segs, d_aca_segs1, d_compact_segs;
   GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (solves) and its column map
   long col_Rtot = -1;
   std::vector<int> col_sig;
@@ -1717,7 +1717,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     return GH_OK;
   };
   // all clustered levels `cl` as ONE launch of at most 256 workgroups (al[l].G already balanced)
-  auto enqueue_fused = [&](const std::vector<int>& cl, int rc, hipStream_t sx) -> int {
+  auto enqueue_fused = [&](const std::vector<int>& cl, int rc, hipStream_t sx, GhBuf& segbuf) -> int {
     std::vector<AcaSeg> segs;
     int wg = 0;
     for (int l : cl) {
@@ -1732,13 +1732,13 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
                       d_fail, d_fail + 1, l, a.G, wg, nn * a.G});
       wg += nn * a.G;
     }
-    GH_CHECK(upload(h->d_aca_segs, segs, sx));
+    GH_CHECK(upload(segbuf, segs, sx));
 #define GH_ACA_LAUNCH(F)                                                                                          \
     hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(ACA_THREADS), 0, sx, k->d_nodes, (int)k->nodes.size(),    \
                        k->fast, ndim, h->x.d(), (const LvlNode*)nullptr, (double*)nullptr, (long)n, rc, (int*)nullptr, \
                        (int*)nullptr, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, 0,                     \
                        1, (unsigned*)nullptr, (double*)nullptr, pstride, (int*)nullptr, (int*)nullptr, aca_multi, aca_fence, \
-                       (int*)nullptr, (const AcaSeg*)h->d_aca_segs.p, (int)segs.size())
+                       (int*)nullptr, (const AcaSeg*)segbuf.p, (int)segs.size())
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
@@ -1869,7 +1869,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       }
       if (h->aca_fused_ev[0] == nullptr) { GH_HIP(hipEventCreate(&h->aca_fused_ev[0])); GH_HIP(hipEventCreate(&h->aca_fused_ev[1])); }
       GH_HIP(hipEventRecord(h->aca_fused_ev[0], st));
-      GH_CHECK(enqueue_fused(fused, rcap0, st));
+      GH_CHECK(enqueue_fused(fused, rcap0, st, h->d_aca_segs));
       GH_HIP(hipEventRecord(h->aca_fused_ev[1], st));
       h->aca_timed = true;
       // The one-workgroup-per-node levels and the leaf stage are independent of the fused launch and of
@@ -1894,11 +1894,28 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       static const bool leaves_after0 = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
       std::vector<int> ones = single;
       for (int l = l0; l < nlev; ++l) if (gmax[l] == 1) ones.push_back(l);
+      // The one-workgroup-per-node levels as ONE launch too (segments in order of decreasing block size: the long
+      // workgroups are dispatched first): launched one per queue they were balanced by hand over three queues with last
+      // compute()'s durations, and the queue that drew the two slowest levels ended 0.4 ms after the others.  One grid
+      // leaves the balancing to the dispatcher: C4 5.36 -> 5.24 ms.  (GEORGE_AMD_HODLR_NO_FUSED_SINGLES: the per-level
+      // launches.  EVERY level in one grid, clustered segments first, was no better: 5.30.)
+      static const bool no_fused_singles = getenv("GEORGE_AMD_HODLR_NO_FUSED_SINGLES") != nullptr;
+      if (!no_fused_singles && ones.size() >= 2 && h->st_c) {
+        std::sort(ones.begin(), ones.end());
+        GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));
+        if (h->st_d) GH_HIP(hipStreamWaitEvent(h->st_d, h->ev_b, 0));
+        GH_CHECK(enqueue_fused(ones, rcap0, h->st_b, h->d_aca_segs1));
+        if (!leaves_after0) GH_CHECK(leaf_stage(h->st_c));
+        GH_HIP(hipEventRecord(h->ev_c, h->st_c));
+        GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0));
+        h->aca_timed = false;
+        ones.clear();
+      }
       struct Item { int level; double cost; };             // level -1: the leaf stage
       std::vector<Item> items;
       const bool have = (int)h->aca_ms.size() == nlev + 2;     // [0..nlev): levels, [nlev]: fused launch, [nlev+1]: leaf stage
       for (int l : ones) items.push_back({l, have && h->aca_ms[l] > 0 ? h->aca_ms[l] : 1.0});
-      if (!leaves_after0) items.push_back({-1, have && h->aca_ms[nlev + 1] > 0 ? h->aca_ms[nlev + 1] : 1.2});
+      if (!leaves_after0 && !leaves_done) items.push_back({-1, have && h->aca_ms[nlev + 1] > 0 ? h->aca_ms[nlev + 1] : 1.2});
       std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
       hipStream_t qs[4] = {st, h->st_b, h->st_c ? h->st_c : h->st_b, h->st_d ? h->st_d : h->st_b};
       double load[4] = {have && h->aca_ms[nlev] > 0 ? h->aca_ms[nlev] : 1.5, 0.0, h->st_c ? 0.0 : 1e30, h->st_d ? 0.0 : 1e30};
