@@ -45,6 +45,7 @@ class HODLRSolver(BasicSolver):
     # option set (at most _HPOOL_MAX each) and picked up by the next solver with the same options.
     _HPOOL = {}
     _HPOOL_MAX = 2
+    _HPOOL_TOTAL = 4           # over all option sets: a scan over tolerances must not leave a trail of parked handles
 
     def _hkey(self):
         return (self._hopts["device"], int(self.min_size), int(self.seed), self._hopts["max_rank"], float(self.tol))
@@ -55,6 +56,8 @@ class HODLRSolver(BasicSolver):
             free = HODLRSolver._HPOOL.get(self._handle_key)
             if free:
                 self._handle = free.pop()
+                if not free:
+                    del HODLRSolver._HPOOL[self._handle_key]
                 return self._handle
             o = N.gh_hodlr_opts()
             o.device, o.min_size, o.seed = self._hopts["device"], int(self.min_size), int(self.seed)
@@ -68,11 +71,22 @@ class HODLRSolver(BasicSolver):
         h, self._handle = getattr(self, "_handle", None), None
         if h is not None and h.value:
             try:
-                free = HODLRSolver._HPOOL.setdefault(getattr(self, "_handle_key", None), [])
-                if getattr(self, "_handle_key", None) is not None and len(free) < HODLRSolver._HPOOL_MAX:
-                    free.append(h)
-                else:
+                key = getattr(self, "_handle_key", None)
+                pool = HODLRSolver._HPOOL
+                if key is None:
                     N.lib.gh_hodlr_destroy(h)
+                    return
+                free = pool.pop(key, [])                       # (re-inserted last: the dict keeps the option sets oldest first)
+                if len(free) >= HODLRSolver._HPOOL_MAX:
+                    N.lib.gh_hodlr_destroy(free.pop(0))
+                free.append(h)
+                pool[key] = free
+                while sum(len(v) for v in pool.values()) > HODLRSolver._HPOOL_TOTAL:
+                    oldest = next(iter(pool))
+                    if pool[oldest]:
+                        N.lib.gh_hodlr_destroy(pool[oldest].pop(0))
+                    if not pool[oldest]:
+                        del pool[oldest]
             except Exception:
                 pass
 

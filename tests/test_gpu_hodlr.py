@@ -324,3 +324,30 @@ def test_hodlr_not_positive_definite_leaf(leaf_gj):
             s.compute(x, np.zeros(n))
         except (np.linalg.LinAlgError, RuntimeError):
             assert not s.computed
+
+
+def test_parked_handles_are_bounded_and_reused():
+    """A dropped HODLRSolver parks its native handle for the next solver with the same options (GP makes a new solver
+    per compute, gp.py:327): at most two per option set and four in all, oldest option set evicted first."""
+    kernel, x, yerr, y, kw = HCONF["solver1000"]
+    HODLRSolver.release_pool()
+    X = x[:, None]
+    want = None
+    for tol in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8):
+        for _ in range(3):
+            s = HODLRSolver(kernel, min_size=100, tol=tol, seed=42)
+            s.compute(X, yerr)
+            del s
+    parked = sum(len(v) for v in HODLRSolver._HPOOL.values())
+    assert 1 <= parked <= HODLRSolver._HPOOL_TOTAL
+    assert all(len(v) <= HODLRSolver._HPOOL_MAX for v in HODLRSolver._HPOOL.values())
+    assert 1e-3 not in [k[4] for k in HODLRSolver._HPOOL]            # the oldest option set went first
+    # a parked handle answers like a fresh one
+    a = HODLRSolver(kernel, min_size=100, tol=1e-8, seed=42)
+    before = sum(len(v) for v in HODLRSolver._HPOOL.values())
+    a.compute(X, yerr)
+    assert sum(len(v) for v in HODLRSolver._HPOOL.values()) == before - 1
+    HODLRSolver.release_pool()
+    b = HODLRSolver(kernel, min_size=100, tol=1e-8, seed=42)
+    b.compute(X, yerr)
+    assert a.log_determinant == b.log_determinant and a.ranks() == b.ranks()
