@@ -103,6 +103,7 @@ SIGNATURES = {
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
     "gh_debug_set_gemm_tall": (C.c_int, [C.c_int]),
     "gh_debug_stream_overlap": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
+    "gh_debug_stream_dispatch": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_microbench_suite": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "gh_kernel_create": (C.c_int, [C.POINTER(gh_knode), C.c_int, C.POINTER(_vp)]),
     "gh_kernel_destroy": (None, [_vp]),

@@ -603,6 +603,8 @@ struct SharedStreams { hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr}; 
 std::mutex g_ss_mu;
 std::map<int, SharedStreams> g_ss;
 }
+// (Where the runtime puts these streams matters more than which streams there are: DESIGN.md, "One set of streams per
+//  process" -- gh_prime_device() takes care of the common case, gh_debug_stream_dispatch() shows the placement.)
 bool gh_shared_streams(int device, hipStream_t q[4]) {
   std::lock_guard<std::mutex> lk(g_ss_mu);
   SharedStreams& ss = g_ss[device];
@@ -708,6 +710,31 @@ extern "C" int gh_debug_stream_overlap(gh_chol* s, double* out, int n) {
       hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, q[j], 30000LL);
       GH_HIP(hipDeviceSynchronize());
       out[i * 6 + j] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  return GH_OK;
+}
+// The other way two streams can be in each other's way: a grid with far more workgroups than the chip holds keeps
+// its queue's dispatcher busy for its whole duration.  out[i * 6 + j] (i != j) = milliseconds until a ONE-workgroup
+// kernel launched on stream j right after such a grid on stream i (2^18 workgroups of 64 threads spinning ~50 us:
+// ~2 ms) has completed: tens of microseconds when the two queues dispatch independently, the grid's duration when the
+// small kernel has to wait for the big one's dispatch to end.  Streams as in gh_debug_stream_overlap.
+extern "C" int gh_debug_stream_dispatch(gh_chol* s, double* out, int n) {
+  if (!s || !out || n < 36) { gh_set_error("bad argument"); return GH_ERR_BAD_ARG; }
+  int rc = set_device(s);
+  if (rc != GH_OK) return rc;
+  hipStream_t q[6] = {nullptr, s->st, s->st2, s->st3, s->st4, s->st_mask};
+  for (int i = 0; i < 36; ++i) out[i] = 0.0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      if (i == j) continue;
+      if ((i > 0 && !q[i]) || (j > 0 && !q[j])) { out[i * 6 + j] = -1.0; continue; }
+      GH_HIP(hipDeviceSynchronize());
+      hipLaunchKernelGGL(spin_kernel, dim3(1 << 18), dim3(64), 0, q[i], 5000LL);
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, q[j], 0LL);
+      GH_HIP(hipStreamSynchronize(q[j]));
+      out[i * 6 + j] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      GH_HIP(hipDeviceSynchronize());
     }
   return GH_OK;
 }

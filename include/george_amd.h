@@ -111,6 +111,9 @@ int gh_debug_set_gemm_tall(int on);
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */
 int gh_debug_stream_overlap(gh_chol* s, double* out, int n);
+/* out[i * 6 + j], i != j: ms until a one-workgroup kernel on stream j completes when it is launched right after a grid of
+ * 2^18 workgroups (~2 ms) on stream i: small = the two queues dispatch independently (same stream numbering) */
+int gh_debug_stream_dispatch(gh_chol* s, double* out, int n);
 int gh_microbench_hbm_copy(double* gbps_out);
 /* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
  * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
