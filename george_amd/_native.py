@@ -159,6 +159,8 @@ SIGNATURES = {
     "gh_hodlr_mgpu_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "gh_hodlr_mgpu_ranks": (C.c_int, [_vp, C.POINTER(C.c_int32), _i32, C.POINTER(C.c_int32)]),
     "gh_hodlr_mgpu_rows": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gh_hodlr_mgpu_layout": (C.c_int, [_i64, _i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), _i32,
+                                       C.POINTER(C.c_int32)]),
     "gh_dev_kmat_block": (C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64, _i64, _i64, _i64, _dp, _i64, _vp]),
     "gh_dev_gemv": (C.c_int, [_dp, _i64, _i64, _i64, _i32, _dp, _dp, C.c_double, C.c_double, _vp]),
     "gh_dev_potrf_block": (C.c_int, [_dp, _i64, _i64, _dp, _dp, _i64, _vp]),

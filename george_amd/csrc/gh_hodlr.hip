@@ -2516,6 +2516,61 @@ extern "C" int gh_hodlr_mgpu_create(const gh_hodlr_mgpu_opts* opts, gh_hodlr_mgp
   return GH_OK;
 }
 
+// Host logic only (no device is touched): the rows of every sub-tree and, per level of the sub-trees, the index of each
+// sub-tree's first internal node in the GLOBAL level (what keys a node's random stream) for a tree of n points split
+// over n_dev devices.  seed_off: n_dev x max_levels, row-major, zero padded.  GH_ERR_BAD_ARG when a node above the split
+// would be a leaf.  gh_hodlr_mgpu_compute lays its tree out through this function.
+extern "C" int gh_hodlr_mgpu_layout(int64_t n, int32_t n_dev, int32_t min_size, int64_t* row0, int64_t* nrows,
+                                    int32_t* seed_off, int32_t max_levels, int32_t* n_levels) {
+  if (n <= 0 || n > 0x3fffffffL || n_dev < 1 || n_dev > 16 || (n_dev & (n_dev - 1)) || !row0 || !nrows) {
+    gh_set_error("bad argument to layout"); return GH_ERR_BAD_ARG;
+  }
+  if (min_size < 1) min_size = 1;
+  int depth = 0;
+  while ((1 << depth) < n_dev) ++depth;
+  struct Seg { int64_t start, size; };
+  std::vector<Seg> cur(1, Seg{0, n});
+  for (int l = 0; l < depth; ++l) {
+    std::vector<Seg> next;
+    for (const Seg& sg : cur) {
+      const int64_t half = sg.size / 2;                      // hodlr.h:48: internal iff size / 2 >= min_size
+      if (half < min_size) {
+        gh_set_error("HODLR split: %lld points are too few for %d devices with min_size = %d (a node of level %d would be a leaf)",
+                     (long long)n, n_dev, min_size, l);
+        return GH_ERR_BAD_ARG;
+      }
+      next.push_back({sg.start, half});
+      next.push_back({sg.start + half, sg.size - half});
+    }
+    cur.swap(next);
+  }
+  std::vector<std::vector<int>> cnt(n_dev);
+  size_t maxl = 0;
+  for (int p = 0; p < n_dev; ++p) {
+    row0[p] = cur[p].start; nrows[p] = cur[p].size;
+    std::vector<int64_t> sizes(1, cur[p].size);
+    while (!sizes.empty()) {
+      std::vector<int64_t> nx;
+      int internal = 0;
+      for (int64_t sz : sizes) if (sz / 2 >= min_size) { ++internal; nx.push_back(sz / 2); nx.push_back(sz - sz / 2); }
+      if (internal == 0) break;
+      cnt[p].push_back(internal);
+      sizes.swap(nx);
+    }
+    maxl = std::max(maxl, cnt[p].size());
+  }
+  if (n_levels) *n_levels = (int32_t)maxl;
+  if (seed_off) {
+    for (int p = 0; p < n_dev; ++p)
+      for (int l = 0; l < max_levels; ++l) {
+        int v = 0;
+        for (int o = 0; o < p; ++o) if ((size_t)l < cnt[o].size()) v += cnt[o][l];
+        seed_off[(size_t)p * max_levels + l] = v;
+      }
+  }
+  return GH_OK;
+}
+
 extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
                                      const double* yerr, double* logdet_out) {
   if (!H || !k || !x || !yerr || n <= 0) { gh_set_error("bad argument to compute"); return GH_ERR_BAD_ARG; }
@@ -2554,28 +2609,18 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
     }
     cur.swap(next);
   }
-  // internal nodes per level of every sub-tree: a node's random stream is keyed by its index in the GLOBAL level
-  std::vector<std::vector<int>> cnt(P);
-  size_t maxl = 0;
-  for (int p = 0; p < P; ++p) {
-    H->ranks[p].row0 = cur[p].start; H->ranks[p].n = cur[p].size;
-    std::vector<int> sizes(1, cur[p].size);
-    while (!sizes.empty()) {
-      std::vector<int> nx;
-      int internal = 0;
-      for (int sz : sizes) if (sz / 2 >= min_size) { ++internal; nx.push_back(sz / 2); nx.push_back(sz - sz / 2); }
-      if (internal == 0) break;
-      cnt[p].push_back(internal);
-      sizes.swap(nx);
+  // rows of every sub-tree, and where its nodes sit in the global levels (a node's random stream is keyed by that)
+  {
+    int64_t r0[16], nr[16];
+    int32_t nl = 0;
+    GH_CHECK(gh_hodlr_mgpu_layout(n, P, min_size, r0, nr, nullptr, 0, &nl));
+    std::vector<int32_t> so((size_t)P * std::max(nl, 1), 0);
+    GH_CHECK(gh_hodlr_mgpu_layout(n, P, min_size, r0, nr, so.data(), nl, &nl));
+    for (int p = 0; p < P; ++p) {
+      H->ranks[p].row0 = (long)r0[p]; H->ranks[p].n = (long)nr[p];
+      H->ranks[p].seed_off.assign(so.begin() + (size_t)p * nl, so.begin() + (size_t)(p + 1) * nl);
     }
-    maxl = std::max(maxl, cnt[p].size());
   }
-  for (int p = 0; p < P; ++p) {
-    H->ranks[p].seed_off.assign(maxl, 0);
-    for (size_t l = 0; l < maxl; ++l)
-      for (int o = 0; o < p; ++o) if (l < cnt[o].size()) H->ranks[p].seed_off[l] += cnt[o][l];
-  }
-
   static const bool dbg = getenv("GEORGE_AMD_HODLR_SPLIT_DEBUG") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };

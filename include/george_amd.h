@@ -327,6 +327,11 @@ int  gh_hodlr_mgpu_solve(gh_hodlr_mgpu* h, const double* b, int64_t nrhs, double
 int  gh_hodlr_mgpu_dot_solve(gh_hodlr_mgpu* h, const double* y, double* out);                /* hodlr.h:116-120 */
 /* ranks of all internal nodes, level by level, left to right (the order gh_hodlr_ranks uses) */
 int  gh_hodlr_mgpu_ranks(const gh_hodlr_mgpu* h, int32_t* ranks_out, int32_t max_out, int32_t* n_out);
+/* host logic only, no device needed: the rows of every sub-tree of an n-point tree split over n_dev devices (hodlr.h:47-64
+ * applied log2(n_dev) times) and, per sub-tree level, the index of each sub-tree's first internal node in the global
+ * level (seed_off: n_dev x max_levels, may be NULL); *n_levels = levels of the deepest sub-tree */
+int  gh_hodlr_mgpu_layout(int64_t n, int32_t n_dev, int32_t min_size, int64_t* row0, int64_t* nrows,
+                          int32_t* seed_off, int32_t max_levels, int32_t* n_levels);
 /* rows [row0[p], row0[p] + nrows[p]) live on devices[p]; arrays of n_dev entries (after compute()) */
 int  gh_hodlr_mgpu_rows(const gh_hodlr_mgpu* h, int64_t* row0, int64_t* nrows);
 

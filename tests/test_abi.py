@@ -119,3 +119,61 @@ def test_fails_loudly_without_gpu():
     gp = george_amd.GP(k)
     with pytest.raises(RuntimeError):
         gp.compute(np.arange(4.0), 0.1)
+
+
+def _reference_tree_levels(n, min_size):
+    """hodlr.h:47-64: a node of `size` points is internal iff size // 2 >= min_size; children (start, half) and
+    (start + half, size - half).  Returns, per level, the (start, size, internal) triples left to right."""
+    levels, cur = [], [(0, n)]
+    while cur:
+        lvl, nxt = [], []
+        for start, size in cur:
+            half = size // 2
+            internal = half >= min_size
+            lvl.append((start, size, internal))
+            if internal:
+                nxt += [(start, half), (start + half, size - half)]
+        levels.append(lvl)
+        cur = nxt
+    return levels
+
+
+@pytest.mark.parametrize("n,n_dev,min_size", [(262144, 8, 100), (3000, 4, 64), (1000, 2, 100), (8191, 8, 100), (100000, 16, 37),
+                                              (4096, 1, 100), (801, 4, 100)])
+def test_split_layout_follows_the_reference_tree(n, n_dev, min_size):
+    """gh_hodlr_mgpu_layout is host code: the sub-trees of the split are the nodes of level log2(n_dev) of the reference's
+    tree, and the seed offsets are the positions of their internal nodes in the global levels (what makes the split draw
+    the same pivot rows as the single-GPU solver)."""
+    from george_amd import _native as N
+    levels = _reference_tree_levels(n, min_size)
+    depth = n_dev.bit_length() - 1
+    row0, nrows = (ctypes.c_int64 * 16)(), (ctypes.c_int64 * 16)()
+    nl = ctypes.c_int32(0)
+    N.check(N.lib.gh_hodlr_mgpu_layout(n, n_dev, min_size, row0, nrows, None, 0, ctypes.byref(nl)))
+    subs = levels[depth]
+    assert len(subs) == n_dev
+    assert [(row0[p], nrows[p]) for p in range(n_dev)] == [(s, z) for s, z, _ in subs]
+    assert sum(nrows[p] for p in range(n_dev)) == n
+    L = max(nl.value, 1)
+    so = (ctypes.c_int32 * (n_dev * L))()
+    N.check(N.lib.gh_hodlr_mgpu_layout(n, n_dev, min_size, row0, nrows, so, L, ctypes.byref(nl)))
+    for lv in range(nl.value):
+        glob = [(s, z) for s, z, internal in levels[depth + lv] if internal]          # internal nodes of the global level, in order
+        for p in range(n_dev):
+            lo, hi = row0[p], row0[p] + nrows[p]
+            mine = [i for i, (s, z) in enumerate(glob) if lo <= s < hi]
+            if mine:
+                assert so[p * L + lv] == mine[0], (p, lv)
+            else:                                                                      # no internal node of its own there: the count before it
+                assert so[p * L + lv] == sum(1 for s, z in glob if s < lo)
+    assert nl.value == max(0, len([lvl for lvl in levels[depth:] if any(i for _, _, i in lvl)]))
+
+
+def test_split_layout_rejects_a_leaf_above_the_split():
+    from george_amd import _native as N
+    row0, nrows = (ctypes.c_int64 * 16)(), (ctypes.c_int64 * 16)()
+    nl = ctypes.c_int32(0)
+    with pytest.raises(ValueError):
+        N.check(N.lib.gh_hodlr_mgpu_layout(700, 8, 100, row0, nrows, None, 0, ctypes.byref(nl)))     # level 2: 175 points, half 87
+    with pytest.raises(ValueError):
+        N.check(N.lib.gh_hodlr_mgpu_layout(4096, 3, 100, row0, nrows, None, 0, ctypes.byref(nl)))
