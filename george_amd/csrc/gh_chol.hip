@@ -550,6 +550,7 @@ struct gh_chol {
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;
   std::vector<hipEvent_t> ev_p, ev_w, ev_nf;   // deep look-ahead: panel j factored / W(j) done / U(j, j+2) done
   hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
+  hipStream_t tail = nullptr;            // where the last factor() ended: the stream on which its results are complete in stream order
 
 
   int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
@@ -599,12 +600,40 @@ struct gh_chol {
 #include <map>
 #include <mutex>
 namespace {
-struct SharedStreams { hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr}; bool made = false; std::map<int, hipStream_t> masked; };
+struct SharedStreams {
+  hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool made = false;
+  bool main_crowded = false;       // the main stream shares a dispatcher with the chain, rows-below or near stream (measured when they are made)
+  std::map<int, hipStream_t> masked;
+};
 std::mutex g_ss_mu;
 std::map<int, SharedStreams> g_ss;
 }
 // (Where the runtime puts these streams matters more than which streams there are: DESIGN.md, "One set of streams per
 //  process" -- gh_prime_device() takes care of the common case, gh_debug_stream_dispatch() shows the placement.)
+namespace {
+__global__ void place_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+// ms until a one-workgroup kernel on `small` has completed when it is launched right after a ~1 ms grid (2^17 workgroups,
+// far more than the chip holds) on `big`: ~0.05 when the two queues dispatch independently, the grid's duration when not
+double dispatch_wait_ms(hipStream_t big, hipStream_t small) {
+  (void)hipDeviceSynchronize();
+  hipLaunchKernelGGL(place_spin_kernel, dim3(1 << 17), dim3(64), 0, big, 5000LL);
+  const auto t0 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(place_spin_kernel, dim3(1), dim3(64), 0, small, 0LL);
+  (void)hipStreamSynchronize(small);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  (void)hipDeviceSynchronize();
+  return ms;
+}
+}  // namespace
+bool gh_shared_main_crowded(int device) {
+  std::lock_guard<std::mutex> lk(g_ss_mu);
+  auto it = g_ss.find(device);
+  return it != g_ss.end() && it->second.main_crowded;
+}
 bool gh_shared_streams(int device, hipStream_t q[4]) {
   std::lock_guard<std::mutex> lk(g_ss_mu);
   SharedStreams& ss = g_ss[device];
@@ -617,6 +646,18 @@ bool gh_shared_streams(int device, hipStream_t q[4]) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     for (int i = 1; i < 4 && ss.q[0]; ++i)
       if (hipStreamCreateWithPriority(&ss.q[i], hipStreamNonBlocking, hi) != hipSuccess) { ss.q[i] = nullptr; (void)hipGetLastError(); break; }
+    // Does the main stream share a dispatcher with one of the panel streams?  (Which queues end up together depends on how
+    // many the process made before: never in a process that made none, with the rows-below stream after five application
+    // streams, with the chain stream after six.)  Decides where a look-ahead factorisation is joined: factor_lookahead_deep.
+    if (ss.q[0] && ss.q[1] && ss.q[2] && ss.q[3] && !getenv("GEORGE_AMD_NO_PLACEMENT_PROBE")) {
+      for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(place_spin_kernel, dim3(1), dim3(64), 0, ss.q[i], 0LL);   // (queues are made at first use)
+      (void)hipDeviceSynchronize();
+      for (int i = 1; i < 4 && !ss.main_crowded; ++i)
+        ss.main_crowded = dispatch_wait_ms(ss.q[0], ss.q[i]) > 0.3 || dispatch_wait_ms(ss.q[i], ss.q[0]) > 0.3;
+      (void)hipGetLastError();
+      if (getenv("GEORGE_AMD_DEBUG_STREAMS"))
+        fprintf(stderr, "[george_amd streams] device %d: the main stream %s a dispatcher with a panel stream\n", device, ss.main_crowded ? "SHARES" : "does not share");
+    }
   }
   for (int i = 0; i < 4; ++i) q[i] = ss.q[i];
   return ss.q[0] != nullptr;
@@ -1072,7 +1113,30 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     }
     GH_HIP(hipEventRecord(s->ev_w[j], sm));
   }
-  // join: the handle's stream continues after all three
+  // JOIN -- on the CHAIN stream, not on the main stream.  The host is far ahead of the device here, and a
+  // hipStreamWaitEvent on the main stream issued now would sit at the head of that queue as a barrier packet for the whole
+  // factorisation.  That is not free: whichever stream shares a DISPATCHER with the main stream (gh_debug_stream_dispatch;
+  // which one does depends on how many queues the process made before) is served between polls of that barrier -- with the
+  // chain or the rows-below stream there, N = 8192 took 11.0-12.8 instead of 7.2 ms per step (an application with five or
+  // six streams of its own: profiles/r03/stream_placement_states.txt).  At the END of the chain's queue the same barriers
+  // hold nothing up: the queue reaches them after its own last panel.  The caller continues on s->tail (log-det, copies).
+  // (Waiting on the host for the last panel and joining on the main stream then works too, but costs 0.4 ms per step with a
+  //  blocking wait and slows the device work by ~0.6 % when the host polls the event.)
+  // In the placement a process gets that made no queues before, the main stream shares its dispatcher with the CU-masked
+  // stream only, and there the join on the main stream is the faster one (N = 8192: 7.0 vs 7.3 ms, same box): the chain
+  // join is used when the main stream was FOUND to share a dispatcher with a panel stream when the set was made
+  // (gh_shared_main_crowded), and always with streams of the handle's own.  GEORGE_AMD_JOIN=main|chain forces one.
+  static const char* const join_env = getenv("GEORGE_AMD_JOIN");
+  const bool join_on_chain = join_env ? join_env[0] == 'c' : (!s->shared_streams || gh_shared_main_crowded(s->opts.device));
+  if (sm != s->st && join_on_chain) {
+    GH_HIP(hipEventRecord(s->ev_sync[2], sn));
+    GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[2], 0));
+    GH_HIP(hipEventRecord(s->ev_xfer, sm));
+    GH_HIP(hipStreamWaitEvent(sp, s->ev_xfer, 0));
+    s->tail = sp;
+    return GH_OK;
+  }
+  // (the trailing updates ran on the main stream itself -- large matrices -- or the old arm: the main stream joins)
   GH_HIP(hipEventRecord(s->ev_sync[1], sp));
   GH_HIP(hipStreamWaitEvent(s->st, s->ev_sync[1], 0));
   GH_HIP(hipEventRecord(s->ev_sync[2], sn));
@@ -1174,9 +1238,10 @@ static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n,
   if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].a, st));
   GH_CHECK(gh_launch_kmat(k, s->x.d(), n, s->x.d(), n, s->yerr.d(), s->A.d(), np, np, np, 0, 0, true, true, st));
   if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].b, st));
-  GH_CHECK(factor(s));
-  GH_CHECK(launch_logdet(s->A.d(), np, np, s->scal.d(), s->scal.d() + 8, st));
-  if (c.e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_all].b, st));
+  s->tail = st;
+  GH_CHECK(factor(s));                                  // (may move s->tail to the chain stream)
+  GH_CHECK(launch_logdet(s->A.d(), np, np, s->scal.d(), s->scal.d() + 8, s->tail));
+  if (c.e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_all].b, s->tail));
   return GH_OK;
 }
 // after the stream has been synchronised and logdet / info copied to the host
@@ -1227,7 +1292,7 @@ extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_
                                const double* yerr, double* logdet_out) {
   ComputeCtx c;
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
-  hipStream_t st = s->st;
+  hipStream_t st = s->tail;                             // (the stream the factorisation ended on: compute_enqueue)
   double back[3] = {0.0, 0.0, 0.0};                     // [0] log-det, [1] (quadratic form), [2] the failure word's bits
   GH_HIP(hipMemcpyAsync(back, s->scal.d(), 3 * sizeof(double), hipMemcpyDeviceToHost, st));
   GH_HIP(hipStreamSynchronize(st));
@@ -1544,6 +1609,10 @@ extern "C" int gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int6
   ComputeCtx c;
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
   hipStream_t st = s->st;
+  if (s->tail && s->tail != st && s->ev_sync[1]) {      // (the solves and the gradient run on the main stream: it joins here)
+    GH_HIP(hipEventRecord(s->ev_sync[1], s->tail));
+    GH_HIP(hipStreamWaitEvent(st, s->ev_sync[1], 0));
+  }
   const int64_t np = s->np, nt = np / T;
   const bool want_alpha = grad || alpha || diagA;
   GH_CHECK(load_vec(s, s->v0, r));

@@ -140,5 +140,8 @@ bool gh_shared_streams(int device, hipStream_t q[4]);
 // is the same in both cases (gh_debug_stream_overlap), so it is not queue sharing; which hardware queue the runtime
 // hands out first is not visible from here.  GEORGE_AMD_NO_NULL_PRIME=1 skips it (A/B).
 void gh_prime_device(int device);
+// measured when the process-wide streams of `device` were made: does the main stream share a dispatcher with the chain,
+// rows-below or near stream?  (gh_chol.hip, factor_lookahead_deep: where a look-ahead factorisation is joined)
+bool gh_shared_main_crowded(int device);
 hipStream_t gh_shared_masked_stream(int device, int reserve_cus);
 bool gh_use_mfma();               // false when GEORGE_AMD_NO_MFMA=1 (VALU validation path)
