@@ -7,10 +7,12 @@ Loads the *real* reference (dfm/george) for oracle pinning:
   ``oracle/Makefile`` into ``oracle/_ref/``.  The shared object travels to the
   GPU box, so this works there too (it only needs a *spec object* exposing the
   attributes ``parser.h:14-35,344-403`` reads -- our own host classes do).
-* ``load_reference()`` -- the full reference Python package, assembled from
-  the sources where they lie under ``/root/reference`` (nothing is copied)
-  plus the compiled ``kernel_interface``.  Only possible in the build
-  container; returns ``None`` when ``/root/reference`` is absent.
+* ``load_reference()`` -- the full reference Python package as ``george``: from
+  the sources where they lie under ``/root/reference`` in the build container,
+  else from ``oracle/_ref/george`` (byte-code compiled from those sources by
+  ``oracle/Makefile``'s ``stage`` target: a git-ignored build output that
+  travels to the GPU box like the shared objects), plus the compiled
+  ``kernel_interface`` / ``_hodlr``.  ``None`` when neither is there.
 
 * ``load_hodlr()`` -- the reference's HODLR solver: its unmodified
   ``include/george/hodlr.h`` compiled against ``oracle/mini_eigen`` behind
@@ -28,6 +30,7 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("GEORGE_REFERENCE", "/root/reference")
 REF_SRC = os.path.join(REF_ROOT, "src", "george")
+STAGED = os.path.join(HERE, "_ref", "george")          # byte-code of the reference package (oracle/Makefile: stage)
 
 
 def _so_path():
@@ -71,15 +74,19 @@ def load_reference():
     """Import the reference package as ``george`` (build container only)."""
     if "george" in sys.modules and getattr(sys.modules["george"], "_is_oracle_ref", False):
         return sys.modules["george"]
-    if not os.path.isdir(REF_SRC):
+    if os.path.isdir(REF_SRC):
+        src, init = REF_SRC, os.path.join(REF_SRC, "__init__.py")
+    elif os.path.isfile(os.path.join(STAGED, "__init__.pyc")):
+        # the GPU box: /root/reference does not exist there, the compiled package travelled with the snapshot
+        src, init = STAGED, os.path.join(STAGED, "__init__.pyc")
+    else:
         return None
     KI = load_kernel_interface()
     if KI is None:
         return None
 
-    init = os.path.join(REF_SRC, "__init__.py")
     spec = importlib.util.spec_from_file_location(
-        "george", init, submodule_search_locations=[REF_SRC])
+        "george", init, submodule_search_locations=[src])
     pkg = importlib.util.module_from_spec(spec)
     sys.modules["george"] = pkg
 

@@ -1,0 +1,298 @@
+"""The reference's OWN package (`george.GP`, `george.kernels`, `george.modeling`) with the HIP solver classes
+plugged in through its documented `solver=` slot -- INTEGRATION.md section 1's zero-change claim, executed.
+
+`george` here is dfm/george itself: byte-code of /root/reference/src/george compiled by `oracle/Makefile` (target
+`stage`) into the git-ignored `oracle/_ref/george`, which travels to the GPU box like `oracle/_ref/*.so`
+(`oracle/ref_loader.load_reference`).  Nothing of `george_amd`'s own GP facade is involved: the orchestration
+(gp.py:303-337 compute, :369-397 log_likelihood, :406-468 grad_log_likelihood, :482-545 predict, :547-600 sample)
+is the reference's, and every solver call it makes (`solver_type(kernel, **kwargs)` gp.py:327, `.compute`,
+`.apply_inverse`, `.dot_solve`, `.get_inverse`, `.apply_sqrt`, `.log_determinant`, `.computed`) lands in
+`george_amd.BasicSolver` / `george_amd.HODLRSolver`, i.e. in libgeorge_amd.so through the C ABI.
+
+The test bodies restate, as parametrised calls, what the reference's suite asserts of its solver classes:
+tests/test_solvers.py:29-75, tests/test_gp.py:16-171, tests/test_pickle.py:21-36, tests/test_tutorial.py:8-43.
+A second family runs each scenario TWICE -- once with the reference's CPU solver, once with the HIP solver --
+and compares the numbers the reference GP hands back.
+"""
+import pickle
+from itertools import product
+
+import numpy as np
+import pytest
+
+from oracle import ref_loader
+import george_amd
+
+pytestmark = pytest.mark.gpu
+
+george = ref_loader.load_reference()
+if george is None:                                           # (collection on a box where oracle/_ref was not built)
+    pytest.skip("oracle/_ref/george is not staged (make -C oracle)", allow_module_level=True)
+kernels, GP = george.kernels, george.GP
+
+HIP = {"basic": george_amd.BasicSolver, "hodlr": george_amd.HODLRSolver}
+CPU = {"basic": george.BasicSolver, "hodlr": george.HODLRSolver}
+
+
+def test_the_package_under_test_is_the_reference_and_the_solver_is_native():
+    assert george.__name__ == "george" and george.GP.__module__ == "george.gp"
+    assert "george_amd" not in george.GP.__module__
+    gp = GP(kernels.ExpSquaredKernel(1.0), solver=george_amd.BasicSolver)
+    gp.compute(np.linspace(0, 1, 40), 0.1)
+    assert type(gp.solver) is george_amd.BasicSolver and gp.solver.computed
+    from george_amd import _native
+    assert _native.LIB_PATH.endswith("libgeorge_amd.so")
+    with open("/proc/self/maps") as f:                       # the HIP library is mapped into THIS process
+        assert "libgeorge_amd.so" in f.read()
+
+
+# ------------------------------------------------------------------ tests/test_solvers.py:29-62
+@pytest.mark.parametrize("which,kw", [("basic", {}), ("hodlr", {"tol": 1e-10})])
+def test_solver_against_numpy(which, kw, N=300, seed=1234):
+    kernel = 1.0 * kernels.ExpSquaredKernel(1.0)             # a reference kernel object
+    solver = HIP[which](kernel, **kw)
+    np.random.seed(seed)
+    x = np.atleast_2d(np.sort(10 * np.random.randn(N))).T
+    yerr = np.ones(N)
+    solver.compute(x, yerr)
+    K = kernel.get_value(x)                                  # the reference's C++ evaluator
+    K[np.diag_indices_from(K)] += yerr ** 2
+    sgn, lndet = np.linalg.slogdet(K)
+    assert sgn == 1.0
+    assert np.allclose(solver.log_determinant, lndet)
+    y = np.sin(x[:, 0])
+    assert np.allclose(solver.apply_inverse(y).flatten(), np.linalg.solve(K, y))
+    assert np.allclose(solver.apply_inverse(K), np.eye(N))
+
+
+def test_strange_hodlr_bug():                                # tests/test_solvers.py:64-75
+    np.random.seed(1234)
+    x = np.sort(np.random.uniform(0, 10, 50000))
+    yerr = 0.1 * np.ones_like(x)
+    y = np.sin(x)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    gp = GP(kernel, solver=george_amd.HODLRSolver, seed=42)
+    n = 200
+    gp.compute(x[:n], yerr[:n])
+    assert np.isfinite(gp.log_likelihood(y[:n]))
+
+
+# ------------------------------------------------------------------ tests/test_gp.py:16-57
+@pytest.mark.parametrize("which,white_noise", product(["basic", "hodlr"], [None, 0.1]))
+def test_gradient(which, white_noise, seed=123, N=305, ndim=3, eps=1.32e-3):
+    np.random.seed(seed)
+    kernel = 1.0 * kernels.ExpSquaredKernel(0.5, ndim=ndim)
+    kwargs = dict()
+    if white_noise is not None:
+        kwargs = dict(white_noise=white_noise, fit_white_noise=True)
+    if which == "hodlr":
+        kwargs["tol"] = 1e-8
+    gp = GP(kernel, solver=HIP[which], **kwargs)
+    x = np.random.rand(N, ndim)
+    x = x[np.argsort(x[:, 0])]
+    y = gp.sample(x)
+    gp.compute(x, yerr=0.1)
+    grad0 = gp.grad_log_likelihood(y)
+    vector = gp.get_parameter_vector()
+    for i, v in enumerate(vector):
+        vector[i] = v + eps
+        gp.set_parameter_vector(vector)
+        lp = gp.lnlikelihood(y)
+        vector[i] = v - eps
+        gp.set_parameter_vector(vector)
+        lm = gp.lnlikelihood(y)
+        vector[i] = v
+        gp.set_parameter_vector(vector)
+        grad = 0.5 * (lp - lm) / eps
+        assert np.abs(grad - grad0[i]) < 5 * eps, (i, which, grad, grad0[i])
+
+
+# ------------------------------------------------------------------ tests/test_gp.py:59-83
+@pytest.mark.parametrize("which", ["basic", "hodlr"])
+def test_prediction(which, seed=42):
+    np.random.seed(seed)
+    kwargs = {"tol": 1e-8} if which == "hodlr" else {}
+    gp = GP(kernels.ExpSquaredKernel(1.0), solver=HIP[which], white_noise=0.0, **kwargs)
+    x0 = np.linspace(-10, 10, 500)
+    x = np.sort(np.random.uniform(-10, 10, 300))
+    gp.compute(x)
+    y = np.sin(x)
+    mu, cov = gp.predict(y, x0)
+    Kstar = gp.get_matrix(x0, x)
+    K = gp.get_matrix(x)
+    K[np.diag_indices_from(K)] += 1.0
+    assert np.allclose(mu, np.dot(Kstar, np.linalg.solve(K, y)))
+
+
+# ------------------------------------------------------------------ tests/test_gp.py:86-120
+def test_repeated_prediction_cache():
+    gp = GP(kernels.ExpSquaredKernel(1.0), solver=george_amd.BasicSolver)
+    x = np.array((-1, 0, 1))
+    gp.compute(x)
+    t = np.array((-.5, .3, 1.2))
+    y = x / x.std()
+    mu0, mu1 = (gp.predict(y, t, return_cov=False) for _ in range(2))
+    assert np.array_equal(mu0, mu1)
+    y2 = 2 * y
+    assert not np.array_equal(mu0, gp.predict(y2, t, return_cov=False))
+    a0 = gp._alpha
+    gp.kernel[0] += 0.1
+    gp.recompute()
+    gp._compute_alpha(y2, True)
+    assert not np.allclose(a0, gp._alpha)
+    mu, cov = gp.predict(y2, t)
+    _, var = gp.predict(y2, t, return_var=True)
+    assert np.allclose(np.diag(cov), var)
+
+
+# ------------------------------------------------------------------ tests/test_gp.py:123-149
+@pytest.mark.parametrize("which", ["basic", "hodlr"])
+def test_apply_inverse(which, seed=1234, N=201, yerr=0.1):
+    np.random.seed(seed)
+    kwargs = {"tol": 1e-10} if which == "hodlr" else {}
+    gp = GP(1.0 * kernels.ExpSquaredKernel(0.5), solver=HIP[which], **kwargs)
+    x = np.sort(np.random.rand(N))
+    y = gp.sample(x)
+    gp.compute(x, yerr=yerr)
+    K = gp.get_matrix(x)
+    K[np.diag_indices_from(K)] += yerr ** 2
+    assert np.allclose(np.linalg.solve(K, y), gp.apply_inverse(y))
+    y = gp.sample(x, size=5).T
+    assert np.allclose(np.linalg.solve(K, y), gp.apply_inverse(y))
+
+
+# ------------------------------------------------------------------ tests/test_gp.py:152-171
+@pytest.mark.parametrize("which", ["basic", "hodlr"])
+def test_predict_single(which, seed=1234, N=201, yerr=0.1):
+    np.random.seed(seed)
+    kwargs = {"tol": 1e-8} if which == "hodlr" else {}
+    gp = GP(1.0 * kernels.ExpSquaredKernel(0.5), solver=HIP[which], **kwargs)
+    x = np.sort(np.random.rand(N))
+    y = gp.sample(x)
+    gp.compute(x, yerr=yerr)
+    mu0, var0 = gp.predict(y, [0.0], return_var=True)
+    mu, var = gp.predict(y, [0.0, 1.0], return_var=True)
+    _, cov = gp.predict(y, [0.0, 1.0])
+    assert np.allclose(mu0, mu[0])
+    assert np.allclose(var0, var[0])
+    assert np.allclose(var0, cov[0, 0])
+
+
+# ------------------------------------------------------------------ tests/test_pickle.py:21-36
+def _fake_compute(arg, *args, **kwargs):
+    assert 0, "Unpickled GP shouldn't need to be computed"
+
+
+@pytest.mark.parametrize("which,success", [("basic", True), ("hodlr", False)])
+def test_pickle(which, success, seed=123):
+    np.random.seed(seed)
+    kernel = 0.1 * kernels.ExpSquaredKernel(1.5)
+    kernel.pars = [1, 2]
+    gp = GP(kernel, solver=HIP[which])
+    x = np.random.rand(100)
+    gp.compute(x, 1e-2)
+    ll0 = gp.lnlikelihood(np.sin(x))
+    gp = pickle.loads(pickle.dumps(gp, -1))
+    assert type(gp) is george.GP and type(gp.solver) is HIP[which]
+    if success:
+        gp.compute = _fake_compute                           # the device factor came back with the pickle
+    assert np.allclose(gp.lnlikelihood(np.sin(x)), ll0, rtol=1e-12 if success else 1e-6)
+
+
+# ------------------------------------------------------------------ tests/test_tutorial.py:8-43
+def test_tutorial():
+    def model(params, t):
+        _, _, amp, loc, sig2 = params
+        return amp * np.exp(-0.5 * (t - loc) ** 2 / sig2)
+
+    def lnlike(p, t, y, yerr, solver):
+        a, tau = np.exp(p[:2])
+        gp = GP(a * kernels.Matern32Kernel(tau) + 0.001, solver=solver)
+        gp.compute(t, yerr)
+        return gp.lnlikelihood(y - model(p, t))
+
+    np.random.seed(1234)
+    x = np.sort(np.random.rand(50))
+    yerr = 0.05 + 0.01 * np.random.rand(len(x))
+    y = np.sin(x) + yerr * np.random.randn(len(x))
+    p = [0, 0, -1.0, 0.1, 0.4]
+    lb = lnlike(p, x, y, yerr, george_amd.BasicSolver)
+    assert np.isfinite(lb)
+    assert np.allclose(lb, lnlike(p, x, y, yerr, george_amd.HODLRSolver))       # default tol = 0.1, as the tutorial
+    assert np.allclose(lb, lnlike(p, x, y, yerr, george.BasicSolver), rtol=1e-10)   # and the reference's own solver
+
+
+# ------------------------------------------------------------------ CPU solver vs HIP solver under the SAME reference GP
+def _scenario(solver_cls, kernel_fn, x, yerr, y, t, **kw):
+    gp = GP(kernel_fn(), solver=solver_cls, **kw)
+    gp.compute(x, yerr)
+    out = {"ll": gp.log_likelihood(y), "grad": gp.grad_log_likelihood(y), "alpha": gp.apply_inverse(y)}
+    mu, var = gp.predict(y, t, return_var=True)
+    _, cov = gp.predict(y, t)
+    out.update(mu=mu, var=var, cov=cov, nll=gp.nll(gp.get_parameter_vector(), y),
+               gnll=gp.grad_nll(gp.get_parameter_vector(), y))
+    return out
+
+
+SCEN = {
+    "expsq_1d": (lambda: 2.3 * kernels.ExpSquaredKernel(0.7), 1),
+    "matern32_1d": (lambda: 0.6 * kernels.Matern32Kernel(1.3), 1),
+    "sum_3d": (lambda: kernels.Matern52Kernel(0.5, ndim=3) + kernels.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3), 3),
+    "product_axis_2d": (lambda: 1.1 * kernels.ExpSquaredKernel([0.5, 1.5], ndim=2) * kernels.ExpSine2Kernel(gamma=0.8, log_period=0.3, ndim=2, axes=0), 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCEN))
+@pytest.mark.parametrize("which,kw,rtol", [("basic", {}, 1e-9), ("hodlr", {"tol": 1e-12, "min_size": 64}, 1e-7)])
+def test_reference_gp_gives_the_same_numbers_on_either_solver(name, which, kw, rtol, n=700, m=60):
+    kernel_fn, ndim = SCEN[name]
+    rng = np.random.RandomState(77)
+    x = rng.uniform(0, 4, (n, ndim))
+    x = x[np.argsort(x[:, 0])]
+    y = np.sin(x.sum(axis=1)) + 0.05 * rng.randn(n)
+    t = rng.uniform(0, 4, (m, ndim))
+    yerr = 0.1 + 0.05 * rng.rand(n)
+    if ndim == 1:
+        x, t = x[:, 0], t[:, 0]
+    kw = dict(kw, white_noise=np.log(0.02), fit_white_noise=True, mean=0.3, fit_mean=True)
+    a = _scenario(CPU[which], kernel_fn, x, yerr, y, t, **kw)
+    b = _scenario(HIP[which], kernel_fn, x, yerr, y, t, **kw)
+    assert abs(a["ll"] - b["ll"]) <= rtol * abs(a["ll"])
+    assert abs(a["nll"] - b["nll"]) <= rtol * abs(a["nll"])
+    sc = 1e3 if which == "hodlr" else 1.0                     # (two HODLR builds differ by O(tol) x cond(K) in the vectors)
+    for k in ("grad", "gnll", "alpha", "mu", "var", "cov"):
+        scale = np.abs(a[k]).max() + 1e-300
+        assert np.abs(a[k] - b[k]).max() <= sc * 1e-7 * scale, (k, np.abs(a[k] - b[k]).max(), scale)
+
+
+def test_optimiser_loop_on_the_reference_gp(n=400):
+    """docs/tutorials/hyper.rst:131-152: scipy.optimize.minimize over gp.nll / gp.grad_nll -- the reference GP, HIP solver."""
+    from scipy.optimize import minimize
+    rng = np.random.RandomState(3)
+    x = np.sort(rng.uniform(0, 10, n))
+    y = np.sin(x) + 0.1 * rng.randn(n)
+    res = {}
+    for tag, cls in (("cpu", george.BasicSolver), ("hip", george_amd.BasicSolver)):
+        gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0), solver=cls, white_noise=np.log(0.01), fit_white_noise=True)
+        gp.compute(x)
+
+        def nll(p):
+            return gp.nll(p, y)
+
+        def gnll(p):
+            return gp.grad_nll(p, y)
+
+        r = minimize(nll, gp.get_parameter_vector(), jac=gnll, method="L-BFGS-B")
+        res[tag] = (r.fun, r.x)
+    assert abs(res["cpu"][0] - res["hip"][0]) <= 1e-8 * abs(res["cpu"][0])
+    assert np.allclose(res["cpu"][1], res["hip"][1], atol=1e-5)
+
+
+def test_linalg_error_surfaces_as_the_reference_expects():
+    """gp.py:351-360: `recompute(quiet=True)` swallows ValueError / LinAlgError from the solver and returns False."""
+    gp = GP(kernels.ExpSquaredKernel(1.0), solver=george_amd.BasicSolver, white_noise=-80.0)
+    x = np.zeros(5)                                          # five identical points, no noise: singular
+    with pytest.raises((ValueError, np.linalg.LinAlgError)):
+        gp.compute(x, 0.0)
+    assert gp.recompute(quiet=True) is False
+    assert gp.log_likelihood(np.zeros(5), quiet=True) == -np.inf
