@@ -96,6 +96,27 @@ def cpu_baseline(n_cpu):
     }
 
 
+def cpu_baseline_second_point(n_cpu, local_rank):
+    """A second, larger same-box CPU point (default N = 32768, ~40 s on the GPU box's host cores): the reference's
+    compiled evaluator for K + the LAPACK/BLAS routines of basic.py:68,87 applied to 8192-column blocks
+    (oracle/solver_np.BlockedDenseOracle: this image's whole-matrix dpotrf is unreliable from n ~ 20000 up,
+    oracle/potrf_probe.py), and the GPU's log-likelihood at the same N beside it."""
+    import george_amd.kernels as K
+    from oracle import solver_np
+    x, yerr, y = make_inputs(n_cpu)
+    kernel = np.var(y) * K.ExpSquaredKernel(1.0)
+    t0 = time.perf_counter()
+    ll = solver_np.gp_log_likelihood(solver_np.BlockedDenseOracle(kernel), x[:, None], yerr, y)
+    dt = time.perf_counter() - t0
+    jp = DenseJob(n_cpu, 0, local_rank, profile=False)
+    jp.step()
+    e, llg = run_timed(jp, 2, 0, lambda: None)
+    jp.close()
+    return {"n": n_cpu, "seconds": dt, "value": flops_alg(n_cpu) / dt * 1e-12, "unit": "TFLOP/s", "log_likelihood": float(ll),
+            "gpu_seconds": e / 2, "gpu_over_cpu": dt / (e / 2), "rel": abs(llg - ll) / abs(ll),
+            "how": "reference evaluator (1 thread) + dpotrf/dtrsm/dgemm on 8192-column blocks (all host threads)"}
+
+
 class DenseJob(object):
     """compute()+log_likelihood() straight through the C ABI with device-resident inputs."""
 
@@ -363,6 +384,34 @@ def multi_device_probe(timeout_s=240):
     return json.loads(lines[-1])
 
 
+def abi_form_report(args, world):
+    """N > 1, rank 0, after the process group is gone: the OTHER multi-GPU form -- gh_mgpu_* behind the C ABI, ONE
+    process driving all `world` devices with host threads and grouped RCCL send/recv (george_amd.MultiGPUSolver) --
+    on the same workload, in a child process with a hard time limit, so that one driver run returns both forms.
+    Never part of `value`; a failure or a time-out is reported in place."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "abi_multi_device_probe.py"), "--dense-n", str(args.n),
+           "--dense-kernel", args.kernel, "--devices", str(world), "--no-hodlr", "--no-single", "--reps", "2"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.abi_timeout, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": "no answer within %d s" % args.abi_timeout}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "exit %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
+    d = json.loads(lines[-1]).get("dense_rccl", {})
+    if "error" in d:
+        return {"error": d["error"][:300]}
+    gold = golden_ll(args.n, KERNEL_NAMES[args.kernel])
+    res = {"what": "gh_mgpu_create/compute/dot_solve over RCCL, one process, %d devices" % world, "seconds_per_step": d["sharded_s"],
+           "value_tflops": flops_alg(args.n) / d["sharded_s"] * 1e-12, "grid": d["grid"], "nb": d["nb"],
+           "log_likelihood": d["ll_sharded"], "wall_s": time.perf_counter() - t0}
+    if gold is not None:
+        res["rel"] = abs(d["ll_sharded"] - gold[0]) / abs(gold[0])
+    return res
+
+
 def public_api_report(n, local_rank, steps=2):
     """The headline work through the public facade: NumPy x, yerr, y -> GP.compute -> log_likelihood,
     host->device of the inputs included (SURVEY.md 8d's statement of the metric)."""
@@ -381,6 +430,149 @@ def public_api_report(n, local_rank, steps=2):
     del gp
     return {"seconds_per_step": sec, "value_tflops": flops_alg(n) / sec * 1e-12, "steps": steps, "log_likelihood": ll,
             "note": "GP.compute(x, yerr); GP.log_likelihood(y) on NumPy arrays: 3*8*N bytes over PCIe + the Python facade"}
+
+
+# the ONLY numbers the reference publishes for this path -- a log-log plot
+# (docs/tutorials/scaling.rst:156-176,224, scaling_files/scaling_16_0.png), read off by eye (+-20 %), unstated CPU of ~2018
+REF_CURVE_SECONDS = {"BasicSolver": {1000: 2.0e-2, 5000: 1.2, 10000: 7.0},
+                     "HODLRSolver(default tol=0.1, seed=42)": {1000: 2.5e-3, 10000: 4.5e-2, 50000: 0.4}}
+
+
+def curve_report(local_rank):
+    """The reference's own benchmark loop (docs/tutorials/scaling.rst:56-59,67,84,156-176) at the sizes BASELINE.md
+    quotes from its plot: best-of-K ``gp.compute(x[:n], yerr[:n]); gp.log_likelihood(y[:n])`` on the first n of the
+    50000 sorted points, NumPy in, through the GP facade, for BasicSolver and for HODLRSolver at its DEFAULT
+    tol = 0.1 (seed = 42).  The HODLR log-likelihood is checked against the dense one with the tutorial's own
+    criterion at that tolerance (tests/test_tutorial.py:39-43: allclose)."""
+    from george_amd import GP, kernels, HODLRSolver
+    x, yerr, y = make_inputs(50000)
+    kernel = float(np.var(y)) * kernels.ExpSquaredKernel(1.0)
+    gps = {"BasicSolver": GP(kernel, device=local_rank),
+           "HODLRSolver(default tol=0.1, seed=42)": GP(kernel, solver=HODLRSolver, seed=42, device=local_rank)}
+    rows, dense_ll = [], {}
+    for name in ("BasicSolver", "HODLRSolver(default tol=0.1, seed=42)"):
+        gp = gps[name]
+        for n, ref_s in sorted(REF_CURVE_SECONDS[name].items()):
+            best, ll = np.inf, None
+            for it in range(max(3, min(20, 100000 // n)) + 1):
+                t0 = time.perf_counter()
+                gp.compute(x[:n], yerr[:n])
+                ll = gp.log_likelihood(y[:n])
+                dt = time.perf_counter() - t0
+                if it > 0:
+                    best = min(best, dt)
+            row = {"solver": name, "n": n, "seconds": best, "reference_plot_seconds": ref_s, "speedup_vs_plot": ref_s / best,
+                   "log_likelihood": float(ll)}
+            if name == "BasicSolver":
+                dense_ll[n] = ll
+            else:
+                if n not in dense_ll:                        # N = 50000: the dense answer from the device solver
+                    g0 = gps["BasicSolver"]
+                    g0.compute(x[:n], yerr[:n])
+                    dense_ll[n] = g0.log_likelihood(y[:n])
+                row["rel_vs_dense"] = abs(ll - dense_ll[n]) / abs(dense_ll[n])
+            rows.append(row)
+    return {"what": "compute(x[:n], yerr[:n]) + log_likelihood(y[:n]), best of K, NumPy in (scaling.rst:156-176); "
+                    "reference_plot_seconds = BASELINE.md section 1, read off the reference's plot by eye (+-20 %), unstated CPU",
+            "rows": rows}
+
+
+def _r(v, nd=4):
+    """round floats for the printed line (the detail file keeps full precision)"""
+    if isinstance(v, float):
+        return float("%.*g" % (nd + 2, v))
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def compact_line(out):
+    """The ONE printed line: the contract's keys + every secondary config in a few numbers each, < 6 kB, so that the
+    driver's stored stdout tail holds all of it.  The full record (texts, per-phase splits, every parity operand)
+    goes to the detail file named in the line."""
+    keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "log_likelihood", "frac_of_fp64_mfma_peak"]
+    line = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "N", "kernel", "solver", "parallelism", "flops_model", "grid", "nb") if k in cfg}
+    if "value_public_api" in out:
+        line["value_public_api"] = out["value_public_api"]
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                               "traffic_algorithmic_bytes", "launches", "avg_launch_ms",
+                                               "algorithmic_flops_per_launch", "peak_measured", "frac_of_measured",
+                                               "scope") if k in rf}
+        line["roofline"]["kernel"] = line["roofline"]["kernel"][:96]
+        w = rf.get("with_overlapped_block_column_launches")
+        if w:
+            line["roofline"]["with_overlapped_block_column_launches"] = {k: w[k] for k in ("achieved", "frac", "busy_ms_per_step")}
+    kb = out.get("roofline_kernel_build")
+    if kb:
+        line["roofline_kernel_build"] = {"kernel": "kmat_interior_kernel", "bound": "hbm", "achieved": kb["achieved"], "peak": kb["peak"],
+                                         "unit": kb["unit"], "frac": kb["frac"], "ms": kb["ms"], "traffic": kb.get("traffic")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "n", "seconds") if k in cb}
+        line["cpu_baseline"]["sample"] = cb.get("sample", "")[:150]
+        if cb.get("second_point"):
+            sp = cb["second_point"]
+            line["cpu_baseline"]["second_point"] = {k: sp[k] for k in ("n", "seconds", "value", "gpu_seconds", "gpu_over_cpu", "rel") if k in sp}
+        if cb.get("full_size_run"):
+            line["cpu_baseline"]["full_size_other_box_s"] = cb["full_size_run"].get("seconds_total")
+    if "phases_ms" in out:
+        line["phases_ms"] = out["phases_ms"]
+    also = {}
+    a = cfg.get("also_configs1_N16384")
+    if a:
+        also["configs1_N16384"] = {"ms": a["seconds_per_step"] * 1e3, "tflops": a["value_tflops"], "frac": a["frac_of_fp64_mfma_peak"]}
+    a = cfg.get("also_C4")
+    if a and "seconds_per_step" in a:
+        also["C4_hodlr_N262144"] = {"ms": a["seconds_per_step"] * 1e3, "rank_per_level": a.get("rank_per_level"),
+                                    "roofline": {k: a["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                                   "algorithmic_bytes", "streamed_bytes", "achieved_streamed")
+                                                 if k in a["roofline"]},
+                                    "cpu_ref_s": (a.get("cpu_baseline") or {}).get("value"),
+                                    "cpu_ref_full_size_s": (a.get("cpu_baseline") or {}).get("full_size_seconds_build_container")}
+    a = cfg.get("also_C5")
+    if a and "compute_loglike_s" in a:
+        also["C5_N32768_3d"] = {"compute_loglike_s": a["compute_loglike_s"], "predict_var_s": a["predict_var_s"], "grad_s": a["grad_s"],
+                                "fused_nll_and_grad_s": a["fused_nll_and_grad_s"], "fused_frac": a["roofline"]["frac"]}
+    a = cfg.get("also_abi_multi_gpu_world_of_one")
+    if a:
+        also["abi_mgpu_world1_N32768"] = {"s": a.get("seconds_per_step"), "tflops": a.get("value_tflops")} if "error" not in a else {"error": a["error"][:120]}
+    a = cfg.get("also_abi_multi_device")
+    if a:
+        d = {"devices": a.get("devices_visible")}
+        if "dense_rccl" in a:
+            d["dense_rccl"] = {k: a["dense_rccl"].get(k) for k in ("n", "grid", "nb", "single_gpu_s", "sharded_s", "speedup", "rel", "error") if k in a["dense_rccl"]}
+        if "hodlr_split" in a:
+            d["hodlr_split"] = [{k: c.get(k) for k in ("n", "single_gpu_s", "split_s", "rel", "error") if k in c} for c in a["hodlr_split"].get("cases", [])]
+        if "error" in a:
+            d["error"] = a["error"][:160]
+        also["abi_multi_device"] = d
+    a = cfg.get("also_C3_matern32")
+    if a:
+        also["C3_matern32"] = {"s": a["seconds_per_step"], "tflops": a["value_tflops"]}
+    a = cfg.get("also_curve")
+    if a:
+        also["reference_plot_sizes"] = [[r["solver"].split("(")[0], r["n"], r["seconds"], r["reference_plot_seconds"]] for r in a["rows"]]
+    if also:
+        line["also"] = also
+    par = out.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = {"bound": par.get("bound"), "ok": par.get("ok"),
+                          "rel": {k: v["rel"] for k, v in par.items() if isinstance(v, dict) and "rel" in v}}
+    for k in ("rccl_ranks_seen", "timeline_rank0_ms", "abi_form"):
+        if k in out:
+            line[k] = out[k]
+    if "rccl" in out:
+        line["rccl"] = {k: out["rccl"][k] for k in ("backend", "ranks_seen", "distinct_devices")}
+    if "detail" in out:
+        line["detail"] = out["detail"]
+    return _r(line)
 
 
 def golden_ll(n, kernel_name="ExpSquared"):
@@ -422,8 +614,8 @@ def hodlr_main(args, local_rank):
     emit(out)
 
 
-def emit(out):
-    """Print THE line.  RCCL writes a version banner to C stdout at communicator creation ("RCCL version : ...",
+def emit(out, detail_path=None):
+    """Write the full record to the detail file, print THE (compact) line.  RCCL writes a version banner to C stdout at communicator creation ("RCCL version : ...",
     five lines); through a pipe that stdio buffer is flushed at exit, i.e. AFTER Python's line.  Flush it first so
     that the JSON line is the last thing on stdout."""
     sys.stdout.flush()
@@ -431,7 +623,18 @@ def emit(out):
         C.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(out))
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            out["detail"] = os.path.relpath(detail_path, ROOT)
+        except OSError as e:
+            out["detail"] = "not written: %r" % (e,)
+    line = json.dumps(compact_line(out))
+    if len(line) > 6000:                                     # the driver keeps the last 8 kB of stdout
+        sys.stderr.write("bench.py: the printed line is %d bytes (> 6000)\n" % len(line))
+    print(line)
     sys.stdout.flush()
 
 
@@ -492,7 +695,13 @@ def main():
                          "torch.distributed.run, whose own parser trips over the abbreviation --n")
     ap.add_argument("--nb", type=int, default=0, help="outer panel width (0 = library default)")
     ap.add_argument("--cpu-n", type=int, default=20480, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n2", type=int, default=32768, help="size of the second, larger same-box CPU point (0 = skip; ~40 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the FULL record goes (the printed line is its < 6 kB digest); '' = nowhere")
+    ap.add_argument("--abi-timeout", type=int, default=420,
+                    help="N > 1: time limit in seconds for the second multi-GPU form (gh_mgpu_* behind the C ABI, one process) "
+                         "that rank 0 runs in a child process after the ranks have left; 0 = skip")
     ap.add_argument("--no-lookahead", action="store_true", help="single-stream factorisation (profiling aid)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary N=16384 (configs[1]) measurement")
     ap.add_argument("--workload", default="dense", choices=["dense", "hodlr"],
@@ -680,36 +889,28 @@ def main():
             p = job.profile()
             if p.n_trailing > 0 and p.ms_trailing > 0:
                 ach_syrk = p.trailing_flops / (p.ms_trailing * 1e-3) * 1e-12
+                nl = int(p.n_trailing)
+                # THE roofline object: the dominant kernel alone -- algorithmic flops of a wide lower-triangular SYRK
+                # launch / that launch's own start-to-end time (HIP events on the stream it is launched on), averaged
+                # over the timed steps.  rocprofv3's average duration of the same kernel must agree
+                # (profiles/r04/kernel_trace_N65536_*.md).
+                out["roofline"] = {
+                    "kernel": "gemm_f64_mfma_dma<k-major, k-major, lower> (trailing SYRK A22 -= L21 L21^T, one wide launch per panel)",
+                    "bound": "mfma", "achieved": ach_syrk, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach_syrk / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "launches": nl, "avg_launch_ms": p.ms_trailing / nl,
+                    "algorithmic_flops_per_launch": p.trailing_flops / nl}
                 union = getattr(p, "ms_update_union", 0.0)
                 if union > 0 and p.update_flops > 0:
-                    # The trailing update A22 -= L21 L21^T is issued as one wide lower-triangular launch per
-                    # panel on the main stream plus the block-column launch U(j, j+1) on the panel-chain
-                    # stream, and the two overlap: a wide launch's own start-to-end time then contains the
-                    # share of the chip it lent to the other.  achieved = algorithmic flops of ALL these
-                    # launches / the time during which any of them was running (union of their HIP-event
-                    # intervals, each taken on the stream the launch went to).
+                    # With the depth-1 look-ahead the block-column launch U(j, j+1) of the chain stream runs BESIDE the
+                    # wide launch and borrows part of the chip from it: flops of all update launches / the time during
+                    # which any of them ran (union of their HIP-event intervals) says what the chip delivered meanwhile.
                     ach = p.update_flops / (union * 1e-3) * 1e-12
-                    nl = int(p.n_trailing)
-                    out["roofline"] = {
-                        "kernel": "gemm_f64_mfma_dma<k-major, k-major, *> (trailing update A22 -= L21 L21^T: the wide lower-"
-                                  "triangular SYRK launches + the block-column launches that overlap them)",
-                        "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                        "busy_ms_per_step": union, "algorithmic_flops_per_step": p.update_flops,
-                        "wide_syrk_launches_alone": {
-                            "launches": nl, "avg_launch_ms": p.ms_trailing / nl,
-                            "algorithmic_flops_per_launch": p.trailing_flops / nl, "achieved": ach_syrk,
-                            "frac": ach_syrk / PEAK_FP64_MFMA_TFLOPS,
-                            "note": "start-to-end time of each wide launch, block-column launches of the chain stream "
-                                    "running beside it included"}}
-                else:
-                    out["roofline"] = {
-                        "kernel": "gemm_f64_mfma_dma<k-major, k-major, lower> (trailing SYRK update)",
-                        "bound": "mfma", "achieved": ach_syrk, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach_syrk / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                        "launches": int(p.n_trailing), "avg_launch_ms": p.ms_trailing / p.n_trailing,
-                        "algorithmic_flops_per_launch": p.trailing_flops / p.n_trailing,
-                    }
+                    out["roofline"]["with_overlapped_block_column_launches"] = {
+                        "achieved": ach, "frac": ach / PEAK_FP64_MFMA_TFLOPS, "busy_ms_per_step": union,
+                        "algorithmic_flops_per_step": p.update_flops,
+                        "note": "union of the HIP-event intervals of the wide SYRK launches and the block-column launches "
+                                "that overlap them; per-launch list: --dump-intervals"}
                 out["roofline"].update(pmc_traffic(args.n))
                 # the launches behind `achieved`, so that the union can be re-derived from the line itself (and from
                 # profiles/<round>/update_intervals_N<n>.json, written by --dump-intervals)
@@ -723,10 +924,8 @@ def main():
                         elif iv[q, 1] > hi:
                             hi = iv[q, 1]
                     tot += hi - lo
-                    out["roofline"]["launch_intervals"] = {
-                        "unit": "ms from the start of the last step's compute(); [start, end, algorithmic GFLOP] per launch",
-                        "launches": [[round(float(a), 3), round(float(b), 3), round(float(f) * 1e-9, 1)] for a, b, f in iv],
-                        "union_ms_recomputed": tot, "sum_gflop": float(iv[:, 2].sum() * 1e-9)}
+                    out["roofline"]["launch_intervals"] = {"n": int(len(iv)), "union_ms_recomputed": tot,
+                                                           "sum_gflop": float(iv[:, 2].sum() * 1e-9)}
                     if args.dump_intervals:
                         with open(args.dump_intervals, "w") as f:
                             json.dump({"n": args.n, "nb": args.nb, "ms_update_union": union, "update_flops": p.update_flops,
@@ -755,6 +954,11 @@ def main():
                                              "container (oracle/gen_golden_large.py)" % gold[1]}
             if not args.no_extra:
                 out["public_api"] = public_api_report(args.n, local_rank)
+                out["value_public_api"] = {
+                    "value": out["public_api"]["value_tflops"], "ms_per_step": out["public_api"]["seconds_per_step"] * 1e3,
+                    "rel_to_value": out["public_api"]["value_tflops"] / value,
+                    "note": "the metric as SURVEY 8(d) words it: GP.compute(x, yerr); GP.log_likelihood(y) on NumPy arrays, host->device "
+                            "of x / yerr / y and the Python facade inside; `value` itself has the inputs resident in HBM"}
                 if args.n != 16384:
                     j2 = DenseJob(16384, args.nb, local_rank, profile=False)
                     e2, ll2 = run_timed(j2, 5, 2, lambda: None)
@@ -778,6 +982,10 @@ def main():
                 except Exception as e:                               # (RCCL missing on the box: say so, keep the line)
                     out["config"]["also_abi_multi_gpu_world_of_one"] = {"error": repr(e)}
                 out["config"]["also_abi_multi_device"] = multi_device_probe()
+                try:
+                    out["config"]["also_curve"] = curve_report(local_rank)
+                except Exception as e:
+                    out["config"]["also_curve_error"] = repr(e)
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_n)
                 jp = DenseJob(args.cpu_n, args.nb, local_rank, profile=False)       # the GPU at the SAME N as the CPU sample
@@ -785,13 +993,33 @@ def main():
                 jp.close()
                 llr = out["cpu_baseline"]["log_likelihood"]
                 parity["cpu_sample"] = {"n": args.cpu_n, "ll_gpu": llp, "ll_ref": llr, "rel": abs(llp - llr) / abs(llr)}
+                if args.cpu_n2 > 0 and not args.no_extra:
+                    try:
+                        sp = cpu_baseline_second_point(args.cpu_n2, local_rank)
+                        out["cpu_baseline"]["second_point"] = sp
+                        parity["cpu_second_point"] = {"n": sp["n"], "rel": sp["rel"]}
+                    except Exception as e:
+                        out["cpu_baseline"]["second_point_error"] = repr(e)
             if parity:
                 out["parity"] = parity
                 out["parity"]["bound"] = 1e-6
                 out["parity"]["ok"] = all(v["rel"] <= 1e-6 for v in parity.values() if isinstance(v, dict))
         if world > 1:
             out["timeline_rank0_ms"] = tline                     # panel / exchange / gather chain over the timed steps
-        emit(out)
+    if world > 1:
+        # the ranks leave (and give their GPUs back) BEFORE rank 0 runs the second multi-GPU form and prints the line
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+        job = None
+        if not selftest:
+            torch.cuda.empty_cache()
+            if args.abi_timeout > 0 and not args.share_gpu:
+                out["abi_form"] = abi_form_report(args, world)
+    if rank == 0:
+        emit(out, args.detail or None)
         c5 = out.get("config", {}).get("also_C5", {})
         if c5 and (not c5.get("fused_not_slower_than_separate_calls", True) or "flop_model_error" in c5):
             sys.stderr.write("bench.py: C5 CHECK FAILED: fused objective slower than the separate calls, or a rate above "
@@ -801,10 +1029,6 @@ def main():
         if isinstance(out.get("parity"), dict) and not out["parity"].get("ok", True):
             sys.stderr.write("bench.py: PARITY FAILURE (relative log-likelihood difference above 1e-6): %r\n" % (out["parity"],))
             sys.exit(3)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -55,44 +55,7 @@ def _save(res):
         json.dump(res, f, indent=1, sort_keys=True)
 
 
-def blocked_cholesky_lower(K, nb=8192):
-    """In-place lower Cholesky of the C-contiguous symmetric K by LAPACK/BLAS calls on blocks of at most
-    n x nb elements: dpotrf on the diagonal block, dtrsm on the rows below, dgemm on the trailing
-    block columns -- LAPACK's own right-looking blocked algorithm, written out.  Used where the
-    whole-matrix ``dpotrf`` of this image's OpenBLAS cannot be (see main())."""
-    from scipy.linalg import solve_triangular
-    n = len(K)
-    for k in range(0, n, nb):
-        e = min(k + nb, n)
-        Lkk = cholesky(K[k:e, k:e], lower=True, check_finite=False)
-        K[k:e, k:e] = Lkk
-        if e < n:
-            # P <- P L_kk^-T
-            K[e:, k:e] = solve_triangular(Lkk, K[e:, k:e].T, lower=True, check_finite=False).T
-            for j in range(e, n, nb):
-                je = min(j + nb, n)
-                K[j:, j:je] -= K[j:, k:e] @ K[j:je, k:e].T
-    return K
-
-
-def blocked_solve_lower(L, b, nb=8192, trans=False):
-    from scipy.linalg import solve_triangular
-    n = len(L)
-    x = np.array(b, dtype=np.float64, copy=True)
-    starts = list(range(0, n, nb))
-    if not trans:
-        for k in starts:
-            e = min(k + nb, n)
-            x[k:e] = solve_triangular(L[k:e, k:e], x[k:e], lower=True, check_finite=False)
-            if e < n:
-                x[e:] -= L[e:, k:e] @ x[k:e]
-    else:
-        for k in reversed(starts):
-            e = min(k + nb, n)
-            x[k:e] = solve_triangular(L[k:e, k:e], x[k:e], lower=True, trans=1, check_finite=False)
-            if k > 0:
-                x[:k] -= L[k:e, :k].T @ x[k:e]
-    return x
+from oracle.solver_np import blocked_cholesky_lower, blocked_solve_lower  # noqa: E402
 
 
 def dense_case(george, kernel, x, yerr, y, want_inverse_for_grad=False, t=None, blocked=False):

@@ -80,6 +80,73 @@ class DenseOracle(object):
         return self.apply_inverse(np.eye(len(self._factor[0])), in_place=True)   # basic.py:121
 
 
+def blocked_cholesky_lower(K, nb=8192):
+    """In-place lower Cholesky of the C-contiguous symmetric K by LAPACK/BLAS calls on blocks of at most n x nb
+    elements: dpotrf on the diagonal block, dtrsm on the rows below, dgemm on the trailing block columns -- LAPACK's
+    own right-looking blocked algorithm written out, for sizes at which this image's whole-matrix ``dpotrf`` (the call
+    of basic.py:68) is unreliable (oracle/potrf_probe.py, oracle/gen_golden_large.py)."""
+    from scipy.linalg import solve_triangular
+    n = len(K)
+    for k in range(0, n, nb):
+        e = min(k + nb, n)
+        Lkk = cholesky(K[k:e, k:e], lower=True, check_finite=False)
+        K[k:e, k:e] = Lkk
+        if e < n:
+            K[e:, k:e] = solve_triangular(Lkk, K[e:, k:e].T, lower=True, check_finite=False).T
+            for j in range(e, n, nb):
+                je = min(j + nb, n)
+                K[j:, j:je] -= K[j:, k:e] @ K[j:je, k:e].T
+    return K
+
+
+def blocked_solve_lower(L, b, nb=8192, trans=False):
+    from scipy.linalg import solve_triangular
+    n = len(L)
+    x = np.array(b, dtype=np.float64, copy=True)
+    starts = list(range(0, n, nb))
+    if not trans:
+        for k in starts:
+            e = min(k + nb, n)
+            x[k:e] = solve_triangular(L[k:e, k:e], x[k:e], lower=True, check_finite=False)
+            if e < n:
+                x[e:] -= L[e:, k:e] @ x[k:e]
+    else:
+        for k in reversed(starts):
+            e = min(k + nb, n)
+            x[k:e] = solve_triangular(L[k:e, k:e], x[k:e], lower=True, trans=1, check_finite=False)
+            if k > 0:
+                x[:k] -= L[k:e, :k].T @ x[k:e]
+    return x
+
+
+class BlockedDenseOracle(DenseOracle):
+    """DenseOracle with the factorisation and the solves on ``nb``-column blocks (same LAPACK/BLAS routines)."""
+
+    def __init__(self, spec, force_port=False, nb=8192):
+        DenseOracle.__init__(self, spec, force_port)
+        self.nb = nb
+
+    def compute(self, x, yerr):
+        K = kernel_matrix(self.kernel, x, force_port=self.force_port)
+        K[np.diag_indices_from(K)] += yerr ** 2
+        self._L = blocked_cholesky_lower(K, self.nb)
+        self.log_determinant = 2 * np.sum(np.log(np.diag(self._L)))
+        self.computed = True
+
+    def apply_inverse(self, y, in_place=False):
+        return blocked_solve_lower(self._L, blocked_solve_lower(self._L, y, self.nb), self.nb, trans=True)
+
+    def dot_solve(self, y):
+        z = blocked_solve_lower(self._L, y, self.nb)
+        return float(np.dot(z.T, z))
+
+    def apply_sqrt(self, r):
+        return np.dot(r, np.triu(self._L.T))
+
+    def get_inverse(self):
+        return self.apply_inverse(np.eye(len(self._L)))
+
+
 TINY = 1.25e-12      # reference src/george/gp.py:19
 
 

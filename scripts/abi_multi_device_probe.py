@@ -37,11 +37,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dense-n", type=int, default=32768)
     ap.add_argument("--hodlr-n", type=int, nargs="*", default=[262144, 2097152])
+    ap.add_argument("--dense-kernel", default="matern32", choices=["expsquared", "matern32"])
+    ap.add_argument("--devices", type=int, default=0, help="use the first D devices (0 = all visible, at most 16)")
+    ap.add_argument("--no-hodlr", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="dense: do not time the single-GPU solver beside the sharded one")
+    ap.add_argument("--reps", type=int, default=2)
     args = ap.parse_args()
     import george_amd
     from george_amd import kernels, BasicSolver, HODLRSolver, MultiGPUSolver, MultiGPUHODLRSolver
     ndev = george_amd.device_count()
     out = {"devices_visible": ndev}
+    if args.devices > 0:
+        if ndev < args.devices:
+            out["dense_rccl"] = {"error": "%d devices asked for, %d visible" % (args.devices, ndev)}
+            print(json.dumps(out))
+            return
+        ndev = args.devices
     if ndev < 1:
         print(json.dumps(out))
         return
@@ -50,8 +61,9 @@ def main():
     while P * 2 <= min(ndev, 16):
         P *= 2
     devs = list(range(P)) if P > 1 else [0, 0]
-    out["hodlr_split"] = {"devices": devs, "virtual": P == 1, "cases": []}
-    for n in args.hodlr_n:
+    if not args.no_hodlr:
+        out["hodlr_split"] = {"devices": devs, "virtual": P == 1, "cases": []}
+    for n in ([] if args.no_hodlr else args.hodlr_n):
         try:
             x, yerr, y = inputs(n)
             kernel = float(np.var(y)) * kernels.ExpSquaredKernel(1.0)
@@ -76,20 +88,23 @@ def main():
         try:
             n = args.dense_n
             x, yerr, y = inputs(n)
-            kernel = float(np.var(y)) * kernels.Matern32Kernel(1.0)
+            K_ = kernels.Matern32Kernel if args.dense_kernel == "matern32" else kernels.ExpSquaredKernel
+            kernel = float(np.var(y)) * K_(1.0)
             X, sig = np.ascontiguousarray(x[:, None]), np.sqrt(yerr ** 2 + 1.25e-12)
-            d = BasicSolver(kernel)
             s = MultiGPUSolver(kernel, devices=list(range(min(ndev, 16))), transport="rccl")
 
             def stepd(q):
                 q.compute(X, sig)
                 return -0.5 * (n * np.log(2 * np.pi) + q.log_determinant) - 0.5 * q.dot_solve(y)
-            t1, ll1 = best_of(lambda: stepd(d), reps=2)
-            tp, llp = best_of(lambda: stepd(s), reps=2)
+            tp, llp = best_of(lambda: stepd(s), reps=args.reps)
             pr, pc, nb = s.grid_shape()
-            out["dense_rccl"] = {"n": n, "devices": min(ndev, 16), "grid": "%dx%d" % (pr, pc), "nb": nb, "single_gpu_s": t1,
-                                 "sharded_s": tp, "speedup": t1 / tp, "ll_single": ll1, "ll_sharded": llp,
-                                 "rel": abs(llp - ll1) / abs(ll1)}
+            out["dense_rccl"] = {"n": n, "kernel": args.dense_kernel, "devices": min(ndev, 16), "grid": "%dx%d" % (pr, pc), "nb": nb,
+                                 "sharded_s": tp, "ll_sharded": llp}
+            del s
+            if not args.no_single:
+                d = BasicSolver(kernel)
+                t1, ll1 = best_of(lambda: stepd(d), reps=args.reps)
+                out["dense_rccl"].update({"single_gpu_s": t1, "speedup": t1 / tp, "ll_single": ll1, "rel": abs(llp - ll1) / abs(ll1)})
         except Exception as e:
             out["dense_rccl"] = {"error": repr(e)}
     print(json.dumps(out))

@@ -36,20 +36,26 @@ def _json_lines(text):
     return out
 
 
-def test_gpus_2_launches_two_ranks_and_prints_one_line():
+def test_gpus_2_launches_two_ranks_and_prints_one_line(tmp_path):
+    detail = str(tmp_path / "detail.json")
     r = _run(["--gpus", "2", "--backend", "gloo", "--tile-ops", "numpy", "--n", "600", "--nb", "128",
-              "--steps", "1", "--warmup", "0", "--no-cpu"])
+              "--steps", "1", "--warmup", "0", "--no-cpu", "--detail", detail])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [d for d in _json_lines(r.stdout) if "metric" in d]
     assert len(lines) == 1
+    assert r.stdout.strip().splitlines()[-1].startswith("{")     # THE line is the last thing on stdout
+    assert len(r.stdout.strip().splitlines()[-1]) < 6000          # ... and fits the driver's 8 kB stdout tail
     d = lines[0]
-    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and len(d["rccl"]["members"]) == 2
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["rccl"]["ranks_seen"] == 2
     assert d["config"]["grid"] == "1x2" and d["config"]["parallelism"] == "block-cyclic-2"
     assert d["scaling"] == "strong" and d["steps"] == 1 and d["warmup"] == 0
     assert "NOT a measurement" in d["data"]
     p = d["parity"]
-    assert p["ok"] and p["headline"]["rel"] <= 1e-9 and p["ranks_agree"]["spread"] == 0.0
-    assert "also_C3_matern32" in d["config"]                 # configs[2]'s kernel on the same workspace
+    assert p["ok"] and p["rel"]["headline"] <= 1e-9 and p["rel"]["ranks_agree"] == 0.0
+    assert "C3_matern32" in d["also"]                        # configs[2]'s kernel on the same workspace
+    full = json.load(open(detail))                           # the full record behind the line
+    assert len(full["rccl"]["members"]) == 2 and full["parity"]["ranks_agree"]["spread"] == 0.0
+    assert "also_C3_matern32" in full["config"]
 
 
 def test_matern32_kernel_flag():
@@ -58,7 +64,7 @@ def test_matern32_kernel_flag():
     assert r.returncode == 0, r.stderr[-2000:]
     d = [x for x in _json_lines(r.stdout) if "metric" in x][0]
     assert d["n_gpus"] == 2 and d["config"]["kernel"] == "Matern32" and d["parity"]["ok"]
-    assert "also_C3_matern32" not in d["config"]
+    assert "C3_matern32" not in d.get("also", {})
 
 
 @pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has the GPUs: would really launch")
