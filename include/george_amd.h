@@ -267,21 +267,33 @@ int  gh_hodlr_ranks(const gh_hodlr* h, int32_t* ranks_out, int32_t max_out, int3
  * over xGMI (grouped ncclSend / ncclRecv on the communicator of ncclCommInitAll; librccl is dlopen'ed at the
  * first create).  The reference has nothing here: it is single-process, single-host (gp.py:327).  The
  * multi-PROCESS form of the same algorithm (one rank per GPU under torch.distributed; what bench.py
- * --gpus N runs) is george_amd/distributed.py.  get_inverse / apply_sqrt / predict: not offered on this
- * handle (K^-1 is N x N on the host: use gh_mgpu_solve on the columns that are needed). */
+ * --gpus N runs) is george_amd/distributed.py.  Default grid: pr = n_dev, pc = 1 -- whole tile rows per rank in
+ * "snake" order (0 1 .. P-1 P-1 .. 1 0: equal shares of the lower triangle) -- because on the xGMI full mesh
+ * the critical chain potrf(k) -> TRSM -> block column k+1 -> potrf(k+1) then moves only two nb x nb tiles per
+ * step, over all links at once (george_amd/csrc/gh_mgpu.hip; profiles/r04/scale_model.md).  The whole solver
+ * protocol is offered: the O(N^2 R) operations are left-looking tile sweeps on the sharded factor. */
 typedef struct gh_mgpu gh_mgpu;
 enum {
   GH_MGPU_RCCL = 0,      /* RCCL point-to-point over xGMI; one rank per physical device                      */
   GH_MGPU_COPY = 1       /* peer copies behind events; the same device may be listed several times ("virtual
                             devices": exercises the n_dev-rank ownership and ordering logic on one GPU)     */
 };
+enum {
+  GH_MGPU_PLAIN_CYCLIC = 1,  /* pc == 1: tile row I on rank I mod pr instead of the snake order                    */
+  GH_MGPU_CHAIN_ONLY   = 2,  /* timing aid: skip every trailing update except block column k+1 and the bulk gather
+                                -- what is left is the critical chain; results are meaningless, NOT_PD is not raised */
+  GH_MGPU_TRACE        = 4   /* record (rank, step, phase, ms, flops or bytes) of every phase: gh_mgpu_get_trace.  With
+                                GH_MGPU_COPY the compute phases of all ranks run one at a time and to completion, so
+                                that virtual devices sharing one GPU give the durations of a rank alone on its GPU  */
+};
 typedef struct gh_mgpu_opts {
   int32_t n_dev;             /* 1..16 */
   int32_t devices[16];       /* HIP device ordinals, rank i runs on devices[i] */
-  int32_t pr, pc;            /* process grid, pr * pc == n_dev; 0, 0: as square as n_dev allows (1x2, 2x2, 2x4) */
+  int32_t pr, pc;            /* process grid, pr * pc == n_dev; 0, 0: n_dev x 1 (whole tile rows per rank) */
   int32_t nb;                /* tile edge, multiple of 128; 0: 1024 from N = 24576 up, else 512 */
   int32_t transport;         /* GH_MGPU_RCCL | GH_MGPU_COPY */
-  int32_t reserved[4];
+  int32_t flags;             /* GH_MGPU_PLAIN_CYCLIC | GH_MGPU_CHAIN_ONLY | GH_MGPU_TRACE */
+  int32_t reserved[3];
 } gh_mgpu_opts;
 int  gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out);      /* communicators + an all-reduce self-check */
 void gh_mgpu_destroy(gh_mgpu* h);
@@ -291,8 +303,21 @@ int  gh_mgpu_compute(gh_mgpu* h, gh_kernel* k, const double* x, int64_t n, int32
                      const double* yerr, double* logdet_out);
 int64_t gh_mgpu_info(const gh_mgpu* h);
 int  gh_mgpu_grid(const gh_mgpu* h, int32_t* pr, int32_t* pc, int32_t* nb);
+int  gh_mgpu_owner(const gh_mgpu* h, int64_t tile_row, int64_t tile_col);              /* rank that holds tile (I, J); -1 on bad arguments */
+/* all of the following take HOST pointers; every right-hand side of a call is swept together (chunks of 2048 columns) */
 int  gh_mgpu_dot_solve(gh_mgpu* h, const double* y, double* out);                     /* basic.py:89-102 */
 int  gh_mgpu_solve(gh_mgpu* h, const double* b, int64_t nrhs, double* out);           /* basic.py:72-87; (n, nrhs) row-major, may alias */
+int  gh_mgpu_apply_sqrt(gh_mgpu* h, const double* r, int64_t nrows, double* out);     /* basic.py:104-114; r, out: (nrows, n) */
+int  gh_mgpu_get_inverse(gh_mgpu* h, double* out /* n*n */);                          /* basic.py:116-121 */
+/* gp.py:482-545 on the sharded factor (forward sweep only: K* K^-1 K*^T = V^T V with V = L^-1 K(x, xs));
+ * var / cov may be NULL; cov is offered for m <= 2048 */
+int  gh_mgpu_predict(gh_mgpu* h, gh_kernel* k, const double* r /* n: y - mean */, const double* xs, int64_t m,
+                     double* mu /* m */, double* var /* m or NULL */, double* cov /* m*m or NULL */);
+/* GH_MGPU_TRACE: rows of 5 doubles (rank, step k, phase, milliseconds, flops or bytes) of the last compute();
+ * phases: 0 potrf, 1 column TRSM (+ pack), 2 update of block column k+1, 3 the rest of the trailing update,
+ * 4 L_kk transfer, 5 row-panel transfer, 6 panel tile k+1 sent ahead, 7 column-panel gather.  *n_rows = rows
+ * recorded (out may be NULL to ask for the count). */
+int  gh_mgpu_get_trace(const gh_mgpu* h, double* out, int64_t max_rows, int64_t* n_rows);
 
 /* --------------------------------------------------- HODLR solver, tree split over several GPUs
  * hodlr::Node (include/george/hodlr.h:29-254) with the top log2(n_dev) levels of the tree shared and the
