@@ -697,6 +697,8 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=20480, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-n2", type=int, default=32768, help="size of the second, larger same-box CPU point (0 = skip; ~40 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--grid", default="", help="N > 1: process grid PrxPc (default: N x 1, whole tile rows per rank in snake order; "
+                    "'square' = 1x2 / 2x2 / 2x4)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="where the FULL record goes (the printed line is its < 6 kB digest); '' = nowhere")
     ap.add_argument("--abi-timeout", type=int, default=420,
@@ -777,7 +779,8 @@ def main():
             from np_tile_ops import NumpyTileOps
             amp = float(np.var(make_inputs(args.n)[2]))
             ops = NumpyTileOps(make_kernel(args.kernel, amp))
-        job = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs, kernel=make_kernel, kernel_name=args.kernel, ops=ops)
+        job = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs, kernel=make_kernel, kernel_name=args.kernel, ops=ops,
+                                  grid=args.grid or None)
         barrier = dist.barrier
     else:
         job = DenseJob(args.n, args.nb, local_rank, profile=True, lookahead=not args.no_lookahead, kernel=args.kernel)
@@ -912,6 +915,15 @@ def main():
                         "note": "union of the HIP-event intervals of the wide SYRK launches and the block-column launches "
                                 "that overlap them; per-launch list: --dump-intervals"}
                 out["roofline"].update(pmc_traffic(args.n))
+                try:                                         # the measured instruction ceiling (include/george_amd_debug.h), after the timed region
+                    mo = (C.c_double * 8)()
+                    job.N.check(job.N.lib.gh_microbench_mfma_f64_ceiling(mo, 8))
+                    out["roofline"]["peak_measured"] = float(mo[3])
+                    out["roofline"]["frac_of_measured"] = ach_syrk / float(mo[3])
+                    out["roofline"]["peak_measured_note"] = ("bare v_mfma_f64_16x16x4_f64 issue loop, 64x more workgroups than slots, "
+                                                             "%.1f / %.1f / %.1f TFLOP/s at 1 / 2 / 4 wavefronts per SIMD" % (mo[0], mo[1], mo[2]))
+                except Exception as e:
+                    out["roofline"]["peak_measured_error"] = repr(e)
                 # the launches behind `achieved`, so that the union can be re-derived from the line itself (and from
                 # profiles/<round>/update_intervals_N<n>.json, written by --dump-intervals)
                 iv = job.update_intervals()

@@ -52,7 +52,7 @@ class gh_hodlr_opts(C.Structure):
 
 class gh_mgpu_opts(C.Structure):
     _fields_ = [("n_dev", C.c_int32), ("devices", C.c_int32 * 16), ("pr", C.c_int32), ("pc", C.c_int32),
-                ("nb", C.c_int32), ("transport", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("nb", C.c_int32), ("transport", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class gh_hodlr_mgpu_opts(C.Structure):
@@ -61,6 +61,7 @@ class gh_hodlr_mgpu_opts(C.Structure):
 
 
 GH_MGPU_RCCL, GH_MGPU_COPY = 0, 1
+GH_MGPU_PLAIN_CYCLIC, GH_MGPU_CHAIN_ONLY, GH_MGPU_TRACE = 1, 2, 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -105,6 +106,7 @@ SIGNATURES = {
     "gh_debug_stream_overlap": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_debug_stream_dispatch": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_microbench_suite": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "gh_microbench_mfma_f64_ceiling": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "gh_kernel_create": (C.c_int, [C.POINTER(gh_knode), C.c_int, C.POINTER(_vp)]),
     "gh_kernel_destroy": (None, [_vp]),
     "gh_kernel_ndim": (C.c_int, [_vp]),
@@ -152,6 +154,11 @@ SIGNATURES = {
     "gh_mgpu_grid": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gh_mgpu_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "gh_mgpu_solve": (C.c_int, [_vp, _dp, _i64, _dp]),
+    "gh_mgpu_owner": (C.c_int, [_vp, _i64, _i64]),
+    "gh_mgpu_apply_sqrt": (C.c_int, [_vp, _dp, _i64, _dp]),
+    "gh_mgpu_get_inverse": (C.c_int, [_vp, _dp]),
+    "gh_mgpu_predict": (C.c_int, [_vp, _vp, _dp, _dp, _i64, _dp, _dp, _dp]),
+    "gh_mgpu_get_trace": (C.c_int, [_vp, _dp, _i64, C.POINTER(C.c_int64)]),
     "gh_hodlr_mgpu_create": (C.c_int, [C.POINTER(gh_hodlr_mgpu_opts), C.POINTER(_vp)]),
     "gh_hodlr_mgpu_destroy": (None, [_vp]),
     "gh_hodlr_mgpu_compute": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, C.POINTER(C.c_double)]),

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include "gh_common.h"
+#include "../../include/george_amd_debug.h"
 
 #define T 128                 // tile edge
 #define LP 129                // LDS row pitch of the potf2 tile (odd -> conflict-free columns)

@@ -18,7 +18,9 @@
 // gemm_f64_valu is a plain-VALU kernel with the same semantics that cross-checks the MFMA lane maps
 // on the device (GEORGE_AMD_MFMA_MODE=0 / gh_debug_set_mfma(0)).
 #include <stdlib.h>
+#include <algorithm>
 #include "gh_common.h"
+#include "../../include/george_amd_debug.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -918,6 +920,74 @@ extern "C" int gh_microbench_suite(double* out, int n) {
   GH_CHECK(run_rate<1>(2048, iters * 4, 8 * 128.0, &tf, &cyc, &ghz, 8)); out[10] = tf;
   // f64 MFMA 4x4x4 (4 blocks): 4*4*4*4*2 = 512 flop per instruction
   GH_CHECK(run_rate<2>(512, iters, 4 * 512.0, &tf, &cyc, &ghz, 4)); out[11] = tf; out[12] = cyc;
+  return GH_OK;
+}
+
+// ---- the fp64 matrix-pipe CEILING (SURVEY 8d's second roofline denominator) ------------------------------------------
+// A bare v_mfma_f64_16x16x4_f64 issue loop that is limited by the pipe and nothing else.  The suite above launches as many
+// workgroups as the chip has slots for (256 / 512 / 1024 on 256 CUs) and reads 34-47 TFLOP/s -- BELOW what the GEMM kernel
+// sustains -- because the dispatcher does not deal a grid of exactly that size evenly: some CUs get one workgroup more, others
+// one less, and the launch lasts as long as the fullest CU (2:1 at one workgroup per CU = 39 of 78.6; 3:2 at two = 52).  It was
+// never an instruction ceiling.  Here: (i) 64x more workgroups than slots, each short, so that the dispatcher's greedy
+// refill evens the load out exactly as it does for a GEMM grid; (ii) the number of resident wavefronts per SIMD is pinned by a
+// dynamic LDS request (96 KiB -> one 4-wavefront workgroup per CU = 1 wavefront per SIMD, 64 KiB -> 2, 40 KiB -> 4 -- 160 KiB per
+// CU); (iii) 8 independent accumulators, no other vector instruction in the loop.  One instruction occupies a SIMD's pipe for 64
+// cycles (scripts/dev/valu_probe.hip), so the ceiling is 256 CU x 4 SIMD x 2048 flop / 64 cycles x the clock the chip holds
+// under that load -- which is what this measures.
+extern __shared__ double mfma_ceiling_lds[];
+__global__ __launch_bounds__(256) void mfma_f64_ceiling_kernel(double* out, int iters) {
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9, a2 = a + 0.5, b2 = b - 0.5;
+  v4d m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0, m6 = m0, m7 = m0;
+  for (int i = 0; i < iters; ++i) {
+    m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, m0, 0, 0, 0);
+    m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, m1, 0, 0, 0);
+    m2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, m2, 0, 0, 0);
+    m3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, m3, 0, 0, 0);
+    m4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, m4, 0, 0, 0);
+    m5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, m5, 0, 0, 0);
+    m6 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, m6, 0, 0, 0);
+    m7 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, m7, 0, 0, 0);
+  }
+  const v4d s = m0 + m1 + m2 + m3 + m4 + m5 + m6 + m7;
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678) { out[0] = s[0]; mfma_ceiling_lds[threadIdx.x] = s[1]; }   // keep the chain (and the LDS) live
+}
+// out[0..2] = TFLOP/s at 1 / 2 / 4 resident wavefronts per SIMD, out[3] = the best of them, out[4..6] = milliseconds (n >= 8)
+extern "C" int gh_microbench_mfma_f64_ceiling(double* out, int n) {
+  if (gh_device_count() <= 0) { gh_set_error("no HIP device"); return GH_ERR_HIP; }
+  if (!out || n < 8) { gh_set_error("need room for 8 doubles"); return GH_ERR_BAD_ARG; }
+  double* d = nullptr;
+  GH_HIP(hipMalloc((void**)&d, 64));
+  GH_HIP(hipFuncSetAttribute((const void*)mfma_f64_ceiling_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  hipEvent_t e0, e1;
+  GH_HIP(hipEventCreate(&e0)); GH_HIP(hipEventCreate(&e1));
+  hipDeviceProp_t prop;
+  GH_HIP(hipGetDeviceProperties(&prop, 0));
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  GH_HIP(hipGetDeviceProperties(&prop, dev));
+  const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const int lds[3] = {96 * 1024, 64 * 1024, 40 * 1024}, per_cu[3] = {1, 2, 4};
+  out[3] = 0.0;
+  for (int v = 0; v < 3; ++v) {
+    const int iters = 600, blocks = ncu * per_cu[v] * 64;
+    hipLaunchKernelGGL(mfma_f64_ceiling_kernel, dim3(ncu * per_cu[v]), dim3(256), lds[v], 0, d, 50);
+    GH_HIP(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      GH_HIP(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(mfma_f64_ceiling_kernel, dim3(blocks), dim3(256), lds[v], 0, d, iters);
+      GH_HIP(hipEventRecord(e1, 0));
+      GH_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      GH_HIP(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, ms);
+    }
+    GH_HIP(hipGetLastError());
+    out[v] = (double)blocks * 4.0 * iters * 8.0 * 2048.0 / (best * 1e-3) * 1e-12;
+    out[4 + v] = best;
+    out[3] = std::max(out[3], out[v]);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
   return GH_OK;
 }
 

@@ -133,7 +133,7 @@ struct MRank {
 };
 }  // namespace
 
-enum { MG_PH_POTRF = 0, MG_PH_TRSM = 1, MG_PH_BCOL = 2, MG_PH_REST = 3, MG_PH_LKK = 4, MG_PH_ROWX = 5, MG_PH_AHEAD = 6, MG_PH_GATHER = 7 };
+enum { MG_PH_POTRF = 0, MG_PH_TRSM = 1, MG_PH_BCOL = 2, MG_PH_REST = 3, MG_PH_LKK = 4, MG_PH_ROWX = 5, MG_PH_AHEAD = 6, MG_PH_GATHER = 7, MG_PH_BUILD = 8 };
 
 struct gh_mgpu {
   gh_mgpu_opts opts;
@@ -391,7 +391,7 @@ int rank_factor(gh_mgpu* h, MRank& r) {
   // rank on the same physical device ("virtual devices") the durations are then those of a rank alone on its GPU.
   auto phase = [&](int step, int ph, hipStream_t s, double units, auto&& body) -> int {
     if (!tracing) return body();
-    const bool compute = ph <= MG_PH_REST && h->opts.transport == GH_MGPU_COPY;   // (RCCL: a rank inside the turnstile may wait for a send its peer has not issued)
+    const bool compute = (ph <= MG_PH_REST || ph == MG_PH_BUILD) && h->opts.transport == GH_MGPU_COPY;   // (RCCL: a rank inside the turnstile may wait for a send its peer has not issued)
     std::unique_lock<std::mutex> lk(h->turn, std::defer_lock);
     if (compute) lk.lock();
     hipEvent_t a = r.next_ev(), b = r.next_ev();
@@ -404,11 +404,18 @@ int rank_factor(gh_mgpu* h, MRank& r) {
     return GH_OK;
   };
   // ---- build: every rank evaluates its own tiles (lower tile triangle only)
-  for (int i : r.rows)
-    for (int j : r.cols)
-      if (j <= i)
-        GH_CHECK(gh_dev_kmat_block(&r.kern, r.x.d(), h->n, (int32_t)h->ndim, r.yerr.d(), (int64_t)i * nb, nb, (int64_t)j * nb, nb,
-                                   tile(i, j), ld, r.st));
+  {
+    double bytes = 0.0;
+    for (int i : r.rows) for (int j : r.cols) if (j <= i) bytes += 8.0 * (double)nb * nb;
+    GH_CHECK(phase(-1, MG_PH_BUILD, r.st, bytes, [&]() -> int {
+      for (int i : r.rows)
+        for (int j : r.cols)
+          if (j <= i)
+            GH_CHECK(gh_dev_kmat_block(&r.kern, r.x.d(), h->n, (int32_t)h->ndim, r.yerr.d(), (int64_t)i * nb, nb, (int64_t)j * nb, nb,
+                                       tile(i, j), ld, r.st));
+      return GH_OK;
+    }));
+  }
   // P(k), chain part, on stream sp into workspace `buf`: ends with "row panel + panel tile k+1 are here" (ev_fast[buf])
   auto panel = [&](int k, int buf) -> int {
     hipStream_t sp = r.sp;

@@ -1,9 +1,18 @@
 """Dense GP solve sharded over several MI355X: 2-D block-cyclic Cholesky, one process per GPU.
 
 The N x N covariance matrix is cut into NB x NB tiles; tile (I, J) lives on the rank at position
-(I mod Pr, J mod Pc) of a Pr x Pc process grid (1x1, 1x2, 2x2, 2x4 for 1/2/4/8 GPUs).  Every rank
-BUILDS its own tiles on its own GPU from (kernel, x) -- nothing is scattered -- and the factorisation
-proceeds right-looking, one tile column per step:
+(prow(I), J mod Pc) of a Pr x Pc process grid.  DEFAULT GRID: Pr = world, Pc = 1 -- whole tile rows per
+rank, dealt in "snake" order (prow(I) = I mod 2Pr folded back: 0 1 .. Pr-1 Pr-1 .. 1 0), so that every rank
+holds the same share of the lower triangle.  On the xGMI full mesh every pair of GPUs has a link of its
+own, and what bounds a step is the CHAIN potrf(k) -> L_kk to the others -> TRSM -> what block column k+1
+needs -> potrf(k+1): with whole tile rows per rank only two NB x NB tiles travel on that chain, the TRSM
+and the block-column update are split over ALL ranks, and the bulk of the panel (the all-gather every
+rank's trailing update needs) moves beside it on a communicator and a stream of its own.  A 2 x 4 grid
+puts (N - k NB) / 2 x NB doubles of row panel on one link inside the chain at every step
+(profiles/r04/scale_model.md prices both).  `grid=(Pr, Pc)` / GEORGE_AMD_DIST_GRID=PrxPc select any other
+grid (then prow(I) = I mod Pr: plain 2-D block-cyclic).  Every rank BUILDS its own tiles on its own GPU
+from (kernel, x) -- nothing is scattered -- and the factorisation proceeds right-looking, one tile column
+per step:
 
   P(k) "panel"   1. the owner of the diagonal tile factors it (gh_dev_potrf_block) and broadcasts
                     L_kk and its diagonal-block inverses down its process column;
@@ -14,8 +23,9 @@ proceeds right-looking, one tile column per step:
                     every process column of the tiles that column needs transposed ("column panel");
   U(k) "update"  4. every rank updates its own trailing tiles with fp64-MFMA GEMMs (gh_dev_gemm).
 
-With look-ahead (default on GPUs) U(k) is split: the tiles of block column k+1 first, then P(k+1)
-is issued on a second HIP stream -- its kernels AND its collectives -- while the rest of U(k) runs
+With look-ahead (default on GPUs) U(k) is split: the tiles of block column k+1 first, then the chain of
+P(k+1) is issued on a second (high-priority) HIP stream -- its kernels AND its collectives -- and the
+column-panel all-gather on a third stream with a communicator of its own, while the rest of U(k) runs
 on the main stream; panel workspaces are double-buffered.  Collectives are torch.distributed
 (backend "nccl" == RCCL over xGMI on the GPUs; "gloo" in the CPU tests): a broadcast to the 1-3
 peers of a row/column is a direct-link transfer on the xGMI mesh.  log|K| and the failure flag need
@@ -73,7 +83,10 @@ def _grid_groups(dist, world, Pr, Pc):
     if hit is None:
         rows = [_new_group(dist, [r * Pc + c for c in range(Pc)]) for r in range(Pr)]
         cols = [_new_group(dist, [r * Pc + c for r in range(Pr)]) for c in range(Pc)]
-        hit = _GROUP_CACHE[key] = {"rows": rows, "cols": cols, "a2a": None}
+        # a second communicator per process column for the bulk all-gather of the column panel: a collective in flight
+        # on the first one would hold up the next chain transfer (one communicator = one in-order queue)
+        bulk = [_new_group(dist, [r * Pc + c for r in range(Pr)]) for c in range(Pc)] if Pr > 1 else [None] * Pc
+        hit = _GROUP_CACHE[key] = {"rows": rows, "cols": cols, "bulk": bulk, "a2a": None}
     return hit
 
 
@@ -102,12 +115,25 @@ _CHOL_CACHE = {}          # (n, nb, world, rank, device, lookahead, group) -> [p
 _CHOL_CACHE_MAX = 2       # parked workspaces in total
 
 
-def grid_shape(world):
-    """Pr x Pc with Pr <= Pc, as square as the world size allows."""
-    pr = int(math.isqrt(world))
-    while world % pr:
-        pr -= 1
-    return pr, world // pr
+def grid_shape(world, grid=None):
+    """(Pr, Pc): `grid` if given, else GEORGE_AMD_DIST_GRID=PrxPc, else world x 1 (whole tile rows per rank: the
+    module docstring says why); "square" asks for the grid a switched network would want (Pr <= Pc, as square as
+    the world size allows: 1x2, 2x2, 2x4)."""
+    if grid is None:
+        grid = os.environ.get("GEORGE_AMD_DIST_GRID") or None
+    if grid is None:
+        return world, 1
+    if isinstance(grid, str):
+        if grid == "square":
+            pr = int(math.isqrt(world))
+            while world % pr:
+                pr -= 1
+            return pr, world // pr
+        grid = tuple(int(v) for v in grid.lower().split("x"))
+    pr, pc = int(grid[0]), int(grid[1])
+    if pr < 1 or pc < 1 or pr * pc != world:
+        raise ValueError("grid %dx%d does not hold %d ranks" % (pr, pc, world))
+    return pr, pc
 
 
 class HipTileOps(object):
@@ -210,6 +236,9 @@ class HipTileOps(object):
         lo, hi = self.torch.cuda.Stream.priority_range()
         return self.torch.cuda.Stream(device=self.device, priority=hi)
 
+    def make_bulk_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
     def main_stream(self):
         return self.torch.cuda.current_stream(self.device)
 
@@ -234,21 +263,25 @@ class HipTileOps(object):
 
 class BlockCyclicCholesky(object):
 
-    def __init__(self, ops, n, nb=512, rank=None, world=None, lookahead=None):
+    def __init__(self, ops, n, nb=512, rank=None, world=None, lookahead=None, grid=None, snake=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.ops = torch, dist, ops
         self.live = dist.is_available() and dist.is_initialized()
         self.world = world if world is not None else (dist.get_world_size() if self.live else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if self.live else 0)
-        self.Pr, self.Pc = grid_shape(self.world)
+        self.Pr, self.Pc = grid_shape(self.world, grid)
         self.pr, self.pc = divmod(self.rank, self.Pc)
+        if snake is None:
+            snake = os.environ.get("GEORGE_AMD_DIST_SNAKE", "1") != "0"
+        self.snake = bool(snake) and self.Pc == 1 and self.Pr > 1
+        self.chain_only = os.environ.get("GEORGE_AMD_DIST_CHAIN_ONLY", "0") == "1"       # timing aid: no trailing update but block column k+1
         if nb % 128:
             raise ValueError("nb must be a multiple of 128")
         self.n, self.nb = int(n), int(nb)
         self.nt = -(-self.n // self.nb)
-        self.rows = [i for i in range(self.nt) if i % self.Pr == self.pr]
-        self.cols = [j for j in range(self.nt) if j % self.Pc == self.pc]
+        self.rows = [i for i in range(self.nt) if self.prow(i) == self.pr]
+        self.cols = [j for j in range(self.nt) if self.pcol(j) == self.pc]
         self.lrow = {i: li for li, i in enumerate(self.rows)}
         self.lcol = {j: lj for lj, j in enumerate(self.cols)}
         if lookahead is None:
@@ -259,7 +292,7 @@ class BlockCyclicCholesky(object):
         self.dinv = ops.zeros(self.nt, nbk // 128, 128, 128)        # inverses of the 128-blocks of every L_kk I see
         self.Lkk = ops.zeros(nbk, nbk)
         # panel workspaces, double-buffered for the look-ahead pipeline
-        cmax0 = max([len([j for j in range(1, self.nt) if j % self.Pc == self.pc and j % self.Pr == mm])
+        cmax0 = max([len([j for j in range(1, self.nt) if self.pcol(j) == self.pc and self.prow(j) == mm])
                      for mm in range(self.Pr)] + [1])
         # (padded so that a row panel splits into `world` equal chunks for the all-links exchange)
         self._ws_row_flat = [ops.zeros(-(-(nlr * nbk * nbk) // self.world) * self.world) for _ in range(2)]
@@ -284,13 +317,23 @@ class BlockCyclicCholesky(object):
         self._upd = []                # (event before, event after, flops launched) per _update call
         self._tl = []                 # (step, [events: start, panel factored, row panel here, column panel here])
         # sub-communicators (created once per process group, _grid_groups)
-        self.row_groups, self.col_groups = [None] * self.Pr, [None] * self.Pc
+        self.row_groups, self.col_groups, self.bulk_groups = [None] * self.Pr, [None] * self.Pc, [None] * self.Pc
         if groups is not None:
-            self.row_groups, self.col_groups = groups["rows"], groups["cols"]
+            self.row_groups, self.col_groups, self.bulk_groups = groups["rows"], groups["cols"], groups["bulk"]
 
     # -- helpers ---------------------------------------------------------------------------------
     def grank(self, pr, pc):
         return pr * self.Pc + pc
+
+    def prow(self, i):
+        """process row of global tile row i (snake order when whole tile rows are dealt: equal lower-triangle shares)"""
+        if not self.snake:
+            return i % self.Pr
+        t = i % (2 * self.Pr)
+        return t if t < self.Pr else 2 * self.Pr - 1 - t
+
+    def pcol(self, j):
+        return j % self.Pc
 
     def tile(self, i, j):
         nb = self.nb
@@ -348,8 +391,8 @@ class BlockCyclicCholesky(object):
         Both are one all_to_all_single on the world group (uneven splits, zeros where nothing
         moves); every link then carries S_r / world per phase instead of S_r."""
         W, Pr, Pc, nb = self.world, self.Pr, self.Pc, self.nb
-        kc = k % Pc
-        cnt = [len([i for i in range(k + 1, self.nt) if i % Pr == r]) for r in range(Pr)]
+        kc = self.pcol(k)
+        cnt = [len([i for i in range(k + 1, self.nt) if self.prow(i) == r]) for r in range(Pr)]
         chunk = [-(-(c * nb * nb) // W) for c in cnt]                      # doubles per chunk, per process row
         if max(chunk) == 0:
             return
@@ -379,12 +422,12 @@ class BlockCyclicCholesky(object):
             out2, dst2 = [chunk[my_r]] * W, mine[:chunk[my_r] * W]
         self.dist.all_to_all_single(dst2, fwd, output_split_sizes=out2, input_split_sizes=in2)
 
-    # -- P(k): factor panel k and distribute it; returns (li0, wrow, {j: P_j}) -----------------------
+    # -- P(k), chain part: factor panel k, move what block column k+1 needs; returns the panel state ---------------
     def _panel(self, k, buf, mark=None):
         nb, nt, Pr, Pc, pr, pc = self.nb, self.nt, self.Pr, self.Pc, self.pr, self.pc
         ops = self.ops
         nloc_r = len(self.rows)
-        kr, kc = k % Pr, k % Pc
+        kr, kc = self.prow(k), self.pcol(k)
         in_col = (pc == kc)
         timed = self.profile and getattr(ops, "has_streams", False)
         tl = [ops.event(ops.main_stream(), timing=True)] if timed else None
@@ -415,11 +458,11 @@ class BlockCyclicCholesky(object):
         # The next panel only waits for block column k+1, whose update needs ONE tile of the column
         # panel, P_{k+1}: send that one ahead (a tile to the Pr - 1 column peers of the process
         # column that owns block column k+1) and let `mark` record "enough for block column k+1";
-        # the gather of all the other tiles then runs while that block column is updated.
+        # the gather of all the other tiles (_gather) then runs beside that update and the next chain.
         pj_fast = {}
-        if pc == (k + 1) % Pc:
+        if pc == self.pcol(k + 1):
             nxt = self.ws_next[buf]
-            src_pr = (k + 1) % Pr
+            src_pr = self.prow(k + 1)
             if pr == src_pr:
                 s0 = (self.lrow[k + 1] - li0) * nb
                 nxt.copy_(wrow[s0:s0 + nb])
@@ -430,36 +473,45 @@ class BlockCyclicCholesky(object):
             tl.append(ops.event(ops.main_stream(), timing=True))       # row panel + tile k+1 have travelled
         if mark is not None:
             mark()
-        # column panel: tiles P_j, j > k, j % Pc == pc, gathered inside my process column
-        mine = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == pr]
-        cnt = [len([j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]) for mm in range(Pr)]
-        cmax = max(cnt) if cnt else 0
+        return [li0, wrow, None, pj_fast, k, buf, tl]
+
+    # -- P(k), bulk part: the column panel -- tiles P_j, j > k + 1, pcol(j) == pc -- gathered inside my process column
+    def _gather(self, panel):
+        if panel is None:
+            return
+        li0, wrow, _, _, k, buf, tl = panel
+        nb, nt, Pr, pr, pc = self.nb, self.nt, self.Pr, self.pr, self.pc
+        ops = self.ops
         pj = {}
-        if cmax > 0:
+        first = k + 2                                   # (block column k+1 is served by the tile that travelled ahead)
+        mine = [j for j in range(first, nt) if self.pcol(j) == pc and self.prow(j) == pr]
+        cnt = [len([j for j in range(first, nt) if self.pcol(j) == pc and self.prow(j) == mm]) for mm in range(Pr)]
+        cmax = max(cnt) if cnt else 0
+        if cmax > 0 and not self.chain_only:
             send = self.ws_send[buf][:cmax]
             for t, j in enumerate(mine):
                 s = (self.lrow[j] - li0) * nb
                 send[t].copy_(wrow[s:s + nb])
             if Pr > 1 and self.live:
                 gathered = [g[:cmax] for g in self.ws_gath[buf]]
-                self.dist.all_gather(gathered, send, group=self.col_groups[pc])
+                self.dist.all_gather(gathered, send, group=self.bulk_groups[pc])
             else:
                 gathered = [send]
             for mm in range(Pr):
-                js = [j for j in range(k + 1, nt) if j % Pc == pc and j % Pr == mm]
+                js = [j for j in range(first, nt) if self.pcol(j) == pc and self.prow(j) == mm]
                 for t, j in enumerate(js):
                     pj[j] = gathered[mm][t]
-        if timed:
+        panel[2] = pj
+        if tl is not None:
             tl.append(ops.event(ops.main_stream(), timing=True))       # column panel gathered
             self._tl.append((k, tl))
-        return li0, wrow, pj, pj_fast
 
     # -- U(k) restricted to the given global tile columns ---------------------------------------------
     def _update(self, panel, cols, fast=False):
         """fast: `cols` is block column k+1 alone, served by the tile that travelled ahead."""
         if panel is None:
             return
-        li0, wrow, pj_full, pj_fast = panel
+        li0, wrow, pj_full, pj_fast = panel[:4]
         pj = pj_fast if fast else pj_full
         nb, nloc_r = self.nb, len(self.rows)
         todo = []
@@ -509,35 +561,47 @@ class BlockCyclicCholesky(object):
         if not self.lookahead:
             for k in range(nt):
                 panel = self._panel(k, 0)
-                self._update(panel, [j for j in self.cols if j > k])
+                self._gather(panel)
+                self._update(panel, [j for j in self.cols if j == k + 1], fast=True)
+                if not self.chain_only:
+                    self._update(panel, [j for j in self.cols if j > k + 1])
         else:
+            # three streams: s_side (high priority) the chain of P(k+1), s_bulk the column-panel gather, s_main the updates
             s_main, s_side = ops.main_stream(), ops.make_side_stream()
+            s_bulk = ops.make_bulk_stream() if hasattr(ops, "make_bulk_stream") else s_side
             ops.wait(s_side, ops.event(s_main))                    # the build is complete
             ev = {}
 
             def mark():
                 ev["fast"] = ops.event(s_side)
 
-            with ops.on(s_side):
-                panel = self._panel(0, 0, mark)
-                done = ops.event(s_side)
+            def chain_and_gather(k, buf):
+                with ops.on(s_side):
+                    p = self._panel(k, buf, mark)
+                fast_k = ev.get("fast")
+                if p is None:
+                    return p, ops.event(s_side), ops.event(s_side)
+                ops.wait(s_bulk, fast_k)
+                with ops.on(s_bulk):
+                    self._gather(p)
+                    gath = ops.event(s_bulk)
+                return p, fast_k, gath
+
+            panel, fast, gath = chain_and_gather(0, 0)
             for k in range(nt):
-                fast = ev.get("fast")
-                if k == nt - 1 or fast is None:
-                    ops.wait(s_main, done)                         # (the last panel is a diagonal tile only)
-                    if k == nt - 1:
-                        break
-                else:
-                    ops.wait(s_main, fast)                         # row panel + tile k+1 of the column panel are here
+                ops.wait(s_main, fast)                             # row panel + tile k+1 of the column panel are here
+                if k == nt - 1:
+                    break
                 self._update(panel, [j for j in self.cols if j == k + 1], fast=True)      # block column k+1 first
                 ops.wait(s_side, ops.event(s_main))
-                done_k = done
-                with ops.on(s_side):
-                    nxt = self._panel(k + 1, (k + 1) % 2, mark)
-                    done = ops.event(s_side)
-                ops.wait(s_main, done_k)                           # the whole column panel of step k
-                self._update(panel, [j for j in self.cols if j > k + 1])       # the rest, under P(k+1)
+                gath_k = gath
+                nxt, fast, gath = chain_and_gather(k + 1, (k + 1) % 2)
+                ops.wait(s_main, gath_k)                           # the whole column panel of step k
+                if not self.chain_only:
+                    self._update(panel, [j for j in self.cols if j > k + 1])       # the rest, under P(k+1)
                 panel = nxt
+            ops.wait(s_main, ops.event(s_side))
+            ops.wait(s_main, ops.event(s_bulk))
         # scalars: log-det and failure flag
         tot = self.logdet_dev.clone()
         info = self.info.clone()
@@ -547,6 +611,10 @@ class BlockCyclicCholesky(object):
             self.dist.all_reduce(big, op=self.dist.ReduceOp.MIN)
             info = self.torch.where(big == 2 ** 62, self.torch.zeros_like(big), big)
         bad = int(info.item())
+        if self.chain_only:                                        # (a timing run: the numbers mean nothing)
+            self.log_determinant = float(tot.item())
+            self.computed = False
+            return
         if bad != 0:
             raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % bad)
         self.log_determinant = float(tot.item())
@@ -563,7 +631,7 @@ class BlockCyclicCholesky(object):
         zk = ops.zeros(nb)
         acc = ops.zeros(1)
         for k in range(nt):
-            kr, kc = k % Pr, k % Pc
+            kr, kc = self.prow(k), self.pcol(k)
             if pr == kr:
                 cend = len([j for j in self.cols if j < k])
                 lk = self.lrow[k]
@@ -629,7 +697,7 @@ class BlockCyclicCholesky(object):
         part = ops.zeros(nb, rp)
         if forward:
             for k in range(nt):
-                kr, kc = k % Pr, k % Pc
+                kr, kc = self.prow(k), self.pcol(k)
                 owner = self.grank(kr, kc)
                 xk = X[k * nb:(k + 1) * nb]
                 if pr == kr:
@@ -648,7 +716,7 @@ class BlockCyclicCholesky(object):
                     self.dist.broadcast(xk, src=owner)
         if backward:
             for k in range(nt - 1, -1, -1):
-                kr, kc = k % Pr, k % Pc
+                kr, kc = self.prow(k), self.pcol(k)
                 owner = self.grank(kr, kc)
                 xk = X[k * nb:(k + 1) * nb]
                 if pc == kc:
@@ -676,7 +744,7 @@ class BlockCyclicCholesky(object):
         out = ops.zeros(*Rt.shape)
         part = ops.zeros(nb, Rt.shape[1])
         for k in range(nt):
-            kr, kc = k % Pr, k % Pc
+            kr, kc = self.prow(k), self.pcol(k)
             owner = self.grank(kr, kc)
             if pr == kr:
                 part.zero_()
@@ -709,8 +777,9 @@ class DistributedBasicSolver(object):
     makes a new solver at every optimiser evaluation -- and sub-communicators are created once per
     process group."""
 
-    def __init__(self, kernel, nb=512, device=None, ops=None, lookahead=None):
+    def __init__(self, kernel, nb=512, device=None, ops=None, lookahead=None, grid=None):
         self.kernel, self.nb = kernel, nb
+        self._grid = grid
         self._ops = ops
         self._device = device
         self._lookahead = lookahead
@@ -723,11 +792,11 @@ class DistributedBasicSolver(object):
         world = dist.get_world_size() if live else 1
         rank = dist.get_rank() if live else 0
         if self._ops is not None:                       # caller-supplied tile ops (CPU tests): no caching
-            return BlockCyclicCholesky(self._ops, n, self.nb, lookahead=self._lookahead)
+            return BlockCyclicCholesky(self._ops, n, self.nb, lookahead=self._lookahead, grid=self._grid)
         import torch
         dev = self._device if self._device is not None else torch.cuda.current_device()
         ndim = getattr(self.kernel, "ndim", None)           # (a parked workspace's tile ops are bound to an input dimension)
-        key = (n, self.nb, world, rank, dev, self._lookahead, id(dist.group.WORLD) if live else 0, ndim)
+        key = (n, self.nb, world, rank, dev, self._lookahead, id(dist.group.WORLD) if live else 0, ndim, str(self._grid))
         if getattr(self, "_chol", None) is not None and self._key == key:
             chol = self._chol                           # recompute on the same solver object
         else:
@@ -735,7 +804,7 @@ class DistributedBasicSolver(object):
             free = _CHOL_CACHE.get(key)
             chol = free.pop() if free else None
         if chol is None:
-            chol = BlockCyclicCholesky(HipTileOps(dev, self.kernel), n, self.nb, lookahead=self._lookahead)
+            chol = BlockCyclicCholesky(HipTileOps(dev, self.kernel), n, self.nb, lookahead=self._lookahead, grid=self._grid)
         else:
             chol.ops.set_kernel(self.kernel)
             chol.computed = False
@@ -832,7 +901,7 @@ class DistributedDenseJob(object):
     inputs, sharded over the launched ranks.  ``kernel(name, amplitude)`` builds the kernel
     (bench.make_kernel); ``ops`` replaces the HIP tile kernels (launcher self-test only)."""
 
-    def __init__(self, n, nb, local_rank, make_inputs, kernel=None, kernel_name="expsquared", ops=None):
+    def __init__(self, n, nb, local_rank, make_inputs, kernel=None, kernel_name="expsquared", ops=None, grid=None):
         import george_amd.kernels as K
         x, yerr, y = make_inputs(n)
         self._amp = float(np.var(y))
@@ -840,7 +909,7 @@ class DistributedDenseJob(object):
         spec = self._mk(kernel_name, self._amp)
         self.ops = ops if ops is not None else HipTileOps(local_rank, spec)
         self.n, self.nb = n, (nb or (1024 if n >= 24576 else 512))
-        self.chol = BlockCyclicCholesky(self.ops, n, self.nb)
+        self.chol = BlockCyclicCholesky(self.ops, n, self.nb, grid=grid)
         self.chol.profile = True
         self.x = self.ops.to_device(x[:, None])
         self.yerr = self.ops.to_device(np.sqrt(yerr ** 2 + 1.25e-12))

@@ -190,6 +190,7 @@ class HODLRSolver(BasicSolver):
         state["_factor_state"] = None
         state["_computed"] = False
         state["_dense"] = None
+        state["dense_fallback"] = False          # (it described the factor that is not pickled)
         return state
 
     def __setstate__(self, state):

@@ -1,12 +1,13 @@
 """``MultiGPUSolver`` -- the dense solver on several MI355X of ONE process, behind the C ABI.
 
 ``GP(kernel, solver=MultiGPUSolver, devices=[0, 1, 2, 3, 4, 5, 6, 7])`` shards the factorisation of
-``BasicSolver`` (reference ``src/george/solvers/basic.py:51-102``) 2-D block-cyclically over the
-listed devices (``gh_mgpu_*``, george_amd/csrc/gh_mgpu.hip: one host thread per device, RCCL over
-xGMI).  Protocol: ``compute`` / ``log_determinant`` / ``computed`` / ``dot_solve`` /
-``apply_inverse``; ``get_inverse`` solves against the identity column by column (N right-hand sides:
-meant for small N), ``apply_sqrt`` is not offered (``NotImplementedError``, as the reference's HODLR
-solver does, hodlr.py:62-64).  The multi-PROCESS form (one rank per GPU under torch.distributed) is
+``BasicSolver`` (reference ``src/george/solvers/basic.py:51-121``) block-cyclically over the listed
+devices (``gh_mgpu_*``, george_amd/csrc/gh_mgpu.hip: one host thread per device, RCCL over xGMI;
+default grid ``len(devices) x 1``: whole tile rows per device in snake order).  The whole solver
+protocol: ``compute`` / ``log_determinant`` / ``computed`` / ``dot_solve`` / ``apply_inverse`` /
+``apply_sqrt`` / ``get_inverse``, plus the device-resident ``predict`` of ``george_amd.GP`` -- every
+O(N^2 R) operation is a tile sweep on the sharded factor with all its right-hand sides together.  The
+multi-PROCESS form (one rank per GPU under torch.distributed) is
 ``george_amd.distributed.DistributedBasicSolver``.
 """
 import ctypes as C
@@ -21,7 +22,7 @@ __all__ = ["MultiGPUSolver", "MultiGPUHODLRSolver"]
 
 class MultiGPUSolver(object):
 
-    def __init__(self, kernel, devices=None, nb=0, grid=None, transport="rccl"):
+    def __init__(self, kernel, devices=None, nb=0, grid=None, transport="rccl", plain_cyclic=False, chain_only=False, trace=False):
         self.kernel = kernel
         if devices is None:
             devices = list(range(max(int(N.lib.gh_device_count()), 1)))
@@ -33,6 +34,8 @@ class MultiGPUSolver(object):
         self.nb = int(nb)
         self.grid = tuple(grid) if grid is not None else (0, 0)
         self.transport = transport
+        self.flags = ((N.GH_MGPU_PLAIN_CYCLIC if plain_cyclic else 0) | (N.GH_MGPU_CHAIN_ONLY if chain_only else 0) |
+                      (N.GH_MGPU_TRACE if trace else 0))
         self._handle = None
         self._dk = None
         self._computed = False
@@ -63,6 +66,7 @@ class MultiGPUSolver(object):
             o.pr, o.pc = int(self.grid[0]), int(self.grid[1])
             o.nb = self.nb
             o.transport = N.GH_MGPU_RCCL if self.transport == "rccl" else N.GH_MGPU_COPY
+            o.flags = self.flags
             h = N._vp()
             N.check(N.lib.gh_mgpu_create(C.byref(o), C.byref(h)))
             self._handle = h
@@ -96,13 +100,28 @@ class MultiGPUSolver(object):
         logdet = C.c_double(0.0)
         N.check(N.lib.gh_mgpu_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
         self._n = len(x)
+        self._x_host = x
         self.log_determinant = logdet.value
-        self.computed = True
+        self.computed = not (self.flags & N.GH_MGPU_CHAIN_ONLY)       # (a chain-only run is a timing aid: nothing to solve with)
 
     def _need(self):
         if not self._computed or self._handle is None:
             raise RuntimeError("you must call 'compute' first")
         return self._handle
+
+    def owner(self, tile_row, tile_col):
+        """rank (index into ``devices``) that holds tile (I, J)"""
+        return int(N.lib.gh_mgpu_owner(self._ensure_handle(), int(tile_row), int(tile_col)))
+
+    def trace(self):
+        """``trace=True``: array of (rank, step, phase, milliseconds, flops or bytes) rows of the last compute()
+        (phases: include/george_amd.h, gh_mgpu_get_trace)"""
+        h = self._ensure_handle()
+        cnt = C.c_int64(0)
+        N.check(N.lib.gh_mgpu_get_trace(h, None, 0, C.byref(cnt)))
+        out = np.zeros((max(cnt.value, 1), 5))
+        N.check(N.lib.gh_mgpu_get_trace(h, N.ptr(out), cnt.value, C.byref(cnt)))
+        return out[:cnt.value]
 
     def apply_inverse(self, y, in_place=False):
         """basic.py:72-87: ``y`` is (n,) or (n, nrhs)."""
@@ -135,11 +154,42 @@ class MultiGPUSolver(object):
         return out.value
 
     def get_inverse(self):
-        """basic.py:116-121 (N right-hand sides through the sharded factor: small N only)."""
-        return self.apply_inverse(np.eye(self._n))
+        """basic.py:116-121: ``cho_solve(factor, I)`` in column chunks through the sharded sweeps."""
+        h = self._need()
+        out = np.empty((self._n, self._n), dtype=np.float64)
+        N.check(N.lib.gh_mgpu_get_inverse(h, N.ptr(out)))
+        return out
 
     def apply_sqrt(self, r):
-        raise NotImplementedError("apply_sqrt is not implemented for the MultiGPUSolver")
+        """basic.py:104-114: ``r @ U`` with ``U^T U = K``."""
+        h = self._need()
+        r = N.as_f64(r)
+        one_d = r.ndim == 1
+        r2 = np.ascontiguousarray(r.reshape(1, -1) if one_d else r)
+        if r2.shape[1] != self._n:
+            raise ValueError("dimension mismatch")
+        out = np.empty_like(r2)
+        N.check(N.lib.gh_mgpu_apply_sqrt(h, N.ptr(r2), r2.shape[0], N.ptr(out)))
+        return out[0] if one_d else out
+
+    def predict(self, kernel, r, xs, return_var=False, return_cov=False):
+        """mean / variance / covariance terms of gp.py:532-545 on the sharded factor (as ``BasicSolver.predict``)."""
+        h = self._need()
+        dk = DeviceKernel(kernel) if kernel is not self.kernel else self._dk
+        r, xs = N.as_f64(r).reshape(-1), N.as_f64(xs)
+        m = len(xs)
+        mu = np.empty(m)
+        var = np.empty(m) if return_var else None
+        if return_cov and m > 2048:
+            # the device call offers the full covariance up to 2048 test points: beyond it, the mean from the device and
+            # gp.py:543-545 as written, on the sharded solves
+            N.check(N.lib.gh_mgpu_predict(h, dk.handle, N.ptr(r), N.ptr(xs), m, N.ptr(mu), None, None))
+            Kxs = kernel.get_value(xs, self._x_host)
+            cov = kernel.get_value(xs) - np.dot(Kxs, self.apply_inverse(np.ascontiguousarray(Kxs.T)))
+            return mu, var, cov
+        cov = np.empty((m, m)) if return_cov else None
+        N.check(N.lib.gh_mgpu_predict(h, dk.handle, N.ptr(r), N.ptr(xs), m, N.ptr(mu), N.ptr(var), N.ptr(cov)))
+        return mu, var, cov
 
     # pickling drops the (device-resident, sharded) factor, as the reference's native solver does (hodlr.py:69-76)
     def __getstate__(self):
@@ -163,6 +213,9 @@ class MultiGPUHODLRSolver(MultiGPUSolver):
     (hodlr.py:62-64); pickling drops the factor (:69-76)."""
 
     def __init__(self, kernel, min_size=100, tol=0.1, seed=42, devices=None, max_rank=0):
+        if devices is None:                                  # all visible devices, cut down to a power of two (3, 6, 7 GPUs: 2, 4, 4)
+            have = max(int(N.lib.gh_device_count()), 1)
+            devices = list(range(1 << (min(have, 16).bit_length() - 1)))
         super(MultiGPUHODLRSolver, self).__init__(kernel, devices=devices)
         n = len(self.devices)
         if n & (n - 1):
@@ -190,8 +243,15 @@ class MultiGPUHODLRSolver(MultiGPUSolver):
                 pass
             self._handle = None
 
+    predict = None           # (GP.predict then takes the reference's generic path on apply_inverse, gp.py:482-545)
+    owner = trace = get_inverse_sharded = None
+
     def grid_shape(self):
         raise NotImplementedError("the HODLR split has no process grid: see rows()")
+
+    def get_inverse(self):
+        """hodlr.h / _hodlr.cpp:194-199: solve against the identity."""
+        return self.apply_inverse(np.eye(self._n))
 
     def rows(self):
         """[(first row, number of rows)] of every device's sub-tree (after compute())."""

@@ -95,32 +95,6 @@ typedef struct gh_hodlr  gh_hodlr;
 int         gh_device_count(void);
 const char* gh_last_error(void);
 const char* gh_version(void);
-/* fp64 MFMA / HBM micro-benchmarks used to pin the roofline denominators
- * (SURVEY.md 8d): returns TFLOP/s of a v_mfma_f64_16x16x4_f64-only kernel and
- * GB/s of a 16-B/lane copy. */
-int gh_microbench_mfma_f64(double* tflops_out);
-/* validation / A-B switch for every GEMM: 0 = plain-VALU kernel (same semantics, cross-checks the
- * MFMA lane maps on the device), anything else = v_mfma_f64_16x16x4 with LDS-DMA operand staging
- * (default); returns the previous setting. */
-int gh_debug_set_mfma(int mode);
-/* A/B switch: 256 x 128 tiles (one 512-thread workgroup per CU) for the chip-filling k-major GEMM
- * launches -- the trailing SYRK and the block-column updates -- instead of 128 x 128 (two 256-thread
- * workgroups per CU); returns the previous setting. */
-int gh_debug_set_gemm_tall(int on);
-/* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
- * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
- * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */
-int gh_debug_stream_overlap(gh_chol* s, double* out, int n);
-/* out[i * 6 + j], i != j: ms until a one-workgroup kernel on stream j completes when it is launched right after a grid of
- * 2^18 workgroups (~2 ms) on stream i: small = the two queues dispatch independently (same stream numbering) */
-int gh_debug_stream_dispatch(gh_chol* s, double* out, int n);
-int gh_microbench_hbm_copy(double* gbps_out);
-/* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
- * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
- * TFLOP/s, cycles/instr, GHz at 4 waves/SIMD; out[10] TFLOP/s at 8 waves/SIMD; out[11..12]
- * v_mfma_f64_4x4x4 TFLOP/s and cycles/instr. */
-int gh_microbench_suite(double* out, int n);
-
 /* ---------------------------------------------- kernel-function evaluator
  * Replaces the pybind11 class KernelInterface, src/george/kernel_interface.cpp:
  *   ctor + parse_kernel_spec  :12-14   -> gh_kernel_create
@@ -315,7 +289,8 @@ int  gh_mgpu_predict(gh_mgpu* h, gh_kernel* k, const double* r /* n: y - mean */
                      double* mu /* m */, double* var /* m or NULL */, double* cov /* m*m or NULL */);
 /* GH_MGPU_TRACE: rows of 5 doubles (rank, step k, phase, milliseconds, flops or bytes) of the last compute();
  * phases: 0 potrf, 1 column TRSM (+ pack), 2 update of block column k+1, 3 the rest of the trailing update,
- * 4 L_kk transfer, 5 row-panel transfer, 6 panel tile k+1 sent ahead, 7 column-panel gather.  *n_rows = rows
+ * 4 L_kk transfer, 5 row-panel transfer, 6 panel tile k+1 sent ahead, 7 column-panel gather, 8 kernel-matrix build
+ * (step -1).  *n_rows = rows
  * recorded (out may be NULL to ask for the count). */
 int  gh_mgpu_get_trace(const gh_mgpu* h, double* out, int64_t max_rows, int64_t* n_rows);
 

@@ -1,0 +1,49 @@
+/*
+ * george_amd_debug.h -- NOT part of the drop-in boundary (that is george_amd.h): validation switches, stream-placement
+ * probes and the on-device micro-benchmarks that pin the roofline denominators.  Exported by libgeorge_amd.so for
+ * tests/, bench.py and scripts/; a george maintainer binds nothing from here.
+ */
+#ifndef GEORGE_AMD_DEBUG_H_
+#define GEORGE_AMD_DEBUG_H_
+
+#include "george_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* fp64 MFMA / HBM micro-benchmarks used to pin the roofline denominators
+ * (SURVEY.md 8d): returns TFLOP/s of a v_mfma_f64_16x16x4_f64-only kernel and
+ * GB/s of a 16-B/lane copy. */
+int gh_microbench_mfma_f64(double* tflops_out);
+/* validation / A-B switch for every GEMM: 0 = plain-VALU kernel (same semantics, cross-checks the
+ * MFMA lane maps on the device), anything else = v_mfma_f64_16x16x4 with LDS-DMA operand staging
+ * (default); returns the previous setting. */
+int gh_debug_set_mfma(int mode);
+/* A/B switch: 256 x 128 tiles (one 512-thread workgroup per CU) for the chip-filling k-major GEMM
+ * launches -- the trailing SYRK and the block-column updates -- instead of 128 x 128 (two 256-thread
+ * workgroups per CU); returns the previous setting. */
+int gh_debug_set_gemm_tall(int on);
+/* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
+ * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
+ * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */
+int gh_debug_stream_overlap(gh_chol* s, double* out, int n);
+/* out[i * 6 + j], i != j: ms until a one-workgroup kernel on stream j completes when it is launched right after a grid of
+ * 2^18 workgroups (~2 ms) on stream i: small = the two queues dispatch independently (same stream numbering) */
+int gh_debug_stream_dispatch(gh_chol* s, double* out, int n);
+int gh_microbench_hbm_copy(double* gbps_out);
+/* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
+ * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
+ * TFLOP/s, cycles/instr, GHz at 4 waves/SIMD; out[10] TFLOP/s at 8 waves/SIMD; out[11..12]
+ * v_mfma_f64_4x4x4 TFLOP/s and cycles/instr. */
+int gh_microbench_suite(double* out, int n);
+/* THE fp64 matrix-pipe ceiling: a bare v_mfma_f64_16x16x4_f64 issue loop with 64x more (short) workgroups than the chip
+ * has slots, resident wavefronts per SIMD pinned by an LDS request (gh_gemm.hip says why the suite above is NOT a ceiling:
+ * it measures how unevenly the dispatcher deals a grid of exactly one slot per workgroup).  out[0..2] = TFLOP/s at 1 / 2 / 4
+ * wavefronts per SIMD, out[3] = the best, out[4..6] = milliseconds; n >= 8. */
+int gh_microbench_mfma_f64_ceiling(double* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* GEORGE_AMD_DEBUG_H_ */

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "george_amd.h")).read()
+def _declared(header="george_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gh_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,8 +23,14 @@ def test_header_symbols_exported():
     assert len(names) >= 35
     for n in names:
         assert hasattr(lib, n), "libgeorge_amd.so does not export %s" % n
-    # and the ctypes signature table covers exactly the header
-    assert sorted(_native.SIGNATURES) == names
+    # the validation switches, probes and micro-benchmarks live in a header of their own: none of them is in the boundary
+    dbg = _declared("george_amd_debug.h")
+    assert dbg and all(n.startswith(("gh_debug_", "gh_microbench_")) for n in dbg)
+    assert not [n for n in names if n.startswith(("gh_debug_", "gh_microbench_"))]
+    for n in dbg:
+        assert hasattr(lib, n), "libgeorge_amd.so does not export %s" % n
+    # and the ctypes signature table covers exactly the two headers
+    assert sorted(_native.SIGNATURES) == sorted(names + dbg)
 
 
 def test_struct_layout_matches_header():
@@ -60,7 +66,8 @@ def test_multi_gpu_entry_points_declared_and_validated():
     no device visible creation fails loudly (RuntimeError), never a silent single-GPU or CPU path."""
     from george_amd import _native as N, MultiGPUSolver
     for name in ("gh_mgpu_create", "gh_mgpu_destroy", "gh_mgpu_compute", "gh_mgpu_info", "gh_mgpu_grid",
-                 "gh_mgpu_dot_solve", "gh_mgpu_solve", "gh_dev_trsv_lower_t"):
+                 "gh_mgpu_dot_solve", "gh_mgpu_solve", "gh_mgpu_apply_sqrt", "gh_mgpu_get_inverse", "gh_mgpu_predict",
+                 "gh_mgpu_owner", "gh_mgpu_get_trace", "gh_dev_trsv_lower_t"):
         assert name in N.SIGNATURES and hasattr(N.lib, name)
     o = N.gh_mgpu_opts()
     h = N._vp()

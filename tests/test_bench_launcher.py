@@ -47,7 +47,7 @@ def test_gpus_2_launches_two_ranks_and_prints_one_line(tmp_path):
     assert len(r.stdout.strip().splitlines()[-1]) < 6000          # ... and fits the driver's 8 kB stdout tail
     d = lines[0]
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["rccl"]["ranks_seen"] == 2
-    assert d["config"]["grid"] == "1x2" and d["config"]["parallelism"] == "block-cyclic-2"
+    assert d["config"]["grid"] == "2x1" and d["config"]["parallelism"] == "block-cyclic-2"
     assert d["scaling"] == "strong" and d["steps"] == 1 and d["warmup"] == 0
     assert "NOT a measurement" in d["data"]
     p = d["parity"]

@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: the 2-D block-cyclic driver (george_amd/distributed.py) run with world_size
-2 and 4 under the gloo backend.  The tile kernels are replaced by a NumPy stand-in with the same
+"""N > 1 path on CPU: the block-cyclic driver (george_amd/distributed.py) run with world_size
+2, 3, 4 and 8 under the gloo backend, on its default grid (world x 1, snake order) and on 2-D grids.  The tile kernels are replaced by a NumPy stand-in with the same
 interface (test infrastructure; the product path uses HipTileOps), so what is exercised here is
 tile ownership, the broadcast / all-gather / reduce pattern and the loop order -- against a dense
 NumPy Cholesky of the same matrix."""
@@ -28,7 +28,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, nb, q, xchg="auto"):
+def _worker(rank, world, port, n, nb, q, xchg="auto", grid=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,9 +42,10 @@ def _worker(rank, world, port, n, nb, q, xchg="auto"):
         x = np.sort(rng.uniform(0, 10, n))
         y = np.sin(x)
         kernel = 0.5 * K.Matern32Kernel(1.3)
-        solver = DistributedBasicSolver(kernel, nb=nb, ops=NumpyTileOps(kernel))
+        solver = DistributedBasicSolver(kernel, nb=nb, ops=NumpyTileOps(kernel), grid=grid)
         solver.compute(x[:, None], 0.1)
         quad = solver.dot_solve(y)
+        owners = [solver._chol.prow(i) for i in range(4 * world)]
         # the rest of the solver protocol on the sharded factor (basic.py:72-121)
         Y3 = np.stack([y, np.cos(3 * x), x ** 2], axis=1)
         alpha = solver.apply_inverse(y)
@@ -54,7 +55,7 @@ def _worker(rank, world, port, n, nb, q, xchg="auto"):
         # a second solver of the same shape picks up the parked workspace / cached sub-groups
         from george_amd import distributed as D
         ngroups = len(D._GROUP_CACHE)
-        again = DistributedBasicSolver(kernel, nb=nb, ops=NumpyTileOps(kernel))
+        again = DistributedBasicSolver(kernel, nb=nb, ops=NumpyTileOps(kernel), grid=grid)
         again.compute(x[:, None], 0.1)
         assert len(D._GROUP_CACHE) == ngroups and again.log_determinant == solver.log_determinant
         # every rank must hold the same scalars
@@ -64,7 +65,7 @@ def _worker(rank, world, port, n, nb, q, xchg="auto"):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi)
         # not-positive-definite must surface as LinAlgError on EVERY rank
-        bad = DistributedBasicSolver(K.CosineKernel(log_period=0.0), nb=nb, ops=NumpyTileOps(K.CosineKernel(log_period=0.0)))
+        bad = DistributedBasicSolver(K.CosineKernel(log_period=0.0), nb=nb, ops=NumpyTileOps(K.CosineKernel(log_period=0.0)), grid=grid)
         raised = False
         try:
             bad.compute(x[:, None], 0.0)
@@ -72,23 +73,25 @@ def _worker(rank, world, port, n, nb, q, xchg="auto"):
             raised = True
         assert raised
         if rank == 0:
-            q.put((solver.log_determinant, quad, grid_shape(world), alpha, alpha3, sq, inv))
+            q.put((solver.log_determinant, quad, (solver._chol.Pr, solver._chol.Pc, owners), alpha, alpha3, sq, inv))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nb,xchg", [(2, 700, 128, "auto"), (4, 1100, 128, "auto"), (2, 900, 256, "a2a"),
-                                             (4, 513, 128, "bcast"), (8, 1300, 128, "auto"), (8, 900, 128, "bcast")])
-def test_block_cyclic_cholesky_gloo(world, n, nb, xchg):
+@pytest.mark.parametrize("world,n,nb,xchg,grid", [
+    (2, 700, 128, "auto", None), (4, 1100, 128, "auto", None), (8, 1300, 128, "auto", None), (3, 800, 128, "auto", None),     # world x 1, snake
+    (2, 900, 256, "a2a", (1, 2)), (4, 513, 128, "bcast", "square"), (4, 1100, 128, "auto", (2, 2)),
+    (8, 1300, 128, "auto", (2, 4)), (8, 900, 128, "bcast", (2, 4)), (8, 900, 128, "auto", (4, 2))])
+def test_block_cyclic_cholesky_gloo(world, n, nb, xchg, grid):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, q, xchg)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, q, xchg, grid)) for r in range(world)]
     for p in procs:
         p.start()
     try:
         # (read BEFORE joining: a child that has put large arrays cannot exit until they are consumed)
-        logdet, quad, grid, alpha, alpha3, sq, inv = q.get(timeout=600)
+        logdet, quad, grid_got, alpha, alpha3, sq, inv = q.get(timeout=600)
     finally:
         for p in procs:
             p.join(120)
@@ -96,7 +99,14 @@ def test_block_cyclic_cholesky_gloo(world, n, nb, xchg):
             if p.is_alive():
                 p.kill()
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert grid == {2: (1, 2), 4: (2, 2), 8: (2, 4)}[world]
+    Pr, Pc, owners = grid_got
+    if grid is None:
+        assert (Pr, Pc) == (world, 1)                    # whole tile rows per rank, in snake order
+        snake = [t if t < world else 2 * world - 1 - t for t in range(2 * world)]
+        assert owners == [snake[i % (2 * world)] for i in range(4 * world)]
+    else:
+        assert (Pr, Pc) == ({4: (2, 2)}[world] if grid == "square" else tuple(grid))
+        assert owners == [i % Pr for i in range(4 * world)]
     # dense reference
     sys.path.insert(0, ROOT)
     import george_amd.kernels as K
@@ -123,7 +133,10 @@ def test_single_process_degenerate_grid():
     import george_amd.kernels as K
     from george_amd.distributed import DistributedBasicSolver, grid_shape
     from oracle import kernels_np
-    assert grid_shape(1) == (1, 1) and grid_shape(8) == (2, 4) and grid_shape(2) == (1, 2)
+    assert grid_shape(1) == (1, 1) and grid_shape(8) == (8, 1) and grid_shape(2) == (2, 1)
+    assert grid_shape(8, "square") == (2, 4) and grid_shape(8, "4x2") == (4, 2) and grid_shape(6, (2, 3)) == (2, 3)
+    with pytest.raises(ValueError):
+        grid_shape(8, (3, 2))
     n = 300
     x = np.linspace(0, 5, n)
     kernel = 1.0 * K.ExpSquaredKernel(0.7)

@@ -42,9 +42,10 @@ def test_bench_job_single_rank():
 
 
 # ---- several ranks sharing the ONE GPU of the test box, gloo as the transport: the real tile kernels,
-# ---- streams and look-ahead pipeline on block-cyclic local storage with Pr x Pc > 1 (RCCL refuses two
+# ---- streams and look-ahead pipeline (chain / bulk gather / updates) on block-cyclic local storage, default world x 1 snake grid
+# ---- and 2-D grids (RCCL refuses two
 # ---- ranks on one device, so the collectives themselves are gloo's; the call pattern is the same).
-def _shared_gpu_worker(rank, world, port, n, nb, lookahead, q):
+def _shared_gpu_worker(rank, world, port, n, nb, lookahead, q, grid=None):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -61,7 +62,7 @@ def _shared_gpu_worker(rank, world, port, n, nb, lookahead, q):
         x = np.sort(rng.uniform(0, 10, n))
         y = np.sin(x)
         kernel = float(np.var(y)) * K.ExpSquaredKernel(1.0)
-        s = DistributedBasicSolver(kernel, nb=nb, device=0, lookahead=lookahead)
+        s = DistributedBasicSolver(kernel, nb=nb, device=0, lookahead=lookahead, grid=grid)
         s.compute(x[:, None], 0.1)
         quad = s.dot_solve(y)
         if rank == 0:
@@ -70,16 +71,17 @@ def _shared_gpu_worker(rank, world, port, n, nb, lookahead, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nb,lookahead", [(2, 1500, 256, True), (2, 1500, 256, False),
-                                                 (4, 2500, 256, True), (4, 1100, 128, False),
-                                                 (8, 3000, 128, True)])
-def test_ranks_sharing_one_gpu_gloo(world, n, nb, lookahead):
+@pytest.mark.parametrize("world,n,nb,lookahead,grid", [(2, 1500, 256, True, None), (2, 1500, 256, False, (1, 2)),
+                                                      (4, 2500, 256, True, None), (4, 1100, 128, False, (2, 2)),
+                                                      (8, 3000, 128, True, None), (8, 3000, 128, True, (2, 4)),
+                                                      (4, 2500, 256, True, (2, 2))])
+def test_ranks_sharing_one_gpu_gloo(world, n, nb, lookahead, grid):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, n, nb, lookahead, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, n, nb, lookahead, q, grid)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

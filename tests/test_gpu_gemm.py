@@ -41,6 +41,33 @@ def test_microbench_peaks():
           "mfma_f64_4x4x4: %.1f TF (%.1f cyc/instr)" % (o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12]))
 
 
+def test_mfma_f64_ceiling_is_a_ceiling():
+    """SURVEY 8(d)'s second denominator: the bare issue loop must reach at least what the GEMM kernel sustains (round 3's
+    loop read 34-47 TFLOP/s against 68-70 in the GEMM: it measured the dispatcher's uneven deal of a one-slot-per-workgroup
+    grid, not the pipe) and cannot exceed the datasheet's 78.6 by more than clock tolerance."""
+    import torch
+    from george_amd import _native as N
+    out = (C.c_double * 8)()
+    N.check(N.lib.gh_microbench_mfma_f64_ceiling(out, 8))
+    o = list(out)
+    print("\n[ceiling] v_mfma_f64_16x16x4 bare issue: %.1f / %.1f / %.1f TFLOP/s at 1 / 2 / 4 wavefronts per SIMD (%.2f / %.2f / %.2f ms)"
+          % (o[0], o[1], o[2], o[4], o[5], o[6]))
+    M, K = 16384, 4096
+    a = torch.randn(M, K, dtype=torch.float64, device="cuda")
+    c = torch.zeros(M, M, dtype=torch.float64, device="cuda")
+    _gemm(c, a, a, M, M, K, -1.0, 1.0, 0, K, K, M)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        N.check(N.lib.gh_dev_gemm(c.data_ptr(), M, a.data_ptr(), K, a.data_ptr(), K, M, M, K, -1.0, 1.0, 0, None))
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_tf = 3 * 2.0 * M * M * K / (e0.elapsed_time(e1) * 1e-3) * 1e-12
+    print("[ceiling] gemm_f64_mfma_dma at M = N = %d, K = %d: %.1f TFLOP/s = %.3f of the measured ceiling" % (M, K, gemm_tf, gemm_tf / o[3]))
+    assert o[3] >= 0.98 * gemm_tf, (o, gemm_tf)
+    assert o[3] <= 78.6 * 1.05
+
+
 @pytest.mark.parametrize("mfma", [1, 0])
 @pytest.mark.parametrize("a_mm,b_nm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_layouts(mfma, a_mm, b_nm):

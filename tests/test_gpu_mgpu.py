@@ -3,9 +3,11 @@ the test box:
 
 * transport "rccl" with n_dev = 1 -- communicator creation (ncclCommInitAll), the all-reduce self-check
   and the whole driver as a world of one;
-* transport "copy" with the SAME device listed 2, 4 and 8 times ("virtual devices") -- the ownership,
-  ordering and hand-over logic of a 1x2, 2x2 and 2x4 grid with real tile kernels, against the
-  single-GPU solver (itself pinned to the reference, tests/test_gpu_fullsize.py).
+* transport "copy" with the SAME device listed 2, 4, 6 and 8 times ("virtual devices") -- the ownership,
+  ordering and hand-over logic of the default P x 1 snake grid and of 1x2 / 2x2 / 2x3 / 2x4 / 4x1 / 1x4 grids
+  with real tile kernels, against the single-GPU solver (itself pinned to the reference,
+  tests/test_gpu_fullsize.py): factorisation, the sweeps with one and many right-hand sides, apply_sqrt,
+  get_inverse, predict; the chain-only and trace modes behind profiles/r04/scale_model.md.
 
 What this cannot cover is RCCL between two physical devices; see DESIGN.md section 7."""
 import numpy as np
@@ -34,10 +36,13 @@ def _case(n, ndim=1):
     ([0], "copy", 1000, 128, None),
     ([0, 0], "copy", 2500, 256, None),
     ([0, 0, 0, 0], "copy", 3000, 256, None),
-    ([0, 0, 0, 0], "copy", 1700, 128, (4, 1)),
+    ([0, 0, 0, 0], "copy", 1700, 128, (2, 2)),
     ([0, 0, 0, 0], "copy", 1700, 128, (1, 4)),
     ([0] * 8, "copy", 4100, 256, None),
+    ([0] * 8, "copy", 4100, 256, (2, 4)),
+    ([0] * 8, "copy", 2600, 128, (4, 2)),
     ([0] * 6, "copy", 2900, 128, (2, 3)),
+    ([0] * 3, "copy", 2000, 128, None),
 ])
 def test_sharded_solver_matches_single_gpu(devices, transport, n, nb, grid):
     kernel, X, yerr, y, d = _case(n)
@@ -46,7 +51,12 @@ def test_sharded_solver_matches_single_gpu(devices, transport, n, nb, grid):
     pr, pc, nb_used = s.grid_shape()
     assert pr * pc == len(devices) and nb_used == nb
     if grid is None:
-        assert (pr, pc) == {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}[len(devices)]
+        assert (pr, pc) == (len(devices), 1)                     # whole tile rows per rank ...
+        W = len(devices)
+        snake = [t if t < W else 2 * W - 1 - t for t in range(2 * W)]
+        assert [s.owner(i, 0) for i in range(4 * W)] == [snake[i % (2 * W)] for i in range(4 * W)]      # ... in snake order
+    else:
+        assert [s.owner(i, j) for i in range(3) for j in range(3)] == [(i % pr) * pc + j % pc for i in range(3) for j in range(3)]
     assert s.computed
     assert abs(s.log_determinant - d.log_determinant) <= 1e-11 * abs(d.log_determinant)
     q = d.dot_solve(y)
@@ -78,13 +88,68 @@ def test_sharded_solver_through_gp_and_3d():
     mu0, var0 = ref.predict(y, t, return_var=True)
     np.testing.assert_allclose(mu, mu0, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(var, var0, rtol=1e-6, atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        gp.solver.apply_sqrt(y)
-    inv = MultiGPUSolver(kernel, devices=[0, 0], transport="copy", nb=128)
-    inv.compute(X[:300], yerr[:300])
-    dd = BasicSolver(kernel)
-    dd.compute(X[:300], yerr[:300])
-    np.testing.assert_allclose(inv.get_inverse(), dd.get_inverse(), rtol=1e-7, atol=1e-8)
+    mu, cov = gp.predict(y, t)
+    mu0, cov0 = ref.predict(y, t)
+    np.testing.assert_allclose(cov, cov0, rtol=1e-6, atol=1e-9)
+    assert type(gp.solver) is MultiGPUSolver
+
+
+@pytest.mark.parametrize("devices,grid,nb,n", [([0, 0, 0, 0], None, 128, 1100), ([0] * 6, (2, 3), 128, 1500), ([0] * 8, None, 256, 4000),
+                                               ([0, 0], (1, 2), 256, 900), ([0], None, 256, 700)])
+def test_whole_protocol_on_the_sharded_factor(devices, grid, nb, n):
+    """basic.py:72-121 and gp.py:482-545 as tile sweeps: many right-hand sides at once, apply_sqrt, get_inverse, predict"""
+    kernel, X, yerr, y, d = _case(n)
+    s = MultiGPUSolver(kernel, devices=devices, transport="copy", nb=nb, grid=grid)
+    s.compute(X, yerr)
+    rng = np.random.RandomState(5)
+    B = rng.randn(n, 131)                                        # not a multiple of anything
+    a = d.apply_inverse(B)
+    np.testing.assert_allclose(s.apply_inverse(B), a, rtol=0, atol=1e-9 * np.abs(a).max())
+    B2 = B.copy()
+    assert s.apply_inverse(B2, in_place=True) is B2
+    np.testing.assert_allclose(B2, a, rtol=0, atol=1e-9 * np.abs(a).max())
+    R = rng.randn(5, n)
+    u = d.apply_sqrt(R)
+    np.testing.assert_allclose(s.apply_sqrt(R), u, rtol=0, atol=1e-11 * np.abs(u).max())
+    np.testing.assert_allclose(s.apply_sqrt(R[0]), u[0], rtol=0, atol=1e-11 * np.abs(u).max())
+    Ki = d.get_inverse()
+    np.testing.assert_allclose(s.get_inverse(), Ki, rtol=0, atol=1e-8 * np.abs(Ki).max())
+    t = np.ascontiguousarray(X[::7] + 0.013)
+    r = y - 0.1
+    mu0, var0, _ = d.predict(kernel, r, t, return_var=True)
+    _, _, cov0 = d.predict(kernel, r, t, return_cov=True)
+    mu, var, _ = s.predict(kernel, r, t, return_var=True)
+    np.testing.assert_allclose(mu, mu0, rtol=0, atol=1e-9 * np.abs(mu0).max())
+    np.testing.assert_allclose(var, var0, rtol=0, atol=1e-9)
+    mu2, _, cov = s.predict(kernel, r, t, return_cov=True)
+    np.testing.assert_allclose(mu2, mu0, rtol=0, atol=1e-9 * np.abs(mu0).max())
+    np.testing.assert_allclose(cov, cov0, rtol=0, atol=1e-9)
+    other = 0.7 * kernels.ExpSquaredKernel(2.0)                  # predict with ANOTHER kernel object (gp.py:482: the `kernel` argument)
+    m1, v1, _ = d.predict(other, r, t, return_var=True)
+    m2, v2, _ = s.predict(other, r, t, return_var=True)
+    np.testing.assert_allclose(m2, m1, rtol=0, atol=1e-9 * np.abs(m1).max())
+    np.testing.assert_allclose(v2, v1, rtol=0, atol=1e-9)
+
+
+def test_chain_only_and_trace_modes():
+    """the two timing aids behind profiles/r04/scale_model.md: the trace leaves the numbers alone, chain-only does not raise"""
+    kernel, X, yerr, y, d = _case(3000)
+    s = MultiGPUSolver(kernel, devices=[0] * 4, transport="copy", nb=256, trace=True)
+    s.compute(X, yerr)
+    assert abs(s.log_determinant - d.log_determinant) <= 1e-11 * abs(d.log_determinant)
+    tr = s.trace()
+    nt = -(-3000 // 256)
+    assert tr.shape[1] == 5 and set(tr[:, 2].astype(int)) >= {0, 1, 2, 3, 4, 6, 7}
+    assert (tr[:, 3] > 0).all()
+    potrf = tr[tr[:, 2] == 0]
+    assert len(potrf) == nt and sorted(potrf[:, 1].astype(int)) == list(range(nt))             # one diagonal tile per step ...
+    assert [int(r_) for r_ in potrf[np.argsort(potrf[:, 1]), 0]] == [s.owner(k, k) for k in range(nt)]     # ... on its owner
+    c = MultiGPUSolver(kernel, devices=[0] * 4, transport="copy", nb=256, chain_only=True, trace=True)
+    c.compute(X, yerr)                                           # (garbage numbers, no exception)
+    assert not c.computed
+    with pytest.raises(RuntimeError):
+        c.dot_solve(y)
+    assert 3 not in set(c.trace()[:, 2].astype(int)) and 7 not in set(c.trace()[:, 2].astype(int))
 
 
 def test_sharded_solver_errors():
