@@ -924,29 +924,35 @@ extern "C" int gh_microbench_suite(double* out, int n) {
 }
 
 // ---- the fp64 matrix-pipe CEILING (SURVEY 8d's second roofline denominator) ------------------------------------------
-// A bare v_mfma_f64_16x16x4_f64 issue loop that is limited by the pipe and nothing else.  The suite above launches as many
-// workgroups as the chip has slots for (256 / 512 / 1024 on 256 CUs) and reads 34-47 TFLOP/s -- BELOW what the GEMM kernel
-// sustains -- because the dispatcher does not deal a grid of exactly that size evenly: some CUs get one workgroup more, others
-// one less, and the launch lasts as long as the fullest CU (2:1 at one workgroup per CU = 39 of 78.6; 3:2 at two = 52).  It was
-// never an instruction ceiling.  Here: (i) 64x more workgroups than slots, each short, so that the dispatcher's greedy
-// refill evens the load out exactly as it does for a GEMM grid; (ii) the number of resident wavefronts per SIMD is pinned by a
-// dynamic LDS request (96 KiB -> one 4-wavefront workgroup per CU = 1 wavefront per SIMD, 64 KiB -> 2, 40 KiB -> 4 -- 160 KiB per
-// CU); (iii) 8 independent accumulators, no other vector instruction in the loop.  One instruction occupies a SIMD's pipe for 64
-// cycles (scripts/dev/valu_probe.hip), so the ceiling is 256 CU x 4 SIMD x 2048 flop / 64 cycles x the clock the chip holds
-// under that load -- which is what this measures.
+// A bare v_mfma_f64_16x16x4_f64 issue loop that is limited by the pipe and nothing else.  The suite above reads 34-47 TFLOP/s
+// -- BELOW what the GEMM kernel sustains -- and is NOT a ceiling: written with the builtin, its loop is compiled into eight
+// matrix instructions wrapped in 128 v_accvgpr_write / v_accvgpr_read moves per iteration (hipcc parks the accumulators in
+// VGPRs across iterations and shuttles them through AGPRs), so it measures the vector ALU's move rate (visible with
+// `hipcc -S --cuda-device-only`; profiles/r04/README.md).  Here the loop body is inline assembly with the accumulators pinned
+// to VGPRs: eight independent matrix instructions and a scalar loop counter, nothing else.  Also: 64x more workgroups than
+// slots, each short, so that the dispatcher's refill evens the load as it does for a GEMM grid, and the resident wavefronts
+// per SIMD pinned by a dynamic LDS request (96 KiB -> one 4-wavefront workgroup per CU = 1 wavefront per SIMD, 64 KiB -> 2,
+// 40 KiB -> 4; 160 KiB per CU).  One instruction occupies a SIMD's pipe for 64 cycles (scripts/dev/valu_probe.hip), so the
+// ceiling is 256 CU x 4 SIMD x 2048 flop / 64 cycles x the clock the chip holds under that load -- which is what this measures.
 extern __shared__ double mfma_ceiling_lds[];
 __global__ __launch_bounds__(256) void mfma_f64_ceiling_kernel(double* out, int iters) {
   const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9, a2 = a + 0.5, b2 = b - 0.5;
   v4d m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0, m6 = m0, m7 = m0;
+  // Inline assembly, accumulators pinned to VGPRs: written with the builtin, hipcc keeps the eight accumulators in VGPRs ACROSS
+  // iterations and copies all 64 registers into AGPRs and back around the eight MFMAs of every iteration (128 v_accvgpr moves
+  // per 8 matrix instructions) -- THAT is what round 3's loops measured (34-47 TFLOP/s), and this kernel's first form too
+  // (35 / 48 / 51); the GEMM kernel, whose accumulators live in one place, sustains 70.
   for (int i = 0; i < iters; ++i) {
-    m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, m0, 0, 0, 0);
-    m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, m1, 0, 0, 0);
-    m2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, m2, 0, 0, 0);
-    m3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, m3, 0, 0, 0);
-    m4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, m4, 0, 0, 0);
-    m5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, m5, 0, 0, 0);
-    m6 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, m6, 0, 0, 0);
-    m7 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, m7, 0, 0, 0);
+    asm volatile("v_mfma_f64_16x16x4_f64 %0, %8, %9, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %1, %8, %11, %1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %2, %10, %9, %2\n\t"
+                 "v_mfma_f64_16x16x4_f64 %3, %10, %11, %3\n\t"
+                 "v_mfma_f64_16x16x4_f64 %4, %8, %9, %4\n\t"
+                 "v_mfma_f64_16x16x4_f64 %5, %8, %11, %5\n\t"
+                 "v_mfma_f64_16x16x4_f64 %6, %10, %9, %6\n\t"
+                 "v_mfma_f64_16x16x4_f64 %7, %10, %11, %7"
+                 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5), "+v"(m6), "+v"(m7)
+                 : "v"(a), "v"(b), "v"(a2), "v"(b2));
   }
   const v4d s = m0 + m1 + m2 + m3 + m4 + m5 + m6 + m7;
   if (s[0] + s[1] + s[2] + s[3] == 12345.678) { out[0] = s[0]; mfma_ceiling_lds[threadIdx.x] = s[1]; }   // keep the chain (and the LDS) live

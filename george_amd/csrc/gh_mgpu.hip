@@ -497,30 +497,42 @@ int rank_factor(gh_mgpu* h, MRank& r) {
     GH_HIP(hipEventRecord(r.ev_panel[buf], sg));
     return GH_OK;
   };
-  // U(k) restricted to my tile columns with global index in [jlo, jhi], on stream st, from workspace `buf`
-  // (ahead: [jlo, jhi] is block column k+1 alone, served by the tile that travelled ahead)
+  // U(k) restricted to my tile columns with global index in [jlo, jhi], on stream st, from workspace `buf`.
+  // ahead: [jlo, jhi] is block column k+1 alone, served by the tile that travelled ahead -- one GEMM over all my rows below it.
+  // Else ONE GEMM PER LOCAL TILE ROW i: C[i, jlo..min(i, jhi)] -= W_i P[jlo..]^T -- the column-panel tiles of consecutive local
+  // columns are contiguous in colp, so the B operand is one (n_cols nb) x nb array.  (Round 4, first form: one GEMM per tile
+  // COLUMN -- 64 or 128 launches per step on a P x 1 grid, most of them a few dozen tiles: 39 TFLOP/s per rank at nb = 512,
+  // and the rank that owns tile row 0 at 50 against 61 for the others, profiles/r04/scale_model.md.)
   auto update = [&](int k, int buf, int jlo, int jhi, bool ahead) -> int {
     const int li0 = first_at_least(r.rows, k + 1);
     const size_t l0 = first_at_least(r.cols, jlo);
-    size_t l1 = l0;
-    while (l1 < r.cols.size() && r.cols[l1] <= jhi) ++l1;
     double flops = 0.0;
-    for (size_t lj = l0; lj < l1; ++lj) { const int ls = first_at_least(r.rows, r.cols[lj]); if (ls < nlr) flops += 2.0 * (double)(nlr - ls) * nb * nb * nb; }
+    for (size_t lj = l0; lj < r.cols.size() && r.cols[lj] <= jhi; ++lj) {
+      const int ls = first_at_least(r.rows, r.cols[lj]);
+      if (ls < nlr) flops += 2.0 * (double)(nlr - ls) * nb * nb * nb;
+    }
     if (flops == 0.0) return GH_OK;
     return phase(k, ahead ? MG_PH_BCOL : MG_PH_REST, r.st, flops, [&]() -> int {
-      const bool fan = l1 - l0 >= 3;                               // independent GEMMs dealt over st, su[0], su[1]
+      if (ahead) {
+        const int ls = first_at_least(r.rows, jlo);
+        return gh_dev_gemm_nt(A + (long)ls * nb * ld + (long)l0 * nb, ld, r.wrow[buf].d() + (long)(ls - li0) * nb * nb, nb, r.nxt[buf].d(), nb,
+                              (long)(nlr - ls) * nb, nb, nb, 0, r.st);
+      }
+      const int lr0 = first_at_least(r.rows, jlo);                 // my first tile row that reaches column jlo
+      const bool fan = nlr - lr0 >= 3;                             // independent GEMMs dealt over st, su[0], su[1], largest first
       if (fan) {
         GH_HIP(hipEventRecord(r.ev_fan, r.st));
         for (hipStream_t q : r.su) GH_HIP(hipStreamWaitEvent(q, r.ev_fan, 0));
       }
-      for (size_t lj = l0; lj < l1; ++lj) {
-        const int j = r.cols[lj];
-        const int ls = first_at_least(r.rows, j);
-        if (ls >= nlr) continue;
-        const size_t q = fan ? (lj - l0) % 3 : 0;
-        const double* pj = ahead ? r.nxt[buf].d() : r.colp[buf].d() + (long)lj * nb * nb;
-        GH_CHECK(gh_dev_gemm_nt(A + (long)ls * nb * ld + (long)lj * nb, ld, r.wrow[buf].d() + (long)(ls - li0) * nb * nb, nb,
-                                pj, nb, (long)(nlr - ls) * nb, nb, nb, 0, q == 0 ? r.st : r.su[q - 1]));
+      int dealt = 0;
+      for (int li = nlr - 1; li >= lr0; --li, ++dealt) {
+        const int i = r.rows[li];
+        size_t l1 = l0;
+        while (l1 < r.cols.size() && r.cols[l1] <= std::min(i, jhi)) ++l1;
+        if (l1 == l0) continue;
+        const size_t q = fan ? (size_t)dealt % 3 : 0;
+        GH_CHECK(gh_dev_gemm_nt(A + (long)li * nb * ld + (long)l0 * nb, ld, r.wrow[buf].d() + (long)(li - li0) * nb * nb, nb,
+                                r.colp[buf].d() + (long)l0 * nb * nb, nb, nb, (long)(l1 - l0) * nb, nb, 0, q == 0 ? r.st : r.su[q - 1]));
       }
       if (fan)
         for (int q = 0; q < 2; ++q) { GH_HIP(hipEventRecord(r.ev_su[q], r.su[q])); GH_HIP(hipStreamWaitEvent(r.st, r.ev_su[q], 0)); }

@@ -309,6 +309,10 @@ class BlockCyclicCholesky(object):
         self.ws_send = [ops.zeros(cmax0, nbk, nbk) for _ in range(2)]
         self.ws_gath = [[ops.zeros(cmax0, nbk, nbk) for _ in range(self.Pr)] for _ in range(2)] if self.Pr > 1 else None
         self.ws_next = [ops.zeros(nbk, nbk) for _ in range(2)]      # tile k+1 of the column panel, ahead of the gather
+        # the column panel in LOCAL COLUMN ORDER (tile lj of my tile columns at [lj]): the rest of U(k) is one GEMM per local
+        # tile row whose B operand is a run of consecutive local columns
+        self.ws_colp = [ops.zeros(max(len(self.cols), 1), nbk, nbk) for _ in range(2)]
+        self._idx_cache = {}
         self.info = ops.zeros(1, dtype=torch.int64)
         self.logdet_dev = ops.zeros(1)
         self.log_determinant = None
@@ -497,10 +501,18 @@ class BlockCyclicCholesky(object):
                 self.dist.all_gather(gathered, send, group=self.bulk_groups[pc])
             else:
                 gathered = [send]
+            colp = self.ws_colp[buf]
             for mm in range(Pr):
                 js = [j for j in range(first, nt) if self.pcol(j) == pc and self.prow(j) == mm]
-                for t, j in enumerate(js):
-                    pj[j] = gathered[mm][t]
+                if not js:
+                    continue
+                key = (k, mm)
+                idx = self._idx_cache.get(key)
+                if idx is None:
+                    idx = self._idx_cache[key] = self.torch.tensor([self.lcol[j] for j in js], dtype=self.torch.int64,
+                                                                   device=colp.device)
+                colp.index_copy_(0, idx, gathered[mm][:len(js)])
+            pj = colp
         panel[2] = pj
         if tl is not None:
             tl.append(ops.event(ops.main_stream(), timing=True))       # column panel gathered
@@ -508,27 +520,41 @@ class BlockCyclicCholesky(object):
 
     # -- U(k) restricted to the given global tile columns ---------------------------------------------
     def _update(self, panel, cols, fast=False):
-        """fast: `cols` is block column k+1 alone, served by the tile that travelled ahead."""
-        if panel is None:
+        """fast: `cols` is block column k+1 alone, served by the tile that travelled ahead -- one GEMM over all my rows
+        below it.  Else one GEMM per local tile ROW i: C[i, first col .. min(i, last col)] -= W_i P^T with P a run of
+        consecutive local columns of the re-packed column panel (one launch per tile COLUMN -- round 4's first form -- was
+        64-128 small launches per step on a P x 1 grid: 39-59 TFLOP/s per rank, profiles/r04/scale_model.md)."""
+        if panel is None or not cols:
             return
-        li0, wrow, pj_full, pj_fast = panel[:4]
-        pj = pj_fast if fast else pj_full
+        li0, wrow, colp, pj_fast = panel[:4]
         nb, nloc_r = self.nb, len(self.rows)
-        todo = []
-        for j in cols:
-            ls = self._first_local_row_at_least(j)
-            if ls >= nloc_r:
-                continue
-            lj = self.lcol[j]
-            todo.append(lambda ls=ls, lj=lj, j=j: self.ops.gemm_nt(
-                self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj[j]))
+        todo, flops = [], 0.0
+        if fast:
+            for j in cols:
+                ls = self._first_local_row_at_least(j)
+                if ls >= nloc_r:
+                    continue
+                lj = self.lcol[j]
+                flops += 2.0 * (nloc_r - ls) * nb * nb * nb
+                todo.append(lambda ls=ls, lj=lj, j=j: self.ops.gemm_nt(
+                    self.A[ls * nb:, lj * nb:(lj + 1) * nb], wrow[(ls - li0) * nb:], pj_fast[j]))
+        else:
+            jlo, jhi = min(cols), max(cols)
+            l0 = self.lcol[jlo]
+            flat = colp.view(-1, nb)                              # (n_local_cols * nb) x nb
+            for li in range(nloc_r - 1, self._first_local_row_at_least(jlo) - 1, -1):      # largest first
+                i = self.rows[li]
+                l1 = len([j for j in self.cols if j <= min(i, jhi)])
+                if l1 <= l0:
+                    continue
+                flops += 2.0 * (l1 - l0) * nb * nb * nb
+                todo.append(lambda li=li, l1=l1: self.ops.gemm_nt(
+                    self.A[li * nb:(li + 1) * nb, l0 * nb:l1 * nb], wrow[(li - li0) * nb:(li - li0 + 1) * nb], flat[l0 * nb:l1 * nb]))
         timed = self.profile and todo and getattr(self.ops, "has_streams", False)
         if timed:
             e0 = self.ops.event(self.ops.main_stream(), timing=True)
         self._fanout(todo)
         if timed:
-            flops = sum(2.0 * (nloc_r - self._first_local_row_at_least(j)) * nb * nb * nb
-                        for j in cols if self._first_local_row_at_least(j) < nloc_r)
             self._upd.append((e0, self.ops.event(self.ops.main_stream(), timing=True), flops))
 
     def timeline(self):

@@ -37,9 +37,9 @@ int gh_microbench_hbm_copy(double* gbps_out);
  * TFLOP/s, cycles/instr, GHz at 4 waves/SIMD; out[10] TFLOP/s at 8 waves/SIMD; out[11..12]
  * v_mfma_f64_4x4x4 TFLOP/s and cycles/instr. */
 int gh_microbench_suite(double* out, int n);
-/* THE fp64 matrix-pipe ceiling: a bare v_mfma_f64_16x16x4_f64 issue loop with 64x more (short) workgroups than the chip
- * has slots, resident wavefronts per SIMD pinned by an LDS request (gh_gemm.hip says why the suite above is NOT a ceiling:
- * it measures how unevenly the dispatcher deals a grid of exactly one slot per workgroup).  out[0..2] = TFLOP/s at 1 / 2 / 4
+/* THE fp64 matrix-pipe ceiling: a bare v_mfma_f64_16x16x4_f64 issue loop in inline assembly (accumulators pinned to VGPRs),
+ * 64x more (short) workgroups than the chip has slots, resident wavefronts per SIMD pinned by an LDS request.  gh_gemm.hip
+ * says why the suite above is NOT a ceiling: its builtin-based loop compiles to 128 accumulator moves per 8 matrix instructions.  out[0..2] = TFLOP/s at 1 / 2 / 4
  * wavefronts per SIMD, out[3] = the best, out[4..6] = milliseconds; n >= 8. */
 int gh_microbench_mfma_f64_ceiling(double* out, int n);
 

@@ -93,7 +93,7 @@ def prow(i, Pr, snake):
     return t if t < Pr else 2 * Pr - 1 - t
 
 
-def replay(cfg, n, link_gbs, lat_us, shared_gpu=False, chain_only=False, hbm_copy_gbs=2500.0):
+def replay(cfg, n, link_gbs, lat_us, shared_gpu=False, chain_only=False, hbm_copy_gbs=2500.0, median_rate=False):
     """finish time (s) of rank_factor()'s schedule with measured compute durations and modelled transfers.
     shared_gpu: all ranks' compute phases contend for ONE device (exclusive use, earliest-ready first) and transfers are
     device-to-device copies -- the virtual-device configuration the trace was taken on."""
@@ -102,6 +102,19 @@ def replay(cfg, n, link_gbs, lat_us, shared_gpu=False, chain_only=False, hbm_cop
     T = {}
     for r_, k_, ph_, ms_, u_ in cfg["trace"]:
         T[(int(r_), int(k_), int(ph_))] = (ms_ * 1e-3, u_)
+    if median_rate:
+        # the update phases priced at the MEDIAN rate the ranks reached at that step: on virtual devices the rank whose update
+        # runs first shares the one GPU's HBM with the other ranks' gather copies (rank 0: 57-58 TFLOP/s against 66-67 for the
+        # others at the same shapes) -- an artefact of eight ranks on one device, not of the rank
+        for ph_ in (PH["bcol"], PH["rest"]):
+            for k_ in range(-(-n // cfg["nb"])):
+                rates = sorted(T[(r_, k_, ph_)][1] / T[(r_, k_, ph_)][0] for r_ in range(cfg["W"]) if (r_, k_, ph_) in T and T[(r_, k_, ph_)][0] > 0)
+                if not rates:
+                    continue
+                med = rates[len(rates) // 2]
+                for r_ in range(cfg["W"]):
+                    if (r_, k_, ph_) in T:
+                        T[(r_, k_, ph_)] = (T[(r_, k_, ph_)][1] / med, T[(r_, k_, ph_)][1])
     bw = (hbm_copy_gbs if shared_gpu else link_gbs) * 1e9
     lat = (5.0 if shared_gpu else lat_us) * 1e-6
 
@@ -289,7 +302,8 @@ def terms(cfg, n):
 
 
 def report(path):
-    res = json.load(open(path))
+    import gzip
+    res = json.load(gzip.open(path, "rt") if path.endswith(".gz") else open(path))
     n = res["n"]
     t1 = res["single_gpu_s"]
     budget = t1 / 6.0
@@ -310,8 +324,8 @@ def report(path):
         P("W = 1 (grid 1x1, nb = %d): measured wall clock of `gh_mgpu_compute` **%.4f s**; its trace replayed: **%.4f s** (%.1f %%).\n"
           % (c["nb"], c["wall_full_s"], sim, 100.0 * (sim / c["wall_full_s"] - 1.0)))
     P("## Configurations (W = 8)\n")
-    P("| grid | nb | snake | chain compute: sum_k potrf / max TRSM / max block column (ms) | bytes on one link inside the chain | update per rank: mean ms (TFLOP/s), max/mean | predicted 8-GPU time at 45 / 60 / 75 GB/s (ms) | speed-up at 60 GB/s | virtual 8-on-1: measured full / chain-only (s); replayed as shared GPU |")
-    P("|---|---|---|---|---|---|---|---|---|")
+    P("| grid | nb | snake | chain compute: sum_k potrf / max TRSM / max block column (ms) | bytes on one link inside the chain | update per rank: mean ms (TFLOP/s), max/mean | predicted 8-GPU time at 45 / 60 / 75 GB/s (ms) | speed-up at 60 GB/s | same, updates at the ranks' median rate (ms, x) | virtual 8-on-1: measured full / chain-only (s); replayed as shared GPU |")
+    P("|---|---|---|---|---|---|---|---|---|---|")
     rows = []
     for c in res["configs"]:
         if c["W"] != 8 or "trace" not in c:
@@ -321,15 +335,16 @@ def report(path):
         tm = terms(c, n)
         preds = [replay(c, n, bw, 25.0) for bw in (45.0, 60.0, 75.0)]
         chain_pred = replay(c, n, 60.0, 25.0, chain_only=True)
+        pred_med = replay(c, n, 60.0, 25.0, median_rate=True)
         sh_full = replay(c, n, 60.0, 25.0, shared_gpu=True)
         sh_chain = replay(c, n, 60.0, 25.0, shared_gpu=True, chain_only=True)
         upd = tm["update_per_rank_ms"]
-        rows.append((c, tm, preds, chain_pred))
-        P("| %dx%d | %d | %s | %.1f / %.1f / %.1f | %.2f GB (%.0f ms at 60 GB/s) | %.1f (%.1f), %.3f | **%.1f / %.1f / %.1f** | **%.2fx** | %.3f / %.3f; %.3f / %.3f |"
+        rows.append((c, tm, preds, chain_pred, pred_med))
+        P("| %dx%d | %d | %s | %.1f / %.1f / %.1f | %.2f GB (%.0f ms at 60 GB/s) | %.1f (%.1f), %.3f | **%.1f / %.1f / %.1f** | **%.2fx** | %.1f, %.2fx | %.3f / %.3f; %.3f / %.3f |"
           % (c["Pr"], c["Pc"], c["nb"], "yes" if c["snake"] else "no", tm["potrf_max_ms"], tm["trsm_max_ms"], tm["bcol_max_ms"],
              tm["chain_link_bytes"] * 1e-9, tm["chain_link_bytes"] / 60e9 * 1e3, sum(upd) / len(upd),
              sum(tm["update_tflops_per_rank"]) / len(upd), tm["update_imbalance"], preds[0] * 1e3, preds[1] * 1e3, preds[2] * 1e3,
-             t1 / preds[1], c["wall_full_s"], c["wall_chain_only_s"], sh_full, sh_chain))
+             t1 / preds[1], pred_med * 1e3, t1 / pred_med, c["wall_full_s"], c["wall_chain_only_s"], sh_full, sh_chain))
     P("")
     P("Columns: *chain compute* = per-step potrf on the diagonal owner + the slowest rank's TRSM + the slowest rank's block-column update,")
     P("summed over the steps (what the chain costs with free transfers); *bytes on one link inside the chain* = L_kk + diagonal inverses +")
@@ -339,15 +354,16 @@ def report(path):
     P("exclusively -- a pessimistic stand-in for eight ranks whose small kernels overlap on the real shared GPU.\n")
     if rows:
         best = min(rows, key=lambda r: r[2][1])
-        c, tm, preds, chain_pred = best
+        c, tm, preds, chain_pred, pred_med = best
         P("## Verdict\n")
         P("Best: **%dx%d, nb = %d** -> **%.1f ms at 60 GB/s per link = %.2fx** the single GPU (budget %.1f ms; %.1f ms at 45 GB/s, %.1f at 75)."
           % (c["Pr"], c["Pc"], c["nb"], preds[1] * 1e3, t1 / preds[1], budget * 1e3, preds[0] * 1e3, preds[2] * 1e3))
         P("Its chain alone (chain-only replay, transfers included): %.1f ms; its per-rank update: %.1f ms -- the step is bound by the"
           % (chain_pred * 1e3, max(tm["update_per_rank_ms"])))
-        P("%s.\n" % ("UPDATES (the chain hides behind them)" if chain_pred < max(tm["update_per_rank_ms"]) * 1e-3 else "CHAIN"))
+        P("%s.  With every rank's updates at the median rate of the eight (the rank whose update runs first on the shared test GPU" % ("UPDATES (the chain hides behind them)" if chain_pred < max(tm["update_per_rank_ms"]) * 1e-3 else "CHAIN"))
+        P("competes with the others' gather copies for the one HBM): **%.1f ms = %.2fx**.\n" % (pred_med * 1e3, t1 / pred_med))
     print(json.dumps({"n": n, "single_gpu_s": t1, "budget_s": budget,
-                      "configs": [{"grid": "%dx%d" % (c["Pr"], c["Pc"]), "nb": c["nb"], "pred_ms_45_60_75": [p * 1e3 for p in preds]} for c, tm, preds, _ in rows]}),
+                      "configs": [{"grid": "%dx%d" % (c["Pr"], c["Pc"]), "nb": c["nb"], "pred_ms_45_60_75": [p * 1e3 for p in preds], "pred_ms_60_median_rate": pm * 1e3} for c, tm, preds, _, pm in rows]}),
           file=sys.stderr)
 
 

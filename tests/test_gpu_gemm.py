@@ -43,8 +43,8 @@ def test_microbench_peaks():
 
 def test_mfma_f64_ceiling_is_a_ceiling():
     """SURVEY 8(d)'s second denominator: the bare issue loop must reach at least what the GEMM kernel sustains (round 3's
-    loop read 34-47 TFLOP/s against 68-70 in the GEMM: it measured the dispatcher's uneven deal of a one-slot-per-workgroup
-    grid, not the pipe) and cannot exceed the datasheet's 78.6 by more than clock tolerance."""
+    loop read 34-47 TFLOP/s against 68-70 in the GEMM: hipcc had wrapped its eight matrix instructions in 128 VGPR <-> AGPR
+    accumulator moves per iteration, so it measured the vector ALU's move rate, not the pipe) and cannot exceed the datasheet's 78.6 by more than clock tolerance."""
     import torch
     from george_amd import _native as N
     out = (C.c_double * 8)()
