@@ -239,10 +239,10 @@ def hodlr_report(n, local_rank, steps=10, warmup=3, cpu_n=32768):
     rtot = sum(lv)
     foot = 2.0 * 8.0 * n * rtot + 8.0 * n * 128            # U and V of every level + the 128-row leaves
     # bytes the factorisation sweep + the log-likelihood's solve actually STREAM (not the footprint touched once): per level l
-    # with rank R and off = sum of the shallower ranks -- update of U[:, 0:off) read + written, U_l and V_l read; the reduce's
-    # own read of U[:, 0:off+R) only at the deepest level since round 4 (hodlr_updred_kernel fuses it into the update of the
-    # level below); leaves applied to all of U (read + written) + the leaf inverses read; the solve reads U, V and the leaf
-    # inverses once each
+    # with rank R and off = sum of the shallower ranks -- the reduce reads U[:, 0:off+R) and V_l, the update reads and writes
+    # U[:, 0:off) and reads U_l; leaves applied to all of U (read + written) + the leaf inverses read; the solve reads U, V and
+    # the leaf inverses once each.  (Fusing update and reduce -- 2/3 of these bytes -- was built in round 4 and is NOT faster:
+    # scripts/dev/arms/hodlr_fused_sweep_r04.patch.)
     offs = np.concatenate([[0], np.cumsum(lv)[:-1]]) if lv else np.zeros(0)
     active = [l for l in range(len(lv)) if lv[l] > 0]
     streamed = 2.0 * 8.0 * n * rtot + 8.0 * n * 128        # leaf apply
@@ -250,17 +250,18 @@ def hodlr_report(n, local_rank, steps=10, warmup=3, cpu_n=32768):
         streamed += 8.0 * n * (2.0 * offs[l] + 2.0 * lv[l])
     if active:
         streamed += 8.0 * n * (offs[active[-1]] + lv[active[-1]])
-    streamed_unfused = streamed + sum(8.0 * n * (offs[l] + lv[l]) for l in active[:-1])
+    streamed_fused = streamed
+    streamed += sum(8.0 * n * (offs[l] + lv[l]) for l in active[:-1])
     streamed += 2.0 * 8.0 * n * rtot + 8.0 * n * 128       # the solve
-    streamed_unfused += 2.0 * 8.0 * n * rtot + 8.0 * n * 128
+    streamed_fused += 2.0 * 8.0 * n * rtot + 8.0 * n * 128
     out = {"workload": "N=%d 1-D ExpSquared, HODLRSolver(tol=1e-10, min_size=100, seed=42): compute()+log_likelihood()" % n,
            "seconds_per_step": sec, "steps": steps, "log_likelihood": ll, "rank_per_level": lv, "rank_total": rtot,
            "roofline": {"kernel": "whole HODLR compute()+log_likelihood() (ACA, leaf / core factorisation, Woodbury sweeps)",
                         "bound": "hbm", "achieved": foot / sec * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": foot / sec * 1e-9 / PEAK_HBM_GBS, "traffic": streamed,
                         "traffic_note": "bytes the sweep + solve stream by construction (model from the measured ranks; the ACA "
-                                        "phase evaluates kernel entries, it streams nothing); %.2f GB with update and reduce as two "
-                                        "passes (round 3)" % (streamed_unfused * 1e-9),
+                                        "phase evaluates kernel entries, it streams nothing); %.2f GB with update and reduce fused "
+                                        "(built in round 4, not faster: scripts/dev/arms)" % (streamed_fused * 1e-9),
                         "streamed_bytes": streamed, "achieved_streamed": streamed / sec * 1e-9,
                         "algorithmic_bytes": foot, "note": "footprint 2*8*N*Rtot + 8*N*128 touched once; the step is "
                         "latency-bound (a chain of ~%d dependent launches), not bandwidth-bound" % (12 * len(lv))}}

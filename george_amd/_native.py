@@ -99,6 +99,7 @@ SIGNATURES = {
     "gh_device_count": (C.c_int, []),
     "gh_last_error": (C.c_char_p, []),
     "gh_version": (C.c_char_p, []),
+    "gh_release_caches": (None, [C.c_int32]),
     "gh_microbench_mfma_f64": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_microbench_hbm_copy": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),

@@ -41,6 +41,7 @@ bool gh_is_device_ptr(const void* p);
 // reused while the previous user's kernels are still queued -- stream order then protects it).
 void* gh_pool_acquire(size_t bytes, size_t* capacity);     // nullptr on allocation failure
 void gh_pool_release(void* p, size_t capacity);
+void gh_pool_trim();                                       // really free every cached block of the current device
 
 // RAII device buffer
 struct GhBuf {
@@ -64,7 +65,12 @@ struct GhBuf {
       return GH_OK;
     }
     hipError_t e = hipMalloc(&p, nbytes ? nbytes : 8);
-    if (e != hipSuccess) { p = nullptr; gh_set_error("hipMalloc of %zu bytes failed: %s", nbytes, hipGetErrorString(e)); return GH_ERR_NOMEM; }
+    if (e != hipSuccess) {                                  // (the block cache may hold tens of GB of released blocks: drop them, once)
+      (void)hipGetLastError();
+      gh_pool_trim();
+      e = hipMalloc(&p, nbytes ? nbytes : 8);
+    }
+    if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); gh_set_error("hipMalloc of %zu bytes failed: %s", nbytes, hipGetErrorString(e)); return GH_ERR_NOMEM; }
     bytes = nbytes;
     return GH_OK;
   }

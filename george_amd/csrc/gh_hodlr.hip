@@ -964,10 +964,6 @@ struct HLevel {
   int R = 0, off = 0, nchunks = 0;
   GhPooledBuf d_nodes, d_chunks, d_crange, d_red_jobs, d_upd_jobs, d_smul_jobs, d_ranks, sinv;   // (one stream: h->st)
   GhPooledBuf d_gj_offs, d_gj_sizes, d_gj_sc, d_updl_jobs;
-  // update of THIS level fused with the reduce of the next shallower level with a non-zero rank (hodlr_updred_kernel):
-  // jobs over all rows in row order, and that level's (node, half) -> job ranges
-  GhPooledBuf d_fus_jobs, d_fus_crange;
-  int fus_next = -1, fus_njobs = 0, fus_sig[6] = {-1, -1, -1, -1, -1, -1};
   std::vector<int> ranks;
   // The job tables depend on the tree and on (R, off, Rtot) only: inside an optimiser loop neither
   // changes from one compute() to the next, and re-uploading them (~9 small copies per level, each a
@@ -1294,105 +1290,6 @@ __global__ __launch_bounds__(256) void hodlr_upd_kernel(const MMJob* __restrict_
       }
   }
 }
-// Update of level l FUSED with the reduce of the next shallower level lp (round 4): the sweep applies level l's inverse to
-// columns [0, off_l) of U and the very next thing that happens to those columns is lp's reduce V_lp^T U[:, 0:off_l) -- off_l =
-// off_lp + R_lp, the reduce's whole column range.  The freshly updated accumulators ARE the reduce's B operand: a lane holds
-// U[row = fk + 4 r (+ tile base), col = 16 j + fr] in acc[j][r], and the k-step kk of v_mfma_f64_16x16x4 wants B(k = 4 kk + fk,
-// n = fr) -- the same element with kk = r.  So after storing a 16-row tile the wavefront multiplies it into its partial
-// V_lp^T U without another byte of traffic; the four wavefronts' partial tiles are added in a fixed order through LDS as in
-// hodlr_red_kernel.  One pass over U per level instead of two (the reduce's separate read: sum_l off_l N 8 B, a third of the
-// 3.1 GB the sweep streams at C4).  Jobs cover ALL rows in row order: chunks of level l's nodes (kd = R_l > 0) and "gap" chunks
-// of rows that level l has no node for (kd = 0: nothing to update, their current U still belongs in the sum).
-//   O[(o_row + r) * ldo + c] -= sum_k A[a_off + r * a_rs + k] * B[(b_row + k) * ldb + c]                 (kd > 0)
-//   P[(job * R2 + k2) * ldp + c] = sum_r V2[(o_row + r) * R2 + k2] * O_new[(o_row + r) * ldo + c]
-template <int CT>
-__global__ __launch_bounds__(256) void hodlr_updred_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ A, long a_rs,
-                                                           const double* __restrict__ B, long ldb, double* __restrict__ O, long ldo, int C,
-                                                           const double* __restrict__ V2, int R2, double* __restrict__ P, long ldp) {
-  typedef double uk_v4d __attribute__((ext_vector_type(4)));
-  __shared__ double part[3 * CT * 4 * 64];
-  const MMJob job = jobs[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, fk = lane >> 4;
-  const int R = job.kd, nkk = (R + 3) >> 2, ct = (C + 15) >> 4;        // (uniform)
-  double a[2][4], b[4][CT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int row = 32 * wave + 16 * i + fr, k = 4 * kk + fk;
-      a[i][kk] = (row < job.m && k < R) ? -A[job.a_off + (long)row * a_rs + k] : 0.0;
-    }
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-    for (int j = 0; j < CT; ++j) {
-      const int k = 4 * kk + fk, c = 16 * j + fr;
-      b[kk][j] = (k < R && c < C) ? B[(long)(job.b_row + k) * ldb + c] : 0.0;
-    }
-  double* const ob = O + (long)job.o_row * ldo;
-  const double* const v2 = V2 + (long)job.o_row * R2;
-  uk_v4d red[CT];
-#pragma unroll
-  for (int j = 0; j < CT; ++j) red[j] = (uk_v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (32 * wave + 16 * i >= job.m) continue;                         // (uniform)
-    uk_v4d acc[CT];
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 32 * wave + 16 * i + fk + 4 * r, c = 16 * j + fr;
-        acc[j][r] = (j < ct && row < job.m && c < C) ? ob[(long)row * ldo + c] : 0.0;
-      }
-    if (R > 0) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk >= nkk) continue;
-#pragma unroll
-        for (int j = 0; j < CT; ++j)
-          if (j < ct) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][kk], b[kk][j], acc[j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < CT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 32 * wave + 16 * i + fk + 4 * r, c = 16 * j + fr;
-          if (j < ct && row < job.m && c < C) ob[(long)row * ldo + c] = acc[j][r];
-        }
-    }
-    // V_lp^T (R2 x 16 rows of this tile) times the tile: A operand (m = fr: the rank index, k = 4 kk + fk: the row)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int row = 32 * wave + 16 * i + 4 * kk + fk;
-      const double av = (fr < R2 && row < job.m) ? v2[(long)row * R2 + fr] : 0.0;
-#pragma unroll
-      for (int j = 0; j < CT; ++j)
-        if (j < ct) red[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[j][kk], red[j], 0, 0, 0);
-    }
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part[(((wave - 1) * CT + j) * 4 + r) * 64 + lane] = red[j][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = fk + 4 * r, c = 16 * j + fr;
-        if (k < R2 && c < C) {
-          const double v = ((red[j][r] + part[((0 * CT + j) * 4 + r) * 64 + lane]) + part[((1 * CT + j) * 4 + r) * 64 + lane]) +
-                           part[((2 * CT + j) * 4 + r) * 64 + lane];
-          P[((long)blockIdx.x * R2 + k) * ldp + c] = v;
-        }
-      }
-  }
-}
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
                      const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1);
 static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* V, const double* B, long ldb, long b_col0,
@@ -1431,23 +1328,6 @@ static int launch_upd(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const do
     default: GH_UPD_LAUNCH(8); break;
   }
 #undef GH_UPD_LAUNCH
-  GH_HIP(hipGetLastError());
-  return GH_OK;
-}
-
-static int launch_updred(gh_hodlr* h, const MMJob* jobs, int njobs, const double* A, long a_rs, const double* B, long ldb,
-                         double* O, long ldo, int C, const double* V2, int R2, double* P, long ldp) {
-  if (njobs <= 0 || C <= 0) return GH_OK;
-#define GH_UR_LAUNCH(CT) hipLaunchKernelGGL(hodlr_updred_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, A, a_rs, B, ldb, O, ldo, C, V2, R2, P, ldp)
-  switch ((C + 15) / 16) {
-    case 1: GH_UR_LAUNCH(1); break;
-    case 2: GH_UR_LAUNCH(2); break;
-    case 3: GH_UR_LAUNCH(3); break;
-    case 4: GH_UR_LAUNCH(4); break;
-    case 5: GH_UR_LAUNCH(5); break;
-    default: GH_UR_LAUNCH(8); break;
-  }
-#undef GH_UR_LAUNCH
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
@@ -2218,64 +2098,6 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(upload(L->d_smul_jobs, smul, st));
     L->tab_R = R; L->tab_off = L->off; L->tab_Rtot = Rtot;
   }
-  // ---- update(l) fused with reduce(lp), lp = the next shallower level with a rank (hodlr_updred_kernel): job list over ALL
-  // rows in row order -- level l's chunks and gap chunks for rows level l has no node for -- and lp's (node, half) -> job ranges
-  for (int l = nlev - 1; l >= 0; --l) {
-    HLevel* L = h->levels[l];
-    L->fus_next = -1;
-    if (L->R == 0 || L->top || L->off == 0 || L->R > 16 || L->off > 128 || l < l0) continue;
-    int lp = l - 1;
-    while (lp >= 0 && h->levels[lp]->R == 0) --lp;
-    if (lp < 0 || lp < l0) continue;
-    HLevel* Lp = h->levels[lp];
-    if (Lp->top || Lp->R > 16 || Lp->off + Lp->R != L->off || L->off > std::max(CPASS, (h->maxR + 63) / 64 * 64)) continue;
-    L->fus_next = lp;
-    const int sig[6] = {L->R, L->off, (int)Rtot, Lp->R, Lp->off, (int)n};
-    bool same = L->fus_njobs > 0;
-    for (int q = 0; q < 6; ++q) same = same && L->fus_sig[q] == sig[q];
-    if (same) { h->max_chunks = std::max(h->max_chunks, L->fus_njobs); continue; }
-    // level l's node intervals, by first row
-    std::vector<std::pair<int, int>> iv;       // (start, index into node_ids)
-    for (int q = 0; q < (int)L->node_ids.size(); ++q) iv.push_back({h->nodes[L->node_ids[q]].start, q});
-    std::sort(iv.begin(), iv.end());
-    std::vector<MMJob> jobs;
-    std::vector<int> crange(Lp->node_ids.size() * 4);
-    const int R = L->R;
-    size_t at = 0;
-    for (int q2 = 0; q2 < (int)Lp->node_ids.size(); ++q2) {
-      const HNode& nd2 = h->nodes[Lp->node_ids[q2]];
-      for (int half = 0; half < 2; ++half) {
-        const int lo = half == 0 ? nd2.start : nd2.start + nd2.half;
-        const int hi = half == 0 ? nd2.start + nd2.half : nd2.start + nd2.size;
-        crange[(q2 * 2 + half) * 2] = (int)jobs.size();
-        int row = lo;
-        auto gap = [&](int upto) {
-          for (; row < upto; row += std::min(HCH, upto - row)) jobs.push_back({0L, 0, row, std::min(HCH, upto - row), 0});
-        };
-        while (at < iv.size() && iv[at].first < hi) {
-          const int q = iv[at].second;
-          const HNode& nd = h->nodes[L->node_ids[q]];
-          if (nd.start < lo) { ++at; continue; }               // (cannot happen in a nested tree)
-          gap(nd.start);
-          for (int hf = 0; hf < 2; ++hf) {
-            const int r0 = hf == 0 ? nd.start : nd.start + nd.half;
-            const int cnt = hf == 0 ? nd.half : nd.size - nd.half;
-            for (int sft = 0; sft < cnt; sft += HCH)
-              jobs.push_back({(long)(r0 + sft) * Rtot, q * 2 * R + (hf == 0 ? 0 : R), r0 + sft, std::min(HCH, cnt - sft), R});
-          }
-          row = nd.start + nd.size;
-          ++at;
-        }
-        gap(hi);
-        crange[(q2 * 2 + half) * 2 + 1] = (int)jobs.size();
-      }
-    }
-    L->fus_njobs = (int)jobs.size();
-    h->max_chunks = std::max(h->max_chunks, L->fus_njobs);
-    GH_CHECK(upload(L->d_fus_jobs, jobs, st));
-    GH_CHECK(upload(L->d_fus_crange, crange, st));
-    for (int q = 0; q < 6; ++q) L->fus_sig[q] = sig[q];
-  }
   mark("tables enqueued");
   GH_HIP(hipStreamSynchronize(st));
   mark("U, V assembled");
@@ -2303,8 +2125,6 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   if (h->Rtot > 0) GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot));
   std::vector<size_t> top_ld(l0, (size_t)-1);        // where in ld_all the core of pseudo-level l put its log|det|
   bool local_done = (l0 == 0);
-  int fused_for = -1;                                  // level whose reduce partials are already in P
-  const int* fused_crange = nullptr;
   for (int l = nlev - 1; l >= 0; --l) {
     HLevel* L = h->levels[l];
     if (l < l0 && !local_done) {
@@ -2342,11 +2162,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     static const bool no_merge = getenv("GEORGE_AMD_HODLR_NO_MERGED_REDUCE") != nullptr;
     const int Call = L->off + R;
     const bool merged = !no_merge && Call <= h->cpass;
-    if (fused_for == l && merged) {
-      // the update of the level below already left V_l^T U[:, 0:Call), chunk by chunk, in P (hodlr_updred_kernel): sum only
-      hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), fused_crange, R, (long)h->cpass, Call, h->Tsum.d());
-      GH_HIP(hipGetLastError());
-    } else if (merged) {
+    if (merged) {
       GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
                           h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
       hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, Call, h->Tsum.d());
@@ -2372,17 +2188,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // (Tsum already holds V_l^T U[:, 0:off]: core product and update only)
       GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
                          h->Tsum.d(), h->cpass, 0, h->Tout.d(), h->cpass, 0, L->off, false));
-      static const bool no_fuse = getenv("GEORGE_AMD_HODLR_NO_FUSED_SWEEP") != nullptr;     // validation arm: update and reduce as two passes
-      if (L->fus_next >= 0 && !no_fuse && !no_merge) {
-        HLevel* Lp = h->levels[L->fus_next];
-        GH_CHECK(launch_updred(h, (const MMJob*)L->d_fus_jobs.p, L->fus_njobs, h->UA.d() + L->off, Rtot, h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off,
-                               h->VA.d() + (long)n * Lp->off, Lp->R, h->P.d(), h->cpass));
-        fused_for = L->fus_next;
-        fused_crange = (const int*)L->d_fus_crange.p;
-      } else {
-        GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
-                            h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
-      }
+      GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
+                          h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
     } else {
       GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
     }

@@ -99,9 +99,35 @@ void* gh_pool_acquire(size_t bytes, size_t* capacity) {
   }
   const size_t cap = (bytes + 255) & ~(size_t)255;
   void* p = nullptr;
-  if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    // out of device memory with up to 48 GB of released blocks parked here: give them back and try once more
+    (void)hipGetLastError();
+    gh_pool_trim();
+    if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  }
   *capacity = cap;
   return p;
+}
+// really free every cached block of the current device
+void gh_pool_trim() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    for (auto& kv : g_cache.free_blocks[dev]) drop.push_back(kv.second);
+    g_cache.free_blocks[dev].clear();
+    g_cache.cached_bytes[dev] = 0;
+  }
+  for (void* q : drop) (void)hipFree(q);
+}
+extern "C" void gh_release_caches(int32_t device) {
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+  gh_pool_trim();
+  (void)hipSetDevice(prev);
 }
 void gh_pool_release(void* p, size_t capacity) {
   if (!p) return;

@@ -110,6 +110,18 @@ class BasicSolver(object):
                 pass
             self._handle = None
 
+    def _retry_without_parked_memory(self, call):
+        """Run ``call(handle)``; on MemoryError give back what dead solvers left parked on the device -- the handle pool
+        (up to _POOL_MAX_BYTES, work arrays included) and the native block cache (up to 48 GB) -- and try ONCE more: a
+        new pool key, a multi-GPU handle or the application's own allocations must not fail because of memory nobody uses."""
+        try:
+            return call(self._ensure_handle())
+        except MemoryError:
+            type(self).release_pool()
+            BasicSolver.release_pool()
+            N.lib.gh_release_caches(int(self._opts["device"]))
+            return call(self._ensure_handle())
+
     @classmethod
     def release_pool(cls):
         """Destroy every parked native handle (frees their device memory)."""
@@ -170,7 +182,8 @@ class BasicSolver(object):
         h = self._ensure_handle()
         logdet = C.c_double(0.0)
         self._factor_state = None
-        N.check(N.lib.gh_chol_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+        self._retry_without_parked_memory(lambda hh: N.check(N.lib.gh_chol_compute(
+            hh, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet))))
         self._n = len(x)
         self._x_host = x                     # (the inputs travel with a pickled factor: predict / grad need them)
         self.log_determinant = logdet.value
@@ -201,8 +214,9 @@ class BasicSolver(object):
             wh = np.ascontiguousarray(np.ones(max(self._dk.size, 1)) if which is None else which, dtype=np.uint32)
             g = np.zeros(max(self._dk.size, 1))
             alpha, diagA = np.empty(n), np.empty(n)
-        N.check(N.lib.gh_chol_objective(h, self._dk.handle, N.ptr(x), n, x.shape[1], N.ptr(yerr), N.ptr(r), N.ptr(wh),
-                                        C.byref(logdet), C.byref(quad), N.ptr(g), N.ptr(alpha), N.ptr(diagA)))
+        self._retry_without_parked_memory(lambda hh: N.check(N.lib.gh_chol_objective(
+            hh, self._dk.handle, N.ptr(x), n, x.shape[1], N.ptr(yerr), N.ptr(r), N.ptr(wh),
+            C.byref(logdet), C.byref(quad), N.ptr(g), N.ptr(alpha), N.ptr(diagA))))
         self._n = n
         self._x_host = x
         self.log_determinant = logdet.value

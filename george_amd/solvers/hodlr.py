@@ -119,7 +119,18 @@ class HODLRSolver(BasicSolver):
         logdet = C.c_double(0.0)
         self.dense_fallback, self._dense = False, None
         try:
-            N.check(N.lib.gh_hodlr_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+            try:
+                N.check(N.lib.gh_hodlr_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
+            except MemoryError:
+                # memory that dead solvers left parked (dense handle pool, HODLR handle pool, native block cache) goes back
+                # to the device, and the call is tried once more
+                self._handle = None
+                N.lib.gh_hodlr_destroy(h)
+                BasicSolver.release_pool()
+                HODLRSolver.release_pool()
+                N.lib.gh_release_caches(self._hopts["device"])
+                h = self._ensure_handle()
+                N.check(N.lib.gh_hodlr_compute(h, self._dk.handle, N.ptr(x), len(x), x.shape[1], N.ptr(yerr), C.byref(logdet)))
         except N.RankCeilingError as e:
             if len(x) > HODLRSolver.DENSE_FALLBACK_MAX_N:
                 raise

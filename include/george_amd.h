@@ -95,6 +95,10 @@ typedef struct gh_hodlr  gh_hodlr;
 int         gh_device_count(void);
 const char* gh_last_error(void);
 const char* gh_version(void);
+/* Device memory the library keeps for re-use -- released transient blocks (up to 48 GB per device) -- is really freed.  The
+ * library does this itself before it reports GH_ERR_NOMEM; an application that needs the memory for its own allocations
+ * calls it directly (solver handles keep what they hold: gh_chol_trim / gh_chol_release_buffers / *_destroy). */
+void gh_release_caches(int32_t device);
 /* ---------------------------------------------- kernel-function evaluator
  * Replaces the pybind11 class KernelInterface, src/george/kernel_interface.cpp:
  *   ctor + parse_kernel_spec  :12-14   -> gh_kernel_create

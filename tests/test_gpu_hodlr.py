@@ -352,33 +352,3 @@ def test_parked_handles_are_bounded_and_reused():
     b.compute(X, yerr)
     assert a.log_determinant == b.log_determinant and a.ranks() == b.ranks()
 
-
-def test_fused_sweep_agrees_with_the_two_pass_arm():
-    """Round 4: the update of a level is fused with the reduce of the next shallower level (hodlr_updred_kernel: one pass
-    over U per level instead of two).  GEORGE_AMD_HODLR_NO_FUSED_SWEEP=1 restores the two passes; the two arms differ only
-    in how the V^T U partial sums are chunked.  Complete trees, trees whose bottom level is incomplete (gap chunks), a
-    3-D case with larger ranks, repeated computes on one handle."""
-    import subprocess, sys, os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
-            "import numpy as np, zoo\n"
-            "from george_amd import kernels, HODLRSolver\n"
-            "for n, ndim, tol in ((4096, 1, 1e-10), (5000, 1, 1e-10), (1531, 1, 1e-12), (3000, 3, 1e-6), (20000, 1, 1e-8)):\n"
-            "    x, yerr, y = zoo.bench_data(n, ndim=ndim)\n"
-            "    k = np.var(y) * kernels.ExpSquaredKernel(1.0, ndim=ndim)\n"
-            "    s = HODLRSolver(k, tol=tol)\n"
-            "    out = []\n"
-            "    for rep in range(2):\n"
-            "        s.compute(np.ascontiguousarray(x.reshape(n, -1)), yerr)\n"
-            "        out += [s.log_determinant, s.dot_solve(y), float(np.abs(s.apply_inverse(y)).sum())]\n"
-            "    print(' '.join(repr(float(v)) for v in out))\n") % (root, root)
-    outs = []
-    for env in ({}, {"GEORGE_AMD_HODLR_NO_FUSED_SWEEP": "1"}):
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-5:]])
-    for a, b in zip(outs[0], outs[1]):
-        assert a[:3] == a[3:] and b[:3] == b[3:]                          # each arm repeatable on one handle
-        for u, v in zip(a[:3], b[:3]):
-            assert abs(u - v) <= 1e-9 * abs(v), (a, b)
