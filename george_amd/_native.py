@@ -103,7 +103,6 @@ SIGNATURES = {
     "gh_microbench_mfma_f64": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_microbench_hbm_copy": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
-    "gh_debug_set_gemm_tall": (C.c_int, [C.c_int]),
     "gh_debug_stream_overlap": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_debug_stream_dispatch": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_microbench_suite": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

@@ -651,14 +651,13 @@ bool gh_shared_streams(int device, hipStream_t q[4]) {
     // Does the main stream share a dispatcher with one of the panel streams?  (Which queues end up together depends on how
     // many the process made before: never in a process that made none, with the rows-below stream after five application
     // streams, with the chain stream after six.)  Decides where a look-ahead factorisation is joined: factor_lookahead_deep.
-    if (ss.q[0] && ss.q[1] && ss.q[2] && ss.q[3] && !getenv("GEORGE_AMD_NO_PLACEMENT_PROBE")) {
+    // (GEORGE_AMD_JOIN=main|chain decides by itself: nothing to measure then)
+    if (ss.q[0] && ss.q[1] && ss.q[2] && ss.q[3] && !getenv("GEORGE_AMD_JOIN")) {
       for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(place_spin_kernel, dim3(1), dim3(64), 0, ss.q[i], 0LL);   // (queues are made at first use)
       (void)hipDeviceSynchronize();
       for (int i = 1; i < 4 && !ss.main_crowded; ++i)
         ss.main_crowded = dispatch_wait_ms(ss.q[0], ss.q[i]) > 0.3 || dispatch_wait_ms(ss.q[i], ss.q[0]) > 0.3;
       (void)hipGetLastError();
-      if (getenv("GEORGE_AMD_DEBUG_STREAMS"))
-        fprintf(stderr, "[george_amd streams] device %d: the main stream %s a dispatcher with a panel stream\n", device, ss.main_crowded ? "SHARES" : "does not share");
     }
   }
   for (int i = 0; i < 4; ++i) q[i] = ss.q[i];
@@ -697,9 +696,8 @@ extern "C" int gh_chol_create(const gh_chol_opts* opts, gh_chol** out) {
   if (s->opts.nb % T) { delete s; gh_set_error("nb must be a multiple of 128"); return GH_ERR_BAD_ARG; }
   int rc = set_device(s);
   if (rc != GH_OK) { delete s; return rc; }
-  static const bool private_streams = getenv("GEORGE_AMD_PRIVATE_STREAMS") != nullptr;
   hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (!private_streams && gh_shared_streams(s->opts.device, shq)) {
+  if (gh_shared_streams(s->opts.device, shq)) {
     s->shared_streams = true;
     s->st = shq[0];
   } else {
@@ -937,12 +935,11 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   const int64_t np = s->np, ld = np;
   double* dinv = s->dinv.d() + (k0 / T) * T * T;
   const int64_t m = np - (k0 + nb);
-  static const bool no_split = getenv("GEORGE_AMD_NO_PANEL_SPLIT") != nullptr;
   const bool on_panel_stream = (st == s->st2);
   // (Retired arms, all measured and slower, sources under scripts/dev/arms/: only row block j+1 on the chain and the
   //  other in-panel rows on a third stream; the chain on CUs of its own; only the potf2 launches on reserved CUs; the
   //  whole panel as two persistent flag-driven launches.  DESIGN.md section 4, "Where N < 24k stands".)
-  if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || no_split || use_simple_potf2()) {
+  if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
     if (m > 0) {
       GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
@@ -1036,8 +1033,7 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   // U(j, j+1), and the first thing that needs them is the rows-below TRSM of panel j+1 on st3 -- so it
   // goes to st3 itself: one hardware queue less.  (The process degrades by 20-40 % at N <= 16384 once
   // eight queues are in use -- null stream + this handle's + the application's; scripts/dev/queue_pattern.py.)
-  static const bool own_near = getenv("GEORGE_AMD_NEAR_STREAM") != nullptr;        // A/B: the fourth stream also at depth 1
-  hipStream_t sm = trailing_stream(s), sn = (depth == 1 && !own_near && s->st3) ? s->st3 : s->st4;
+  hipStream_t sm = trailing_stream(s), sn = (depth == 1 && s->st3) ? s->st3 : s->st4;
   hipStream_t sp = s->st2;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);
@@ -1395,7 +1391,7 @@ extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
 static int trsm_multi(gh_chol* s, double* B, int64_t rp, bool forward, bool backward, bool tri = false) {
   // (tiles per super-block; measured at N = 32768 with 4096 right-hand sides, both sweeps: 2 -> 167 ms, 4 -> 158.5,
   //  8 -> 151.6, 16 -> 149.5; no difference at N = 8192.  GEORGE_AMD_TRSM_SB overrides)
-  static const int64_t SB = getenv("GEORGE_AMD_TRSM_SB") ? std::max(1, atoi(getenv("GEORGE_AMD_TRSM_SB"))) : 8;
+  const int64_t SB = 8;
   const int64_t np = s->np, nt = np / T;
   const double* L = s->A.d();
   auto mm = [&](double* Cp, const double* Ap, int64_t lda, bool a_km, const double* Bp, int64_t M, int64_t N, int64_t K,

@@ -299,111 +299,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
 #undef GH_DMA_ISSUE
 
 // ---------------------------------------------------------------------------------------------
-// 256 x 128 C tile per 512-thread workgroup (4 x 2 wavefronts of 64 x 64, one workgroup per CU, 96 KiB of
-// LDS): the same slab pipeline as gemm_f64_mfma_dma with the A slab twice as tall, so that every B slab
-// fetched from the L2 feeds 256 rows instead of 128 -- operand traffic per flop x 0.75 (A unchanged, B
-// halved), half as many workgroups, and one barrier domain of 8 wavefronts instead of two of 4.
-// k-major x k-major operands without K clipping only (the trailing SYRK and the block-column updates).
-// Tile rows are PAIRS of 128-row blocks; with an odd number of blocks the last tile row is a half tile:
-// its wavefronts 4-7 move rows of the first half again (never out of bounds) and neither compute nor
-// store.  LOWER: tile row i holds the columns 0 .. 2i+1 (the tile at column 2i+1 has only its second
-// 128-row block below the diagonal: wavefronts 0-3 idle there).
-template <bool LOWER>
-__global__ __launch_bounds__(512, 1) void gemm_f64_mfma_dma_tall(GemmDev g) {
-  __shared__ __attribute__((aligned(1024))) double sA[2][256 * BK];
-  __shared__ __attribute__((aligned(1024))) double sB[2][128 * BK];
-  const long l = xcd_remap(blockIdx.x, g.nblk);
-  int ti, tn;
-  if (LOWER) {                                        // tile rows 0 .. i-1 hold i (i + 1) tiles
-    long i = (long)((sqrt(4.0 * (double)l + 1.0) - 1.0) * 0.5);
-    while (i * (i + 1) > l) --i;
-    while ((i + 1) * (i + 2) <= l) ++i;
-    ti = (int)i; tn = (int)(l - i * (i + 1));
-  } else {
-    ti = (int)(l / g.tiles_n); tn = (int)(l % g.tiles_n);
-  }
-  const long row0 = (long)ti * 256, col0 = (long)tn * 128;
-  const bool half = 2 * ti + 1 >= g.tiles_m;          // only the first 128 rows of this tile exist
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-  const bool active = !(half && wm >= 2) && !(LOWER && tn > 2 * ti + (wm >> 1));
-  const long nk = g.K / BK;
-
-  const double* ga[4];
-  const double* gb[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + (lane >> 3);
-    const int rs = (half && r >= 128) ? r - 128 : r;
-    ga[i] = g.A + (row0 + rs) * g.lda + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wave * 16 + i * 8 + (lane >> 3);
-    gb[i] = g.B + (col0 + r) * g.ldb + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
-  }
-  const int dstA = wave * 4 * 128, dstB = wave * 2 * 128;
-#define GH_TALL_ISSUE(buf)                                                                             \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-    __builtin_amdgcn_global_load_lds((gh_glb_void*)ga[i_], (gh_lds_void*)(sA[buf] + dstA + i_ * 128), 16, 0, 0); \
-    ga[i_] += BK;                                                                                      \
-  }                                                                                                    \
-  _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
-    __builtin_amdgcn_global_load_lds((gh_glb_void*)gb[i_], (gh_lds_void*)(sB[buf] + dstB + i_ * 128), 16, 0, 0); \
-    gb[i_] += BK;                                                                                      \
-  }
-  const int sw = (fr >> 1) & 7;
-  int offk[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
-  const int rowA = (wm * 64 + fr) * BK, rowB = (wn * 64 + fr) * BK;
-
-  v4d acc[4][4];
-  if (nk > 0) { GH_TALL_ISSUE(0) }
-  if (active) gemm_init_acc(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
-  __syncthreads();
-  for (long kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    double a[4][4], b[4][4];
-    if (active) {
-      const double* pa = sA[cur] + rowA;
-      const double* pb = sB[cur] + rowB;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[kk][i] = pa[i * 16 * BK + offk[kk]];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      if (cur) { GH_TALL_ISSUE(0) } else { GH_TALL_ISSUE(1) }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (active) {
-#pragma unroll
-      for (int kk = 1; kk < 4; ++kk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-#undef GH_TALL_ISSUE
-  if (active) gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
-}
-
-// ---------------------------------------------------------------------------------------------
 // 64x64-tile variant for launches that cannot fill the chip anyway (the GEMMs inside the panel
 // chain: <= 128 tiles of 128x128, K = 128..1024).  A 128x128x128 tile is 512 MFMAs per wavefront
 // = 15 us on its one CU no matter how idle the other 255 are; four times as many workgroups of a
@@ -679,28 +574,13 @@ __global__ __launch_bounds__(256) void gemm_f64_valu(GemmDev g) {
 }
 
 // 0 = plain VALU (validation arm: cross-checks the MFMA lane maps on the device), 1 = the LDS-DMA
-// v_mfma_f64_16x16x4 kernels (default).  GEORGE_AMD_NO_MFMA=1 / GEORGE_AMD_MFMA_MODE=0 / gh_debug_set_mfma(0).
+// v_mfma_f64_16x16x4 kernels (default).  GEORGE_AMD_NO_MFMA=1 / gh_debug_set_mfma(0).
 static int g_mfma = -1;
 static int mfma_mode() {
-  if (g_mfma < 0) {
-    const char* e = getenv("GEORGE_AMD_MFMA_MODE");
-    g_mfma = (e && e[0] == '0') ? 0 : 1;
-    if (getenv("GEORGE_AMD_NO_MFMA")) g_mfma = 0;
-  }
+  if (g_mfma < 0) g_mfma = getenv("GEORGE_AMD_NO_MFMA") ? 0 : 1;
   return g_mfma;
 }
 bool gh_use_mfma() { return mfma_mode() != 0; }
-// 256 x 128 tiles for the chip-filling k-major launches (GEORGE_AMD_GEMM_TALL=0/1, gh_debug_set_gemm_tall)
-static int g_tall = -1;
-static int gemm_tall_mode() {
-  if (g_tall < 0) { const char* e = getenv("GEORGE_AMD_GEMM_TALL"); g_tall = e ? atoi(e) : 0; if (g_tall < 0 || g_tall > 2) g_tall = 0; }
-  return g_tall;
-}
-extern "C" int gh_debug_set_gemm_tall(int on) {
-  const int prev = gemm_tall_mode();
-  g_tall = (on < 0 || on > 2) ? 0 : on;        // 2: also for launches that do not fill the chip (tests)
-  return prev;
-}
 extern "C" int gh_debug_set_mfma(int mode) {
   const int prev = mfma_mode();
   g_mfma = mode == 0 ? 0 : 1;
@@ -718,7 +598,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
   g.nblk = h.lower ? (long)g.tiles_m * (g.tiles_m + 1) / 2 : (long)g.tiles_m * g.tiles_n;
   g.prio = g.nblk <= 512 ? 1 : 0;
-  g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha) && !getenv("GEORGE_AMD_GEMM_NO_PRELOAD")) ? 1 : 0;
+  g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha)) ? 1 : 0;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);
   const int mode = mfma_mode();
@@ -732,10 +612,8 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     if (h.lower) hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, true>), grid, block, 0, st, g);          \
     else         hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, false>), grid, block, 0, st, g);         \
   } while (0)
-  static const bool no_small = getenv("GEORGE_AMD_GEMM_NO_SMALL") != nullptr;
-  static const bool no_k128 = getenv("GEORGE_AMD_GEMM_NO_K128") != nullptr;       // A/B: the K-loop kernels for K = 128 too
   const bool inplace = (const double*)h.C == h.A || (const double*)h.C == h.B;
-  if (dma && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small && !no_k128 && !h.small_lds &&
+  if (dma && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !h.small_lds &&
       (!inplace || ((const double*)h.C == h.A && (const double*)h.C != h.B && h.N == 128 && !h.lower))) {
     GemmDev q = g;
     if (inplace) {                      // whole rows per workgroup: 16 x 128 tiles
@@ -751,15 +629,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     GH_HIP(hipGetLastError());
     return GH_OK;
   }
-  if (dma && h.a_km && h.b_km && !h.klo_max && !h.khi_col && !h.khi_row && !inplace && (gemm_tall_mode() == 2 || (gemm_tall_mode() == 1 && g.nblk >= 1024))) {
-    // chip-filling launch (trailing SYRK, block-column update): 256 x 128 tiles, one 512-thread workgroup per CU
-    GemmDev q = g;
-    const long R = (g.tiles_m + 1) / 2;
-    q.nblk = h.lower ? R * (R + 1) - (g.tiles_m & 1) : R * g.tiles_n;
-    if (h.lower) hipLaunchKernelGGL((gemm_f64_mfma_dma_tall<true>), dim3((unsigned)q.nblk), dim3(512), 0, st, q);
-    else         hipLaunchKernelGGL((gemm_f64_mfma_dma_tall<false>), dim3((unsigned)q.nblk), dim3(512), 0, st, q);
-  }
-  else if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !no_small &&
+  if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row &&
       (!inplace || (h.N == 128 && !h.lower))) {
     // sub-chip launch: 64-row tiles, 2-4x the workgroups (see gemm_f64_mfma_dma64)
     GemmDev q = g;
@@ -1044,7 +914,6 @@ extern "C" int gh_microbench_hbm_copy(double* gbps_out) {
     float ms = 0;
     GH_HIP(hipEventElapsedTime(&ms, e0, e1));
     const double rate = 5.0 * 2.0 * n * sizeof(double2) / (ms * 1e-3) * 1e-9;
-    if (getenv("GEORGE_AMD_MICROBENCH_VERBOSE")) fprintf(stderr, "[hbm copy] variant %d grid %d: %.0f GB/s\n", variant, grids[variant], rate);
     if (rate > best) best = rate;
   }
   *gbps_out = best;

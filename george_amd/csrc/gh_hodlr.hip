@@ -1058,9 +1058,8 @@ extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
   if (h->opts.max_rank < 0) h->opts.max_rank = 0;              // 0: as much as the tolerance asks for, up to RANK_CAP
   if (h->opts.max_rank > RANK_CAP) h->opts.max_rank = RANK_CAP;
   if (hipSetDevice(h->opts.device) != hipSuccess) { delete h; gh_set_error("cannot initialise HIP device %d", opts ? opts->device : 0); return GH_ERR_HIP; }
-  static const bool private_streams = getenv("GEORGE_AMD_PRIVATE_STREAMS") != nullptr;
   hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (!private_streams && gh_shared_streams(h->opts.device, shq) && shq[2] && shq[3]) {
+  if (gh_shared_streams(h->opts.device, shq) && shq[2] && shq[3]) {
     h->shared_streams = true;                 // the process-wide streams: main, and two side streams for compute()
     h->st = shq[0];
   } else if ((gh_prime_device(h->opts.device), hipStreamCreate(&h->st)) != hipSuccess) {
@@ -1294,9 +1293,8 @@ static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const
                      const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1);
 static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* V, const double* B, long ldb, long b_col0,
                       double* O, long ldo, long o_col0, int C) {
-  static const bool no_red = getenv("GEORGE_AMD_HODLR_NO_RED_KERNEL") != nullptr;
   if (njobs <= 0 || C <= 0 || R <= 0) return GH_OK;
-  if (no_red || R > 16 || C > 128) return launch_mm(h, jobs, njobs, R, V, 1, R, B, ldb, b_col0, O, ldo, o_col0, C, false, 1);
+  if (R > 16 || C > 128) return launch_mm(h, jobs, njobs, R, V, 1, R, B, ldb, b_col0, O, ldo, o_col0, C, false, 1);
   // (one instantiation per number of 16-column tiles: the LDS image is 128 x (16 CT + 1) doubles, and with 17-50 KB
   //  instead of 83 several workgroups share a CU at the shallow levels, whose U has few columns yet)
 #define GH_RED_LAUNCH(CT) hipLaunchKernelGGL(hodlr_red_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, V, R, B, ldb, b_col0, O, ldo, o_col0, C)
@@ -1315,9 +1313,8 @@ static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const do
 
 static int launch_upd(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* A, long a_rs, const double* B, long ldb,
                       double* O, long ldo, int C) {
-  static const bool no_upd = getenv("GEORGE_AMD_HODLR_NO_UPD_KERNEL") != nullptr;
   if (njobs <= 0 || C <= 0 || R <= 0) return GH_OK;
-  if (no_upd || R > 16 || C > 128 || HCH > 128) return launch_mm(h, jobs, njobs, HCH, A, a_rs, 1, B, ldb, 0, O, ldo, 0, C, true, HCH / 32);
+  if (R > 16 || C > 128 || HCH > 128) return launch_mm(h, jobs, njobs, HCH, A, a_rs, 1, B, ldb, 0, O, ldo, 0, C, true, HCH / 32);
 #define GH_UPD_LAUNCH(CT) hipLaunchKernelGGL(hodlr_upd_kernel<CT>, dim3(njobs), dim3(256), 0, h->st, jobs, A, a_rs, B, ldb, O, ldo, C)
   switch ((C + 15) / 16) {
     case 1: GH_UPD_LAUNCH(1); break;
@@ -1352,8 +1349,7 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
   if (L->R == 0 || C <= 0) return GH_OK;
   const int R = L->R, nn = (int)L->node_ids.size();
   const double* Vl = h->VA.d() + (long)h->n * L->off;
-  static const bool no_narrow = getenv("GEORGE_AMD_HODLR_NO_NARROW") != nullptr;
-  if (C <= MV_C && R <= 32 && !no_narrow) {
+  if (C <= MV_C && R <= 32) {
     const long Cp = h->cpass;
     const double* Ub = U ? U + L->off : h->UL.d() + (long)h->n * L->off;
     const long u_rs = U ? ldu : R;
@@ -1397,15 +1393,13 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
 // X rows of every leaf <- K_leaf^-1 X
 static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
   if (C <= 0) return GH_OK;
-  static const bool no_narrow = getenv("GEORGE_AMD_HODLR_NO_NARROW") != nullptr;
-  if (C <= MV_C && h->max_leaf <= 256 && !no_narrow) {
+  if (C <= MV_C && h->max_leaf <= 256) {
     hipLaunchKernelGGL(hodlr_mv_leaf_kernel, dim3((unsigned)h->leaves.size()), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p,
                        h->leaf_inv.d(), (long)h->leaf_pitch, X, ldx, xcol0, C);
     GH_HIP(hipGetLastError());
     return GH_OK;
   }
-  static const bool no_leaf_apply = getenv("GEORGE_AMD_HODLR_NO_LEAF_APPLY") != nullptr;
-  if (!no_leaf_apply && h->leaf_pitch == 128 && h->max_leaf <= 128) {
+  if (h->leaf_pitch == 128 && h->max_leaf <= 128) {
     // one workgroup per leaf, in place; column passes of <= 128 (80 where that covers the rest: less LDS, fewer MFMAs)
     for (int cp = 0; cp < C;) {
       const int cw = std::min(128, C - cp);
@@ -1459,8 +1453,7 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
   }
   int nmax = 0;
   for (int v : sizes) nmax = std::max(nmax, v);
-  static const bool no_small = getenv("GEORGE_AMD_HODLR_NO_SMALL_GJ") != nullptr;
-  if (nmax <= 32 && !no_small) {                  // the Woodbury cores: one wavefront per matrix
+  if (nmax <= 32) {                  // the Woodbury cores: one wavefront per matrix
     const dim3 grid((unsigned)((nb + 3) / 4));
     if (nmax <= 8) hipLaunchKernelGGL(gj_small_kernel<8>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
     else if (nmax <= 16) hipLaunchKernelGGL(gj_small_kernel<16>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
@@ -1476,7 +1469,7 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
   GH_CHECK(d_si.ensure(tot * sizeof(int)));
   // dynamic LDS for the in-LDS path: the largest matrix of the batch if it fits (<= 144 KiB), else none
   size_t lds_bytes = ((size_t)nmax * (nmax | 1) + nmax) * sizeof(double);
-  if (lds_bytes > 144 * 1024 || getenv("GEORGE_AMD_HODLR_GJ_GLOBAL")) lds_bytes = 0;
+  if (lds_bytes > 144 * 1024) lds_bytes = 0;
   if (lds_bytes > 0) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1498,11 +1491,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   GH_HIP(hipSetDevice(h->opts.device));
   GH_CHECK(k->upload());
   hipStream_t st = h->st;
-  static const bool dbg_phases = getenv("GEORGE_AMD_HODLR_SPLIT_DEBUG") != nullptr;
+  // phase stamps on stderr (how the stalls of the split tree were found): a build-time aid, -DGH_HODLR_PHASE_MARKS
+#ifdef GH_HODLR_PHASE_MARKS
   const auto dbg_t0 = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
-    if (dbg_phases) fprintf(stderr, "[hodlr %p] %s at %.2f ms\n", (void*)h, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
+    fprintf(stderr, "[hodlr %p] %s at %.2f ms\n", (void*)h, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
   };
+#else
+  auto mark = [](const char*) {};
+#endif
   h->computed = false;
   h->n = n; h->ndim = ndim;
   GH_CHECK(h->x.ensure((size_t)n * ndim * sizeof(double)));
@@ -1567,8 +1564,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   auto leaf_stage = [&](hipStream_t st) -> int {
     struct StreamSwap { gh_hodlr* h; hipStream_t keep; ~StreamSwap() { h->st = keep; } } swap_guard{h, h->st};
     h->st = st;                                  // (launch_mm / batched_inverse issue on h->st)
-  static const bool leaf_gj = getenv("GEORGE_AMD_HODLR_LEAF_GJ") != nullptr;
-  if (h->max_leaf <= 128 && !leaf_gj) {
+  if (h->max_leaf <= 128) {
     // Leaves are symmetric positive definite and fit the dense solver's 128 x 128 diagonal-block
     // kernel: build them identity-padded into 128 x 128 slots, factor + invert the factors as ONE
     // batched launch of potf2_inv_mfma_kernel (79 us per block, a workgroup each), log-det from the
@@ -1664,10 +1660,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   const bool user_cap = h->opts.max_rank > 0;
   const int rcap0 = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
   const int nlev = (int)h->levels.size();
-  static const int aca_fence = getenv("GEORGE_AMD_HODLR_FENCE") ? 1 : 0;
-  static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
-  static const bool aca_serial = getenv("GEORGE_AMD_HODLR_SERIAL_LEVELS") != nullptr;
-  const bool concurrent = !aca_serial && nlev - l0 > 1 && (double)n * rcap0 * sizeof(double) * (nlev - l0) <= 12.0 * (1u << 30);
+  const int aca_fence = 0, aca_multi = 1;         // (fence-free cluster barrier, 8 then 64 candidate rows per search pass: DESIGN.md section 4)
+  const bool concurrent = nlev - l0 > 1 && (double)n * rcap0 * sizeof(double) * (nlev - l0) <= 12.0 * (1u << 30);
   if (concurrent && !h->st_b) {
     hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
     if (h->shared_streams && gh_shared_streams(h->opts.device, shq)) h->st_b = shq[2];
@@ -1817,8 +1811,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // 4 -> 13.1, 8 -> 14.1, 16 -> 16.0: the step is bound by per-thread memory latency, not by the
     // barriers, so more and smaller workgroups win)
     int G = 1;
-    if (!getenv("GEORGE_AMD_HODLR_NO_CLUSTER")) {
-      static const int ept = getenv("GEORGE_AMD_HODLR_EPT") ? std::max(1, atoi(getenv("GEORGE_AMD_HODLR_EPT"))) : 2;
+    {
+      const int ept = 2;
       int min_half = INT32_MAX;
       for (int q = 0; q < nn; ++q) min_half = std::min(min_half, ln[q].half);
       while (G * 2 * nn <= 256 && (long)(G * 2) * ACA_THREADS * ept <= min_half) G *= 2;
@@ -1832,9 +1826,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // as it gets (start from <= 32 workgroups per level, then keep doubling the cluster of the level
     // whose threads carry most columns).
     std::vector<int> cl;
-    static const bool no_fused = getenv("GEORGE_AMD_HODLR_NO_FUSED_ACA") != nullptr;
     for (int l = l0; l < nlev; ++l) if (al[l].G > 1) cl.push_back(l);
-    if (cl.size() >= 2 && !no_fused) {
+    if (cl.size() >= 2) {
       std::vector<int> gmax(nlev, 1), half(nlev, 1);
       int total = 0;
       for (int l : cl) {
@@ -1863,10 +1856,6 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       }
       std::vector<int> fused, single;
       for (int l : cl) (al[l].G > 1 ? fused : single).push_back(l);
-      if (getenv("GEORGE_AMD_HODLR_DEBUG")) {
-        for (int l : cl) fprintf(stderr, "[hodlr] level %d: nodes %d half %d G %d (max %d)\n", l, (int)h->levels[l]->node_ids.size(), half[l], al[l].G, gmax[l]);
-        fprintf(stderr, "[hodlr] total %d\n", total);
-      }
       if (h->aca_fused_ev[0] == nullptr) { GH_HIP(hipEventCreate(&h->aca_fused_ev[0])); GH_HIP(hipEventCreate(&h->aca_fused_ev[1])); }
       GH_HIP(hipEventRecord(h->aca_fused_ev[0], st));
       GH_CHECK(enqueue_fused(fused, rcap0, st, h->d_aca_segs));
@@ -1885,27 +1874,24 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         if ((!h->shared_streams && hipStreamCreateWithFlags(&h->st_c, hipStreamNonBlocking) != hipSuccess) ||
             hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_c = nullptr; }
       }
-      static const int nqueues = getenv("GEORGE_AMD_HODLR_QUEUES") ? atoi(getenv("GEORGE_AMD_HODLR_QUEUES")) : 4;
-      if (!h->st_d && nqueues >= 4 && h->shared_streams && h->st_c) {
+      if (!h->st_d && h->shared_streams && h->st_c) {
         hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
         if (gh_shared_streams(h->opts.device, shq) && shq[1] && hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming) == hipSuccess) h->st_d = shq[1];
         else (void)hipGetLastError();
       }
-      static const bool leaves_after0 = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
       std::vector<int> ones = single;
       for (int l = l0; l < nlev; ++l) if (gmax[l] == 1) ones.push_back(l);
       // The one-workgroup-per-node levels as ONE launch too (segments in order of decreasing block size: the long
       // workgroups are dispatched first): launched one per queue they were balanced by hand over three queues with last
       // compute()'s durations, and the queue that drew the two slowest levels ended 0.4 ms after the others.  One grid
-      // leaves the balancing to the dispatcher: C4 5.36 -> 5.24 ms.  (GEORGE_AMD_HODLR_NO_FUSED_SINGLES: the per-level
-      // launches.  EVERY level in one grid, clustered segments first, was no better: 5.30.)
-      static const bool no_fused_singles = getenv("GEORGE_AMD_HODLR_NO_FUSED_SINGLES") != nullptr;
-      if (!no_fused_singles && ones.size() >= 2 && h->st_c) {
+      // leaves the balancing to the dispatcher: C4 5.36 -> 5.24 ms.  (EVERY level in one grid, clustered segments first, was
+      // no better: 5.30.)
+      if (ones.size() >= 2 && h->st_c) {
         std::sort(ones.begin(), ones.end());
         GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));
         if (h->st_d) GH_HIP(hipStreamWaitEvent(h->st_d, h->ev_b, 0));
         GH_CHECK(enqueue_fused(ones, rcap0, h->st_b, h->d_aca_segs1));
-        if (!leaves_after0) GH_CHECK(leaf_stage(h->st_c));
+        GH_CHECK(leaf_stage(h->st_c));
         GH_HIP(hipEventRecord(h->ev_c, h->st_c));
         GH_HIP(hipStreamWaitEvent(st, h->ev_c, 0));
         h->aca_timed = false;
@@ -1915,7 +1901,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       std::vector<Item> items;
       const bool have = (int)h->aca_ms.size() == nlev + 2;     // [0..nlev): levels, [nlev]: fused launch, [nlev+1]: leaf stage
       for (int l : ones) items.push_back({l, have && h->aca_ms[l] > 0 ? h->aca_ms[l] : 1.0});
-      if (!leaves_after0 && !leaves_done) items.push_back({-1, have && h->aca_ms[nlev + 1] > 0 ? h->aca_ms[nlev + 1] : 1.2});
+      if (!leaves_done) items.push_back({-1, have && h->aca_ms[nlev + 1] > 0 ? h->aca_ms[nlev + 1] : 1.2});
       std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
       hipStream_t qs[4] = {st, h->st_b, h->st_c ? h->st_c : h->st_b, h->st_d ? h->st_d : h->st_b};
       double load[4] = {have && h->aca_ms[nlev] > 0 ? h->aca_ms[nlev] : 1.5, 0.0, h->st_c ? 0.0 : 1e30, h->st_d ? 0.0 : 1e30};
@@ -1946,8 +1932,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       if (h->st_d) { GH_HIP(hipEventRecord(h->ev_d, h->st_d)); GH_HIP(hipStreamWaitEvent(st, h->ev_d, 0)); }
     } else {
       for (int l = l0; l < nlev; ++l) GH_CHECK(enqueue_level(l, rcap0, al[l].G > 1 ? st : h->st_b));
-      static const bool leaves_after = getenv("GEORGE_AMD_HODLR_LEAVES_AFTER") != nullptr;
-      if (!leaves_after) GH_CHECK(leaf_stage(h->st_b));
+      GH_CHECK(leaf_stage(h->st_b));
     }
     GH_HIP(hipEventRecord(h->ev_b, h->st_b));
     GH_HIP(hipStreamWaitEvent(st, h->ev_b, 0));
@@ -2001,10 +1986,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     mark("serial ACA starts");
     for (int l = l0; l < nlev; ++l) {
       GH_CHECK(enqueue_level(l, rcap0, st));
-      if (dbg_phases) mark("  level enqueued");
+      mark("  level enqueued");
       GH_CHECK(fetch_level(l, st));
       GH_HIP(hipStreamSynchronize(st));
-      if (dbg_phases) mark("  level synchronised");
+      mark("  level synchronised");
       GH_CHECK(settle_level(l));
       GH_CHECK(compact_level(l));
     }
@@ -2023,8 +2008,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // has 2^l internal nodes -- the case of C4); only then can the two memsets (157 MB each at C4) be skipped
   bool complete = true;
   for (int l = l0; l < nlev; ++l) if (h->levels[l]->node_ids.size() != ((size_t)1 << (l - l0))) complete = false;   // (a pseudo-level covers every local row)
-  static const bool no_fused_compact = getenv("GEORGE_AMD_HODLR_NO_FUSED_COMPACT") != nullptr;
-  bool fused_compact = !no_fused_compact;
+  bool fused_compact = true;
   for (int l = 0; l < nlev; ++l) if (levelB[l]) fused_compact = false;
   if (!(complete && fused_compact)) {
     GH_HIP(hipMemsetAsync(h->UA.p, 0, (size_t)n * Rtot * sizeof(double), st));
@@ -2159,9 +2143,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // core needs (columns [off, off + R)) and the ones that applying this level's inverse to the shallower
     // levels' U needs (columns [0, off)) read the same V_l chunks and neighbouring columns of the same U
     // rows: ONE reduce + sum over columns [0, off + R) serves both (two launches fewer per level).
-    static const bool no_merge = getenv("GEORGE_AMD_HODLR_NO_MERGED_REDUCE") != nullptr;
     const int Call = L->off + R;
-    const bool merged = !no_merge && Call <= h->cpass;
+    const bool merged = Call <= h->cpass;
     if (merged) {
       GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
                           h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
@@ -2359,12 +2342,11 @@ int aca_top_node(gh_hodlr* h, gh_kernel* k, const double* x_dev, long N, int ndi
   GH_CHECK(d_rank.ensure(sizeof(int)));
   GH_HIP(hipMemcpyAsync(d_node.p, &nd, sizeof(LvlNode), hipMemcpyHostToDevice, st));
   int G = 1;
-  if (!getenv("GEORGE_AMD_HODLR_NO_CLUSTER")) {
-    static const int ept = getenv("GEORGE_AMD_HODLR_EPT") ? std::max(1, atoi(getenv("GEORGE_AMD_HODLR_EPT"))) : 2;
+  {
+    const int ept = 2;
     while (G * 2 <= 256 && (long)(G * 2) * ACA_THREADS * ept <= nd.half) G *= 2;
   }
-  static const int aca_fence = getenv("GEORGE_AMD_HODLR_FENCE") ? 1 : 0;
-  static const int aca_multi = getenv("GEORGE_AMD_HODLR_ONE_ROW") ? 0 : 1;
+  const int aca_fence = 0, aca_multi = 1;
   const int pstride = 8 + 2 * ACA_MAXR;
   const bool user_cap = h->opts.max_rank > 0;
   int rc = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
@@ -2492,9 +2474,7 @@ extern "C" int gh_hodlr_mgpu_create(const gh_hodlr_mgpu_opts* opts, gh_hodlr_mgp
     if (opts->devices[i] < 0 || opts->devices[i] >= ndev) { gh_set_error("HODLR split: device %d does not exist (%d visible)", opts->devices[i], ndev); return GH_ERR_BAD_ARG; }
     for (int j = 0; j < i; ++j) if (opts->devices[j] == opts->devices[i]) dup = true;
   }
-  if (dup && getenv("GEORGE_AMD_PRIVATE_STREAMS")) {
-    gh_set_error("HODLR split: a device listed several times needs the process-wide streams (unset GEORGE_AMD_PRIVATE_STREAMS)"); return GH_ERR_BAD_ARG;
-  }
+  (void)dup;
   gh_hodlr_mgpu* H = new gh_hodlr_mgpu();
   H->opts = *opts;
   H->P = P;
@@ -2621,7 +2601,11 @@ extern "C" int gh_hodlr_mgpu_compute(gh_hodlr_mgpu* H, gh_kernel* k, const doubl
       H->ranks[p].seed_off.assign(so.begin() + (size_t)p * nl, so.begin() + (size_t)(p + 1) * nl);
     }
   }
-  static const bool dbg = getenv("GEORGE_AMD_HODLR_SPLIT_DEBUG") != nullptr;
+#ifdef GH_HODLR_PHASE_MARKS
+  const bool dbg = true;
+#else
+  const bool dbg = false;
+#endif
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   const int rc = hm_run(H, [&](HmRank& r) -> int {

@@ -48,14 +48,6 @@ void gh_prime_device(int device) {
   if (hipSetDevice(device) == hipSuccess) {
     hipLaunchKernelGGL(gh_prime_kernel, dim3(1), dim3(64), 0, (hipStream_t)nullptr);
     (void)hipDeviceSynchronize();
-    // (experiment: k used dummy streams in front of the library's own -- does the placement of ours get better still?)
-    const int extra = getenv("GEORGE_AMD_PRIME_EXTRA") ? atoi(getenv("GEORGE_AMD_PRIME_EXTRA")) : 0;
-    for (int i = 0; i < extra; ++i) {
-      hipStream_t d = nullptr;
-      if (hipStreamCreateWithFlags(&d, hipStreamNonBlocking) != hipSuccess) break;
-      hipLaunchKernelGGL(gh_prime_kernel, dim3(1), dim3(64), 0, d);
-      (void)hipStreamSynchronize(d);          // (kept alive on purpose)
-    }
   }
   (void)hipGetLastError();
   (void)hipSetDevice(cur);

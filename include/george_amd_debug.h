@@ -20,10 +20,6 @@ int gh_microbench_mfma_f64(double* tflops_out);
  * MFMA lane maps on the device), anything else = v_mfma_f64_16x16x4 with LDS-DMA operand staging
  * (default); returns the previous setting. */
 int gh_debug_set_mfma(int mode);
-/* A/B switch: 256 x 128 tiles (one 512-thread workgroup per CU) for the chip-filling k-major GEMM
- * launches -- the trailing SYRK and the block-column updates -- instead of 128 x 128 (two 256-thread
- * workgroups per CU); returns the previous setting. */
-int gh_debug_set_gemm_tall(int on);
 /* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */

@@ -131,39 +131,6 @@ def test_gemm_lower_and_k_clipping():
     assert np.abs(o.cpu().numpy() - R @ L.T).max() < 1e-10
 
 
-@pytest.mark.parametrize("blocks,ncols,lower", [(5, 0, True), (6, 0, True), (1, 0, True), (7, 3, False), (8, 2, False), (1, 1, False)])
-def test_tall_tile_kernel(blocks, ncols, lower):
-    """gemm_f64_mfma_dma_tall (256 x 128 tiles, the chip-filling k-major launches): odd and even numbers
-    of 128-row blocks (half tile at the bottom), lower-triangular and rectangular grids -- against NumPy,
-    and bit-identical to the 128 x 128 kernel (same K order per element); tiles strictly above the
-    diagonal are left untouched."""
-    from george_amd import _native as N
-    rng = np.random.RandomState(blocks * 10 + ncols)
-    M, K = 128 * blocks, 80
-    Nn = M if lower else 128 * ncols
-    A = rng.randn(M, K)
-    B = A if lower else rng.randn(Nn, K)
-    C0 = rng.randn(M, Nn)
-    outs = []
-    for tall in (0, 2):
-        a, b, c = _dev(A), _dev(B), _dev(C0)
-        prev = N.lib.gh_debug_set_gemm_tall(tall)
-        try:
-            _gemm(c, a, b, M, Nn, K, -1.0, 1.0, FLAGS["LOWER"] if lower else 0, K, K, Nn)
-        finally:
-            N.lib.gh_debug_set_gemm_tall(prev)
-        outs.append(c.cpu().numpy())
-    want = C0 - A @ B.T
-    got = outs[1]
-    if lower:
-        blk = np.kron(np.tril(np.ones((blocks, blocks))), np.ones((128, 128))).astype(bool)     # lower 128-tiles
-        assert np.abs(got - want)[blk].max() < 1e-11
-        assert np.array_equal(got[~blk], C0[~blk])                    # upper tiles untouched
-    else:
-        assert np.abs(got - want).max() < 1e-11
-    assert np.array_equal(outs[0], outs[1])
-
-
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_potrf_block_and_trsm(mfma):
     import torch

@@ -143,23 +143,6 @@ def test_rank_grows_past_256_and_cap_is_loud():
         HODLRSolver.DENSE_FALLBACK_MAX_N = old
 
 
-def test_barrier_release_arms_agree():
-    """fence-free cluster barriers (default) vs the __threadfence() arm: same bits."""
-    import subprocess, sys
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import numpy as np, zoo\n"
-            "from george_amd import GP, kernels, HODLRSolver\n"
-            "x, yerr, y = zoo.bench_data(65536)\n"
-            "gp = GP(np.var(y) * kernels.ExpSquaredKernel(1.0), solver=HODLRSolver, tol=1e-10); gp.compute(x, yerr)\n"
-            "print(repr(float(gp.log_likelihood(y))), sum(gp.solver.ranks()))\n") % (ROOT, ROOT)
-    outs = []
-    for env in ({}, {"GEORGE_AMD_HODLR_FENCE": "1"}):
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.split()[-2:])
-    assert outs[0] == outs[1], outs
-
-
 @pytest.mark.parametrize("N", [300, 1000, 417])
 def test_hodlr_solver(N, seed=1234):                                  # tests/test_solvers.py:29-62
     kernel = 1.0 * kernels.ExpSquaredKernel(1.0)

@@ -651,7 +651,7 @@ def test_full_size_c5_properties():
 
 def test_scalar_potf2_validation_arm_agrees():
     """GEORGE_AMD_POTF2=simple selects the scalar 128x128 Cholesky + inverse kernel (the validation arm
-    of the MFMA form, as GEORGE_AMD_MFMA_MODE=0 is for the GEMMs): same factorisation to rounding, on
+    of the MFMA form, as GEORGE_AMD_NO_MFMA=1 is for the GEMMs): same factorisation to rounding, on
     repeated computes with one handle too."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -703,3 +703,32 @@ def test_process_without_torch_runs_at_the_benchmarked_speed():
     assert ll2 == ll
     assert ms <= 1.15 * ms_unprimed, (ms, ms_unprimed)
     assert ms <= 11.0, ms                                  # (7.0-7.4 ms on an MI355X; 13 ms is the failure this guards against)
+
+
+@pytest.mark.parametrize("env", [{"GEORGE_AMD_RESERVE_CUS": "0"}, {"GEORGE_AMD_RESERVE_CUS": "16"}, {"GEORGE_AMD_JOIN": "main"},
+                                 {"GEORGE_AMD_JOIN": "chain"}, {"GEORGE_AMD_LOOKAHEAD_DEPTH": "2"}, {"GEORGE_AMD_LOOKAHEAD_DEPTH": "3"},
+                                 {"GEORGE_AMD_NO_MFMA": "1"}])
+def test_every_switch_the_library_still_reads(env):
+    """Round 4 pruned the A/B switches whose losing arm has a committed measurement (45 -> 9 environment variables: DESIGN.md
+    section 4).  Each one that stayed is exercised: the scheduling knobs (CUs kept free of the trailing update, where a
+    look-ahead factorisation is joined, the look-ahead window) must not change a bit of the answer; the plain-VALU GEMM arm agrees
+    to rounding.  (GEORGE_AMD_POTF2, _TRSV_STEPS, _NO_NULL_PRIME, _NO_KMAT_INTERIOR, _NO_FAST_KERNEL have tests of their own.)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "for n in (1500, 5000, 9000):\n"
+            "    job = bench.DenseJob(n, 0, 0, profile=False)\n"
+            "    print(' '.join(repr(float(job.step())) for _ in range(2)))\n"
+            "    job.close()\n") % root
+    outs = []
+    for e_ in ({}, env):
+        e = dict(os.environ); e.update(e_)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-3:]])
+    for a, b in zip(outs[0], outs[1]):
+        assert a[0] == a[1] and b[0] == b[1]                              # repeatable on one handle
+        if "GEORGE_AMD_NO_MFMA" in env:
+            assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0])
+        else:
+            assert a[0] == b[0], (env, a, b)
