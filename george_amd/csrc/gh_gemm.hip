@@ -60,11 +60,19 @@ __device__ __forceinline__ bool tile_of(const GemmDev& g, int& tm, int& tn) {
   //  would hand one XCD all the long tiles -- deal those round-robin instead)
   const long l = (g.klo_max | g.khi_col | g.khi_row) ? (long)blockIdx.x : xcd_remap(blockIdx.x, g.nblk);
   if (g.lower) {
-    long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
-    while (t * (t + 1) / 2 > l) --t;
-    while ((t + 1) * (t + 2) / 2 <= l) ++t;
-    tm = (int)t;
-    tn = (int)(l - t * (t + 1) / 2);
+    // lower TRAPEZOID: tiles (tm, tn) with tn <= tm and tn < tiles_n (a square C, tiles_n == tiles_m, is the triangle): the first
+    // tiles_n tile rows hold 1, 2, .. tiles_n tiles, every row below them tiles_n
+    const long tri = (long)g.tiles_n * (g.tiles_n + 1) / 2;
+    if (l < tri) {
+      long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
+      while (t * (t + 1) / 2 > l) --t;
+      while ((t + 1) * (t + 2) / 2 <= l) ++t;
+      tm = (int)t;
+      tn = (int)(l - t * (t + 1) / 2);
+    } else {
+      tm = g.tiles_n + (int)((l - tri) / g.tiles_n);
+      tn = (int)((l - tri) % g.tiles_n);
+    }
   } else {
     tm = (int)(l / g.tiles_n);
     tn = (int)(l % g.tiles_n);
@@ -590,13 +598,13 @@ extern "C" int gh_debug_set_mfma(int mode) {
 int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   if (h.M <= 0 || h.N <= 0) return GH_OK;
   if (h.M % BM || h.N % BN || h.K % BK) { gh_set_error("gemm: sizes must be multiples of the tile (%ld %ld %ld)", (long)h.M, (long)h.N, (long)h.K); return GH_ERR_BAD_ARG; }
-  if (h.lower && h.M != h.N) { gh_set_error("gemm: lower needs a square C"); return GH_ERR_BAD_ARG; }
+  if (h.lower && h.M < h.N) { gh_set_error("gemm: lower needs M >= N (a lower trapezoid: the leading N columns of a lower-triangular C)"); return GH_ERR_BAD_ARG; }
   GemmDev g;
   g.C = h.C; g.ldc = h.ldc; g.A = h.A; g.lda = h.lda; g.B = h.B; g.ldb = h.ldb; g.K = h.K;
   g.alpha = h.alpha; g.beta = h.beta;
   g.tiles_m = (int)(h.M / BM); g.tiles_n = (int)(h.N / BN);
   g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
-  g.nblk = h.lower ? (long)g.tiles_m * (g.tiles_m + 1) / 2 : (long)g.tiles_m * g.tiles_n;
+  g.nblk = h.lower ? (long)g.tiles_n * (g.tiles_n + 1) / 2 + (long)(g.tiles_m - g.tiles_n) * g.tiles_n : (long)g.tiles_m * g.tiles_n;
   g.prio = g.nblk <= 512 ? 1 : 0;
   g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha)) ? 1 : 0;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
@@ -629,7 +637,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     GH_HIP(hipGetLastError());
     return GH_OK;
   }
-  if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row &&
+  if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && (!h.lower || h.M == h.N) &&
       (!inplace || (h.N == 128 && !h.lower))) {
     // sub-chip launch: 64-row tiles, 2-4x the workgroups (see gemm_f64_mfma_dma64)
     GemmDev q = g;

@@ -381,7 +381,7 @@ int gh_dev_gemm_nt(double* c, int64_t ldc, const double* a, int64_t lda,
 enum {
   GH_GEMM_A_MMAJOR = 1,   /* A(m,k) = a[k*lda + m]                                   */
   GH_GEMM_B_NMAJOR = 2,   /* B(n,k) = b[k*ldb + n]                                   */
-  GH_GEMM_LOWER    = 4,   /* square c: only tiles on/below the diagonal              */
+  GH_GEMM_LOWER    = 4,   /* m >= n: only tiles on/below the diagonal (a lower trapezoid) */
   GH_GEMM_KLO_MAX  = 8,   /* k starts at max(tile row0, tile col0)                   */
   GH_GEMM_KHI_COL  = 16,  /* k ends at tile col0 + 128                               */
   GH_GEMM_KHI_ROW  = 32   /* k ends at tile row0 + 128                               */

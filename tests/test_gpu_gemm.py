@@ -202,3 +202,25 @@ def test_potrf_failing_pivot_index_matches_lapack(p, bad):
     N.check(N.lib.gh_dev_potrf_block(a.data_ptr(), n, n, dinv.data_ptr(), info.data_ptr(), 0, None))
     torch.cuda.synchronize()
     assert int(info.item()) == p + 1
+
+
+@pytest.mark.parametrize("rows,cols,K", [(5, 2, 80), (9, 9, 48), (12, 1, 1024), (40, 7, 256), (3, 3, 16)])
+def test_lower_trapezoid(rows, cols, K):
+    """GH_GEMM_LOWER with m > n: the leading n columns of a lower-triangular C (tiles with tile row >= tile column) -- the launches of
+    the column-priority factorisation schedule (gh_chol.hip, factor_column_priority); tiles above the diagonal stay untouched, and
+    every computed tile is bit-identical to the same tile of the full lower-triangular launch."""
+    rng = np.random.RandomState(rows * 7 + cols)
+    M, Nn = 128 * rows, 128 * cols
+    A = rng.randn(M, K)
+    C0 = rng.randn(M, M)
+    a, c = _dev(A), _dev(C0)
+    _gemm(c, a, a, M, Nn, K, -1.0, 1.0, FLAGS["LOWER"], K, K, M)
+    got = c.cpu().numpy()
+    cf = _dev(C0)
+    _gemm(cf, a, a, M, M, K, -1.0, 1.0, FLAGS["LOWER"], K, K, M)
+    full = cf.cpu().numpy()
+    blk = np.kron(np.tril(np.ones((rows, rows))), np.ones((128, 128))).astype(bool)
+    blk[:, Nn:] = False
+    assert np.array_equal(got[blk], full[blk])
+    assert np.array_equal(got[~blk], C0[~blk])
+    assert np.abs(got - (C0 - A @ A.T))[blk].max() < 1e-10 * max(1.0, K / 16)

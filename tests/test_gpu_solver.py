@@ -707,7 +707,7 @@ def test_process_without_torch_runs_at_the_benchmarked_speed():
 
 @pytest.mark.parametrize("env", [{"GEORGE_AMD_RESERVE_CUS": "0"}, {"GEORGE_AMD_RESERVE_CUS": "16"}, {"GEORGE_AMD_JOIN": "main"},
                                  {"GEORGE_AMD_JOIN": "chain"}, {"GEORGE_AMD_LOOKAHEAD_DEPTH": "2"}, {"GEORGE_AMD_LOOKAHEAD_DEPTH": "3"},
-                                 {"GEORGE_AMD_NO_MFMA": "1"}])
+                                 {"GEORGE_AMD_NO_MFMA": "1"}, {"GEORGE_AMD_SCHEDULE": "panels"}, {"GEORGE_AMD_SCHEDULE": "columns"}])
 def test_every_switch_the_library_still_reads(env):
     """Round 4 pruned the A/B switches whose losing arm has a committed measurement (45 -> 9 environment variables: DESIGN.md
     section 4).  Each one that stayed is exercised: the scheduling knobs (CUs kept free of the trailing update, where a
@@ -716,8 +716,8 @@ def test_every_switch_the_library_still_reads(env):
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r); import bench\n"
-            "for n in (1500, 5000, 9000):\n"
-            "    job = bench.DenseJob(n, 0, 0, profile=False)\n"
+            "for n in (1500, 5000, 9000, 14000):\n"
+            "    job = bench.DenseJob(n, 0, 0, profile=(n == 9000))\n"
             "    print(' '.join(repr(float(job.step())) for _ in range(2)))\n"
             "    job.close()\n") % root
     outs = []
@@ -725,7 +725,7 @@ def test_every_switch_the_library_still_reads(env):
         e = dict(os.environ); e.update(e_)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-3:]])
+        outs.append([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()[-4:]])
     for a, b in zip(outs[0], outs[1]):
         assert a[0] == a[1] and b[0] == b[1]                              # repeatable on one handle
         if "GEORGE_AMD_NO_MFMA" in env:
