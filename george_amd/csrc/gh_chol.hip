@@ -1146,161 +1146,6 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   return GH_OK;
 }
 
-// Column-priority schedule for the sizes at which the panel chain, not the trailing update, is what a step waits for
-// (one panel < Np < 24576; round 4).  The depth-1 look-ahead above hands the chain ONE launch per panel to wait for: U(j, j+1)
-// can start only when the whole of W(j-1) -- every column from j+1 on -- is over, so in the first panels the chain idles behind the
-// wide SYRK and in the last ones the SYRK idles behind the chain: the step is sum_j max(chain_j, W_j) (N = 16384: 30 ms, of which
-// ~19 are SYRK-bound early panels and ~11 chain-bound late ones).  But panel j+1 needs only block COLUMN
-// j+1 of W(j-1).  Here the trailing update is issued per (panel i, run of block columns c1..c2) on the one CU-masked stream, in
-// an order fixed on the host by a greedy replay of both queues with a cost model -- always the ready update with the smallest
-// target column first, i.e. what gates the chain first and the far columns as filler -- and the chain waits for "column c has all
-// its main-stream updates" (ev_col[c]) instead of "W(c-2) is over".  Runs of adjacent columns of one panel that the replay puts
-// back to back are ONE launch (a lower trapezoid of the same 128 x 128 tile kernel), so the early, SYRK-bound panels still go out
-// as a few big launches.  Per tile the arithmetic is that of the other schedules -- same kernel, same K order, panels applied in
-// ascending order -- so the factor is bit-identical; a wrong cost model costs idle time, never correctness (the order is a
-// linear extension of the dependency graph by construction, and every wait is an event).
-struct ColTask { int i, c1, c2; };
-static void plan_column_schedule(const gh_chol* s, int P, int64_t NB, std::vector<ColTask>& order) {
-  const int64_t np = s->np;
-  auto c0 = [&](int c) { return (int64_t)c * NB; };
-  auto nbc = [&](int c) { return std::min<int64_t>(NB, np - c0(c)); };
-  // cost model (seconds): measured rates of this library on an MI355X with 32 CUs kept free for the chain
-  const double rate_main = 52e12, rate_chain = 45e12, t_launch = 12e-6, t_link = 88e-6;
-  auto t_upd = [&](int i, int c, double rate) { return 2.0 * (double)(np - c0(c)) * (double)nbc(c) * (double)nbc(i) / rate + t_launch; };
-  auto t_panel = [&](int c) { return (double)(nbc(c) / T) * t_link + 40e-6; };
-  std::vector<double> tp(P, -1.0), col_done(P, 0.0);
-  std::vector<int> next_i(P, 0);                 // next panel to apply to column c on the main stream (i <= c - 2)
-  std::vector<int> left(P, 0);
-  int remaining = 0;
-  for (int c = 2; c < P; ++c) { left[c] = c - 1; remaining += c - 1; }
-  double t_main = 0.0, t_chain = t_panel(0);
-  tp[0] = t_chain;
-  int cc = 1;                                    // next column of the chain
-  std::vector<std::pair<int, int>> seq;          // (i, c) in main-stream order
-  while (remaining > 0 || cc < P) {
-    // the chain goes as far as it can: column cc needs all its main-stream updates scheduled
-    while (cc < P && (cc < 2 || left[cc] == 0)) {
-      const double start = std::max(t_chain, cc >= 2 ? col_done[cc] : 0.0);
-      t_chain = start + t_upd(cc - 1, cc, rate_chain) + t_panel(cc);
-      tp[cc] = t_chain;
-      ++cc;
-    }
-    if (remaining == 0) break;
-    // main stream: among the updates whose panel is factored (in the replay), the one that can start first; ties -> smallest column
-    int best_c = -1;
-    double best_t = 0.0;
-    for (int c = 2; c < P; ++c) {
-      if (left[c] == 0) continue;
-      const int i = next_i[c];
-      if (tp[i] < 0.0) continue;
-      const double st = std::max(t_main, tp[i]);
-      if (best_c < 0 || st < best_t - 1e-9) { best_c = c; best_t = st; }
-    }
-    if (best_c < 0) break;                         // (cannot happen: the chain loop above always frees a panel)
-    const int i = next_i[best_c];
-    t_main = best_t + t_upd(i, best_c, rate_main) - (seq.empty() || seq.back().first != i || seq.back().second + 1 != best_c ? 0.0 : t_launch);
-    seq.emplace_back(i, best_c);
-    ++next_i[best_c]; --left[best_c]; --remaining;
-    if (left[best_c] == 0) col_done[best_c] = t_main;
-  }
-  // runs of adjacent columns of one panel -> one launch
-  order.clear();
-  for (auto& t : seq) {
-    if (!order.empty() && order.back().i == t.first && order.back().c2 + 1 == t.second) order.back().c2 = t.second;
-    else order.push_back({t.first, t.second, t.second});
-  }
-}
-
-static int factor_column_priority(gh_chol* s) {
-  hipStream_t sm = trailing_stream(s), sp = s->st2;
-  double* A = s->A.d();
-  const int64_t np = s->np, ld = np, NB = panel_width(s);
-  const int P = (int)((np + NB - 1) / NB);
-  const bool prof = s->opts.profile != 0;
-  while ((int)s->ev_p.size() < P) {
-    hipEvent_t e[3];
-    for (auto& x : e) GH_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-    s->ev_p.push_back(e[0]); s->ev_w.push_back(e[1]); s->ev_nf.push_back(e[2]);
-  }
-  auto c0 = [&](int c) { return (int64_t)c * NB; };
-  auto nbc = [&](int c) { return std::min<int64_t>(NB, np - c0(c)); };
-  // U(i, c1..c2): rows from c0(c1) on, columns c0(c1) .. c0(c2 + 1): a lower trapezoid (lower triangle when c2 is the last column)
-  auto update = [&](hipStream_t st, int i, int c1, int c2, bool lower) -> int {
-    const int64_t r0 = c0(c1), ncols = std::min<int64_t>(c0(c2 + 1), np) - r0, m = np - r0;
-    const double* Pi = blk(A, ld, r0, c0(i));
-    const long eu = prof ? s->next_ev() : -1;
-    if (eu >= 0) { GH_HIP(hipEventRecord(s->ev_pool[eu].a, st)); s->ev_update.push_back((size_t)eu); }
-    GH_CHECK(gemm_nt(st, blk(A, ld, r0, r0), ld, Pi, ld, Pi, ld, m, ncols, nbc(i), -1.0, 1.0, lower));
-    if (eu >= 0) GH_HIP(hipEventRecord(s->ev_pool[eu].b, st));
-    const double tr = (double)m / T, tc = (double)ncols / T;
-    const double fl = (tr * tc - tc * (tc - 1.0) / 2.0) * 2.0 * T * T * (double)nbc(i);
-    s->prof.update_flops += fl;
-    if (eu >= 0) s->ev_update_flops.push_back(fl);
-    if (lower && c2 == P - 1 && m >= 8 * NB) {       // (a wide launch: what the roofline object calls the trailing SYRK)
-      if (eu >= 0) s->ev_trailing.push_back((size_t)eu);
-      s->prof.trailing_flops += fl;
-      s->prof.n_trailing += 1;
-    }
-    return GH_OK;
-  };
-  std::vector<ColTask> order;
-  plan_column_schedule(s, P, NB, order);
-  // everything queued so far (the build, on s->st) before either stream starts
-  GH_HIP(hipEventRecord(s->ev_sync[0], s->st));
-  GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
-  if (s->st3) GH_HIP(hipStreamWaitEvent(s->st3, s->ev_sync[0], 0));
-  if (sm != s->st) GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[0], 0));
-  // The two queues are filled in the replay's order of START times is not needed: each stream is in-order and every cross
-  // dependency is an event that is RECORDED before it is waited for as long as the chain's step c is issued before the first
-  // main-stream task that needs panel c -- so: issue chain steps lazily, right before the first task that waits for them.
-  int chain_issued = -1;                            // last panel whose chain step has been issued
-  std::vector<int> col_left(P, 0);
-  for (int c = 2; c < P; ++c) col_left[c] = c - 1;
-  std::vector<char> col_recorded(P, 0);
-  auto issue_chain_upto = [&](int c) -> int {       // panel(0) .. panel(c)
-    while (chain_issued < c) {
-      const int j = chain_issued + 1;
-      if (j >= 1) {
-        if (j >= 2) {
-          if (!col_recorded[j]) { gh_set_error("column schedule: panel %d asked for before its column is complete", j); return GH_ERR_BAD_ARG; }
-          GH_HIP(hipStreamWaitEvent(sp, s->ev_w[j], 0));       // ev_w[j] here: "column j has all its main-stream updates"
-        }
-        GH_CHECK(update(sp, j - 1, j, j, false));               // U(j-1, j): the whole block column on the chain
-      }
-      const long ep = prof ? s->next_ev() : -1;
-      if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
-      GH_CHECK(panel_step(s, sp, c0(j), nbc(j)));
-      if (ep >= 0) GH_HIP(hipEventRecord(s->ev_pool[ep].b, sp));
-      GH_HIP(hipEventRecord(s->ev_p[j], sp));
-      chain_issued = j;
-    }
-    return GH_OK;
-  };
-  int waited_panel = -1;
-  for (const ColTask& t : order) {
-    GH_CHECK(issue_chain_upto(t.i));
-    if (t.i > waited_panel) { GH_HIP(hipStreamWaitEvent(sm, s->ev_p[t.i], 0)); waited_panel = t.i; }
-    GH_CHECK(update(sm, t.i, t.c1, t.c2, true));
-    for (int c = t.c1; c <= t.c2; ++c)
-      if (--col_left[c] == 0) col_recorded[c] = 1;
-    // one event per launch is enough: the columns this launch completed are complete when it is over
-    bool any = false;
-    for (int c = t.c1; c <= t.c2; ++c) any = any || (col_left[c] == 0 && col_recorded[c] == 1);
-    if (any)
-      for (int c = t.c1; c <= t.c2; ++c)
-        if (col_left[c] == 0 && col_recorded[c] == 1) { GH_HIP(hipEventRecord(s->ev_w[c], sm)); col_recorded[c] = 2; }
-  }
-  GH_CHECK(issue_chain_upto(P - 1));
-  // join on the chain stream (see factor_lookahead_deep: barriers at the head of the main stream's queue are not free)
-  if (sm != s->st) {
-    GH_HIP(hipEventRecord(s->ev_xfer, sm));
-    GH_HIP(hipStreamWaitEvent(sp, s->ev_xfer, 0));
-  }
-  if (s->st3) { GH_HIP(hipEventRecord(s->ev_sync[2], s->st3)); GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[2], 0)); }
-  s->tail = sp;
-  return GH_OK;
-}
-
 static int lookahead_depth(const gh_chol* s) {
   static const int forced = getenv("GEORGE_AMD_LOOKAHEAD_DEPTH") ? atoi(getenv("GEORGE_AMD_LOOKAHEAD_DEPTH")) : -1;
   if (forced >= 1) return forced;
@@ -1316,14 +1161,7 @@ static int factor(gh_chol* s) {
       guard(s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
   // (a matrix of ONE panel has nothing to look ahead to: on the main stream it saves the two cross-stream hand-overs,
   //  ~35 us each -- a tenth of the step at N = 1024)
-  if (s->opts.lookahead && s->st2 && s->st3 && s->st4 && s->np > panel_width(s)) {
-    // GEORGE_AMD_SCHEDULE=columns|panels forces one; default: the column-priority schedule where a CU-masked stream is in use
-    // (one panel < Np < 24576: the chain-bound sizes), the depth-1 panel look-ahead above it (SYRK-bound)
-    static const char* const sched = getenv("GEORGE_AMD_SCHEDULE");
-    const bool columns = sched ? sched[0] == 'c' : (s->np < 24576 && s->np >= 3 * panel_width(s));
-    if (columns && trailing_stream(s) != s->st && s->ev_xfer) return factor_column_priority(s);
-    return factor_lookahead_deep(s, lookahead_depth(s));
-  }
+  if (s->opts.lookahead && s->st2 && s->st3 && s->st4 && s->np > panel_width(s)) return factor_lookahead_deep(s, lookahead_depth(s));
   hipStream_t st = s->st;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);

@@ -707,7 +707,7 @@ def test_process_without_torch_runs_at_the_benchmarked_speed():
 
 @pytest.mark.parametrize("env", [{"GEORGE_AMD_RESERVE_CUS": "0"}, {"GEORGE_AMD_RESERVE_CUS": "16"}, {"GEORGE_AMD_JOIN": "main"},
                                  {"GEORGE_AMD_JOIN": "chain"}, {"GEORGE_AMD_LOOKAHEAD_DEPTH": "2"}, {"GEORGE_AMD_LOOKAHEAD_DEPTH": "3"},
-                                 {"GEORGE_AMD_NO_MFMA": "1"}, {"GEORGE_AMD_SCHEDULE": "panels"}, {"GEORGE_AMD_SCHEDULE": "columns"}])
+                                 {"GEORGE_AMD_NO_MFMA": "1"}])
 def test_every_switch_the_library_still_reads(env):
     """Round 4 pruned the A/B switches whose losing arm has a committed measurement (45 -> 9 environment variables: DESIGN.md
     section 4).  Each one that stayed is exercised: the scheduling knobs (CUs kept free of the trailing update, where a
