@@ -188,6 +188,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDev& g, const v4d (&acc)
 //   m-major operand (k strided, rows contiguous): LDS image [k][128 rows], one instruction = one
 //       k (1 KiB of rows); piece p of k-row k holds row-pair p ^ ((k & 1) << 3), i.e. odd k swap
 //       the two 128-byte halves of every 256 bytes -- for the reader that is "16-row group i^1".
+// which k (of the 16 of a slab) lane group fk feeds into k-step kk of a k-major x k-major product: element offset inside the row's
+// XOR-swizzled image.  k = {2 fk, 2 fk + 1, 2 fk + 8, 2 fk + 9}[kk]: the lane's four values sit in two 16-byte pieces, so the
+// main kernel reads a slab's fragments with 16 ds_read_b128 per wavefront (round 4; the natural assignment k = 4 kk + fk needs
+// 32 ds_read_b64: 68.0 -> 69.1 TFLOP/s on the SYRK shape, -1.3 ... -1.6 % on seven shapes, profiles/r04/gemm_pair_ab.md).
+// EVERY k-major x k-major kernel must use the same assignment (a tile's bits must not depend on which of them computed it:
+// tests compare schedules bit for bit); products with an m-major operand keep k = 4 kk + fk on both sides.
+#define GH_KM_OFFK(kk, fk, sw) (((((fk) + 4 * ((kk) >> 1)) ^ (sw)) * 2) + ((kk) & 1))
 typedef __attribute__((address_space(3))) void gh_lds_void;
 typedef const __attribute__((address_space(1))) void gh_glb_void;
 
@@ -197,6 +204,7 @@ struct DmaOperand {
   long step;                // doubles to advance per slab
   int f0, f1;               // fragment read offsets (doubles), see frag()
   int offk[4];
+  int off2[2];              // k-major x k-major launches: the lane's two 16-byte pieces, see frag2()
 
   __device__ __forceinline__ void init(const double* base, long ld, long r0, long kbeg, int wave, int lane, int wsub) {
     const int fr = lane & 15, fk = lane >> 4;
@@ -210,6 +218,7 @@ struct DmaOperand {
       const int sw = (fr >> 1) & 7;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+      off2[0] = ((fk ^ sw) * 2); off2[1] = (((fk + 4) ^ sw) * 2);
       f0 = (wsub * 64 + fr) * BK;
       f1 = 0;
     } else {
@@ -230,6 +239,13 @@ struct DmaOperand {
   __device__ __forceinline__ double frag(const double* s, int kk, int i) const {
     if (KM) return s[f0 + i * 16 * BK + offk[kk]];
     return s[((i & 1) ? f1 : f0) + i * 16 + offk[kk]];
+  }
+  // k-major image only: pieces fk and fk + 4 of row (16 i + fr) as ONE 16-byte LDS read each -- k-steps 2q and 2q + 1 of the lane.
+  // The k index a lane feeds into k-step kk is then {2 fk, 2 fk + 1, 2 fk + 8, 2 fk + 9}[kk] instead of 4 kk + fk: any
+  // assignment works as long as both operands use the same one (the instruction sums over its four k), and with this one a
+  // slab costs a wavefront 16 ds_read_b128 instead of 32 ds_read_b64.
+  __device__ __forceinline__ double2 frag2(const double* s, int q, int i) const {
+    return *reinterpret_cast<const double2*>(s + f0 + i * 16 * BK + off2[q]);
   }
 };
 
@@ -269,12 +285,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   for (long kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
     double a[4][4], b[4][4];
+    if constexpr (A_KM && B_KM) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+      for (int q = 0; q < 2; ++q) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[kk][i] = oa.frag(sA[cur], kk, i);
+        for (int i = 0; i < 4; ++i) { const double2 v = oa.frag2(sA[cur], q, i); a[2 * q][i] = v.x; a[2 * q + 1][i] = v.y; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[kk][j] = ob.frag(sB[cur], kk, j);
+        for (int j = 0; j < 4; ++j) { const double2 v = ob.frag2(sB[cur], q, j); b[2 * q][j] = v.x; b[2 * q + 1][j] = v.y; }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[kk][i] = oa.frag(sA[cur], kk, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[kk][j] = ob.frag(sB[cur], kk, j);
+      }
     }
     // fragment reads first, THEN the DMA of the next slab into the other buffer (last read one
     // barrier ago): a DMA issued ahead of the reads would make the compiler wait for it
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_dma64(GemmDev g) {
   const int sw = (fr >> 1) & 7;
   int offk[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = GH_KM_OFFK(kk, fk, sw);
   const int rowA = (wm * 32 + fr) * BK, rowB = (wn * 16 * NBJ + fr) * BK;
   const int dstA = wave * 2 * 128, dstB = wave * NBJ * 128;
 #define GH_DMA64_ISSUE(buf)                                                                            \
@@ -504,7 +530,7 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_k128(GemmDev g) {
   const int sw = (fr >> 1) & 7;
   int offk[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = GH_KM_OFFK(kk, fk, sw);
   const int rowA = (wm * 16 * MI + fr) * BK, rowB = (wn * 16 * NJ + fr) * BK;
 #define GH_K128_CHUNK(kc)                                                                              \
   do {                                                                                                 \
