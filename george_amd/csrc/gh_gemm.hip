@@ -200,7 +200,12 @@ typedef const __attribute__((address_space(1))) void gh_glb_void;
 
 template <bool KM>
 struct DmaOperand {
-  const double* src[4];     // this lane's source of the wavefront's 4 DMA instructions per slab
+  // source of instruction i = ubase (wave-uniform: lives in SGPRs, advanced by a scalar add per slab) + voff[i] (this lane's byte
+  // offset, loop-invariant).  Round 4: one 64-bit VGPR pointer per instruction (the first form) cost 8 v_lshl_add_u64 per slab
+  // and wavefront plus a v_readfirstlane per instruction for the LDS address in M0 -- vector instructions that queue behind the
+  // fp64 matrix instructions: 69.3 -> 70.3 TFLOP/s with scalar M0, -> 71.2 with the buffer form (profiles/r04/gemm_dma_addr_ab.md).
+  const char* ubase;
+  unsigned voff[4];
   long step;                // doubles to advance per slab
   int f0, f1;               // fragment read offsets (doubles), see frag()
   int offk[4];
@@ -209,10 +214,11 @@ struct DmaOperand {
   __device__ __forceinline__ void init(const double* base, long ld, long r0, long kbeg, int wave, int lane, int wsub) {
     const int fr = lane & 15, fk = lane >> 4;
     if (KM) {
+      ubase = (const char*)(base + r0 * ld + kbeg);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = wave * 32 + i * 8 + (lane >> 3);
-        src[i] = base + (r0 + r) * ld + kbeg + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+        voff[i] = (unsigned)(((long)r * ld + (((lane & 7) ^ ((r >> 1) & 7)) * 2)) * 8);
       }
       step = BK;
       const int sw = (fr >> 1) & 7;
@@ -222,10 +228,11 @@ struct DmaOperand {
       f0 = (wsub * 64 + fr) * BK;
       f1 = 0;
     } else {
+      ubase = (const char*)(base + kbeg * ld + r0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = wave * 4 + i;
-        src[i] = base + (kbeg + k) * ld + r0 + ((lane ^ ((k & 1) << 3)) * 2);
+        voff[i] = (unsigned)(((long)k * ld + ((lane ^ ((k & 1) << 3)) * 2)) * 8);
       }
       step = BK * ld;
       const int ix = fk & 1;
@@ -249,10 +256,15 @@ struct DmaOperand {
   }
 };
 
+// buffer_load_dwordx4 ... offen lds: resource descriptor in SGPRs (base = the wave-uniform slab pointer, advanced by a scalar add),
+// the lane's byte offset as the 32-bit voffset -- not one vector instruction per DMA.  (global_load_lds with an SGPR base: hipcc
+// still forms a 64-bit vector address per instruction inside the loop, one v_lshl_add_u64 each.)
 #define GH_DMA_ISSUE(op, sbuf)                                                                        \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
-    __builtin_amdgcn_global_load_lds((gh_glb_void*)op.src[i_], (gh_lds_void*)((sbuf) + dst + i_ * 128), 16, 0, 0); \
-    op.src[i_] += op.step;                                                                            \
+  {                                                                                                   \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)op.ubase, 0, 0x7fffffff, 0x00020000); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (gh_lds_void*)((sbuf) + dst + i_ * 128), 16, (int)op.voff[i_], 0, 0, 0); \
+    op.ubase += op.step * 8;                                                                          \
   }
 
 // LOWER (== g.lower) only names the symbol: rocprof then tells the triangular-grid launches (the
@@ -267,7 +279,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   const long row0 = (long)tm * BM, col0 = (long)tn * BN;
   long kbeg, kend;
   k_range(g, row0, col0, kbeg, kend);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wavefront index as a SCALAR: the LDS destination of every DMA goes through M0, and from a vector register that is a
+  //  v_readfirstlane per instruction and slab)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fk = lane >> 4;
 
