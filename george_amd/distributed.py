@@ -307,7 +307,10 @@ class BlockCyclicCholesky(object):
             self.ws_relay = [ops.zeros(self.Pr * nmax) for _ in range(2)]
             self.ws_fwd = [ops.zeros(self.world * nmax) for _ in range(2)]
         self.ws_send = [ops.zeros(cmax0, nbk, nbk) for _ in range(2)]
-        self.ws_gath = [[ops.zeros(cmax0, nbk, nbk) for _ in range(self.Pr)] for _ in range(2)] if self.Pr > 1 else None
+        # gather target: ONE flat buffer per parity, viewed as (Pr, cmax, nb, nb) for the step's cmax -- all_gather_into_tensor then
+        # writes the members' tiles in place (the list form of all_gather goes through a temporary and Pr copy kernels per step)
+        self.ws_gath = [ops.zeros(self.Pr * cmax0 * nbk * nbk) for _ in range(2)] if self.Pr > 1 else None
+        self._gather_into_tensor = hasattr(dist, "all_gather_into_tensor")
         self.ws_next = [ops.zeros(nbk, nbk) for _ in range(2)]      # tile k+1 of the column panel, ahead of the gather
         # the column panel in LOCAL COLUMN ORDER (tile lj of my tile columns at [lj]): the rest of U(k) is one GEMM per local
         # tile row whose B operand is a run of consecutive local columns
@@ -497,8 +500,15 @@ class BlockCyclicCholesky(object):
                 s = (self.lrow[j] - li0) * nb
                 send[t].copy_(wrow[s:s + nb])
             if Pr > 1 and self.live:
-                gathered = [g[:cmax] for g in self.ws_gath[buf]]
-                self.dist.all_gather(gathered, send, group=self.bulk_groups[pc])
+                flat = self.ws_gath[buf][:Pr * cmax * nb * nb].view(Pr, cmax, nb, nb)
+                gathered = [flat[mm] for mm in range(Pr)]
+                if self._gather_into_tensor:
+                    try:
+                        self.dist.all_gather_into_tensor(flat.view(Pr * cmax, nb, nb), send, group=self.bulk_groups[pc])
+                    except (RuntimeError, NotImplementedError, TypeError):     # (a backend without it raises on every rank alike)
+                        self._gather_into_tensor = False
+                if not self._gather_into_tensor:
+                    self.dist.all_gather(gathered, send, group=self.bulk_groups[pc])
             else:
                 gathered = [send]
             colp = self.ws_colp[buf]
