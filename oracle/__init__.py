@@ -10,8 +10,10 @@ Parity status:
   compiled C++ evaluator + reference Python (oracle/_ref, oracle/gen_golden.py)
   and the reference's published golden scalars (docs/tutorials/scaling.rst:76,91;
   first.rst:91,119,129).
-* HODLR path (hodlr_np.py): the reference extension is not buildable here
-  (Eigen submodule absent) -> pinned only through the reference's own HODLR
-  tests' criterion (agreement with the dense answer within allclose) and the
-  N=100 golden log-likelihood; the RNG-dependent pivot sequence is unpinned.
+* HODLR path (hodlr_np.py): PINNED against the reference's own `include/george/hodlr.h`, compiled unmodified against
+  oracle/mini_eigen (the Eigen submodule is empty upstream) behind oracle/hodlr_ref_driver.cpp (oracle/_ref/_hodlr;
+  goldens: oracle/gen_golden_hodlr.py, oracle/gen_golden_large.py C4 at N = 262144); the stand-in's LDLT / FullPivLU are
+  checked against SciPy / NumPy (tests/test_oracle_hodlr.py).
+* oracle/_ref/george/: byte-code of the reference's Python package (oracle/Makefile: stage), loaded by
+  ref_loader.load_reference() where /root/reference is absent (the GPU box): tests/test_gpu_reference_suite.py.
 """
