@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, session h: DMA issued right after the fragment reads, ahead of all 64 MFMAs of the slab (column b128 = new) ("b128" column = new, "b64" column = before)
+# round 4: A/B of one variant of the main GEMM kernel against the tree's (column "b128" = variant)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4h; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $R
