@@ -40,6 +40,7 @@ struct GemmDev {
   long nblk;
   int preload;      // beta == +-alpha != 0: accumulators start from (beta/alpha) * C, write-back is store-only
   int prio;         // launch cannot fill the chip (panel-chain GEMMs): run at top wavefront priority
+  int grouped;      // tile order inside an XCD's chunk: row groups walked column-major (tile_of) instead of row-major
 };
 
 // XCD-aware remap (bijective for any nblk): workgroup b runs on XCD b % 8; give each XCD
@@ -50,29 +51,73 @@ __device__ __forceinline__ long xcd_remap(long bid, long nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Workgroup -> C tile: row-major over the (lower-triangular) tile grid inside each XCD's chunk.
-// (Tried and measured: grouping tiles into 8x8 super-tiles per XCD, which would cut the L2-miss
-// traffic of the operand slabs -- FETCH_SIZE is 4.8x the algorithmic read bytes, profiles/r01 --
-// left the SYRK at the same 51-57 TFLOP/s and cost 8 % end to end through 8x larger grids on the
-// skinny panel GEMMs.  The kernel is MFMA-issue bound, not fabric bound.)
+// Workgroup -> C tile.  Inside each XCD's chunk the order is "row groups, column-major inside a group": GH_TILE_GROUP tile rows
+// at a time, walked column by column, so the ~64 tiles one XCD has in flight form an 8 x 8 block that shares 8 + 8 operand
+// slabs in its L2 instead of the 1 + 64 of a row-major walk (whose column slabs stream from HBM every time: FETCH_SIZE was
+// 4.5x the algorithmic read bytes, profiles/r04/traffic_N65536.json).  Bijective for any shape -- no padded grid -- so the
+// skinny panel GEMMs keep their launch size (the round-1 attempt padded to whole super-tiles and lost 8 % there).
+#ifndef GH_TILE_GROUP
+#define GH_TILE_GROUP 8
+#endif
+__device__ __forceinline__ void grouped_rect(long l, int rows, int cols, int& tm, int& tn) {
+  constexpr int G = GH_TILE_GROUP;
+  const int g = (int)(l / ((long)G * cols));
+  const int gg = min(G, rows - g * G);
+  const long r = l - (long)g * G * cols;
+  tn = (int)(r / gg);
+  tm = g * G + (int)(r % gg);
+}
+__device__ __forceinline__ void grouped_tri(long l, int T, int& tm, int& tn) {
+  // rows g*G .. g*G+G-1 hold G*g*G + G(G+1)/2 tiles; before group g: G*G*g(g-1)/2 + g*G(G+1)/2
+  constexpr int G = GH_TILE_GROUP;
+  constexpr long H = (long)G * (G + 1) / 2;
+  long g = (long)((sqrt(((double)H - 0.5 * G * G) * ((double)H - 0.5 * G * G) + 2.0 * G * G * (double)l) - ((double)H - 0.5 * G * G)) /
+                  ((double)G * G));
+  auto start = [&](long q) { return (long)G * G * q * (q - 1) / 2 + q * H; };
+  while (start(g) > l) --g;
+  while (start(g + 1) <= l) ++g;
+  const int r0 = (int)g * G, gg = min(G, T - r0);
+  long r = l - start(g);
+  const long rect = (long)gg * (r0 + 1);        // columns 0 .. r0 are full height
+  if (r < rect) {
+    tn = (int)(r / gg);
+    tm = r0 + (int)(r % gg);
+    return;
+  }
+  r -= rect;
+  int j = 1;                                    // column r0 + j holds rows r0 + j .. r0 + gg - 1
+  while (r >= gg - j) { r -= gg - j; ++j; }
+  tn = r0 + j;
+  tm = r0 + j + (int)r;
+}
 __device__ __forceinline__ bool tile_of(const GemmDev& g, int& tm, int& tn) {
   // (triangular operands: the K extent shrinks along the tile order, so contiguous per-XCD chunks
-  //  would hand one XCD all the long tiles -- deal those round-robin instead)
+  //  would hand one XCD all the long tiles -- deal those round-robin, in plain row-major order)
+  const bool rowmajor = !g.grouped;
   const long l = (g.klo_max | g.khi_col | g.khi_row) ? (long)blockIdx.x : xcd_remap(blockIdx.x, g.nblk);
   if (g.lower) {
     // lower TRAPEZOID: tiles (tm, tn) with tn <= tm and tn < tiles_n (a square C, tiles_n == tiles_m, is the triangle): the first
     // tiles_n tile rows hold 1, 2, .. tiles_n tiles, every row below them tiles_n
     const long tri = (long)g.tiles_n * (g.tiles_n + 1) / 2;
     if (l < tri) {
-      long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
-      while (t * (t + 1) / 2 > l) --t;
-      while ((t + 1) * (t + 2) / 2 <= l) ++t;
-      tm = (int)t;
-      tn = (int)(l - t * (t + 1) / 2);
+      if (!rowmajor) {
+        grouped_tri(l, g.tiles_n, tm, tn);
+      } else {
+        long t = (long)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
+        while (t * (t + 1) / 2 > l) --t;
+        while ((t + 1) * (t + 2) / 2 <= l) ++t;
+        tm = (int)t;
+        tn = (int)(l - t * (t + 1) / 2);
+      }
+    } else if (!rowmajor) {
+      grouped_rect(l - tri, g.tiles_m - g.tiles_n, g.tiles_n, tm, tn);
+      tm += g.tiles_n;
     } else {
       tm = g.tiles_n + (int)((l - tri) / g.tiles_n);
       tn = (int)((l - tri) % g.tiles_n);
     }
+  } else if (!rowmajor) {
+    grouped_rect(l, g.tiles_m, g.tiles_n, tm, tn);
   } else {
     tm = (int)(l / g.tiles_n);
     tn = (int)(l % g.tiles_n);
@@ -646,6 +691,9 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
   g.nblk = h.lower ? (long)g.tiles_n * (g.tiles_n + 1) / 2 + (long)(g.tiles_m - g.tiles_n) * g.tiles_n : (long)g.tiles_m * g.tiles_n;
   g.prio = g.nblk <= 512 ? 1 : 0;
+  // (grouped tile order only once the column operand outgrows what the 256 MB MALL keeps between tile rows -- 128 MiB, N > 16384
+  //  at K = 1024: below that a row-major walk already finds its slabs on chip and is 1 % faster, profiles/r04/gemm_tile_order_ab.md)
+  g.grouped = (!(h.klo_max | h.khi_col | h.khi_row) && (long)h.N * h.K * 8 > (128L << 20)) ? 1 : 0;
   g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha)) ? 1 : 0;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);

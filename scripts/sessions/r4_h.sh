@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4: A/B of one variant of the main GEMM kernel against the tree's (column "b128" = variant)
+# round 4: whole-factorisation A/B of a variant build of the library (libgeorge_amd_c.so) against the tree's
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4h; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $R
-timeout 900 python scripts/dev/gemm_ab_tmp.py > $O/gemm_ab.md 2> $O/gemm_ab.err; echo "ab rc=$?"; cat $O/gemm_ab.md; tail -3 $O/gemm_ab.err
+timeout 1200 python scripts/dev/factor_ab_tmp.py "$@" > $O/factor_ab.md 2> $O/factor_ab.err; echo "ab rc=$?"; cat $O/factor_ab.md; tail -3 $O/factor_ab.err

@@ -206,8 +206,8 @@ def test_potrf_failing_pivot_index_matches_lapack(p, bad):
 
 @pytest.mark.parametrize("rows,cols,K", [(5, 2, 80), (9, 9, 48), (12, 1, 1024), (40, 7, 256), (3, 3, 16)])
 def test_lower_trapezoid(rows, cols, K):
-    """GH_GEMM_LOWER with m > n: the leading n columns of a lower-triangular C (tiles with tile row >= tile column) -- the launches of
-    the column-priority factorisation schedule (gh_chol.hip, factor_column_priority); tiles above the diagonal stay untouched, and
+    """GH_GEMM_LOWER with m > n: the leading n columns of a lower-triangular C (tiles with tile row >= tile column); tiles above the
+    diagonal stay untouched, and
     every computed tile is bit-identical to the same tile of the full lower-triangular launch."""
     rng = np.random.RandomState(rows * 7 + cols)
     M, Nn = 128 * rows, 128 * cols
@@ -224,3 +224,36 @@ def test_lower_trapezoid(rows, cols, K):
     assert np.array_equal(got[blk], full[blk])
     assert np.array_equal(got[~blk], C0[~blk])
     assert np.abs(got - (C0 - A @ A.T))[blk].max() < 1e-10 * max(1.0, K / 16)
+
+
+@pytest.mark.parametrize("rows,cols,K,lower", [(130, 130, 1024, True), (137, 129, 1024, True), (9, 129, 1024, False),
+                                               (33, 17, 8192, False)])
+def test_grouped_tile_order(rows, cols, K, lower):
+    """Launches whose column operand exceeds 128 MiB walk their tiles in row groups of 8, column-major inside a group
+    (gh_gemm.hip, tile_of / grouped_tri / grouped_rect): a partial last group, a trapezoid (triangle part + rectangular part) and
+    plain rectangles.  Every tile must be produced exactly once -- a tile visited twice would subtract A B^T twice, a tile
+    missed would keep C0 -- and bit-identically to the same tile computed by a launch small enough for the row-major order."""
+    import torch
+    M, Nn = 128 * rows, 128 * cols
+    assert Nn * K * 8 > (128 << 20)
+    g = torch.Generator(device="cuda").manual_seed(rows * 131 + cols)
+    a = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
+    b = a if lower else torch.randn(Nn, K, dtype=torch.float64, device="cuda", generator=g)
+    c0 = torch.randn(M, Nn, dtype=torch.float64, device="cuda", generator=g)
+    c = c0.clone()
+    _gemm(c, a, b, M, Nn, K, -1.0, 1.0, FLAGS["LOWER"] if lower else 0, K, K, Nn)
+    want = c0 - a @ b[:Nn].T
+    tr = torch.arange(M, device="cuda")[:, None] // 128
+    tc = torch.arange(Nn, device="cuda")[None, :] // 128
+    blk = (tr >= tc) if lower else torch.ones(M, Nn, dtype=torch.bool, device="cuda")
+    assert torch.equal(c[~blk], c0[~blk])
+    err = (c - want)[blk].abs().max().item()
+    assert err < 1e-10 * K / 16, err
+    # the same tiles from row-major launches of the same kernel: all rows, half the columns (<= 128 MiB of column operand)
+    half = (cols // 2) * 128
+    for c_lo, c_hi in ((0, half), (half, Nn)):
+        assert (c_hi - c_lo) * K * 8 <= (128 << 20) and rows * (c_hi - c_lo) // 128 > 128
+        ref = c0[:, c_lo:c_hi].contiguous()
+        _gemm(ref, a, b[c_lo:c_hi], M, c_hi - c_lo, K, -1.0, 1.0, 0, K, K, c_hi - c_lo)
+        m = blk[:, c_lo:c_hi]
+        assert torch.equal(ref[m], c[:, c_lo:c_hi][m])
