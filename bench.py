@@ -24,6 +24,7 @@ At N = 1 the same line also carries (all timed in this run, on the GPU the drive
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -169,7 +170,6 @@ def pmc_traffic(n):
     (profiles/*/traffic_N<n>.json, produced by scripts/profile.sh + scripts/traffic_from_pmc.py:
     separate FETCH_SIZE / WRITE_SIZE passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024).  Counters
     cannot be read inside a timed run, so this is the most recent committed measurement."""
-    import glob
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_N%d.json" % n)))
     if not hits:
         return {"traffic": None}
@@ -254,12 +254,18 @@ def hodlr_report(n, local_rank, steps=10, warmup=3, cpu_n=32768):
     streamed += sum(8.0 * n * (offs[l] + lv[l]) for l in active[:-1])
     streamed += 2.0 * 8.0 * n * rtot + 8.0 * n * 128       # the solve
     streamed_fused += 2.0 * 8.0 * n * rtot + 8.0 * n * 128
+    measured = None
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_C4_N%d.json" % n)))
+    if hits:
+        measured = json.load(open(hits[-1]))["bytes_per_step"]
     out = {"workload": "N=%d 1-D ExpSquared, HODLRSolver(tol=1e-10, min_size=100, seed=42): compute()+log_likelihood()" % n,
            "seconds_per_step": sec, "steps": steps, "log_likelihood": ll, "rank_per_level": lv, "rank_total": rtot,
            "roofline": {"kernel": "whole HODLR compute()+log_likelihood() (ACA, leaf / core factorisation, Woodbury sweeps)",
                         "bound": "hbm", "achieved": foot / sec * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": foot / sec * 1e-9 / PEAK_HBM_GBS, "traffic": streamed,
-                        "traffic_note": "bytes the sweep + solve stream by construction (model from the measured ranks; the ACA "
+                        "frac": foot / sec * 1e-9 / PEAK_HBM_GBS, "traffic": measured if measured is not None else streamed,
+                        "traffic_source": os.path.relpath(hits[-1], ROOT) if hits else "model (streamed_bytes)",
+                        "traffic_note": "traffic: bytes per step leaving the L2s, from the committed --pmc passes when present; "
+                                        "streamed_bytes: what the sweep + solve stream by construction (model from the measured ranks; the ACA "
                                         "phase evaluates kernel entries, it streams nothing); %.2f GB with update and reduce fused "
                                         "(built in round 4, not faster: scripts/dev/arms)" % (streamed_fused * 1e-9),
                         "streamed_bytes": streamed, "achieved_streamed": streamed / sec * 1e-9,

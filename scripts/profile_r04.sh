@@ -11,6 +11,7 @@ BENCH="python $R/bench.py --no-cpu --no-extra"
 run() { tag=$1; shift; timeout 900 rocprofv3 "$@" > "$OUT/$tag.log" 2>&1; echo "$tag rc=$?"; }
 # 0. the un-profiled default line (what the driver runs), the per-launch intervals behind its roofline object, the size sweep
 python $R/bench.py --dump-intervals "$OUT/update_intervals_N65536.json" --detail "$OUT/bench_detail_final.json" > "$OUT/bench_line_final.json" 2> "$OUT/bench_line_final.err"; echo "bench rc=$?"
+python $R/bench.py --gpus 1 --steps 20 --warmup 5 --detail "$OUT/bench_detail_driver_form.json" > "$OUT/bench_line_driver_form.json" 2> /dev/null; echo "bench (driver form) rc=$?"
 python $R/scripts/size_sweep.py > "$OUT/size_sweep.md" 2>/dev/null; echo "sweep rc=$?"
 # 1. kernel traces: headline (N = 65536), configs[1] (N = 16384), C4 (HODLR), C5
 run trace64k --kernel-trace --stats -d "$OUT/trace64k" -o trace -- $BENCH --steps 2 --warmup 1
@@ -22,6 +23,9 @@ run pmc_fetch --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o pmc -- $BEN
 run pmc_write --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o pmc -- $BENCH --steps 1 --warmup 0 --no-lookahead
 # 3. matrix pipe and clock under the SYRK (N = 32768, single stream)
 run pmc_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_mfma" -o pmc -- $BENCH --n 32768 --steps 1 --warmup 0 --no-lookahead
+# 3b. the same two counters over whole HODLR steps (config C4): 3 identical compute()+log_likelihood() steps and nothing else
+run c4_fetch --pmc FETCH_SIZE --kernel-trace -d "$OUT/c4_fetch" -o pmc -- python $R/scripts/hodlr_traffic_from_pmc.py --job 262144 3
+run c4_write --pmc WRITE_SIZE --kernel-trace -d "$OUT/c4_write" -o pmc -- python $R/scripts/hodlr_traffic_from_pmc.py --job 262144 3
 # 4. (the kernel-matrix build's VALU / WRITE_SIZE passes are round 3's: that kernel did not change -- profiles/r03/pmc_kmat_*.md)
 # 5. calibration of FETCH_SIZE / WRITE_SIZE on a copy of known size
 CAL="import sys, ctypes; sys.path.insert(0, '$R'); from george_amd import _native as N; v = ctypes.c_double(0); N.check(N.lib.gh_microbench_hbm_copy(ctypes.byref(v))); print(v.value)"
@@ -34,6 +38,7 @@ for d in trace64k trace16k traceC4 traceC5 pmc_fetch pmc_write pmc_mfma cal_fetc
   if [ -n "$f" ]; then python scripts/summarize_prof.py "$f" "$OUT/$d.md" $TMIN; fi
 done
 python scripts/traffic_from_pmc.py "$(find $OUT/pmc_fetch -name '*.db' | head -1)" "$(find $OUT/pmc_write -name '*.db' | head -1)" 65536 1024 "$OUT/traffic_N65536.json"
+python scripts/hodlr_traffic_from_pmc.py "$(find $OUT/c4_fetch -name '*.db' | head -1)" "$(find $OUT/c4_write -name '*.db' | head -1)" 262144 3 "$OUT/traffic_C4_N262144.json"
 f=$(find "$OUT/trace16k" -name "*.db" | head -1); [ -n "$f" ] && python scripts/chain_stats.py "$f" > "$OUT/chain_stats_N16384.txt"
 f=$(find "$OUT/traceC4" -name "*.db" | head -1); [ -n "$f" ] && python scripts/hodlr_levels.py "$f" > "$OUT/hodlr_levels_C4.txt"
 f=$(find "$OUT/traceC4" -name "*.db" | head -1); [ -n "$f" ] && python scripts/dev/hodlr_timeline.py "$f" > "$OUT/hodlr_timeline_C4.txt"
