@@ -97,6 +97,11 @@ __device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* s
 #define ACA_MAXR 2048          // coefficient slots in LDS: rank <= 2048 (one-workgroup nodes) / 1024 (clusters)
 #define ACA_NC 64              // candidate rows tested per search pass once the search has started failing
 #define ACA_LIDX 4096          // row permutations of one-workgroup nodes live in LDS up to this many rows
+#ifndef ACA_CAPD
+#define ACA_CAPD 2048          // doubles of U and of V a one-workgroup node mirrors in LDS (its first CAPD / n rows of each factor)
+#endif
+#define ACA_XC 512             // ... and its coordinates when ndim == 1 (rows, then columns)
+#define ACA_DYN_BYTES (ACA_CAPD > 0 ? (2 * ACA_CAPD + 2 * ACA_XC) * 8 : 0)
 // One node is worked on by a CLUSTER of G workgroups (blockIdx.x = node * G + g): the top levels
 // have 1, 2, 4, ... nodes with blocks of N/2, N/4, ... rows, and one workgroup per node left the
 // single workgroup of level 0 with 70 % of the whole HODLR compute() at N = 262144.  Workgroup g
@@ -176,8 +181,9 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
     int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc,
-    const AcaSeg* segs, int nseg) {
+    const AcaSeg* segs, int nseg, int capd) {
   __shared__ AcaShared sh;
+  extern __shared__ double aca_dyn[];                  // capd > 0: U mirror | V mirror | coordinates (ACA_DYN_BYTES)
   int bid = blockIdx.x;
   if (segs) {
     int q = 0;
@@ -204,6 +210,21 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   // one-workgroup nodes keep the row permutation in LDS (the candidate draws are a serial chain of
   // dependent reads and writes: ~1 us each through HBM, 64 of them per search pass)
   const bool lperm = (G == 1) && n_rows <= ACA_LIDX;
+  // Small one-workgroup nodes (levels 8-10 of C4: 1792 of its 2047 blocks) are a chain of ~10 dependent global round trips
+  // per ACA step -- 13 us per step for 128-entry vectors.  They mirror the first `kcap` rows of U and V (and, in 1-D, their
+  // coordinates) in LDS: every read of a factor entry below comes from the mirror when its row is there, every write goes to
+  // both.  Same values, same order of operations: the factors and ranks do not change by a bit.
+  const int kcap = (lperm && capd > 0 && n_rows <= capd && n_cols <= capd) ? min(capd / n_rows, capd / n_cols) : 0;
+  double* const uc = aca_dyn;
+  double* const vc = aca_dyn + capd;
+  double* const xs = aca_dyn + 2 * capd;
+  const bool xlds = kcap > 0 && nd == 1 && n_rows <= ACA_XC && n_cols <= ACA_XC;
+  if (xlds) {
+    for (int t = tid; t < n_rows; t += nt) xs[t] = x[row0 + t];
+    for (int t = tid; t < n_cols; t += nt) xs[ACA_XC + t] = x[col0 + t];
+  }
+  auto xrow = [&](int m) -> const double* { return xlds ? (const double*)(xs + m) : x + (long)(row0 + m) * nd; };
+  auto xcol = [&](int n) -> const double* { return xlds ? (const double*)(xs + ACA_XC + n) : x + (long)(col0 + n) * nd; };
   if (lperm) { for (int t = tid; t < n_rows; t += nt) sh.lidx[t] = (unsigned short)t; }
   else if (g == 0) { for (int t = tid; t < n_rows; t += nt) idx[row0 + t] = t; }
   int remaining = n_rows, rank = 0;
@@ -214,6 +235,10 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   // (nodev.pad: index of the launch's first node in its tree level -- non-zero only for the sub-trees of a split tree)
   unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)(node + nodev.pad) * 0x9E3779B97F4A7C15ull);
   __syncthreads();
+#ifdef GH_ACA_TIMES
+  const long long dbg_t0 = wall_clock64();
+  int dbg_passes = 0;
+#endif
   while (rank < max_rank) {
     // ---- choose a random unused row with a non-negligible residual (hodlr.h:159-191)
     bool got = false;
@@ -230,6 +255,9 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       int NC = remaining < batch ? remaining : batch;
       if (rank + NC > rcap) NC = rcap - rank;
       if (NC < 1) break;
+#ifdef GH_ACA_TIMES
+      ++dbg_passes;
+#endif
       if (tid == 0) {
         for (int c = 0; c < NC; ++c) {
           st += 0x9E3779B97F4A7C15ull;
@@ -251,17 +279,19 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
         const int i = sh.cand_i[c];
         double* cw = sh.coef + wave * 32;
         __builtin_amdgcn_wave_barrier();              // (the previous candidate's reads of cw are done)
-        for (int k = lane; k < rank; k += 64) cw[k] = Tcm[(long)k * N + row0 + i];
+        for (int k = lane; k < rank; k += 64) cw[k] = k < kcap ? uc[k * n_rows + i] : Tcm[(long)k * N + row0 + i];
         __builtin_amdgcn_s_waitcnt(0);                // (own wavefront's LDS writes, read back below)
         __builtin_amdgcn_wave_barrier();
         double best = -1.0;
         int bestn = -1;
-        const double* xi = x + (long)(row0 + i) * nd;
+        const double* xi = xrow(i);
+        const int kv = rank < kcap ? rank : kcap;
+        // (only the candidate's largest entry is kept: storing 8-64 residual rows per pass to keep one was most of this
+        //  kernel's write traffic; the chosen row is formed again below, by the whole workgroup)
         for (int n = lane; n < n_cols; n += 64) {
-          double v = FAST ? gh_fast_value(fast, xi, x + (long)(col0 + n) * nd)
-                          : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
-          for (int k = 0; k < rank; ++k) v -= cw[k] * Tcm[(long)k * N + col0 + n];
-          Tcm[(long)(rank + c) * N + col0 + n] = v;
+          double v = FAST ? gh_fast_value(fast, xi, xcol(n)) : gh_eval_value(prog, n_prog, xi, xcol(n));
+          for (int k = 0; k < kv; ++k) v -= cw[k] * vc[k * n_cols + n];
+          for (int k = kv; k < rank; ++k) v -= cw[k] * Tcm[(long)k * N + col0 + n];
           const double a = fabs(v);
           if (a > best) { best = a; bestn = n; }
         }
@@ -286,10 +316,24 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       st = sh.cand_st[chosen];                        // (every thread keeps the generator state in step)
       remaining -= chosen + 1;
       j = sh.cand_bestn[chosen];
-      if (chosen > 0)
-        for (int n = tid; n < n_cols; n += nt) Tcm[(long)rank * N + col0 + n] = Tcm[(long)(rank + chosen) * N + col0 + n];
+      {
+        // the chosen candidate's residual row into row `rank` of the scratch: same expression and order of k as in the
+        // search, so the same bits
+        const int i = sh.cand_i[chosen];
+        for (int k = tid; k < rank; k += nt) sh.coef[k] = k < kcap ? uc[k * n_rows + i] : Tcm[(long)k * N + row0 + i];
+        __syncthreads();
+        const double* xi = xrow(i);
+        const int kv = rank < kcap ? rank : kcap;
+        for (int n = tid; n < n_cols; n += nt) {
+          double v = FAST ? gh_fast_value(fast, xi, xcol(n)) : gh_eval_value(prog, n_prog, xi, xcol(n));
+          for (int k = 0; k < kv; ++k) v -= sh.coef[k] * vc[k * n_cols + n];
+          for (int k = kv; k < rank; ++k) v -= sh.coef[k] * Tcm[(long)k * N + col0 + n];
+          Tcm[(long)rank * N + col0 + n] = v;
+          if (rank < kcap) vc[rank * n_cols + n] = v;
+        }
+      }
       __syncthreads();
-      pivot = Tcm[(long)rank * N + col0 + j];
+      pivot = rank < kcap ? vc[rank * n_cols + j] : Tcm[(long)rank * N + col0 + j];
       got = true;
       break;
     }
@@ -319,6 +363,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
                         : gh_eval_value(prog, n_prog, xi, x + (long)(col0 + n) * nd);
         for (int k = 0; k < rank; ++k) v -= sh.coef[k] * Tcm[(long)k * N + col0 + n];
         Tcm[(long)rank * N + col0 + n] = v;           // (rewritten after the pivot is known: owner-only so far)
+        if (rank < kcap) vc[rank * n_cols + n] = v;
         const double a = fabs(v);
         if (a > best) { best = a; bestn = n; }
       }
@@ -359,19 +404,22 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     __syncthreads();
     double vn2 = 0.0;
     for (int n = t0; n < n_cols; n += ts) {
-      const double v = Tcm[(long)rank * N + col0 + n] / pivot;
+      const double v = (rank < kcap ? vc[rank * n_cols + n] : Tcm[(long)rank * N + col0 + n]) / pivot;
       aca_st(Tcm + (long)rank * N + col0 + n, v, sw);
+      if (rank < kcap) vc[rank * n_cols + n] = v;
       vn2 += v * v;
     }
-    for (int k = tid; k < rank; k += nt) sh.coef[k] = aca_ld(Tcm + (long)k * N + col0 + j);    // V(j, 0:rank)
+    for (int k = tid; k < rank; k += nt) sh.coef[k] = k < kcap ? vc[k * n_cols + j] : aca_ld(Tcm + (long)k * N + col0 + j);    // V(j, 0:rank)
     __syncthreads();
     double un2 = 0.0;
-    const double* xj = x + (long)(col0 + j) * nd;
+    const double* xj = xcol(j);
+    const int kvu = rank < kcap ? rank : kcap;
     for (int m = t0; m < n_rows; m += ts) {
-      double u = FAST ? gh_fast_value(fast, x + (long)(row0 + m) * nd, xj)
-                      : gh_eval_value(prog, n_prog, x + (long)(row0 + m) * nd, xj);
-      for (int k = 0; k < rank; ++k) u -= sh.coef[k] * Tcm[(long)k * N + row0 + m];
+      double u = FAST ? gh_fast_value(fast, xrow(m), xj) : gh_eval_value(prog, n_prog, xrow(m), xj);
+      for (int k = 0; k < kvu; ++k) u -= sh.coef[k] * uc[k * n_rows + m];
+      for (int k = kvu; k < rank; ++k) u -= sh.coef[k] * Tcm[(long)k * N + row0 + m];
       aca_st(Tcm + (long)rank * N + row0 + m, u, sw);
+      if (rank < kcap) uc[rank * n_rows + m] = u;
       un2 += u * u;
     }
     ++rank;
@@ -387,14 +435,16 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     for (int k0 = 0; k0 < rank - 1; k0 += 4) {
       double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
       for (int m = t0; m < n_rows; m += ts) {
-        const double u = ul[m];
+        const double u = rank - 1 < kcap ? uc[(rank - 1) * n_rows + m] : ul[m];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) du[q] += Tcm[(long)(k0 + q) * N + row0 + m] * u;
+        for (int q = 0; q < 4; ++q)
+          if (k0 + q < rank - 1) du[q] += (k0 + q < kcap ? uc[(k0 + q) * n_rows + m] : Tcm[(long)(k0 + q) * N + row0 + m]) * u;
       }
       for (int n = t0; n < n_cols; n += ts) {
-        const double v = vl[n];
+        const double v = rank - 1 < kcap ? vc[(rank - 1) * n_cols + n] : vl[n];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (k0 + q < rank - 1) dv[q] += Tcm[(long)(k0 + q) * N + col0 + n] * v;
+        for (int q = 0; q < 4; ++q)
+          if (k0 + q < rank - 1) dv[q] += (k0 + q < kcap ? vc[(k0 + q) * n_cols + n] : Tcm[(long)(k0 + q) * N + col0 + n]) * v;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -442,7 +492,22 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   if (g == 0 && tid == 0) {
     ranks[node] = rank;
     if (!converged && rank < full_rank) atomicExch(trunc, 1);     // stopped by the cap, not by the tolerance
+#ifdef GH_ACA_TIMES                                                // (build-time debugging aid: per-node durations of one-workgroup nodes)
+    if (G == 1) { mypart[0] = (double)(wall_clock64() - dbg_t0); mypart[1] = (double)rank; mypart[2] = (double)remaining; mypart[3] = (double)dbg_passes; mypart[4] = (double)dbg_t0; }
+#endif
   }
+}
+
+// (static + dynamic LDS of a launch with the mirrors is 67 KiB: above the 64 KiB a kernel gets without asking; per device)
+static int aca_lds_attr() {
+  static thread_local unsigned long long done = 0;
+  int dev = 0;
+  GH_HIP(hipGetDevice(&dev));
+  if (dev < 64 && (done >> dev & 1ull)) return GH_OK;
+  GH_HIP(hipFuncSetAttribute((const void*)hodlr_aca_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ACA_DYN_BYTES));
+  GH_HIP(hipFuncSetAttribute((const void*)hodlr_aca_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ACA_DYN_BYTES));
+  if (dev < 64) done |= 1ull << dev;
+  return GH_OK;
 }
 
 // B (rows of this level's nodes x R, row-major, ld = R) <- first rank columns of Tcm, zero padded
@@ -1668,7 +1733,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     if ((!h->shared_streams && hipStreamCreateWithFlags(&h->st_b, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_b = nullptr; }
   }
-  struct AcaLevel { GhPooledBuf Tcm, idx, sync, part; int G = 1, rcap = 0; int flags[2] = {0, 0}; };
+  struct AcaLevel { GhPooledBuf Tcm, idx, sync, part; int G = 1, rcap = 0; int flags[2] = {0, 0}; char* syncp = nullptr; bool sync_cleared = false; };
+  GhPooledBuf sync_all;                                  // the levels' barrier counters / selections / flags: one buffer, ONE memset
   std::vector<AcaLevel> al(nlev);
   GhPooledBuf shared_Tcm;
   std::vector<GhBuf*> levelB(nlev, nullptr);
@@ -1684,9 +1750,14 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GhBuf& T = (concurrent ? (GhBuf&)a.Tcm : (GhBuf&)shared_Tcm);
     GH_CHECK(T.ensure((size_t)n * rc * sizeof(double)));
     GH_CHECK(a.idx.ensure((size_t)n * sizeof(int)));
-    GH_CHECK(a.sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
     GH_CHECK(a.part.ensure((size_t)nn * a.G * pstride * sizeof(double)));
-    GH_HIP(hipMemsetAsync(a.sync.p, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), sx));
+    if (a.sync_cleared) {                                  // (its slice of sync_all was cleared with all the others)
+      a.sync_cleared = false;
+    } else {
+      GH_CHECK(a.sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
+      a.syncp = (char*)a.sync.p;
+      GH_HIP(hipMemsetAsync(a.syncp, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), sx));
+    }
     return GH_OK;
   };
   // enqueue the ACA of level l with column capacity rc on stream sx (no synchronisation)
@@ -1695,16 +1766,17 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     AcaLevel& a = al[l];
     const int nn = (int)L->node_ids.size();
     GH_CHECK(prepare_level(l, rc, sx));
+    GH_CHECK(aca_lds_attr());
     GhBuf& T = (concurrent ? (GhBuf&)a.Tcm : (GhBuf&)shared_Tcm);
-    unsigned* d_bars = (unsigned*)a.sync.p;
+    unsigned* d_bars = (unsigned*)a.syncp;
     int* d_sel = (int*)(d_bars + nn);
     int* d_fail = d_sel + nn;
 #define GH_ACA_LAUNCH(F)                                                                                          \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * a.G), dim3(ACA_THREADS), 0, sx, k->d_nodes, (int)k->nodes.size(),  \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * a.G), dim3(ACA_THREADS), a.G == 1 ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),  \
                        k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, T.d(), (long)n, rc, (int*)a.idx.p,     \
                        (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
                        a.G, d_bars, a.part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_fail + 1,            \
-                       (const AcaSeg*)nullptr, 0)
+                       (const AcaSeg*)nullptr, 0, a.G == 1 ? ACA_CAPD : 0)
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
@@ -1714,12 +1786,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   auto enqueue_fused = [&](const std::vector<int>& cl, int rc, hipStream_t sx, GhBuf& segbuf) -> int {
     std::vector<AcaSeg> segs;
     int wg = 0;
+    bool ones_only = true;                                 // (one-workgroup nodes only: the launch carries the LDS mirrors)
+    for (int l : cl) ones_only = ones_only && al[l].G == 1;
+    GH_CHECK(aca_lds_attr());
     for (int l : cl) {
       HLevel* L = h->levels[l];
       AcaLevel& a = al[l];
       const int nn = (int)L->node_ids.size();
       GH_CHECK(prepare_level(l, rc, sx));
-      unsigned* d_bars = (unsigned*)a.sync.p;
+      unsigned* d_bars = (unsigned*)a.syncp;
       int* d_sel = (int*)(d_bars + nn);
       int* d_fail = d_sel + nn;
       segs.push_back({(const LvlNode*)L->d_nodes.p, a.Tcm.d(), (int*)a.idx.p, (int*)L->d_ranks.p, d_bars, a.part.d(), d_sel,
@@ -1728,11 +1803,11 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     }
     GH_CHECK(upload(segbuf, segs, sx));
 #define GH_ACA_LAUNCH(F)                                                                                          \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(ACA_THREADS), 0, sx, k->d_nodes, (int)k->nodes.size(),    \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(ACA_THREADS), ones_only ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),    \
                        k->fast, ndim, h->x.d(), (const LvlNode*)nullptr, (double*)nullptr, (long)n, rc, (int*)nullptr, \
                        (int*)nullptr, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, 0,                     \
                        1, (unsigned*)nullptr, (double*)nullptr, pstride, (int*)nullptr, (int*)nullptr, aca_multi, aca_fence, \
-                       (int*)nullptr, (const AcaSeg*)segbuf.p, (int)segs.size())
+                       (int*)nullptr, (const AcaSeg*)segbuf.p, (int)segs.size(), ones_only ? ACA_CAPD : 0)
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
@@ -1744,7 +1819,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     HLevel* L = h->levels[l];
     AcaLevel& a = al[l];
     const int nn = (int)L->node_ids.size();
-    int* d_fail = (int*)((unsigned*)a.sync.p + nn) + nn;
+    int* d_fail = (int*)((unsigned*)a.syncp + nn) + nn;
     L->ranks.resize(nn);
     GH_HIP(hipMemcpyAsync(a.flags, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, sx));
     GH_HIP(hipMemcpyAsync(L->ranks.data(), L->d_ranks.p, nn * sizeof(int), hipMemcpyDeviceToHost, sx));
@@ -1820,6 +1895,19 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     al[l].G = G;
   }
   if (concurrent && h->st_b) {
+    {
+      // (a memset per level in front of every launch: thirteen ~7 us fill kernels, 100 us before the one-workgroup levels started)
+      size_t off = 0;
+      std::vector<size_t> at(nlev, 0);
+      for (int l = l0; l < nlev; ++l) {
+        if (h->levels[l]->top) continue;
+        at[l] = off;
+        off += (size_t)gh_round_up((int64_t)(h->levels[l]->node_ids.size() * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)), 256);
+      }
+      GH_CHECK(sync_all.ensure(std::max<size_t>(off, 256)));
+      GH_HIP(hipMemsetAsync(sync_all.p, 0, std::max<size_t>(off, 256), st));
+      for (int l = l0; l < nlev; ++l) if (!h->levels[l]->top) { al[l].syncp = (char*)sync_all.p + at[l]; al[l].sync_cleared = true; }
+    }
     GH_HIP(hipEventRecord(h->ev_b, st));                   // x and the node tables are uploaded
     GH_HIP(hipStreamWaitEvent(h->st_b, h->ev_b, 0));
     // Clustered levels: one launch, the 256 workgroup slots dealt so that the per-thread load is as even
@@ -1944,7 +2032,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         HLevel* L = h->levels[l];
         const int nn = (int)L->node_ids.size();
         items.push_back({(const int*)L->d_ranks.p, nn, tot}); tot += nn;
-        items.push_back({(const int*)((unsigned*)al[l].sync.p + nn) + nn, 2, tot}); tot += 2;
+        items.push_back({(const int*)((unsigned*)al[l].syncp + nn) + nn, 2, tot}); tot += 2;
       }
       // (pinned host memory, read by the kernel in place: the item table needs no copy of its own)
       const size_t need = (size_t)tot + 4 + items.size() * (sizeof(GatherItem) / sizeof(int));
@@ -1980,6 +2068,30 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       }
       h->aca_timed = false;
     }
+#ifdef GH_ACA_TIMES
+    {
+      static int calls = 0;
+      if (++calls == 3)
+        for (int l = l0; l < nlev; ++l) {
+          if (al[l].G != 1) { fprintf(stderr, "[aca] level %d: G = %d\n", l, al[l].G); continue; }
+          const int nn = (int)h->levels[l]->node_ids.size();
+          std::vector<double> hp((size_t)nn * pstride);
+          (void)hipMemcpy(hp.data(), al[l].part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost);
+          double mx = 0, sum = 0, t0min = 1e300, t1max = 0, ps = 0, rem = 0;
+          int who = 0;
+          for (int q = 0; q < nn; ++q) {
+            const double* e = hp.data() + (size_t)q * pstride;
+            sum += e[0]; ps += e[3]; rem += e[2];
+            if (e[0] > mx) { mx = e[0]; who = q; }
+            t0min = std::min(t0min, e[4]); t1max = std::max(t1max, e[4] + e[0]);
+          }
+          const double* w = hp.data() + (size_t)who * pstride;
+          fprintf(stderr, "[aca] level %2d: %4d nodes  per-node us mean %8.1f max %8.1f (node %d: rank %d, rows left %d, passes %d)  mean passes %.1f "
+                  "mean rows left %.1f  first start %.1f .. last end %.1f us (100 MHz clock)\n", l, nn, sum / nn * 0.01, mx * 0.01, who, (int)w[1], (int)w[2], (int)w[3],
+                  ps / nn, rem / nn, t0min * 0.01, t1max * 0.01);
+        }
+    }
+#endif
     for (int l = 0; l < nlev; ++l) { if (l >= l0) GH_CHECK(settle_level(l)); rank_of_level(l); }
   } else {
     for (int l = 0; l < l0; ++l) rank_of_level(l);
@@ -2090,6 +2202,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // for the others in its top levels, and found the cache empty -- tens of GB of hipMalloc / hipFree per compute(),
   // stalls of 1.4-2.8 s at N = 2M over four sub-trees on one GPU.  (Nothing is queued on them any more: just synchronised.)
   for (auto& a : al) { a.Tcm.release(); a.idx.release(); a.sync.release(); a.part.release(); }
+  sync_all.release();
   for (auto*& b : levelB) { delete b; b = nullptr; }
   {
     size_t maxnodes = 1;
@@ -2353,6 +2466,7 @@ int aca_top_node(gh_hodlr* h, gh_kernel* k, const double* x_dev, long N, int ndi
   GH_CHECK(idx.ensure((size_t)N * sizeof(int)));
   GH_CHECK(sync.ensure(sizeof(unsigned) + sizeof(int) + 2 * sizeof(int)));
   GH_CHECK(part.ensure((size_t)G * pstride * sizeof(double)));
+  GH_CHECK(aca_lds_attr());
   for (;;) {
     GH_CHECK(Tcm.ensure((size_t)N * rc * sizeof(double)));
     GH_HIP(hipMemsetAsync(sync.p, 0, sizeof(unsigned) + sizeof(int) + 2 * sizeof(int), st));
@@ -2360,10 +2474,10 @@ int aca_top_node(gh_hodlr* h, gh_kernel* k, const double* x_dev, long N, int ndi
     int* d_sel = (int*)(d_bars + 1);
     int* d_fail = d_sel + 1;
 #define GH_ACA_LAUNCH(F)                                                                                               \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(G), dim3(ACA_THREADS), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(G), dim3(ACA_THREADS), G == 1 ? ACA_DYN_BYTES : 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, \
                        ndim, x_dev, (const LvlNode*)d_node.p, Tcm.d(), N, rc, (int*)idx.p, (int*)d_rank.p, h->opts.tol,  \
                        (unsigned long long)(unsigned)h->opts.seed, level, G, d_bars, part.d(), pstride, d_sel, d_fail,   \
-                       aca_multi, aca_fence, d_fail + 1, (const AcaSeg*)nullptr, 0)
+                       aca_multi, aca_fence, d_fail + 1, (const AcaSeg*)nullptr, 0, G == 1 ? ACA_CAPD : 0)
     if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());

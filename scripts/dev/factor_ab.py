@@ -1,4 +1,5 @@
-"""Whole compute()+log_likelihood() A/B of two builds of the library, by swapping the .so between child processes (ABAB)."""
+"""Whole compute()+log_likelihood() A/B of two builds of the library -- the tree's libgeorge_amd.so against a variant built as
+george_amd/csrc/libgeorge_amd_c.so -- by swapping the .so between child processes (A B A B).  Run on a scratch copy (gpurun)."""
 import os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB = os.path.join(ROOT, "george_amd", "csrc", "libgeorge_amd.so")

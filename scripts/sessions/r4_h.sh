@@ -1,6 +1,7 @@
 #!/bin/bash
-# round 4: whole-factorisation A/B of a variant build of the library (libgeorge_amd_c.so) against the tree's
+# round 4: A/B of a variant build of the library (libgeorge_amd_c.so) against the tree's, one script per argument
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4h; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $R
-timeout 1200 python scripts/dev/factor_ab_tmp.py "$@" > $O/factor_ab.md 2> $O/factor_ab.err; echo "ab rc=$?"; cat $O/factor_ab.md; tail -3 $O/factor_ab.err
+S=${1:-scripts/dev/factor_ab.py}; shift
+timeout 1200 python $S "$@" > $O/ab.md 2> $O/ab.err; echo "ab rc=$?"; cat $O/ab.md; tail -3 $O/ab.err
