@@ -173,6 +173,7 @@ SIGNATURES = {
     "gh_dev_potrf_block": (C.c_int, [_dp, _i64, _i64, _dp, _dp, _i64, _vp]),
     "gh_dev_trsm_right": (C.c_int, [_dp, _i64, _dp, _dp, _i64, _i64, _i64, _vp]),
     "gh_dev_gemm_nt": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "gh_dev_gemm_nt_stair": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i32, C.POINTER(C.c_int64), _i64, _vp]),
     "gh_dev_gemm": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _i32, _vp]),
     "gh_dev_logdet_accum": (C.c_int, [_dp, _i64, _i64, _dp, _vp]),
     "gh_dev_trsv_lower": (C.c_int, [_dp, _i64, _dp, _i64, _dp, _dp, _vp, _vp]),

@@ -128,7 +128,13 @@ struct GhGemm {
   bool khi_col;                   // k ends at col0 + 128            (B lower-triangular: B(n,k) = 0 for k > n)
   bool khi_row;                   // k ends at row0 + 128            (A lower-triangular: A(m,k) = 0 for k > m)
   bool small_lds;                 // keep to <= 32 KiB of LDS per workgroup: the launch runs beside a SYRK that owns every CU
+  // "staircase" C (gh_dev_gemm_nt_stair): M = stair_n * stair_rows; row group g (stair_rows rows) takes columns [0, stair_cols[g]),
+  // non-decreasing in g; N = the widest group.  One launch for all groups; stair_n == 0: a plain rectangle / trapezoid.
+  int stair_n = 0;
+  int64_t stair_rows = 0;
+  const int64_t* stair_cols = nullptr;       // host array
 };
+#define GH_GEMM_STAIR_MAX 64
 int gh_launch_gemm(const GhGemm& g, hipStream_t st);
 // Process-wide streams of a device, shared by every solver handle (gh_chol.hip): q[0] main (blocking,
 // normal priority), q[1..3] non-blocking high-priority.  nullptr where creation failed.  Never destroyed.

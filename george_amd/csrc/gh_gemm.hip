@@ -41,6 +41,10 @@ struct GemmDev {
   int preload;      // beta == +-alpha != 0: accumulators start from (beta/alpha) * C, write-back is store-only
   int prio;         // launch cannot fill the chip (panel-chain GEMMs): run at top wavefront priority
   int grouped;      // tile order inside an XCD's chunk: row groups walked column-major (tile_of) instead of row-major
+  // staircase C: stair_n row groups of stair_h tile rows, the WIDEST FIRST in the tile order (slot s = group stair_n - 1 - s);
+  // stair_pre[s] = tiles before slot s (stair_pre[stair_n] = nblk), so slot s is stair_h x ((pre[s+1] - pre[s]) / stair_h) tiles
+  int stair_n, stair_h;
+  unsigned stair_pre[GH_GEMM_STAIR_MAX + 1];
 };
 
 // XCD-aware remap (bijective for any nblk): workgroup b runs on XCD b % 8; give each XCD
@@ -94,6 +98,15 @@ __device__ __forceinline__ bool tile_of(const GemmDev& g, int& tm, int& tn) {
   // (triangular operands: the K extent shrinks along the tile order, so contiguous per-XCD chunks
   //  would hand one XCD all the long tiles -- deal those round-robin, in plain row-major order)
   const bool rowmajor = !g.grouped;
+  if (g.stair_n) {                                        // staircase: find the slot, walk it column by column (its height is one "row group")
+    const long ls = xcd_remap(blockIdx.x, g.nblk);
+    int s = 0;
+    while (s + 1 < g.stair_n && ls >= (long)g.stair_pre[s + 1]) ++s;
+    const int r = (int)(ls - (long)g.stair_pre[s]);
+    tn = r / g.stair_h;
+    tm = (g.stair_n - 1 - s) * g.stair_h + r % g.stair_h;
+    return true;
+  }
   const long l = (g.klo_max | g.khi_col | g.khi_row) ? (long)blockIdx.x : xcd_remap(blockIdx.x, g.nblk);
   if (g.lower) {
     // lower TRAPEZOID: tiles (tm, tn) with tn <= tm and tn < tiles_n (a square C, tiles_n == tiles_m, is the triangle): the first
@@ -690,6 +703,16 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   g.tiles_m = (int)(h.M / BM); g.tiles_n = (int)(h.N / BN);
   g.lower = h.lower; g.klo_max = h.klo_max; g.khi_col = h.khi_col; g.khi_row = h.khi_row;
   g.nblk = h.lower ? (long)g.tiles_n * (g.tiles_n + 1) / 2 + (long)(g.tiles_m - g.tiles_n) * g.tiles_n : (long)g.tiles_m * g.tiles_n;
+  g.stair_n = 0; g.stair_h = 0;
+  if (h.stair_n > 0) {
+    // (validated by gh_dev_gemm_nt_stair: k-major operands, no k clipping, groups of whole tiles, at most GH_GEMM_STAIR_MAX of them)
+    g.stair_n = h.stair_n; g.stair_h = (int)(h.stair_rows / BM);
+    g.tiles_m = g.stair_n * g.stair_h; g.tiles_n = (int)(h.stair_cols[h.stair_n - 1] / BN);
+    long at = 0;
+    for (int s = 0; s < h.stair_n; ++s) { g.stair_pre[s] = (unsigned)at; at += (long)g.stair_h * (h.stair_cols[h.stair_n - 1 - s] / BN); }
+    g.stair_pre[h.stair_n] = (unsigned)at;
+    g.nblk = at;
+  }
   g.prio = g.nblk <= 512 ? 1 : 0;
   // (grouped tile order only once the column operand outgrows what the 256 MB MALL keeps between tile rows -- 128 MiB, N > 16384
   //  at K = 1024: below that a row-major walk already finds its slabs on chip and is 1 % faster, profiles/r04/gemm_tile_order_ab.md)
@@ -709,7 +732,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     else         hipLaunchKernelGGL((gemm_f64_mfma_dma<AK, BKM, false>), grid, block, 0, st, g);         \
   } while (0)
   const bool inplace = (const double*)h.C == h.A || (const double*)h.C == h.B;
-  if (dma && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !h.small_lds &&
+  if (dma && !h.stair_n && h.a_km && h.b_km && h.K == 128 && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && !h.small_lds &&
       (!inplace || ((const double*)h.C == h.A && (const double*)h.C != h.B && h.N == 128 && !h.lower))) {
     GemmDev q = g;
     if (inplace) {                      // whole rows per workgroup: 16 x 128 tiles
@@ -725,7 +748,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
     GH_HIP(hipGetLastError());
     return GH_OK;
   }
-  if (dma && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && (!h.lower || h.M == h.N) &&
+  if (dma && !h.stair_n && h.a_km && h.b_km && g.nblk <= 128 && !h.klo_max && !h.khi_col && !h.khi_row && (!h.lower || h.M == h.N) &&
       (!inplace || (h.N == 128 && !h.lower))) {
     // sub-chip launch: 64-row tiles, 2-4x the workgroups (see gemm_f64_mfma_dma64)
     GemmDev q = g;
@@ -751,6 +774,37 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
 #undef GH_GEMM_LAUNCH
   GH_HIP(hipGetLastError());
   return GH_OK;
+}
+
+// One launch for a staircase-shaped C: row group g (group_rows rows of c and a) is updated over columns [0, group_cols[g]).
+// The per-rank trailing update of the multi-GPU solvers (whole tile rows per rank: each row reaches as far as its own diagonal
+// tile) was one launch per tile row -- 8 launches of ~1.3 chip-fulls each per step at N = 65536 on 8 ranks; as ONE grid of
+// ~11 chip-fulls the tails of seven launches disappear.  Widest group first; inside a group column by column (the 8 x 8 tile
+// blocks of tile_of's grouped order).  Same kernel, same per-tile arithmetic: bit-identical to the per-group launches.
+extern "C" int gh_dev_gemm_nt_stair(double* c, int64_t ldc, const double* a, int64_t lda, const double* b, int64_t ldb,
+                                    int64_t group_rows, int32_t n_groups, const int64_t* group_cols, int64_t k, void* stream) {
+  if (n_groups <= 0) return GH_OK;
+  if (!group_cols || group_rows <= 0 || group_rows % BM) { gh_set_error("gemm_nt_stair: group_rows must be a positive multiple of 128"); return GH_ERR_BAD_ARG; }
+  long tiles = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    if (group_cols[g] <= 0 || group_cols[g] % BN || (g > 0 && group_cols[g] < group_cols[g - 1])) {
+      gh_set_error("gemm_nt_stair: group_cols must be positive multiples of 128, non-decreasing"); return GH_ERR_BAD_ARG; }
+    tiles += (group_rows / BM) * (group_cols[g] / BN);
+  }
+  const bool aligned = lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
+  if (n_groups > GH_GEMM_STAIR_MAX || tiles <= 128 || tiles > 0x7fffffffL || !aligned || mfma_mode() != 1) {
+    // (too many groups for the kernel's table, a sub-chip launch that the 64-row-tile kernels serve better, or operands the
+    //  LDS-DMA kernel cannot take: one launch per group)
+    for (int g = n_groups - 1; g >= 0; --g)
+      GH_CHECK(gh_dev_gemm_nt(c + (int64_t)g * group_rows * ldc, ldc, a + (int64_t)g * group_rows * lda, lda, b, ldb, group_rows, group_cols[g], k, 0, stream));
+    return GH_OK;
+  }
+  GhGemm h{};
+  h.C = c; h.ldc = ldc; h.A = a; h.lda = lda; h.B = b; h.ldb = ldb;
+  h.M = (int64_t)n_groups * group_rows; h.N = group_cols[n_groups - 1]; h.K = k;
+  h.alpha = -1.0; h.beta = 1.0; h.a_km = true; h.b_km = true;
+  h.stair_n = n_groups; h.stair_rows = group_rows; h.stair_cols = group_cols;
+  return gh_launch_gemm(h, (hipStream_t)stream);
 }
 
 extern "C" int gh_dev_gemm_nt(double* c, int64_t ldc, const double* a, int64_t lda,

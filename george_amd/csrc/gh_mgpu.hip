@@ -24,7 +24,7 @@
 // Schedule (right-looking, one tile column per step, one-panel look-ahead), three streams per rank:
 //   sp (high priority) the chain: potrf, L_kk broadcast, TRSM, row panel (Pc > 1), panel tile k+1 sent ahead;
 //   sg                 the bulk: the rest of the column panel gathered (all links, its own communicator);
-//   st (+ 2 helpers)   the updates: block column k+1 first (then P(k+1) may start), then everything else.
+//   st                 the updates: block column k+1 first (then P(k+1) may start), then everything else as one staircase launch.
 //
 // Transport.  Every transfer is a broadcast from one rank to the other members of its process row or
 // column.  GH_MGPU_RCCL (default): grouped ncclSend / ncclRecv on a world communicator of
@@ -112,8 +112,6 @@ struct MRank {
   hipEvent_t ev_fast[2] = {nullptr, nullptr};              // panel k: row panel + tile k+1 are here (block column k+1 may be updated)
   hipEvent_t ev_panel[2] = {nullptr, nullptr};             // panel k: the whole column panel is here
   hipEvent_t ev_bcol = nullptr, ev_rest = nullptr;
-  hipStream_t su[2] = {nullptr, nullptr};                  // two more streams for the GEMMs of U(k): the tail of one launch overlaps
-  hipEvent_t ev_fan = nullptr, ev_su[2] = {nullptr, nullptr};   // the head of the next (fenced against st on both sides)
   gh_kernel kern;
   GhBuf A, dinv, Lkk, wrow[2], colp[2], nxt[2], x, yerr, scal, flags;
   GhBuf zc, xr, wk, part, red, rhs, acc;                   // sweeps: Z for my tile columns, X for my tile rows, work tile, partial, reduce slots
@@ -156,15 +154,14 @@ struct gh_mgpu {
   ~gh_mgpu() {
     for (auto& r : ranks) {
       (void)hipSetDevice(r.dev);
-      for (hipStream_t q : {r.st, r.sp, r.sg, r.su[0], r.su[1]}) if (q) (void)hipStreamSynchronize(q);
+      for (hipStream_t q : {r.st, r.sp, r.sg}) if (q) (void)hipStreamSynchronize(q);
       for (GhBuf* b : {&r.A, &r.dinv, &r.Lkk, &r.wrow[0], &r.wrow[1], &r.colp[0], &r.colp[1], &r.nxt[0], &r.nxt[1], &r.x, &r.yerr, &r.scal,
                        &r.flags, &r.zc, &r.xr, &r.wk, &r.part, &r.red, &r.rhs, &r.acc}) b->release();
       if (r.kern.d_nodes) { (void)hipFree(r.kern.d_nodes); r.kern.d_nodes = nullptr; }
       if (r.d_info) (void)hipFree(r.d_info);
-      for (hipEvent_t e : {r.ev_ready, r.ev_done, r.ev_fast[0], r.ev_fast[1], r.ev_panel[0], r.ev_panel[1], r.ev_bcol, r.ev_rest, r.ev_fan,
-                           r.ev_su[0], r.ev_su[1]}) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : {r.ev_ready, r.ev_done, r.ev_fast[0], r.ev_fast[1], r.ev_panel[0], r.ev_panel[1], r.ev_bcol, r.ev_rest}) if (e) (void)hipEventDestroy(e);
       for (hipEvent_t e : r.ev_pool) (void)hipEventDestroy(e);
-      for (hipStream_t q : {r.su[0], r.su[1], r.sg, r.sp, r.st}) if (q) (void)hipStreamDestroy(q);
+      for (hipStream_t q : {r.sg, r.sp, r.st}) if (q) (void)hipStreamDestroy(q);
     }
     if (have_comms) for (int i = 0; i < W; ++i) (void)g_rccl.CommDestroy(comms[i]);
     if (have_comms_b) for (int i = 0; i < W; ++i) (void)g_rccl.CommDestroy(comms_b[i]);
@@ -499,10 +496,11 @@ int rank_factor(gh_mgpu* h, MRank& r) {
   };
   // U(k) restricted to my tile columns with global index in [jlo, jhi], on stream st, from workspace `buf`.
   // ahead: [jlo, jhi] is block column k+1 alone, served by the tile that travelled ahead -- one GEMM over all my rows below it.
-  // Else ONE GEMM PER LOCAL TILE ROW i: C[i, jlo..min(i, jhi)] -= W_i P[jlo..]^T -- the column-panel tiles of consecutive local
-  // columns are contiguous in colp, so the B operand is one (n_cols nb) x nb array.  (Round 4, first form: one GEMM per tile
-  // COLUMN -- 64 or 128 launches per step on a P x 1 grid, most of them a few dozen tiles: 39 TFLOP/s per rank at nb = 512,
-  // and the rank that owns tile row 0 at 50 against 61 for the others, profiles/r04/scale_model.md.)
+  // Else ONE STAIRCASE GEMM over all my tile rows: C[i, jlo..min(i, jhi)] -= W_i P[jlo..]^T for every local row i -- my rows are
+  // contiguous in A and in wrow, the column-panel tiles of consecutive local columns are contiguous in colp, and each row reaches
+  // as far as its own diagonal tile (gh_dev_gemm_nt_stair).  (Round 4, first form: one GEMM per tile COLUMN -- 39 TFLOP/s per rank
+  // at nb = 512; second form: one GEMM per tile row dealt over three streams -- 62 TFLOP/s: 8 launches of ~1.3 chip-fulls each per
+  // step at N = 65536 on 8 ranks; profiles/r04/scale_model.md.)
   auto update = [&](int k, int buf, int jlo, int jhi, bool ahead) -> int {
     const int li0 = first_at_least(r.rows, k + 1);
     const size_t l0 = first_at_least(r.cols, jlo);
@@ -518,24 +516,21 @@ int rank_factor(gh_mgpu* h, MRank& r) {
         return gh_dev_gemm_nt(A + (long)ls * nb * ld + (long)l0 * nb, ld, r.wrow[buf].d() + (long)(ls - li0) * nb * nb, nb, r.nxt[buf].d(), nb,
                               (long)(nlr - ls) * nb, nb, nb, 0, r.st);
       }
-      const int lr0 = first_at_least(r.rows, jlo);                 // my first tile row that reaches column jlo
-      const bool fan = nlr - lr0 >= 3;                             // independent GEMMs dealt over st, su[0], su[1], largest first
-      if (fan) {
-        GH_HIP(hipEventRecord(r.ev_fan, r.st));
-        for (hipStream_t q : r.su) GH_HIP(hipStreamWaitEvent(q, r.ev_fan, 0));
-      }
-      int dealt = 0;
-      for (int li = nlr - 1; li >= lr0; --li, ++dealt) {
+      // every tile row of mine that reaches column jlo, as ONE staircase launch: row li takes my columns jlo .. min(i, jhi)
+      const int lr0 = first_at_least(r.rows, jlo);
+      std::vector<int64_t> width;
+      int first = -1;
+      for (int li = lr0; li < nlr; ++li) {
         const int i = r.rows[li];
         size_t l1 = l0;
         while (l1 < r.cols.size() && r.cols[l1] <= std::min(i, jhi)) ++l1;
-        if (l1 == l0) continue;
-        const size_t q = fan ? (size_t)dealt % 3 : 0;
-        GH_CHECK(gh_dev_gemm_nt(A + (long)li * nb * ld + (long)l0 * nb, ld, r.wrow[buf].d() + (long)(li - li0) * nb * nb, nb,
-                                r.colp[buf].d() + (long)l0 * nb * nb, nb, nb, (long)(l1 - l0) * nb, nb, 0, q == 0 ? r.st : r.su[q - 1]));
+        if (l1 == l0) continue;                                     // (widths grow with li: empty rows come first)
+        if (first < 0) first = li;
+        width.push_back((int64_t)(l1 - l0) * nb);
       }
-      if (fan)
-        for (int q = 0; q < 2; ++q) { GH_HIP(hipEventRecord(r.ev_su[q], r.su[q])); GH_HIP(hipStreamWaitEvent(r.st, r.ev_su[q], 0)); }
+      if (first < 0) return GH_OK;
+      GH_CHECK(gh_dev_gemm_nt_stair(A + (long)first * nb * ld + (long)l0 * nb, ld, r.wrow[buf].d() + (long)(first - li0) * nb * nb, nb,
+                                    r.colp[buf].d() + (long)l0 * nb * nb, nb, nb, (int32_t)width.size(), width.data(), nb, r.st));
       return GH_OK;
     });
   };
@@ -751,11 +746,8 @@ extern "C" int gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out) {
     gh_prime_device(r.dev);                  // (gh_common.h: the null stream must have seen a launch before the first stream is made)
     bool ok = hipSetDevice(r.dev) == hipSuccess && hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithPriority(&r.sp, hipStreamNonBlocking, phi) == hipSuccess &&
-              hipStreamCreateWithFlags(&r.sg, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&r.su[0], hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&r.su[1], hipStreamNonBlocking) == hipSuccess;
-    for (hipEvent_t* e : {&r.ev_ready, &r.ev_done, &r.ev_fast[0], &r.ev_fast[1], &r.ev_panel[0], &r.ev_panel[1], &r.ev_bcol, &r.ev_rest,
-                          &r.ev_fan, &r.ev_su[0], &r.ev_su[1]})
+              hipStreamCreateWithFlags(&r.sg, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t* e : {&r.ev_ready, &r.ev_done, &r.ev_fast[0], &r.ev_fast[1], &r.ev_panel[0], &r.ev_panel[1], &r.ev_bcol, &r.ev_rest})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); delete h; gh_set_error("stream / event creation failed on device %d", opts->devices[i]); return GH_ERR_HIP; }
   }

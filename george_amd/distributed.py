@@ -178,6 +178,14 @@ class HipTileOps(object):
         self.N.check(self.N.lib.gh_dev_gemm(c.data_ptr(), c.stride(0), a.data_ptr(), a.stride(0), b.data_ptr(),
                                             b.stride(0), c.shape[0], c.shape[1], a.shape[1], -1.0, 1.0, 0, self._st()))
 
+    def gemm_nt_stair(self, c, a, b, group_rows, widths):
+        """Row group g of c (group_rows rows) -= a[g-th rows] @ b[:widths[g]].T -- one launch for the whole staircase
+        (include/george_amd.h gh_dev_gemm_nt_stair); widths non-decreasing, multiples of 128."""
+        import ctypes as C
+        w = (C.c_int64 * len(widths))(*[int(v) for v in widths])
+        self.N.check(self.N.lib.gh_dev_gemm_nt_stair(c.data_ptr(), c.stride(0), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                                     int(group_rows), len(widths), w, a.shape[1], self._st()))
+
     def gemm(self, c, a, b, alpha=1.0, beta=0.0, a_t=False, b_t=False):
         """c = beta*c + alpha * op(a) @ op(b); all extents multiples of 128 (include/george_amd.h gh_dev_gemm:
         its native operand form is A(m,k) row-major and B(n,k) row-major, i.e. ``a @ b.T``)."""
@@ -531,9 +539,10 @@ class BlockCyclicCholesky(object):
     # -- U(k) restricted to the given global tile columns ---------------------------------------------
     def _update(self, panel, cols, fast=False):
         """fast: `cols` is block column k+1 alone, served by the tile that travelled ahead -- one GEMM over all my rows
-        below it.  Else one GEMM per local tile ROW i: C[i, first col .. min(i, last col)] -= W_i P^T with P a run of
-        consecutive local columns of the re-packed column panel (one launch per tile COLUMN -- round 4's first form -- was
-        64-128 small launches per step on a P x 1 grid: 39-59 TFLOP/s per rank, profiles/r04/scale_model.md)."""
+        below it.  Else every local tile row i takes C[i, first col .. min(i, last col)] -= W_i P^T with P a run of consecutive
+        local columns of the re-packed column panel: one staircase launch over all rows where the tile ops offer it (the HIP
+        ops), one GEMM per row otherwise (one launch per tile COLUMN -- round 4's first form -- was 64-128 small launches per
+        step on a P x 1 grid: 39-59 TFLOP/s per rank, profiles/r04/scale_model.md)."""
         if panel is None or not cols:
             return
         li0, wrow, colp, pj_fast = panel[:4]
@@ -552,14 +561,23 @@ class BlockCyclicCholesky(object):
             jlo, jhi = min(cols), max(cols)
             l0 = self.lcol[jlo]
             flat = colp.view(-1, nb)                              # (n_local_cols * nb) x nb
-            for li in range(nloc_r - 1, self._first_local_row_at_least(jlo) - 1, -1):      # largest first
+            reach = []                                            # (local row, one past its last local column), rows ascending
+            for li in range(self._first_local_row_at_least(jlo), nloc_r):
                 i = self.rows[li]
                 l1 = len([j for j in self.cols if j <= min(i, jhi)])
-                if l1 <= l0:
-                    continue
-                flops += 2.0 * (l1 - l0) * nb * nb * nb
-                todo.append(lambda li=li, l1=l1: self.ops.gemm_nt(
-                    self.A[li * nb:(li + 1) * nb, l0 * nb:l1 * nb], wrow[(li - li0) * nb:(li - li0 + 1) * nb], flat[l0 * nb:l1 * nb]))
+                if l1 > l0:
+                    reach.append((li, l1))
+                    flops += 2.0 * (l1 - l0) * nb * nb * nb
+            if reach and getattr(self.ops, "gemm_nt_stair", None) is not None:
+                # my tile rows are contiguous in A and in wrow, and each reaches as far as its own diagonal tile: ONE staircase
+                # launch (8 launches of ~1.3 chip-fulls each per step at N = 65536 on 8 ranks otherwise: 62 TFLOP/s per rank)
+                first = reach[0][0]
+                todo.append(lambda first=first, reach=reach: self.ops.gemm_nt_stair(
+                    self.A[first * nb:, l0 * nb:], wrow[(first - li0) * nb:], flat[l0 * nb:], nb, [(l1 - l0) * nb for _, l1 in reach]))
+            else:
+                for li, l1 in reversed(reach):                    # largest first
+                    todo.append(lambda li=li, l1=l1: self.ops.gemm_nt(
+                        self.A[li * nb:(li + 1) * nb, l0 * nb:l1 * nb], wrow[(li - li0) * nb:(li - li0 + 1) * nb], flat[l0 * nb:l1 * nb]))
         timed = self.profile and todo and getattr(self.ops, "has_streams", False)
         if timed:
             e0 = self.ops.event(self.ops.main_stream(), timing=True)

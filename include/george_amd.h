@@ -375,6 +375,12 @@ int gh_dev_trsm_right(const double* l11, int64_t ld11, const double* dinv,
 int gh_dev_gemm_nt(double* c, int64_t ldc, const double* a, int64_t lda,
                    const double* b, int64_t ldb, int64_t m, int64_t n, int64_t k,
                    int32_t lower, void* stream);
+/* the same update on a STAIRCASE-shaped c, as ONE launch: row group g (group_rows rows of c and of a, g = 0 .. n_groups-1) is
+ * updated over its first group_cols[g] columns, c[g-th rows, 0:group_cols[g]) -= a[g-th rows] * b[0:group_cols[g])^T; group_cols
+ * (a HOST array) is non-decreasing, everything a multiple of 128.  The per-rank trailing update of a solver that owns whole tile
+ * rows: every tile row reaches as far as its own diagonal tile.  Bit-identical to one gh_dev_gemm_nt per group. */
+int gh_dev_gemm_nt_stair(double* c, int64_t ldc, const double* a, int64_t lda, const double* b, int64_t ldb,
+                         int64_t group_rows, int32_t n_groups, const int64_t* group_cols, int64_t k, void* stream);
 /* general form: c = beta*c + alpha * sum_k A(m,k) B(n,k); by default A(m,k) = a[m*lda + k] and
  * B(n,k) = b[n*ldb + k] ("k-major"); flags select the transposed layouts, SYRK-style lower-only
  * tile sets and k-range clipping for triangular operands. */

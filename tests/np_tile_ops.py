@@ -50,6 +50,14 @@ class NumpyTileOps(object):
     def gemm_nt(self, c, a, b):
         c -= a @ b.T
 
+    def gemm_nt_stair(self, c, a, b, group_rows, widths):
+        """row group g of c -= a[g-th rows] @ b[:widths[g]].T (HipTileOps.gemm_nt_stair / gh_dev_gemm_nt_stair)"""
+        assert all(w0 <= w1 for w0, w1 in zip(widths, widths[1:])) and all(w > 0 and w % 128 == 0 for w in widths)
+        assert c.shape[0] >= group_rows * len(widths) and a.shape[0] >= group_rows * len(widths) and b.shape[0] >= widths[-1]
+        for g, w in enumerate(widths):
+            r = slice(g * group_rows, (g + 1) * group_rows)
+            c[r, :w] -= a[r] @ b[:w].T
+
     def gemm(self, c, a, b, alpha=1.0, beta=0.0, a_t=False, b_t=False):
         A = a.T if a_t else a
         B = b.T if b_t else b
@@ -67,3 +75,8 @@ class NumpyTileOps(object):
 
     def sync(self):
         pass
+
+
+class NumpyTileOpsPerRow(NumpyTileOps):
+    """The same without the staircase launch: the driver then issues one gemm_nt per local tile row."""
+    gemm_nt_stair = None

@@ -150,3 +150,25 @@ def test_single_process_degenerate_grid():
     assert np.allclose(s.apply_sqrt(y), y @ np.linalg.cholesky(Kd).T, rtol=1e-10, atol=1e-12)
     with pytest.raises(RuntimeError):
         DistributedBasicSolver(kernel, nb=128, ops=NumpyTileOps(kernel)).apply_inverse(y)
+
+
+def test_staircase_update_and_per_row_update_agree():
+    """The trailing update of a rank: one staircase launch over all its tile rows where the tile ops offer gemm_nt_stair,
+    one gemm_nt per tile row otherwise -- the same tiles either way, so the same factor bit for bit."""
+    sys.path.insert(0, ROOT)
+    import george_amd.kernels as K
+    from george_amd.distributed import DistributedBasicSolver
+    from oracle import kernels_np
+    from np_tile_ops import NumpyTileOpsPerRow
+    n = 128 * 5 + 37
+    x = np.sort(np.random.RandomState(3).uniform(0, 8, n))
+    kernel = 1.3 * K.Matern32Kernel(0.9)
+    y = np.sin(x)
+    got = []
+    for ops_cls in (NumpyTileOps, NumpyTileOpsPerRow):
+        s = DistributedBasicSolver(kernel, nb=128, ops=ops_cls(kernel))
+        s.compute(x[:, None], 0.1)
+        got.append((s.log_determinant, s.dot_solve(y), s.apply_inverse(y)))
+    assert got[0][0] == got[1][0] and got[0][1] == got[1][1] and np.array_equal(got[0][2], got[1][2])
+    Kd = kernels_np.value_symmetric(kernel, x[:, None]) + 0.01 * np.eye(n)
+    assert abs(got[0][0] - np.linalg.slogdet(Kd)[1]) < 1e-8 * n

@@ -257,3 +257,38 @@ def test_grouped_tile_order(rows, cols, K, lower):
         _gemm(ref, a, b[c_lo:c_hi], M, c_hi - c_lo, K, -1.0, 1.0, 0, K, K, c_hi - c_lo)
         m = blk[:, c_lo:c_hi]
         assert torch.equal(ref[m], c[:, c_lo:c_hi][m])
+
+
+@pytest.mark.parametrize("group_rows,widths,K", [(1024, [1024, 3072, 3072, 9216, 16384, 17408], 1024),     # the multi-GPU update's shape
+                                                  (128, [128 * w for w in range(1, 41)], 256),                 # 40 one-tile-high groups
+                                                  (256, [128] * 3, 128),                                       # sub-chip: per-group fallback
+                                                  (128, [128 * (1 + w // 2) for w in range(70)], 128)])       # > 64 groups: fallback
+def test_staircase_gemm(group_rows, widths, K):
+    """gh_dev_gemm_nt_stair: row group g of c is updated over its first widths[g] columns, all groups in one launch (widest group
+    first, 8 x 8 tile blocks inside a group).  Against torch per group, bit-identical to one gh_dev_gemm_nt per group, and nothing
+    written to the right of a group's last column."""
+    import torch
+    from george_amd import _native as N
+    ng, M, Nn = len(widths), group_rows * len(widths), max(widths)
+    g = torch.Generator(device="cuda").manual_seed(ng * 7 + K)
+    a = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
+    b = torch.randn(Nn, K, dtype=torch.float64, device="cuda", generator=g)
+    c0 = torch.randn(M, Nn + 128, dtype=torch.float64, device="cuda", generator=g)     # (ldc > the widest group)
+    c = c0.clone()
+    w = (C.c_int64 * ng)(*widths)
+    N.check(N.lib.gh_dev_gemm_nt_stair(c.data_ptr(), c.stride(0), a.data_ptr(), K, b.data_ptr(), K, group_rows, ng, w, K, None))
+    ref = c0.clone()
+    for q, wq in enumerate(widths):
+        r = slice(q * group_rows, (q + 1) * group_rows)
+        N.check(N.lib.gh_dev_gemm_nt(ref[r].data_ptr(), ref.stride(0), a[r].data_ptr(), K, b.data_ptr(), K, group_rows, wq, K, 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(c, ref)
+    for q, wq in enumerate(widths):
+        r = slice(q * group_rows, (q + 1) * group_rows)
+        assert torch.equal(c[r, wq:], c0[r, wq:])
+        err = (c[r, :wq] - (c0[r, :wq] - a[r] @ b[:wq].T)).abs().max().item()
+        assert err < 1e-10 * max(1.0, K / 16), (q, err)
+    # arguments the launch refuses
+    bad = (C.c_int64 * 2)(256, 128)
+    assert N.lib.gh_dev_gemm_nt_stair(c.data_ptr(), c.stride(0), a.data_ptr(), K, b.data_ptr(), K, 128, 2, bad, K, None) != 0
+    assert N.lib.gh_dev_gemm_nt_stair(c.data_ptr(), c.stride(0), a.data_ptr(), K, b.data_ptr(), K, 100, 1, w, K, None) != 0
