@@ -134,7 +134,7 @@ struct GhGemm {
   int64_t stair_rows = 0;
   const int64_t* stair_cols = nullptr;       // host array
 };
-#define GH_GEMM_STAIR_MAX 64
+#define GH_GEMM_STAIR_MAX 128
 int gh_launch_gemm(const GhGemm& g, hipStream_t st);
 // Process-wide streams of a device, shared by every solver handle (gh_chol.hip): q[0] main (blocking,
 // normal priority), q[1..3] non-blocking high-priority.  nullptr where creation failed.  Never destroyed.

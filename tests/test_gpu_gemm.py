@@ -262,7 +262,8 @@ def test_grouped_tile_order(rows, cols, K, lower):
 @pytest.mark.parametrize("group_rows,widths,K", [(1024, [1024, 3072, 3072, 9216, 16384, 17408], 1024),     # the multi-GPU update's shape
                                                   (128, [128 * w for w in range(1, 41)], 256),                 # 40 one-tile-high groups
                                                   (256, [128] * 3, 128),                                       # sub-chip: per-group fallback
-                                                  (128, [128 * (1 + w // 2) for w in range(70)], 128)])       # > 64 groups: fallback
+                                                  (128, [128 * (1 + w // 2) for w in range(70)], 128),         # 70 groups: still one launch
+                                                  (128, [128 * (1 + w // 2) for w in range(140)], 128)])      # > 128 groups: per-group fallback
 def test_staircase_gemm(group_rows, widths, K):
     """gh_dev_gemm_nt_stair: row group g of c is updated over its first widths[g] columns, all groups in one launch (widest group
     first, 8 x 8 tile blocks inside a group).  Against torch per group, bit-identical to one gh_dev_gemm_nt per group, and nothing
