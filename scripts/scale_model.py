@@ -34,7 +34,7 @@ CONFIGS = [(8, 1, 1024), (8, 1, 512), (4, 2, 1024), (4, 2, 512), (2, 4, 1024), (
 
 
 # ------------------------------------------------------------------------------------------------ collect
-def collect(out_path, n):
+def collect(out_path, n, configs=None, merge=None):
     import george_amd
     from george_amd import kernels, BasicSolver, MultiGPUSolver
     rng = np.random.RandomState(1234)
@@ -57,7 +57,7 @@ def collect(out_path, n):
             t0 = time.perf_counter(); s.compute(X, sig); best = min(best, time.perf_counter() - t0)
         return best
 
-    for (Pr, Pc, nb) in [(1, 1, 1024)] + CONFIGS:
+    for (Pr, Pc, nb) in (configs if configs else [(1, 1, 1024)] + CONFIGS):
         W = Pr * Pc
         c = {"Pr": Pr, "Pc": Pc, "nb": nb, "W": W, "snake": bool(Pc == 1 and Pr > 1)}
         try:
@@ -81,6 +81,14 @@ def collect(out_path, n):
             c["error"] = repr(e)
         res["configs"].append(c)
         print("collected", Pr, Pc, nb, {k: v for k, v in c.items() if k != "trace"}, flush=True)
+    if merge:                                                    # add to an earlier collection (its single-GPU time is kept beside this one's)
+        import gzip
+        old = json.load(gzip.open(merge, "rt") if merge.endswith(".gz") else open(merge))
+        have = {(c["Pr"], c["Pc"], c["nb"]) for c in res["configs"]}
+        for c in res["configs"]:
+            c["single_gpu_s_of_its_session"] = res["single_gpu_s"]
+        res["configs"] = [c for c in old["configs"] if (c["Pr"], c["Pc"], c["nb"]) not in have] + res["configs"]
+        res["single_gpu_s"] = old["single_gpu_s"]
     with open(out_path, "w") as f:
         json.dump(res, f)
 
@@ -362,6 +370,22 @@ def report(path):
           % (chain_pred * 1e3, max(tm["update_per_rank_ms"])))
         P("%s.  With every rank's updates at the median rate of the eight (the rank whose update runs first on the shared test GPU" % ("UPDATES (the chain hides behind them)" if chain_pred < max(tm["update_per_rank_ms"]) * 1e-3 else "CHAIN"))
         P("competes with the others' gather copies for the one HBM): **%.1f ms = %.2fx**.\n" % (pred_med * 1e3, t1 / pred_med))
+    curve = [c for c in res["configs"] if c["Pc"] == 1 and c["nb"] == 1024 and "trace" in c and (c["W"] == 1 or c["snake"])]
+    if len(curve) > 2:
+        P("## Predicted curve, whole tile rows per GPU (W x 1, snake), nb = 1024, 60 GB/s per link\n")
+        P("| GPUs | predicted ms (45 / 60 / 75 GB/s) | speed-up at 60 | efficiency | update per rank ms (TFLOP/s) | chain alone ms |")
+        P("|---|---|---|---|---|---|")
+        for c in sorted(curve, key=lambda c: c["W"]):
+            if c["W"] == 1:
+                P("| 1 | %.1f (measured, single-GPU solver `gh_chol_*`) | 1.00x | 1.00 | | |" % (t1 * 1e3))
+                continue
+            tm = terms(c, n)
+            pr = [replay(c, n, bw, 25.0) for bw in (45.0, 60.0, 75.0)]
+            upd = tm["update_per_rank_ms"]
+            P("| %d | %.1f / %.1f / %.1f | %.2fx | %.2f | %.1f (%.1f) | %.1f |" % (c["W"], pr[0] * 1e3, pr[1] * 1e3, pr[2] * 1e3, t1 / pr[1], t1 / pr[1] / c["W"],
+                                                                   sum(upd) / len(upd), sum(tm["update_tflops_per_rank"]) / len(upd),
+                                                                   replay(c, n, 60.0, 25.0, chain_only=True) * 1e3))
+        P("")
     print(json.dumps({"n": n, "single_gpu_s": t1, "budget_s": budget,
                       "configs": [{"grid": "%dx%d" % (c["Pr"], c["Pc"]), "nb": c["nb"], "pred_ms_45_60_75": [p * 1e3 for p in preds], "pred_ms_60_median_rate": pm * 1e3} for c, tm, preds, _, pm in rows]}),
           file=sys.stderr)
@@ -370,7 +394,11 @@ def report(path):
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "collect":
         nn = int(sys.argv[sys.argv.index("--n") + 1]) if "--n" in sys.argv else 65536
-        collect(sys.argv[2], nn)
+        cfgs = None
+        if "--configs" in sys.argv:                              # e.g. --configs 2x1x1024,4x1x1024
+            cfgs = [tuple(int(v) for v in t.split("x")) for t in sys.argv[sys.argv.index("--configs") + 1].split(",")]
+        mg = sys.argv[sys.argv.index("--merge") + 1] if "--merge" in sys.argv else None
+        collect(sys.argv[2], nn, cfgs, mg)
     elif len(sys.argv) >= 3 and sys.argv[1] == "report":
         report(sys.argv[2])
     else:
