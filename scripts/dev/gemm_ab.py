@@ -1,7 +1,7 @@
-"""A/B of the k-major x k-major GEMM kernels' LDS fragment reads in ONE process: libgeorge_amd.so (32 ds_read_b64 per slab and wavefront,
-k = 4 kk + fk) against libgeorge_amd_pair.so (make -C george_amd/csrc libgeorge_amd_pair.so: 16 ds_read_b128, k = {2 fk, 2 fk + 1,
-2 fk + 8, 2 fk + 9}[kk]).  SYRK-shaped and rectangular launches of the factorisation's sizes, alternating the two libraries, plus a
-numerical check of the new variant against NumPy."""
+"""A/B of the GEMM kernels in ONE process: the tree's libgeorge_amd.so (column "b64") against a variant built as
+george_amd/csrc/libgeorge_amd_c.so (column "b128"; the names are those of the first use, scripts/dev/arms/gemm_pair_ab_r04.py).
+SYRK-shaped and rectangular launches of the factorisation's sizes, alternating the two libraries, plus a numerical check of the
+variant against NumPy.  Used for profiles/r04/gemm_dma_addr_ab.md (s_setprio) and gemm_tile_order_ab.md."""
 import ctypes as C
 import os
 import sys
