@@ -39,6 +39,8 @@ for (m, n, k, fl) in [(256, 384, 272, 0), (640, 640, 1024, 4), (128, 128, 128, 0
 
 shapes = [(32768, 32768, 1024, 4), (65536, 65536, 1024, 4), (16384, 16384, 1024, 4), (16384, 16384, 4096, 0), (8192, 8192, 1024, 0),
           (14336, 1024, 1024, 0), (2048, 1024, 128, 0)]
+if len(sys.argv) > 1:                                       # shapes as MxNxKxFLAGS (FLAGS: 4 = lower)
+    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 print("| shape | b64 ms (TFLOP/s) | b128 ms (TFLOP/s) | b128 / b64 |\n|---|---|---|---|")
 for (m, n, k, fl) in shapes:
     torch.manual_seed(0)
