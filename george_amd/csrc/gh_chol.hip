@@ -1035,6 +1035,26 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   // eight queues are in use -- null stream + this handle's + the application's; scripts/dev/queue_pattern.py.)
   hipStream_t sm = trailing_stream(s), sn = (depth == 1 && s->st3) ? s->st3 : s->st4;
   hipStream_t sp = s->st2;
+  // Which stream a wide update W(j) runs on when `sm` is the CU-masked one (Np < 24576: 32 CUs kept free for the chain, worth
+  // 12 % of the SYRK's rate): the reservation pays where the step is bound by the chain -- the late panels -- and costs where
+  // it is bound by W(j) itself, the first panels, whose chain ends long before their update does.  W(j) longer than
+  // GH_FULLCHIP_MS (estimated at 60 TFLOP/s) goes to the unmasked main stream; consecutive updates on different streams are
+  // ordered through ev_w, and the chain's K = 128 GEMMs follow (t_gemm_small_lds below).  Measured (profiles/r04/schedule_ab.md):
+  // N = 16384 29.08 -> 28.57 ms, 20480 51.9 -> 50.1, 24064 80.9 -> 76.8; a threshold of 1.2 ms loses 1.6 % at 12288 / 16384;
+  // the same rule above Np = 24576 (late panels on the masked stream) is worth 1.3 % at 24576, nothing at 32768 and 65536 --
+  // not the second it takes to make the masked stream.
+#ifndef GH_FULLCHIP_MS
+#define GH_FULLCHIP_MS 2.5
+#endif
+  auto wide_stream = [&](int j) -> hipStream_t {
+    if (sm == s->st) return sm;
+    const int cwj = j + depth + 1;
+    if (cwj > (int)((s->np + panel_width(s) - 1) / panel_width(s)) - 1) return sm;
+    const double m2 = (double)(s->np - (int64_t)cwj * panel_width(s));
+    const double ms = (m2 / T) * (m2 / T + 1.0) / 2.0 * 2.0 * T * T * (double)panel_width(s) / 60e12 * 1e3;
+    return ms > GH_FULLCHIP_MS ? s->st : sm;
+  };
+  hipStream_t sw_prev = nullptr;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);
   const int P = (int)((np + NB - 1) / NB);
@@ -1072,6 +1092,8 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     {
       const long ep = prof ? s->next_ev() : -1;
       if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, sp)); s->ev_panel.push_back((size_t)ep); }
+      // (panel j runs beside W(j-1): where that update owns every CU, the chain's K = 128 GEMMs keep to 32 KiB of LDS -- t_gemm_small_lds)
+      t_gemm_small_lds = wide_stream(j >= 1 ? j - 1 : 0) == s->st;
       GH_CHECK(panel_step(s, sp, c0(j), nbc(j)));
       if (ep >= 0) GH_HIP(hipEventRecord(s->ev_pool[ep].b, sp));
       GH_HIP(hipEventRecord(s->ev_p[j], sp));
@@ -1093,23 +1115,26 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     if (depth >= 2 && j + 2 > last_near) GH_HIP(hipEventRecord(s->ev_nf[j], sn));        // (nothing to do: keep the event defined)
     // ---- W(j): the rest, one lower-triangular SYRK on the main stream
     const int cw = j + depth + 1;
-    GH_HIP(hipStreamWaitEvent(sm, s->ev_p[j], 0));
+    hipStream_t sw = wide_stream(j);
+    if (sw_prev && sw_prev != sw && j >= 1) GH_HIP(hipStreamWaitEvent(sw, s->ev_w[j - 1], 0));      // W(j-1) ran on the other stream
+    sw_prev = sw;
+    GH_HIP(hipStreamWaitEvent(sw, s->ev_p[j], 0));
     if (cw <= P - 1) {
       const int64_t kw = c0(cw), m2 = np - kw;
       const long et = prof ? s->next_ev() : -1;
       if (et >= 0) {
-        GH_HIP(hipEventRecord(s->ev_pool[et].a, sm)); s->ev_trailing.push_back((size_t)et); s->ev_update.push_back((size_t)et);
+        GH_HIP(hipEventRecord(s->ev_pool[et].a, sw)); s->ev_trailing.push_back((size_t)et); s->ev_update.push_back((size_t)et);
         s->ev_update_flops.push_back((double)(m2 / T) * (m2 / T + 1) / 2.0 * 2.0 * T * T * (double)nbc(j));
       }
       const double* P2 = blk(A, ld, kw, c0(j));
-      GH_CHECK(gemm_nt(sm, blk(A, ld, kw, kw), ld, P2, ld, P2, ld, m2, m2, nbc(j), -1.0, 1.0, true));
-      if (et >= 0) GH_HIP(hipEventRecord(s->ev_pool[et].b, sm));
+      GH_CHECK(gemm_nt(sw, blk(A, ld, kw, kw), ld, P2, ld, P2, ld, m2, m2, nbc(j), -1.0, 1.0, true));
+      if (et >= 0) GH_HIP(hipEventRecord(s->ev_pool[et].b, sw));
       const double tiles = (double)(m2 / T) * (m2 / T + 1) / 2.0;
       s->prof.trailing_flops += tiles * 2.0 * T * T * (double)nbc(j);
       s->prof.update_flops += tiles * 2.0 * T * T * (double)nbc(j);
       s->prof.n_trailing += 1;
     }
-    GH_HIP(hipEventRecord(s->ev_w[j], sm));
+    GH_HIP(hipEventRecord(s->ev_w[j], sw));
   }
   // JOIN -- on the CHAIN stream, not on the main stream.  The host is far ahead of the device here, and a
   // hipStreamWaitEvent on the main stream issued now would sit at the head of that queue as a barrier packet for the whole
@@ -1131,6 +1156,7 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[2], 0));
     GH_HIP(hipEventRecord(s->ev_xfer, sm));
     GH_HIP(hipStreamWaitEvent(sp, s->ev_xfer, 0));
+    if (P >= 2) GH_HIP(hipStreamWaitEvent(sp, s->ev_w[P - 2], 0));          // (whichever stream the last wide update ran on)
     s->tail = sp;
     return GH_OK;
   }
