@@ -24,6 +24,13 @@
 #include "../../include/george_amd_debug.h"
 
 #define T 128                 // tile edge
+// sizes that take the dataflow factorisation by default (Np = N rounded up to 128); see use_dataflow()
+#ifndef GH_DATAFLOW_MIN_NP
+#define GH_DATAFLOW_MIN_NP (1L << 40)
+#endif
+#ifndef GH_DATAFLOW_MAX_NP
+#define GH_DATAFLOW_MAX_NP 24576
+#endif
 #define LP 129                // LDS row pitch of the potf2 tile (odd -> conflict-free columns)
 
 // ============================================================= potf2 + inverse
@@ -554,6 +561,7 @@ struct gh_chol {
   hipStream_t tail = nullptr;            // where the last factor() ended: the stream on which its results are complete in stream order
 
 
+  bool dflow_locked = false;             // this handle holds gh_dflow_mutex(device): a dataflow factorisation is in flight
   int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
   hipEvent_t ev_xfer = nullptr;
   hipEvent_t ev_sync[3] = {nullptr, nullptr, nullptr};
@@ -562,7 +570,7 @@ struct gh_chol {
   bool computed = false;
   int64_t info = 0;
   double logdet = 0.0;
-  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
+  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain, dflow;
   long long* d_info = nullptr;           // = (long long*)(scal + 2): the failure word lives beside the scalars (set in compute_enqueue)
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
@@ -1182,7 +1190,39 @@ static int lookahead_depth(const gh_chol* s) {
   return 1;
 }
 
+// The tile-level dataflow factorisation (gh_dflow.hip): ONE persistent launch on the main stream instead of the launch
+// chain.  -1: by size (GEORGE_AMD_DATAFLOW=0|1 overrides), 0 / 1: forced (gh_debug_set_dataflow, tests and A/B runs).
+static int g_dataflow = -1;
+extern "C" int gh_debug_set_dataflow(int mode) {
+  const int prev = g_dataflow;
+  g_dataflow = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
+}
+static bool use_dataflow(const gh_chol* s) {
+  if (use_simple_potf2() || !gh_use_mfma() || s->np < 2 * T || !s->opts.lookahead || !s->st2 || !s->ev_sync[0]) return false;
+  if (g_dataflow >= 0) return g_dataflow == 1;
+  static const int env = getenv("GEORGE_AMD_DATAFLOW") ? atoi(getenv("GEORGE_AMD_DATAFLOW")) : -1;
+  if (env >= 0) return env != 0;
+  return s->np >= GH_DATAFLOW_MIN_NP && s->np < GH_DATAFLOW_MAX_NP;
+}
+static int factor_dataflow(gh_chol* s) {
+  GH_CHECK(s->dflow.ensure(gh_dflow_counter_bytes(s->np)));
+  // one dataflow factorisation per device at a time: held until the caller has synchronised (DflowRelease)
+  if (!s->dflow_locked) { gh_dflow_mutex(s->opts.device).lock(); s->dflow_locked = true; }
+  GH_CHECK(gh_dflow_factor(s->A.d(), s->np, s->np, s->dinv.d(), s->d_info, (unsigned*)s->dflow.p, s->st, s->st2, s->ev_sync));
+  s->tail = s->st2;
+  return GH_OK;
+}
+// in every function that calls compute_enqueue(): releases the device's dataflow lock when the function returns (it has
+// synchronised by then, or failed before anything was launched)
+struct DflowRelease {
+  gh_chol* s;
+  explicit DflowRelease(gh_chol* h) : s(h) {}
+  ~DflowRelease() { if (s && s->dflow_locked) { s->dflow_locked = false; gh_dflow_mutex(s->opts.device).unlock(); } }
+};
+
 static int factor(gh_chol* s) {
+  if (use_dataflow(s)) return factor_dataflow(s);
   struct Guard { bool prev; Guard(bool v) : prev(t_gemm_small_lds) { t_gemm_small_lds = v; } ~Guard() { t_gemm_small_lds = prev; } }
       guard(s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
   // (a matrix of ONE panel has nothing to look ahead to: on the main stream it saves the two cross-stream hand-overs,
@@ -1301,6 +1341,11 @@ static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long 
     }
     for (size_t i : s->ev_panel) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_panel += ms; }
   }
+  if (info_host == GH_DFLOW_TIMEOUT_INFO) {
+    s->info = 0;
+    gh_set_error("the dataflow factorisation gave up waiting for a tile (2 s): GEORGE_AMD_DATAFLOW=0 selects the launch chain");
+    return GH_ERR_HIP;
+  }
   if (info_host != 0) {
     s->info = info_host;
     gh_set_error("%lld-th leading minor of the array is not positive definite", info_host);
@@ -1315,6 +1360,7 @@ static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long 
 extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
                                const double* yerr, double* logdet_out) {
   ComputeCtx c;
+  DflowRelease dfr(s);
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
   hipStream_t st = s->tail;                             // (the stream the factorisation ended on: compute_enqueue)
   double back[3] = {0.0, 0.0, 0.0};                     // [0] log-det, [1] (quadratic form), [2] the failure word's bits
@@ -1631,6 +1677,7 @@ extern "C" int gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int6
   if (!r || !logdet || !quad) { gh_set_error("bad argument to objective"); return GH_ERR_BAD_ARG; }
   if (grad && !which) { gh_set_error("objective: gradient requested without a parameter mask"); return GH_ERR_BAD_ARG; }
   ComputeCtx c;
+  DflowRelease dfr(s);
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
   hipStream_t st = s->st;
   if (s->tail && s->tail != st && s->ev_sync[1]) {      // (the solves and the gradient run on the main stream: it joins here)

@@ -1,0 +1,515 @@
+// gh_dflow.hip -- the dense factorisation as ONE persistent launch: tile tasks handed out from dependency-ordered
+// queues, progress published in HBM counters.  For the sizes where the launch chain of gh_chol.hip is bound by its
+// own boundaries (Np < 24576: every panel hand-over drains the chip, the chain waits for whole launches although it
+// needs single tiles; DESIGN.md section 4, "The factorisation schedule").
+//
+// Same arithmetic as the launch chain, tile for tile: every tile (i, j) of the lower triangle receives
+//     A_ij -= sum_{k < j} L_ik L_jk^T          k ascending, in slabs of 16 through the same MFMA sequence
+//     L_ij  = A_ij L_jj^-T   (i > j)           or   L_jj, L_jj^-1 = potf2(A_jj)
+// and since the accumulators of every product start from -C and end as C = -acc (exact), HOW the k range of a tile
+// is cut into passes does not change a bit: the factor, its diagonal inverses and the log-determinant are
+// bit-identical to factor_lookahead_deep()'s (tests/test_gpu_dataflow.py).
+//
+// Who does what.  Workgroup 0 is the DIAGONAL worker: for j = 0, 1, ...: L_j,j-1 = A_j,j-1 L_j-1,j-1^-T (the
+// sub-diagonal tile), A_jj -= L_j,j-1 L_j,j-1^T, potf2(A_jj) -- the critical path, on a CU of its own (the workgroup
+// that shares its CU leaves at once).  Every other workgroup is a WORKER that takes tasks from three queues, in
+// priority order:
+//   crit : tiles next to the front (rows that the diagonal worker needs within a panel): one k step at a time, as
+//          64-row half tiles; and the multiplies by L_jj^-T of those rows;
+//   hi   : rows far below the front -- per link j ONE task per half tile: the tile's in-panel k range and the
+//          multiply by L_jj^-T (left-looking inside the panel, as the launch chain's rows-below stream) -- and the
+//          previous panel's contribution to the next block column, in four pieces as its columns complete;
+//   lo   : everything older than the previous panel, 128 x 128 tiles, k ranges of up to 2048 (the bulk of the flops).
+// crit and hi are claimed only when the task at the head has all its inputs (a compare-and-swap on the head index);
+// lo hands out tickets in order and the holder waits for its inputs, serving crit and hi meanwhile.
+//
+// Dependencies are not stored: they follow from a task's fields and three families of monotone counters,
+//   D          diagonal steps finished (L_jj^-1 is readable when D > j),
+//   rowh[i,h]  final L tiles in half-row (i, h), counted from column 0,
+//   kd[t,h]    k steps applied to half-tile (t, h),
+// written behind an agent-scope release by whoever finishes a task and polled relaxed, followed by ONE agent-scope
+// acquire, by whoever wants to start one (/opt/skills/guides: Guideline 16's recipe, the one the retired persistent
+// panel used bit-identically).  Forward progress: the queues are consistent with one topological order of all tasks
+// (tests/test_dataflow_schedule.py replays them), lo's tickets are claimed in that order, crit and hi only when
+// runnable -- so the earliest unfinished task is always either running or claimable by the next free workgroup, and a
+// workgroup that is not resident has claimed nothing.  Every wait gives up after 2 s and raises the abort word.
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+#include "gh_common.h"
+#include "gh_gemm_tile.h"
+#include "gh_potf2_body.h"
+#include "../../include/george_amd_debug.h"
+
+#define DF_PW 8              // panel width in tiles (the launch chain's nb = 1024)
+#define DF_NEARX 8           // rows [8 (p + 1), 8 (p + 1) + NEARX) are handled eagerly while panel p is factored
+#define DF_NEARF 8           // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time
+#define DF_CHUNK 16          // lo queue: tile columns per task (K = 2048)
+#define DF_NQ 3
+
+struct DfTask {              // 16 bytes
+  uint16_t i, j;             // tile
+  uint16_t k0, k1;           // C -= L(i, k0:k1) L(j, k0:k1)^T   (k1 == k0: no update; then k0 = the k steps the tile must have)
+  uint8_t half;              // 0, 1: rows [64 half, 64 half + 64) of the tile;  2: the whole tile
+  uint8_t fin;               // then C <- C L_jj^-T (in place; half tiles only)
+  uint16_t pad[3];
+};
+static_assert(sizeof(DfTask) == 16, "DfTask is one 16-byte load");
+
+// counter words (unsigned), hot ones on lines of their own
+#define DF_D 0
+#define DF_ABORT 32
+#define DF_KEY 64
+#define DF_HEAD 96           // + 32 q
+#define DF_STAT 192          // [0] tasks run, [1] idle polls (debug)
+#define DF_ROWH 256
+static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
+static inline size_t df_words(int nt) { return df_off_kd(nt) + (size_t)nt * (nt + 1); }
+
+// ------------------------------------------------------------------------------------------------ the schedule (host)
+struct DfSchedule {
+  std::vector<DfTask> q[DF_NQ];
+};
+static void df_build(int nt, DfSchedule& s) {
+  typedef std::tuple<int, int, int, int, int, int> Key;
+  std::vector<std::pair<Key, DfTask>> crit, hi, lo;
+  auto task = [](int i, int j, int k0, int k1, int half, int fin) {
+    DfTask t; memset(&t, 0, sizeof(t));
+    t.i = (uint16_t)i; t.j = (uint16_t)j; t.k0 = (uint16_t)k0; t.k1 = (uint16_t)k1; t.half = (uint8_t)half; t.fin = (uint8_t)fin;
+    return t;
+  };
+  for (int j = 0; j < nt; ++j) {
+    const int p = j / DF_PW, q0 = DF_PW * p;
+    for (int i = j; i < nt; ++i) {
+      const int kmax = std::max(0, i == j ? j - 1 : j);      // the workers' share of the tile's k range: [0, kmax)
+      const bool near_row = i < DF_PW * (p + 1) + DF_NEARX;
+      // (1) panels older than the previous one
+      if (p >= 2) {
+        const int wend = std::min(DF_PW * (p - 1), kmax);
+        for (int k0 = 0; k0 < wend; k0 += DF_CHUNK)
+          lo.push_back({Key(p, j, i, k0, 0, 0), task(i, j, k0, std::min(k0 + DF_CHUNK, wend), 2, 0)});
+      }
+      // (2) the previous panel
+      if (p >= 1) {
+        const int a0 = DF_PW * (p - 1), a1 = std::min(DF_PW * p, kmax);
+        if (i < DF_PW * p + DF_NEARF) {
+          for (int k = a0; k < a1; ++k)
+            for (int h = 0; h < 2; ++h) crit.push_back({Key(k, 1, j == k + 1 ? 1 : 0, i, j, h), task(i, j, k, k + 1, h, 0)});
+        } else {
+          static const int cut[5] = {0, 4, 6, 7, 8};
+          for (int c = 0; c < 4; ++c) {
+            const int k0 = a0 + cut[c], k1 = std::min(a0 + cut[c + 1], a1);
+            if (k1 > k0) hi.push_back({Key(k1 - 1, 1, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
+          }
+        }
+      }
+      // (3) inside the panel, eagerly for the rows near the front
+      if (kmax > q0 && near_row)
+        for (int k = q0; k < kmax; ++k)
+          for (int h = 0; h < 2; ++h) crit.push_back({Key(k, 1, j == k + 1 ? 1 : 0, i, j, h), task(i, j, k, k + 1, h, 0)});
+      // (4) the multiply by L_jj^-T (rows j + 2 and below; row j + 1 is the diagonal worker's)
+      if (i >= j + 2) {
+        if (near_row) {
+          for (int h = 0; h < 2; ++h) crit.push_back({Key(j, 0, 0, i, j, h), task(i, j, j, j, h, 1)});
+        } else {
+          for (int h = 0; h < 2; ++h) hi.push_back({Key(j, 0, i, j, h, 0), task(i, j, kmax > q0 ? q0 : j, j, h, 1)});
+        }
+      }
+    }
+  }
+  std::vector<std::pair<Key, DfTask>>* all[DF_NQ] = {&crit, &hi, &lo};
+  for (int q = 0; q < DF_NQ; ++q) {
+    std::stable_sort(all[q]->begin(), all[q]->end(), [](const std::pair<Key, DfTask>& a, const std::pair<Key, DfTask>& b) { return a.first < b.first; });
+    s.q[q].clear();
+    s.q[q].reserve(all[q]->size());
+    for (auto& e : *all[q]) s.q[q].push_back(e.second);
+  }
+}
+
+// the schedule of an nt x nt tile matrix, for the replay in tests/test_dataflow_schedule.py (host only, no device needed):
+// counts[q] = tasks of queue q (0 crit, 1 hi, 2 lo); out (when not NULL): rows of 7 ints {queue, i, j, k0, k1, half, fin},
+// queue by queue in claim order, at most max_rows of them
+extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows) {
+  if (nt <= 0 || nt > 4096 || !counts) { gh_set_error("dflow_schedule: bad argument"); return GH_ERR_BAD_ARG; }
+  DfSchedule s;
+  df_build(nt, s);
+  int64_t r = 0;
+  for (int q = 0; q < DF_NQ; ++q) {
+    counts[q] = (int32_t)s.q[q].size();
+    if (!out) continue;
+    for (const DfTask& t : s.q[q]) {
+      if (r >= max_rows) return GH_OK;
+      int32_t* o = out + 7 * r++;
+      o[0] = q; o[1] = t.i; o[2] = t.j; o[3] = t.k0; o[4] = t.k1; o[5] = t.half; o[6] = t.fin;
+    }
+  }
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the kernel
+struct DfArgs {
+  double* A; long ld;
+  double* dinv;
+  long long* info;
+  unsigned* cnt;
+  const DfTask* tasks[DF_NQ];
+  unsigned count[DF_NQ];
+  unsigned off_kd;
+  int nt;
+  unsigned long long* trace;     // debugging aid (gh_debug_dflow_trace): [0] = records used, then 4 words per record; NULL: off
+  unsigned trace_cap;
+};
+// one record: {start, end} in wall_clock64() ticks (100 MHz), {i | j << 16 | k0 << 32 | k1 << 48}, {kind | half << 8 | fin << 16 | block << 32};
+// kind 0-2 = queue of a worker's task, 8 = diagonal worker waiting, 9 = its sub-diagonal multiply, 10 = its update, 11 = potf2
+__device__ __forceinline__ void df_trace(const DfArgs& a, long long t0, unsigned i, unsigned j, unsigned k0, unsigned k1,
+                                         unsigned kind, unsigned half, unsigned fin) {
+  if (!a.trace || threadIdx.x != 0) return;
+  const long long t1 = wall_clock64();
+  const unsigned long long slot = __hip_atomic_fetch_add(a.trace, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (slot >= a.trace_cap) return;
+  unsigned long long* r = a.trace + 1 + 4 * slot;
+  r[0] = (unsigned long long)t0; r[1] = (unsigned long long)t1;
+  r[2] = (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)k0 << 32) | ((unsigned long long)k1 << 48);
+  r[3] = (unsigned long long)kind | ((unsigned long long)half << 8) | ((unsigned long long)fin << 16) | ((unsigned long long)blockIdx.x << 32);
+}
+
+__device__ __forceinline__ unsigned df_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void df_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define DF_TIMEOUT_TICKS 200000000LL          // wall_clock64() runs at 100 MHz: 2 s
+
+// which CU this wavefront runs on: XCC_ID and the CU / SH / SE fields of HW_ID (bits 8..15), never 0
+__device__ __forceinline__ unsigned df_cu_key() {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return 0x80000000u | ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+}
+
+// all inputs of `t` there?  (one lane; the loads are issued together)
+__device__ __forceinline__ bool df_ready(const DfArgs& a, const DfTask& t) {
+  const unsigned* const cnt = a.cnt;
+  const int h0 = t.half == 2 ? 0 : t.half, h1 = t.half == 2 ? 1 : t.half;
+  const unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)t.i * (t.i + 1u) / 2u + t.j);
+  const unsigned* const rh = cnt + DF_ROWH;
+  const unsigned v0 = t.k0 ? df_ld(kd + h0) : 0xffffu, v1 = t.k0 ? df_ld(kd + h1) : 0xffffu;
+  unsigned b0 = 0xffffu, b1 = 0xffffu, a0 = 0xffffu, a1 = 0xffffu;
+  if (t.k1 > t.k0) {
+    b0 = df_ld(rh + 2 * t.j); b1 = df_ld(rh + 2 * t.j + 1);
+    if (t.i != t.j) { a0 = df_ld(rh + 2 * t.i + h0); a1 = df_ld(rh + 2 * t.i + h1); }
+  }
+  const unsigned d = t.fin ? df_ld(cnt + DF_D) : 0xffffu;
+  return (v0 >= t.k0) & (v1 >= t.k0) & (b0 >= t.k1) & (b1 >= t.k1) & (a0 >= t.k1) & (a1 >= t.k1) & (d >= t.j + 1u);
+}
+
+// results of the calling workgroup to memory, then the counters (Guideline 16: plain stores, every wavefront drained,
+// barrier, one lane: agent release, drained again -- inline assembly, the compiler may drop a wait it can prove
+// redundant -- then the relaxed stores)
+__device__ __forceinline__ void df_publish(unsigned* w0, unsigned v0, unsigned* w1, unsigned v1) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    df_st(w0, v0);
+    if (w1) df_st(w1, v1);
+  }
+}
+
+// the diagonal worker's wait for up to four counters; false: aborted
+__device__ __forceinline__ bool df_wait4(const DfArgs& a, const unsigned* w, unsigned need, int n, int* s_flag) {
+  if (threadIdx.x == 0) {
+    int good = 1;
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+      unsigned lo = 0xffffffffu;
+      for (int q = 0; q < n; ++q) { const unsigned v = df_ld(w + q); lo = v < lo ? v : lo; }
+      if (lo >= need) break;
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 63u) == 0u) {
+        if (df_ld(a.cnt + DF_ABORT) != 0u) { good = 0; break; }
+        if (wall_clock64() - t0 > DF_TIMEOUT_TICKS) { df_st(a.cnt + DF_ABORT, 2u); good = 0; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = good;
+  }
+  __syncthreads();
+  const bool r = *s_flag != 0;
+  __syncthreads();
+  return r;
+}
+
+// The diagonal worker: ONE workgroup, a launch of its own, one wavefront per SIMD (the 128 x 128 kernel needs all 256 vector
+// registers: inlined into the workers' function it pushed 142 of them into scratch; as a called function it does not compile
+// -- its inline assembly wants wave-uniform values in scalar registers; with the whole register file of a CU the compiler
+// parks what the loop keeps alive in accumulation registers).  It is launched FIRST and the workers' stream waits until it runs
+// (dflow_gate_kernel).
+template <bool TR>
+__global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
+  __shared__ __attribute__((aligned(1024))) double smem[9728];        // potf2: 8256 + 1288 doubles; GEMM: 8192
+  __shared__ int s_state;
+  const int tid = threadIdx.x;
+  unsigned* const cnt = a.cnt;
+  const long ld = a.ld;
+  {
+    if (tid == 0) df_st(cnt + DF_KEY, df_cu_key());
+    __builtin_amdgcn_s_setprio(3);
+    double* const s = smem; double* const dscr = smem + GH_POTF2_S_DOUBLES;
+    int* const fail_at = (int*)(smem + 9600);
+    for (int j = 0; j < a.nt; ++j) {
+      double* const Ajj = a.A + (long)j * 128 * ld + (long)j * 128;
+      long long tt = TR ? wall_clock64() : 0;
+      if (j > 0) {
+        double* const Asub = Ajj - 128;                                // tile (j, j - 1)
+        const double* const dprev = a.dinv + (long)(j - 1) * 128 * 128;
+        if (j > 1) {
+          // the workers' share of both tiles: k < j - 1   (kd of (j, j - 1) and (j, j) are four consecutive words)
+          const unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)j * (j + 1u) / 2u + (j - 1));
+          if (!df_wait4(a, kd, (unsigned)(j - 1), 4, &s_state)) return;
+          if (TR) { df_trace(a, tt, j, j, 0, 0, 8, 2, 0); tt = wall_clock64(); }
+        }
+        gh_tile128_nt<false>(smem, Asub, ld, Asub, ld, dprev, 128, 128);                 // L(j, j-1), in place
+        df_publish(cnt + DF_ROWH + 2 * j, (unsigned)j, cnt + DF_ROWH + 2 * j + 1, (unsigned)j);
+        if (TR) { df_trace(a, tt, j, j - 1, 0, 0, 9, 2, 1); tt = wall_clock64(); }
+        // (no barrier: the other wavefronts request the first slab and C while wavefront 0 is in the release)
+        gh_tile128_nt<true>(smem, Ajj, ld, Asub, ld, Asub, ld, 128);                     // A_jj -= L(j, j-1) L(j, j-1)^T
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (TR) { df_trace(a, tt, j, j, j - 1, j, 10, 2, 0); tt = wall_clock64(); }
+      }
+      const bool ok = gh_potf2::potf2_body(Ajj, ld, a.dinv + (long)j * 128 * 128, a.info, (long long)j * 128, s, dscr, fail_at);
+      if (!ok) {                                                      // (uniform) not positive definite: everybody leaves
+        __syncthreads();
+        if (tid == 0) df_st(cnt + DF_ABORT, 1u);
+        return;
+      }
+      df_publish(cnt + DF_D, (unsigned)(j + 1), nullptr, 0u);
+      if (TR) df_trace(a, tt, j, j, 0, 0, 11, 2, 0);
+    }
+  }
+}
+
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
+  __shared__ __attribute__((aligned(1024))) double smem[8192];
+  __shared__ DfTask s_task;
+  __shared__ int s_state;
+  const int tid = threadIdx.x;
+  unsigned* const cnt = a.cnt;
+  const long ld = a.ld;
+  const unsigned mykey = df_cu_key();
+  if (tid == 0) {
+    // the workgroup that shares the diagonal worker's CU leaves (its matrix instructions would halve potf2's rate);
+    // its key is there within microseconds of its launch -- bounded anyway (~0.5 ms)
+    unsigned k = 0;
+    for (int spins = 0; spins < 4000 && (k = df_ld(cnt + DF_KEY)) == 0u; ++spins) __builtin_amdgcn_s_sleep(4);
+    s_state = (k == mykey) ? -1 : 0;
+  }
+  __syncthreads();
+  if (s_state < 0) return;
+  __syncthreads();
+
+  unsigned ticket = 0xffffffffu;                 // (lane 0) a claimed task of the lo queue that waits for its inputs
+  for (;;) {
+    if (tid == 0) {
+      int st = 0;
+      const long long t0 = wall_clock64();
+      unsigned spins = 0;
+      for (;;) {
+        if (df_ld(cnt + DF_ABORT) != 0u) { st = -1; break; }
+        bool anyleft = false;
+#pragma unroll 1
+        for (int q = 0; q < DF_NQ - 1 && st == 0; ++q) {
+          unsigned* const head = cnt + DF_HEAD + 32 * q;
+          unsigned h = df_ld(head);
+          while (h < a.count[q]) {
+            anyleft = true;
+            const DfTask t = a.tasks[q][h];
+            if (!df_ready(a, t)) break;
+            unsigned expect = h;
+            if (__hip_atomic_compare_exchange_strong(head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              s_task = t; st = 1 + q; break;
+            }
+            h = expect;
+          }
+        }
+        if (st) break;
+        unsigned* const head_lo = cnt + DF_HEAD + 32 * (DF_NQ - 1);
+        if (ticket == 0xffffffffu && df_ld(head_lo) < a.count[DF_NQ - 1]) {
+          const unsigned tk = __hip_atomic_fetch_add(head_lo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tk < a.count[DF_NQ - 1]) ticket = tk;
+        }
+        if (ticket != 0xffffffffu) {
+          anyleft = true;
+          const DfTask t = a.tasks[DF_NQ - 1][ticket];
+          if (df_ready(a, t)) { s_task = t; ticket = 0xffffffffu; st = DF_NQ; break; }
+        }
+        if (!anyleft) { st = -1; break; }        // nothing left to claim
+        if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
+        if ((++spins & 63u) == 0u && wall_clock64() - t0 > DF_TIMEOUT_TICKS) { df_st(cnt + DF_ABORT, 2u); st = -1; break; }
+      }
+      if (st > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_state = st;
+    }
+    __syncthreads();
+    if (s_state < 0) return;
+    // (the task's fields as SCALARS: every address below is wave-uniform, and the tile functions want their operand bases
+    //  in scalar registers -- a buffer descriptor built from a vector register costs a v_readfirstlane per DMA)
+    const unsigned* const tw = (const unsigned*)&s_task;
+    const unsigned w0 = __builtin_amdgcn_readfirstlane(tw[0]), w1 = __builtin_amdgcn_readfirstlane(tw[1]),
+                   w2 = __builtin_amdgcn_readfirstlane(tw[2]);
+    struct { unsigned i, j, k0, k1, half, fin; } t = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, w2 & 0xffu, (w2 >> 8) & 0xffu};
+    const int s_q = s_state - 1;
+    const long long tt = TR ? wall_clock64() : 0;
+    __syncthreads();
+    const int r0 = t.half == 1 ? 64 : 0;
+    double* const C = a.A + ((long)t.i * 128 + r0) * ld + (long)t.j * 128;
+    unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)t.i * (t.i + 1u) / 2u + t.j);
+    if (t.k1 > t.k0) {
+      const double* const Ao = a.A + ((long)t.i * 128 + r0) * ld + (long)t.k0 * 128;
+      const double* const Bo = a.A + (long)t.j * 128 * ld + (long)t.k0 * 128;
+      const long K = (long)(t.k1 - t.k0) * 128;
+      if (t.half == 2) gh_tile128_nt<true>(smem, C, ld, Ao, ld, Bo, ld, K);
+      else gh_tile64_nt<true>(smem, C, ld, Ao, ld, Bo, ld, K);
+    }
+    if (t.fin) {
+      if (t.k1 > t.k0) {
+        // the rows just written are this product's A operand: stores done, the CU's L1 dropped
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+      }
+      gh_tile64_nt<false>(smem, C, ld, C, ld, a.dinv + (long)t.j * 128 * 128, 128, 128);
+      df_publish(cnt + DF_ROWH + 2 * t.i + t.half, (unsigned)t.j + 1u, nullptr, 0u);
+    } else if (t.half == 2) {
+      df_publish(kd, t.k1, kd + 1, t.k1);
+    } else {
+      df_publish(kd + t.half, t.k1, nullptr, 0u);
+    }
+    if (TR) df_trace(a, tt, t.i, t.j, t.k0, t.k1, (unsigned)s_q, t.half, t.fin);
+  }
+}
+
+// On the workers' stream, in front of their launch: returns when the diagonal worker is RUNNING (its CU key is there).  That
+// workgroup needs a CU to itself (512 registers per wavefront: the 128 x 128 kernel alone fills 256, and what the loop around
+// it keeps alive would go to scratch); launched second it could find every CU taken by workers that wait for it.  Gives up
+// after 20 ms (the workers then run into their own time-out if the diagonal worker never comes).
+__global__ void dflow_gate_kernel(const unsigned* cnt) {
+  const long long t0 = wall_clock64();
+  while (df_ld(cnt + DF_KEY) == 0u && wall_clock64() - t0 < 2000000LL) __builtin_amdgcn_s_sleep(8);
+}
+
+// the time-out of a wait (not a property of the matrix) as an impossible minor index: compute_finish() of gh_chol.hip tells it apart
+__global__ void dflow_check_kernel(const unsigned* cnt, long long* info) {
+  if (cnt[DF_ABORT] == 2u && *info == 0) *info = GH_DFLOW_TIMEOUT_INFO;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct DfDeviceSchedule {
+  DfTask* d[DF_NQ] = {nullptr, nullptr, nullptr};
+  unsigned count[DF_NQ] = {0, 0, 0};
+};
+static std::mutex g_df_mutex;
+static std::map<std::pair<int, int>, DfDeviceSchedule> g_df_cache;     // (device, nt): never freed (a few MB per size)
+
+// debugging aid: the next factorisations record one line per task (see df_trace); single-threaded use
+static long g_df_trace_cap = 0;
+static unsigned long long* g_df_trace = nullptr;
+extern "C" int gh_debug_dflow_trace(int64_t capacity, uint64_t* out, int64_t max_records, int64_t* n_out) {
+  if (out && n_out && g_df_trace) {                       // read the last factorisation's records (after a synchronisation)
+    unsigned long long used = 0;
+    GH_HIP(hipMemcpy(&used, g_df_trace, sizeof(used), hipMemcpyDeviceToHost));
+    const int64_t n = std::min<int64_t>(std::min<int64_t>((int64_t)used, g_df_trace_cap), max_records);
+    if (n > 0) GH_HIP(hipMemcpy(out, g_df_trace + 1, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *n_out = n;
+  } else if (n_out) *n_out = 0;
+  if (capacity >= 0 && capacity != g_df_trace_cap) {
+    if (g_df_trace) { (void)hipDeviceSynchronize(); (void)hipFree(g_df_trace); g_df_trace = nullptr; }
+    g_df_trace_cap = (long)capacity;
+  }
+  return GH_OK;
+}
+
+size_t gh_dflow_counter_bytes(int64_t np) { return df_words((int)(np / 128)) * sizeof(unsigned); }
+
+// factor the np x np matrix at A in place (lower triangle; np a multiple of 128), dinv[j] = L_jj^-1; counters: at least
+// gh_dflow_counter_bytes(np) of device memory that nothing else uses until the streams have passed this call.
+// `st`: the stream the matrix was built on -- the workers' launch goes there; `sd`: a second stream for the diagonal
+// worker's launch (the two must run side by side); ev[2]: two events of the caller.  On return everything is joined
+// on `sd` (the diagonal worker finishes last by construction), where the caller continues.
+// ONE dataflow factorisation per device at a time (the caller holds gh_dflow_mutex(device) until it has synchronised):
+// the workers of two of them could fill the chip before either diagonal worker is placed.
+int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* d_info, unsigned* counters,
+                    hipStream_t st, hipStream_t sd, hipEvent_t* ev) {
+  const int nt = (int)(np / 128);
+  if (np % 128 || nt <= 0 || nt > 4096) { gh_set_error("dflow: np must be a multiple of 128"); return GH_ERR_BAD_ARG; }
+  if (!sd || sd == st || !ev) { gh_set_error("dflow: needs a second stream"); return GH_ERR_BAD_ARG; }
+  int dev = 0;
+  GH_HIP(hipGetDevice(&dev));
+  DfDeviceSchedule ds;
+  {
+    std::lock_guard<std::mutex> lk(g_df_mutex);
+    auto it = g_df_cache.find({dev, nt});
+    if (it == g_df_cache.end()) {
+      DfSchedule s;
+      df_build(nt, s);
+      DfDeviceSchedule n;
+      for (int q = 0; q < DF_NQ; ++q) {
+        n.count[q] = (unsigned)s.q[q].size();
+        if (s.q[q].empty()) continue;
+        GH_HIP(hipMalloc((void**)&n.d[q], s.q[q].size() * sizeof(DfTask)));
+        GH_HIP(hipMemcpy(n.d[q], s.q[q].data(), s.q[q].size() * sizeof(DfTask), hipMemcpyHostToDevice));
+      }
+      it = g_df_cache.emplace(std::make_pair(dev, nt), n).first;
+    }
+    ds = it->second;
+  }
+  static int ncu = 0;
+  if (ncu == 0) {
+    hipDeviceProp_t prop;
+    GH_HIP(hipGetDeviceProperties(&prop, dev));
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  DfArgs a;
+  a.A = A; a.ld = (long)ld; a.dinv = dinv; a.info = d_info; a.cnt = counters;
+  for (int q = 0; q < DF_NQ; ++q) { a.tasks[q] = ds.d[q]; a.count[q] = ds.count[q]; }
+  a.off_kd = (unsigned)df_off_kd(nt); a.nt = nt;
+  a.trace = nullptr; a.trace_cap = 0;
+  if (g_df_trace_cap > 0) {
+    if (!g_df_trace) GH_HIP(hipMalloc((void**)&g_df_trace, (1 + 4 * (size_t)g_df_trace_cap) * sizeof(unsigned long long)));
+    GH_HIP(hipMemsetAsync(g_df_trace, 0, sizeof(unsigned long long), st));
+    a.trace = g_df_trace; a.trace_cap = (unsigned)g_df_trace_cap;
+  }
+  GH_HIP(hipMemsetAsync(counters, 0, df_words(nt) * sizeof(unsigned), st));
+  GH_HIP(hipEventRecord(ev[0], st));
+  GH_HIP(hipStreamWaitEvent(sd, ev[0], 0));
+  if (a.trace) hipLaunchKernelGGL(dflow_diag_kernel<true>, dim3(1), dim3(256), 0, sd, a);
+  else hipLaunchKernelGGL(dflow_diag_kernel<false>, dim3(1), dim3(256), 0, sd, a);
+  GH_HIP(hipGetLastError());
+  hipLaunchKernelGGL(dflow_gate_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)counters);
+  GH_HIP(hipGetLastError());
+  // two workgroups per CU (64 KiB of LDS each); the diagonal worker's CU takes none (its registers are gone)
+  static const int nwork = getenv("GEORGE_AMD_DATAFLOW_WORKERS") ? std::max(1, atoi(getenv("GEORGE_AMD_DATAFLOW_WORKERS"))) : 0;
+  const unsigned grid = (unsigned)(nwork > 0 ? nwork : 2 * ncu - 2);
+  if (ds.count[0] + ds.count[1] + ds.count[2] > 0) {
+    if (a.trace) hipLaunchKernelGGL(dflow_worker_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dflow_worker_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    GH_HIP(hipGetLastError());
+  }
+  GH_HIP(hipEventRecord(ev[1], st));
+  GH_HIP(hipStreamWaitEvent(sd, ev[1], 0));
+  hipLaunchKernelGGL(dflow_check_kernel, dim3(1), dim3(1), 0, sd, (const unsigned*)counters, d_info);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
+std::mutex& gh_dflow_mutex(int device) {
+  static std::mutex m[64];
+  return m[device >= 0 && device < 64 ? device : 0];
+}

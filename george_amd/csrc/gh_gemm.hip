@@ -22,12 +22,7 @@
 #include "gh_common.h"
 #include "../../include/george_amd_debug.h"
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-#define BM 128
-#define BN 128
-#define BK 16
-#define LS 18
+#include "gh_gemm_tile.h"
 
 struct GemmDev {
   double* C; long ldc;
@@ -246,85 +241,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDev& g, const v4d (&acc)
 //   m-major operand (k strided, rows contiguous): LDS image [k][128 rows], one instruction = one
 //       k (1 KiB of rows); piece p of k-row k holds row-pair p ^ ((k & 1) << 3), i.e. odd k swap
 //       the two 128-byte halves of every 256 bytes -- for the reader that is "16-row group i^1".
-// which k (of the 16 of a slab) lane group fk feeds into k-step kk of a k-major x k-major product: element offset inside the row's
-// XOR-swizzled image.  k = {2 fk, 2 fk + 1, 2 fk + 8, 2 fk + 9}[kk]: the lane's four values sit in two 16-byte pieces, so the
-// main kernel reads a slab's fragments with 16 ds_read_b128 per wavefront (round 4; the natural assignment k = 4 kk + fk needs
-// 32 ds_read_b64: 68.0 -> 69.1 TFLOP/s on the SYRK shape, -1.3 ... -1.6 % on seven shapes, profiles/r04/gemm_pair_ab.md).
-// EVERY k-major x k-major kernel must use the same assignment (a tile's bits must not depend on which of them computed it:
-// tests compare schedules bit for bit); products with an m-major operand keep k = 4 kk + fk on both sides.
-#define GH_KM_OFFK(kk, fk, sw) (((((fk) + 4 * ((kk) >> 1)) ^ (sw)) * 2) + ((kk) & 1))
-typedef __attribute__((address_space(3))) void gh_lds_void;
-typedef const __attribute__((address_space(1))) void gh_glb_void;
-
-template <bool KM>
-struct DmaOperand {
-  // source of instruction i = ubase (wave-uniform: lives in SGPRs, advanced by a scalar add per slab) + voff[i] (this lane's byte
-  // offset, loop-invariant).  Round 4: one 64-bit VGPR pointer per instruction (the first form) cost 8 v_lshl_add_u64 per slab
-  // and wavefront plus a v_readfirstlane per instruction for the LDS address in M0 -- vector instructions that queue behind the
-  // fp64 matrix instructions: 69.3 -> 70.3 TFLOP/s with scalar M0, -> 71.2 with the buffer form (profiles/r04/gemm_dma_addr_ab.md).
-  const char* ubase;
-  unsigned voff[4];
-  long step;                // doubles to advance per slab
-  int f0, f1;               // fragment read offsets (doubles), see frag()
-  int offk[4];
-  int off2[2];              // k-major x k-major launches: the lane's two 16-byte pieces, see frag2()
-
-  __device__ __forceinline__ void init(const double* base, long ld, long r0, long kbeg, int wave, int lane, int wsub) {
-    const int fr = lane & 15, fk = lane >> 4;
-    if (KM) {
-      ubase = (const char*)(base + r0 * ld + kbeg);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + (lane >> 3);
-        voff[i] = (unsigned)(((long)r * ld + (((lane & 7) ^ ((r >> 1) & 7)) * 2)) * 8);
-      }
-      step = BK;
-      const int sw = (fr >> 1) & 7;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
-      off2[0] = ((fk ^ sw) * 2); off2[1] = (((fk + 4) ^ sw) * 2);
-      f0 = (wsub * 64 + fr) * BK;
-      f1 = 0;
-    } else {
-      ubase = (const char*)(base + kbeg * ld + r0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = wave * 4 + i;
-        voff[i] = (unsigned)(((long)k * ld + ((lane ^ ((k & 1) << 3)) * 2)) * 8);
-      }
-      step = BK * ld;
-      const int ix = fk & 1;
-      f0 = fk * 128 + wsub * 64 + fr + 16 * ix;      // even 16-row groups
-      f1 = fk * 128 + wsub * 64 + fr - 16 * ix;      // odd 16-row groups
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) offk[kk] = kk * 512;
-    }
-  }
-  // fragment (k-step kk, 16-row group i) of the slab image at `s`
-  __device__ __forceinline__ double frag(const double* s, int kk, int i) const {
-    if (KM) return s[f0 + i * 16 * BK + offk[kk]];
-    return s[((i & 1) ? f1 : f0) + i * 16 + offk[kk]];
-  }
-  // k-major image only: pieces fk and fk + 4 of row (16 i + fr) as ONE 16-byte LDS read each -- k-steps 2q and 2q + 1 of the lane.
-  // The k index a lane feeds into k-step kk is then {2 fk, 2 fk + 1, 2 fk + 8, 2 fk + 9}[kk] instead of 4 kk + fk: any
-  // assignment works as long as both operands use the same one (the instruction sums over its four k), and with this one a
-  // slab costs a wavefront 16 ds_read_b128 instead of 32 ds_read_b64.
-  __device__ __forceinline__ double2 frag2(const double* s, int q, int i) const {
-    return *reinterpret_cast<const double2*>(s + f0 + i * 16 * BK + off2[q]);
-  }
-};
-
-// buffer_load_dwordx4 ... offen lds: resource descriptor in SGPRs (base = the wave-uniform slab pointer, advanced by a scalar add),
-// the lane's byte offset as the 32-bit voffset -- not one vector instruction per DMA.  (global_load_lds with an SGPR base: hipcc
-// still forms a 64-bit vector address per instruction inside the loop, one v_lshl_add_u64 each.)
-#define GH_DMA_ISSUE(op, sbuf)                                                                        \
-  {                                                                                                   \
-    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)op.ubase, 0, 0x7fffffff, 0x00020000); \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (gh_lds_void*)((sbuf) + dst + i_ * 128), 16, (int)op.voff[i_], 0, 0, 0); \
-    op.ubase += op.step * 8;                                                                          \
-  }
-
 // LOWER (== g.lower) only names the symbol: rocprof then tells the triangular-grid launches (the
 // trailing SYRK updates, the roofline kernel of bench.py) from the rectangular panel GEMMs.
 template <bool A_KM, bool B_KM, bool LOWER>
@@ -402,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
   }
   gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
 }
-#undef GH_DMA_ISSUE
 
 // ---------------------------------------------------------------------------------------------
 // 64x64-tile variant for launches that cannot fill the chip anyway (the GEMMs inside the panel

@@ -1,0 +1,271 @@
+// gh_gemm_tile.h -- device-side pieces of the fp64 MFMA GEMM family that more than one translation unit uses:
+// the LDS-DMA operand path of gh_gemm.hip's kernels (XOR-swizzled slab images, the k assignment every k-major x k-major
+// product shares) and, built from it, one-tile products as DEVICE FUNCTIONS for kernels whose workgroups take tile tasks
+// one after the other (gh_dflow.hip, the tile-level dataflow factorisation).
+//
+// A tile's bits must not depend on which kernel computed it (tests compare schedules bit for bit): gh_tile128_nt follows
+// gemm_f64_mfma_dma<true, true, .> slab for slab and instruction for instruction, gh_tile64_nt follows
+// gemm_f64_mfma_dma64<4>; accumulators start from -C and the write-back is -acc (exact), so any split of K into
+// consecutive multiples of 16 gives the same sums as one pass over all of K.
+#pragma once
+#include "gh_common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LS 18
+
+// which k (of the 16 of a slab) lane group fk feeds into k-step kk of a k-major x k-major product: element offset inside the row's
+// XOR-swizzled image.  k = {2 fk, 2 fk + 1, 2 fk + 8, 2 fk + 9}[kk]: the lane's four values sit in two 16-byte pieces, so the
+// main kernel reads a slab's fragments with 16 ds_read_b128 per wavefront (round 4; the natural assignment k = 4 kk + fk needs
+// 32 ds_read_b64: 68.0 -> 69.1 TFLOP/s on the SYRK shape, -1.3 ... -1.6 % on seven shapes, profiles/r04/gemm_pair_ab.md).
+// EVERY k-major x k-major kernel must use the same assignment (a tile's bits must not depend on which of them computed it:
+// tests compare schedules bit for bit); products with an m-major operand keep k = 4 kk + fk on both sides.
+#define GH_KM_OFFK(kk, fk, sw) (((((fk) + 4 * ((kk) >> 1)) ^ (sw)) * 2) + ((kk) & 1))
+typedef __attribute__((address_space(3))) void gh_lds_void;
+typedef const __attribute__((address_space(1))) void gh_glb_void;
+
+template <bool KM>
+struct DmaOperand {
+  // source of instruction i = ubase (wave-uniform: lives in SGPRs, advanced by a scalar add per slab) + voff[i] (this lane's byte
+  // offset, loop-invariant).  Round 4: one 64-bit VGPR pointer per instruction (the first form) cost 8 v_lshl_add_u64 per slab
+  // and wavefront plus a v_readfirstlane per instruction for the LDS address in M0 -- vector instructions that queue behind the
+  // fp64 matrix instructions: 69.3 -> 70.3 TFLOP/s with scalar M0, -> 71.2 with the buffer form (profiles/r04/gemm_dma_addr_ab.md).
+  const char* ubase;
+  unsigned voff[4];
+  long step;                // doubles to advance per slab
+  int f0, f1;               // fragment read offsets (doubles), see frag()
+  int offk[4];
+  int off2[2];              // k-major x k-major launches: the lane's two 16-byte pieces, see frag2()
+
+  __device__ __forceinline__ void init(const double* base, long ld, long r0, long kbeg, int wave, int lane, int wsub) {
+    const int fr = lane & 15, fk = lane >> 4;
+    if (KM) {
+      ubase = (const char*)(base + r0 * ld + kbeg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        voff[i] = (unsigned)(((long)r * ld + (((lane & 7) ^ ((r >> 1) & 7)) * 2)) * 8);
+      }
+      step = BK;
+      const int sw = (fr >> 1) & 7;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) offk[kk] = (((kk * 2 + (fk >> 1)) ^ sw) * 2) + (fk & 1);
+      off2[0] = ((fk ^ sw) * 2); off2[1] = (((fk + 4) ^ sw) * 2);
+      f0 = (wsub * 64 + fr) * BK;
+      f1 = 0;
+    } else {
+      ubase = (const char*)(base + kbeg * ld + r0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = wave * 4 + i;
+        voff[i] = (unsigned)(((long)k * ld + ((lane ^ ((k & 1) << 3)) * 2)) * 8);
+      }
+      step = BK * ld;
+      const int ix = fk & 1;
+      f0 = fk * 128 + wsub * 64 + fr + 16 * ix;      // even 16-row groups
+      f1 = fk * 128 + wsub * 64 + fr - 16 * ix;      // odd 16-row groups
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) offk[kk] = kk * 512;
+    }
+  }
+  // fragment (k-step kk, 16-row group i) of the slab image at `s`
+  __device__ __forceinline__ double frag(const double* s, int kk, int i) const {
+    if (KM) return s[f0 + i * 16 * BK + offk[kk]];
+    return s[((i & 1) ? f1 : f0) + i * 16 + offk[kk]];
+  }
+  // k-major image only: pieces fk and fk + 4 of row (16 i + fr) as ONE 16-byte LDS read each -- k-steps 2q and 2q + 1 of the lane.
+  // The k index a lane feeds into k-step kk is then {2 fk, 2 fk + 1, 2 fk + 8, 2 fk + 9}[kk] instead of 4 kk + fk: any
+  // assignment works as long as both operands use the same one (the instruction sums over its four k), and with this one a
+  // slab costs a wavefront 16 ds_read_b128 instead of 32 ds_read_b64.
+  __device__ __forceinline__ double2 frag2(const double* s, int q, int i) const {
+    return *reinterpret_cast<const double2*>(s + f0 + i * 16 * BK + off2[q]);
+  }
+};
+
+// buffer_load_dwordx4 ... offen lds: resource descriptor in SGPRs (base = the wave-uniform slab pointer, advanced by a scalar add),
+// the lane's byte offset as the 32-bit voffset -- not one vector instruction per DMA.  (global_load_lds with an SGPR base: hipcc
+// still forms a 64-bit vector address per instruction inside the loop, one v_lshl_add_u64 each.)
+#define GH_DMA_ISSUE(op, sbuf)                                                                        \
+  {                                                                                                   \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)op.ubase, 0, 0x7fffffff, 0x00020000); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (gh_lds_void*)((sbuf) + dst + i_ * 128), 16, (int)op.voff[i_], 0, 0, 0); \
+    op.ubase += op.step * 8;                                                                          \
+  }
+
+
+// ---------------------------------------------------------------------------------------------
+// One 128 x 128 tile on the calling 256-thread workgroup:  ACC: C -= A B^T (accumulators start from -C, store-only
+// write-back), else C = A B^T (C may be A: every slab of A has been read when the first element of C is stored).
+// A, B: 128 x K, k contiguous (lda, ldb even, bases 16-byte aligned), K a multiple of 16.  sm: 8192 doubles of LDS, 1 KiB
+// aligned.  Every wavefront must have passed a barrier since its last read of sm; on return all stores have been ISSUED
+// (not waited for) and every wavefront has passed the loop's last barrier.
+template <bool ACC>
+__device__ __forceinline__ void gh_tile128_nt(double* sm, double* C, long ldc, const double* A, long lda,
+                                              const double* B, long ldb, long K) {
+  double* const sA0 = sm; double* const sA1 = sm + BM * BK;
+  double* const sB0 = sm + 2 * BM * BK; double* const sB1 = sm + 2 * BM * BK + BN * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  v4d acc[4][4];
+  const long nk = K / BK;
+  DmaOperand<true> oa, ob;
+  oa.init(A, lda, 0, 0, wave, lane, wm);
+  ob.init(B, ldb, 0, 0, wave, lane, wn);
+  const int dst = wave * 4 * 128;
+  if (nk > 0) { GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0) }
+  double* const cbase = C + (long)(wm * 64 + fk) * ldc + wn * 64 + fr;
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = -1.0 * cbase[(long)(i * 16 + 4 * r) * ldc + j * 16];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+  for (long kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const double* const ca = cur ? sA1 : sA0;
+    const double* const cb = cur ? sB1 : sB0;
+    double a[4][4], b[4][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double2 v = oa.frag2(ca, q, i); a[2 * q][i] = v.x; a[2 * q + 1][i] = v.y; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const double2 v = ob.frag2(cb, q, j); b[2 * q][j] = v.x; b[2 * q + 1][j] = v.y; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (cur) { GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0) }
+      else     { GH_DMA_ISSUE(oa, sA1) GH_DMA_ISSUE(ob, sB1) }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 1; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  const double alpha = ACC ? -1.0 : 1.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* const crow = cbase + (long)(i * 16 + 4 * r) * ldc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][r];
+    }
+}
+
+// The same for a 64 x 128 tile (2 x 2 wavefronts of 32 x 64): the tasks next to the factorisation's critical path, where
+// a tile's latency counts and not the chip's throughput.  C may be A (whole rows belong to the workgroup).
+// sm: 6144 doubles of LDS, 1 KiB aligned.
+template <bool ACC>
+__device__ __forceinline__ void gh_tile64_nt(double* sm, double* C, long ldc, const double* A, long lda,
+                                             const double* B, long ldb, long K) {
+  double* const sA0 = sm; double* const sA1 = sm + 64 * BK;
+  double* const sB0 = sm + 2 * 64 * BK; double* const sB1 = sm + 2 * 64 * BK + 128 * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const long nk = K / BK;
+  const double* ga[2];
+  const double* gb[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wave * 16 + i * 8 + (lane >> 3);
+    ga[i] = A + (long)r * lda + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + (lane >> 3);
+    gb[i] = B + (long)r * ldb + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
+  }
+  const int sw = (fr >> 1) & 7;
+  int offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = GH_KM_OFFK(kk, fk, sw);
+  const int rowA = (wm * 32 + fr) * BK, rowB = (wn * 64 + fr) * BK;
+  const int dstA = wave * 2 * 128, dstB = wave * 4 * 128;
+#define GH_T64_ISSUE(bufA, bufB)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+    __builtin_amdgcn_global_load_lds((gh_glb_void*)ga[i], (gh_lds_void*)((bufA) + dstA + i * 128), 16, 0, 0); \
+    ga[i] += BK;                                                                                           \
+  }                                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+    __builtin_amdgcn_global_load_lds((gh_glb_void*)gb[i], (gh_lds_void*)((bufB) + dstB + i * 128), 16, 0, 0); \
+    gb[i] += BK;                                                                                           \
+  }
+  v4d acc[2][4];
+  double* const cbase = C + (long)(wm * 32 + fk) * ldc + wn * 64 + fr;
+  if (nk > 0) { GH_T64_ISSUE(sA0, sB0) }
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = -1.0 * cbase[(long)(i * 16 + 4 * r) * ldc + j * 16];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+  for (long kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const double* const pa = (cur ? sA1 : sA0) + rowA;
+    const double* const pb = (cur ? sB1 : sB0) + rowB;
+    double a[4][2], b[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[kk][i] = pa[i * 16 * BK + offk[kk]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (cur) { GH_T64_ISSUE(sA0, sB0) } else { GH_T64_ISSUE(sA1, sB1) }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+#undef GH_T64_ISSUE
+  const double alpha = ACC ? -1.0 : 1.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cbase[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
+}

@@ -28,6 +28,18 @@ int gh_debug_stream_overlap(gh_chol* s, double* out, int n);
  * 2^18 workgroups (~2 ms) on stream i: small = the two queues dispatch independently (same stream numbering) */
 int gh_debug_stream_dispatch(gh_chol* s, double* out, int n);
 int gh_microbench_hbm_copy(double* gbps_out);
+/* the dense factorisation as one persistent launch of tile tasks (gh_dflow.hip): 1 = always (Np >= 256), 0 = never (the
+ * launch chain), -1 = by size (the default; GEORGE_AMD_DATAFLOW=0|1 overrides); returns the previous setting.  Both arms
+ * give bit-identical factors. */
+int gh_debug_set_dataflow(int mode);
+/* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q
+ * (0 crit, 1 hi, 2 lo); out (nullable): rows of 7 ints {queue, i, j, k0, k1, half, fin} in claim order, at most max_rows */
+int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows);
+/* per-task trace of the dataflow factorisation (single-threaded debugging aid).  capacity >= 0: from now on record up to
+ * `capacity` tasks per factorisation (0 = off); out != NULL: first copy the last factorisation's records (4 x uint64 each:
+ * start and end in 10-ns ticks, i | j << 16 | k0 << 32 | k1 << 48, kind | half << 8 | fin << 16 | workgroup << 32; kind 0-2 =
+ * queue, 8-11 = the diagonal worker's wait / multiply / update / 128 x 128 kernel) and their number to *n_out */
+int gh_debug_dflow_trace(int64_t capacity, uint64_t* out, int64_t max_records, int64_t* n_out);
 /* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
  * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
  * TFLOP/s, cycles/instr, GHz at 4 waves/SIMD; out[10] TFLOP/s at 8 waves/SIMD; out[11..12]

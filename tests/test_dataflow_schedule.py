@@ -1,0 +1,267 @@
+"""The task queues of the dataflow factorisation (george_amd/csrc/gh_dflow.hip) replayed on the host.
+
+The device kernel stores no dependencies: a task's inputs follow from its fields and three families of counters
+(D, rowh, kd).  This file restates that rule in Python (`ready`), hands the library's queues (gh_debug_dflow_schedule,
+host only) to a pool of simulated workers that claim exactly as the kernel does -- crit and hi by compare-and-swap on
+a runnable head, lo by ticket -- with random task durations, and checks
+
+  * every claim finds its inputs FINAL in the true state (not only in the counters),
+  * no two tasks in flight touch the same half tile,
+  * every k step reaches every tile exactly once, in ascending order,
+  * the run never stalls (forward progress whatever the timing), every task is consumed,
+  * the tiles, executed with NumPy on a small tile size, give the Cholesky factor.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from george_amd import _native
+
+PW = 8
+
+
+def schedule(nt):
+    lib = _native.lib
+    counts = (C.c_int32 * 3)()
+    assert lib.gh_debug_dflow_schedule(nt, counts, None, 0) == 0
+    tot = sum(counts)
+    out = (C.c_int32 * (7 * max(tot, 1)))()
+    assert lib.gh_debug_dflow_schedule(nt, counts, out, tot) == 0
+    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 7)[:tot]
+    qs = [[], [], []]
+    for r in rows:
+        qs[r[0]].append(tuple(int(v) for v in r[1:]))
+    assert [len(q) for q in qs] == list(counts)
+    return qs
+
+
+class Machine:
+    """True state + the counters the kernel sees + optional numerics on b x b tiles."""
+
+    def __init__(self, nt, b=0, seed=0):
+        self.nt, self.b = nt, b
+        self.D = 0
+        self.rowh = [[0, 0] for _ in range(nt)]
+        self.kd = {}
+        self.kd_true = {}
+        self.final = set()          # (i, j, h) of final L half tiles; (j, j, 2) for a factored diagonal tile
+        self.busy = set()
+        if b:
+            rng = np.random.RandomState(seed)
+            n = nt * b
+            m = rng.randn(n, n)
+            self.A0 = m @ m.T + n * np.eye(n)
+            self.A = np.tril(self.A0).copy()
+            self.dinv = [None] * nt
+
+    def k(self, i, j, h):
+        return self.kd.get((i, j, h), 0)
+
+    def halves(self, half):
+        return (0, 1) if half == 2 else (half,)
+
+    # the kernel's df_ready()
+    def ready(self, t):
+        i, j, k0, k1, half, fin = t
+        ok = all(self.k(i, j, h) >= k0 for h in self.halves(half)) if k0 else True
+        if k1 > k0:
+            ok &= self.rowh[j][0] >= k1 and self.rowh[j][1] >= k1
+            if i != j:
+                ok &= all(self.rowh[i][h] >= k1 for h in self.halves(half))
+        if fin:
+            ok &= self.D >= j + 1
+        return ok
+
+    def rows(self, i, h):
+        b = self.b
+        if h == 2:
+            return slice(i * b, (i + 1) * b)
+        return slice(i * b + h * b // 2, i * b + (h + 1) * b // 2)
+
+    def start(self, t):
+        """Checks against the TRUE state and the arithmetic, at claim time; returns the effects for completion."""
+        i, j, k0, k1, half, fin = t
+        hs = self.halves(half)
+        for h in hs:
+            assert (i, j, h) not in self.busy, ("two tasks on one half tile", t)
+            assert (i, j, h) not in self.final, ("task on a final tile", t)
+            assert self.kd_true.get((i, j, h), 0) == k0, ("k steps out of order", t, self.kd_true.get((i, j, h), 0))
+            self.busy.add((i, j, h))
+        for k in range(k0, k1):
+            assert (j, k, 0) in self.final and (j, k, 1) in self.final, ("B operand not final", t, k)
+            for h in hs:
+                assert (i, k, h) in self.final, ("A operand not final", t, k)
+        if fin:
+            assert half != 2 and i >= j + 2
+            assert k1 == j and (j, j, 2) in self.final, ("L_jj^-1 not there", t)
+        new = None
+        if self.b:
+            b = self.b
+            r = self.rows(i, half)
+            c = self.A[r, j * b:(j + 1) * b].copy()
+            if k1 > k0:
+                c -= self.A[r, k0 * b:k1 * b] @ self.A[j * b:(j + 1) * b, k0 * b:k1 * b].T
+            if fin:
+                c = c @ self.dinv[j].T
+            new = (r, j, c)
+        return (t, new)
+
+    def finish(self, eff):
+        (i, j, k0, k1, half, fin), new = eff
+        if new is not None:
+            r, jj, c = new
+            self.A[r, jj * self.b:(jj + 1) * self.b] = c
+        for h in self.halves(half):
+            self.busy.discard((i, j, h))
+            self.kd_true[(i, j, h)] = k1
+            if fin:                                  # (the kernel publishes the row counter only: nobody reads kd of a final tile)
+                self.final.add((i, j, h))
+                assert self.rowh[i][h] == j, ("row counter out of order", i, j, h, self.rowh[i][h])
+                self.rowh[i][h] = j + 1
+            else:
+                self.kd[(i, j, h)] = k1
+
+    # the diagonal worker, step j, in two parts (the sub-diagonal tile is published before the 128 x 128 kernel runs)
+    def diag_can_start(self, j):
+        if j <= 1:
+            return True
+        return all(self.k(j, j - 1, h) >= j - 1 and self.k(j, j, h) >= j - 1 for h in (0, 1))
+
+    def diag_part1(self, j):
+        if j == 0:
+            return
+        for h in (0, 1):
+            assert self.kd_true.get((j, j - 1, h), 0) == j - 1 and self.kd_true.get((j, j, h), 0) == j - 1, ("diagonal worker too early", j)
+            assert (j, j - 1, h) not in self.busy and (j, j, h) not in self.busy
+        if self.b:
+            b = self.b
+            r = slice(j * b, (j + 1) * b)
+            self.A[r, (j - 1) * b:j * b] = self.A[r, (j - 1) * b:j * b] @ self.dinv[j - 1].T
+        for h in (0, 1):
+            self.final.add((j, j - 1, h))
+            assert self.rowh[j][h] == j - 1
+            self.rowh[j][h] = j
+
+    def diag_part2(self, j):
+        if self.b:
+            b = self.b
+            r = slice(j * b, (j + 1) * b)
+            if j > 0:
+                sub = self.A[r, (j - 1) * b:j * b]
+                self.A[r, r] -= sub @ sub.T
+            ljj = np.linalg.cholesky(np.tril(self.A[r, r]) + np.tril(self.A[r, r], -1).T)
+            self.A[r, r] = ljj
+            self.dinv[j] = np.linalg.inv(ljj)
+        self.final.add((j, j, 2))
+        self.D = j + 1
+
+
+def run(nt, nworkers, b=0, seed=0, max_flight=12):
+    qs = schedule(nt)
+    m = Machine(nt, b, seed)
+    rng = random.Random(seed)
+    heads = [0, 0, 0]
+    tickets = [None] * nworkers      # a claimed lo task waiting for its inputs
+    flight = [None] * nworkers       # (remaining ticks, effects)
+    dj, dphase, dwait = 0, 0, 0      # diagonal worker: step, part, remaining ticks
+    done_tasks = 0
+    total = sum(len(q) for q in qs)
+    stall = 0
+    while dj < nt or done_tasks < total:
+        progressed = False
+        # diagonal worker
+        if dj < nt:
+            if dwait > 0:
+                dwait -= 1
+                progressed = True
+            elif dphase == 0:
+                if m.diag_can_start(dj):
+                    m.diag_part1(dj)
+                    dphase, dwait = 1, rng.randint(0, 3)
+                    progressed = True
+            else:
+                m.diag_part2(dj)
+                dj, dphase, dwait = dj + 1, 0, rng.randint(0, 3)
+                progressed = True
+        order = list(range(nworkers))
+        rng.shuffle(order)
+        for w in order:
+            if flight[w] is not None:
+                rem, eff = flight[w]
+                if rem > 0:
+                    flight[w] = (rem - 1, eff)
+                else:
+                    m.finish(eff)
+                    flight[w] = None
+                    done_tasks += 1
+                progressed = True
+                continue
+            if rng.random() < 0.3:       # this worker does not poll in this tick
+                continue
+            got = None
+            for q in (0, 1):
+                if heads[q] < len(qs[q]) and m.ready(qs[q][heads[q]]):
+                    got = qs[q][heads[q]]
+                    heads[q] += 1
+                    break
+            if got is None:
+                if tickets[w] is None and heads[2] < len(qs[2]):
+                    tickets[w] = qs[2][heads[2]]
+                    heads[2] += 1
+                    progressed = True
+                if tickets[w] is not None and m.ready(tickets[w]):
+                    got, tickets[w] = tickets[w], None
+            if got is not None:
+                flight[w] = (rng.randint(0, max_flight), m.start(got))
+                progressed = True
+        stall = 0 if progressed else stall + 1
+        assert stall < 50, ("no forward progress", dj, heads, [len(q) for q in qs], [t for t in tickets if t])
+    assert heads == [len(q) for q in qs] and all(t is None for t in tickets)
+    return m, qs
+
+
+def check_coverage(nt, m):
+    for j in range(nt):
+        for i in range(j, nt):
+            want = max(0, j - 1 if i == j else j)      # the workers' share
+            for h in (0, 1):
+                assert m.kd_true.get((i, j, h), 0) == want, (i, j, h)
+                if i >= j + 1:
+                    assert (i, j, h) in m.final
+        assert (j, j, 2) in m.final
+
+
+@pytest.mark.parametrize("nt,workers,seed", [(1, 3, 0), (2, 3, 1), (3, 2, 2), (9, 4, 3), (17, 1, 4), (20, 7, 5), (26, 40, 6), (33, 13, 7)])
+def test_replay_gives_the_cholesky_factor(nt, workers, seed):
+    b = 4
+    m, _ = run(nt, workers, b=b, seed=seed)
+    check_coverage(nt, m)
+    ref = np.linalg.cholesky(m.A0)
+    got = np.tril(m.A)
+    assert np.allclose(got, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("nt,workers", [(64, 64), (128, 200)])
+def test_structure_at_product_sizes(nt, workers):
+    m, qs = run(nt, workers, b=0, seed=nt, max_flight=6)
+    check_coverage(nt, m)
+    # flops: every tile product exactly once
+    steps = sum((t[3] - t[2]) * (2 if t[4] == 2 else 1) for q in qs for t in q)
+    want = sum(2 * max(0, j - 1 if i == j else j) for j in range(nt) for i in range(j, nt))
+    assert steps == want
+
+
+def test_queue_shapes():
+    qs = schedule(40)
+    # lo: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns
+    for (i, j, k0, k1, half, fin) in qs[2]:
+        assert half == 2 and not fin and 0 < k1 - k0 <= 16 and k1 <= PW * (j // PW - 1)
+    # crit: half tiles, one k step or a multiply
+    for (i, j, k0, k1, half, fin) in qs[0]:
+        assert half in (0, 1) and (k1 - k0 == 1 and not fin or k1 == k0 == j and fin)
+    # multiplies by L_jj^-T never on whole tiles, never for the diagonal worker's rows
+    for q in qs:
+        for (i, j, k0, k1, half, fin) in q:
+            assert i >= j and (not fin or (half != 2 and i >= j + 2 and k1 == j))

@@ -1,0 +1,276 @@
+"""INTEGRATION.md section 2 executed on the reference package: the ONE line a george maintainer changes to put the HIP
+kernel evaluator behind every `george.kernels` object --
+
+    /root/reference/src/george/kernels.py:28   from .kernel_interface import KernelInterface
+    /root/reference/src/george/kernels.py:67-69   Kernel.kernel -> KernelInterface(self)
+
+is applied here as `george.kernels.KernelInterface = george_amd.kernel_interface.KernelInterface`, and the bodies of the
+reference's own evaluator tests run on the reference's own kernel objects (its `Kernel.get_value / get_gradient /
+get_x1_gradient / get_x2_gradient / test_gradient / test_x?_gradient`, kernels.py:143-262):
+
+    tests/test_kernels.py:11-17     test_dtype
+    tests/test_kernels.py:19-70     the 36 kernel instances
+    tests/test_kernels.py:72-87     test_kernel, test_x_gradient_kernel (finite differences at eps = 1.32e-6)
+    tests/test_kernels.py:90-137    test_stationary (seven families x metrics, axes, block=)
+    tests/test_metrics.py:40-103    general and axis-aligned metrics against the closed form
+    docs/tutorials/first.rst:91,119,129   "-11.82" and fun: 9.225282556043894 through george.GP + HIP solver + HIP evaluator
+
+`george` is dfm/george itself (oracle/ref_loader.load_reference: byte-code staged by oracle/Makefile); with the patch in
+place NOTHING of the reference's C++ (kernel_interface.cpp) is called any more -- asserted below by counting calls.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_loader
+import george_amd
+from george_amd import kernel_interface as hip_ki
+
+pytestmark = pytest.mark.gpu
+
+george = ref_loader.load_reference()
+if george is None:                                           # (collection on a box where oracle/_ref was not built)
+    pytest.skip("oracle/_ref/george is not staged (make -C oracle)", allow_module_level=True)
+kernels, GP = george.kernels, george.GP
+
+CALLS = {"hip": 0}
+
+
+class CountingInterface(hip_ki.KernelInterface):
+    """george_amd's evaluator class, counting constructions (what Kernel.kernel does on every access)."""
+
+    def __init__(self, spec):
+        CALLS["hip"] += 1
+        hip_ki.KernelInterface.__init__(self, spec)
+
+
+@pytest.fixture(autouse=True)
+def hip_evaluator():
+    ref_class = kernels.KernelInterface
+    kernels.KernelInterface = CountingInterface              # <- the maintainer's one-line change
+    try:
+        yield
+    finally:
+        kernels.KernelInterface = ref_class
+
+
+def test_the_patch_routes_the_reference_kernels_to_the_hip_library():
+    k = 2.0 * kernels.Matern32Kernel(0.7)
+    assert type(k).__module__ == "george.kernels"
+    before = CALLS["hip"]
+    x = np.linspace(0, 3, 17)[:, None]
+    K = k.get_value(x)
+    assert CALLS["hip"] > before and isinstance(k.kernel, hip_ki.KernelInterface)
+    r = np.abs(x - x.T) / np.sqrt(0.7)
+    assert np.allclose(K, 2.0 * (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r), rtol=1e-13, atol=1e-15)
+    with open("/proc/self/maps") as f:                       # the HIP library is mapped into THIS process
+        assert "libgeorge_amd.so" in f.read()
+    # the same numbers as the reference's C++ evaluator gives for the same object
+    ref_ki = ref_loader.load_kernel_interface()(k)
+    assert np.allclose(K, ref_ki.value_symmetric(x), rtol=1e-14, atol=1e-16)
+
+
+def test_dtype(seed=123):                                                       # tests/test_kernels.py:11-17
+    np.random.seed(seed)
+    kernel = 0.1 * kernels.ExpSquaredKernel(1.5)
+    kernel.pars = [1, 2]
+    gp = GP(kernel, solver=george_amd.BasicSolver)
+    x = np.random.rand(100)
+    gp.compute(x, 1e-2)
+
+
+def _kernels_to_test():                                                         # tests/test_kernels.py:19-70
+    return [
+        kernels.ConstantKernel(log_constant=0.1),
+        kernels.ConstantKernel(log_constant=10.0, ndim=2),
+        kernels.ConstantKernel(log_constant=5.0, ndim=5),
+        kernels.DotProductKernel(),
+        kernels.DotProductKernel(ndim=2),
+        kernels.DotProductKernel(ndim=5, axes=0),
+        kernels.CosineKernel(log_period=1.0),
+        kernels.CosineKernel(log_period=0.5, ndim=2),
+        kernels.CosineKernel(log_period=0.5, ndim=2, axes=1),
+        kernels.CosineKernel(log_period=0.75, ndim=5, axes=[2, 3]),
+        kernels.ExpSine2Kernel(gamma=0.4, log_period=1.0),
+        kernels.ExpSine2Kernel(gamma=12., log_period=0.5, ndim=2),
+        kernels.ExpSine2Kernel(gamma=17., log_period=0.5, ndim=2, axes=1),
+        kernels.ExpSine2Kernel(gamma=13.7, log_period=-0.75, ndim=5, axes=[2, 3]),
+        kernels.ExpSine2Kernel(gamma=-0.7, log_period=0.75, ndim=5, axes=[2, 3]),
+        kernels.ExpSine2Kernel(gamma=-10, log_period=0.75),
+        kernels.LocalGaussianKernel(log_width=0.5, location=1.0),
+        kernels.LocalGaussianKernel(log_width=0.1, location=0.5, ndim=2),
+        kernels.LocalGaussianKernel(log_width=1.5, location=-0.5, ndim=2, axes=1),
+        kernels.LocalGaussianKernel(log_width=2.0, location=0.75, ndim=5, axes=[2, 3]),
+        kernels.LinearKernel(order=0, log_gamma2=0.0),
+        kernels.LinearKernel(order=2, log_gamma2=0.0),
+        kernels.LinearKernel(order=2, log_gamma2=0.0),
+        kernels.LinearKernel(order=5, log_gamma2=1.0, ndim=2),
+        kernels.LinearKernel(order=3, log_gamma2=-1.0, ndim=5, axes=2),
+        kernels.LinearKernel(order=0, log_gamma2=0.0) +
+        kernels.LinearKernel(order=1, log_gamma2=-1.0) +
+        kernels.LinearKernel(order=2, log_gamma2=-2.0),
+        kernels.PolynomialKernel(order=0, log_sigma2=-10.0),
+        kernels.PolynomialKernel(order=2, log_sigma2=-10.0),
+        kernels.PolynomialKernel(order=2, log_sigma2=0.0),
+        kernels.PolynomialKernel(order=5, log_sigma2=1.0, ndim=2),
+        kernels.PolynomialKernel(order=3, log_sigma2=-1.0, ndim=5, axes=2),
+        12. * kernels.ExpSine2Kernel(gamma=0.4, log_period=1.0, ndim=5),
+        12. * kernels.ExpSquaredKernel(0.4, ndim=3) + 0.1,
+    ]
+
+
+KERNELS = _kernels_to_test()
+
+
+def _test_kernel(kernel, N=20, seed=123, eps=1.32e-6):                          # tests/test_kernels.py:72-77
+    np.random.seed(seed)
+    t1 = np.random.randn(N, kernel.ndim)
+    kernel.test_gradient(t1, eps=eps)
+    kernel.test_gradient(t1, t1[:1], eps=eps)
+
+
+def _test_x_gradient_kernel(kernel, N=20, seed=123, eps=1.32e-6):               # tests/test_kernels.py:80-87
+    np.random.seed(seed)
+    t1 = np.random.randn(N, kernel.ndim)
+    kernel.test_x1_gradient(t1, eps=eps)
+    kernel.test_x1_gradient(t1, np.array(t1[:1]), eps=eps)
+    kernel.test_x2_gradient(t1, eps=eps)
+    kernel.test_x2_gradient(np.array(t1[:1]), t1, eps=eps)
+
+
+@pytest.mark.parametrize("idx", range(len(KERNELS)))
+def test_kernel(idx):
+    before = CALLS["hip"]
+    _test_kernel(KERNELS[idx])
+    assert CALLS["hip"] > before                              # (the finite differences went through the HIP evaluator)
+
+
+@pytest.mark.parametrize("idx", range(len(KERNELS)))
+def test_x_gradient_kernel(idx):
+    _test_x_gradient_kernel(KERNELS[idx])
+
+
+@pytest.mark.parametrize("idx", range(len(KERNELS)))
+def test_values_agree_with_the_reference_evaluator(idx, N=23, seed=5):
+    """Not in the reference's suite: the same object through both evaluators (value, parameter and coordinate gradients)."""
+    kernel = KERNELS[idx]
+    np.random.seed(seed)
+    x1, x2 = np.random.randn(N, kernel.ndim), np.random.randn(N - 4, kernel.ndim)
+    ref = ref_loader.load_kernel_interface()(kernel)
+    hip = kernel.kernel
+    assert isinstance(hip, hip_ki.KernelInterface)
+    which = np.ones(len(kernel.get_parameter_vector(include_frozen=True)), dtype=np.uint32)
+    tol = dict(rtol=1e-12, atol=1e-13)
+    assert np.allclose(hip.value_general(x1, x2), ref.value_general(x1, x2), **tol)
+    assert np.allclose(hip.value_symmetric(x1), ref.value_symmetric(x1), **tol)
+    assert np.allclose(hip.value_diagonal(x1[:N - 4], x2), ref.value_diagonal(x1[:N - 4], x2), **tol)
+    assert np.allclose(hip.gradient_general(which, x1, x2), ref.gradient_general(which, x1, x2), **tol)
+    assert np.allclose(hip.gradient_symmetric(which, x1), ref.gradient_symmetric(which, x1), **tol)
+    assert np.allclose(hip.x1_gradient_general(x1, x2), ref.x1_gradient_general(x1, x2), **tol)
+    assert np.allclose(hip.x2_gradient_general(x1, x2), ref.x2_gradient_general(x1, x2), **tol)
+
+
+STATIONARY = [                                                                  # tests/test_kernels.py:90-98
+    ("ExpKernel", {}),
+    ("ExpSquaredKernel", {}),
+    ("Matern32Kernel", {}),
+    ("Matern52Kernel", {}),
+    ("RationalQuadraticKernel", dict(log_alpha=np.log(1.0))),
+    ("RationalQuadraticKernel", dict(log_alpha=np.log(0.1))),
+    ("RationalQuadraticKernel", dict(log_alpha=np.log(10.0))),
+]
+
+
+@pytest.mark.parametrize("name,kwargs", STATIONARY)
+def test_stationary(name, kwargs):                                              # tests/test_kernels.py:100-137
+    kernel_type = getattr(kernels, name)
+
+    def build_kernel(metric, **more):
+        kws = dict(kwargs, **more)
+        return kernel_type(metric=metric, **kws)
+
+    for args, more in (((0.1,), {}), ((1.0,), {}), ((10.0,), {}), (([1.0, 0.1, 10.0],), dict(ndim=3)), ((1.0,), dict(ndim=3))):
+        kernel = build_kernel(*args, **more)
+        _test_kernel(kernel)
+        _test_x_gradient_kernel(kernel)
+    with pytest.raises(ValueError):
+        build_kernel([1.0, 0.1, 10.0, 500], ndim=3)
+    kernel = build_kernel(1.0, ndim=3, axes=2)
+    _test_kernel(kernel)
+    _test_x_gradient_kernel(kernel)
+    kernel = build_kernel(1.0, ndim=3, axes=2, block=(-0.1, 0.1))
+    _test_kernel(kernel)
+    _test_x_gradient_kernel(kernel)
+
+
+def _general_metric(metric, N=100, ndim=3):                                     # tests/test_metrics.py:40-83
+    kernel = 0.1 * kernels.ExpSquaredKernel(metric, ndim=ndim)
+    x = np.random.rand(N, ndim)
+    M0 = kernel.get_value(x)
+    gp = GP(kernel, solver=george_amd.BasicSolver)
+    M1 = gp.get_matrix(x)
+    assert np.allclose(M0, M1)
+    M2 = np.empty((N, N))
+    for i in range(N):
+        for j in range(N):
+            r = x[i] - x[j]
+            r2 = np.dot(r, np.linalg.solve(metric, r))
+            M2[i, j] = 0.1 * np.exp(-0.5 * r2)
+    assert np.allclose(M0, M2)
+
+
+def test_general_metric(seed=1234, N=2, ndim=3):                                # tests/test_metrics.py:86-95
+    np.random.seed(seed)
+    _general_metric(np.eye(ndim), N=N, ndim=ndim)
+    L = np.random.randn(ndim, ndim)
+    L[np.diag_indices(ndim)] = np.exp(L[np.diag_indices(ndim)])
+    L[np.triu_indices(ndim, 1)] = 0.0
+    metric = np.dot(L, L.T)
+    _general_metric(metric, N=N, ndim=ndim)
+    _general_metric(metric, N=60, ndim=ndim)                 # (more than the reference's two points)
+
+
+def test_axis_aligned_metric(seed=1234, N=100, ndim=3):                         # tests/test_metrics.py:98-112
+    np.random.seed(seed)
+    kernel = 0.1 * kernels.ExpSquaredKernel(np.ones(ndim), ndim=ndim)
+    x = np.random.rand(N, ndim)
+    M0 = kernel.get_value(x)
+    gp = GP(kernel, solver=george_amd.BasicSolver)
+    M1 = gp.get_matrix(x)
+    assert np.allclose(M0, M1)
+    M2 = 0.1 * np.exp(-0.5 * np.sum((x[None, :, :] - x[:, None, :]) ** 2, axis=-1))
+    assert np.allclose(M0, M2)
+
+
+@pytest.mark.parametrize("solver", ["basic", "hodlr"])
+def test_first_tutorial_numbers(solver):
+    """docs/tutorials/first.rst:27-33 (data), :57-59 (model), :91 "Initial ln-likelihood: -11.82", :119 fun: 9.225282556043894,
+    :129 "Final ln-likelihood: -9.23" -- george.GP with the HIP solver AND the HIP evaluator."""
+    from scipy.optimize import minimize
+    np.random.seed(1234)
+    x = 10 * np.sort(np.random.rand(15))
+    yerr = 0.2 * np.ones_like(x)
+    y = np.sin(x) + yerr * np.random.randn(len(x))
+    kernel = np.var(y) * kernels.ExpSquaredKernel(0.5)
+    kw = {} if solver == "basic" else {"tol": 1e-12}
+    gp = GP(kernel, solver=george_amd.BasicSolver if solver == "basic" else george_amd.HODLRSolver, **kw)
+    gp.compute(x, yerr)
+    before = CALLS["hip"]
+    x_pred = np.linspace(0, 10, 500)
+    pred, pred_var = gp.predict(y, x_pred, return_var=True)
+    assert CALLS["hip"] > before and np.all(pred_var > 0) and pred.shape == (500,)
+    assert "{0:.2f}".format(gp.log_likelihood(y)) == "-11.82"
+
+    def neg_ln_like(p):
+        gp.set_parameter_vector(p)
+        return -gp.log_likelihood(y)
+
+    def grad_neg_ln_like(p):
+        gp.set_parameter_vector(p)
+        return -gp.grad_log_likelihood(y)
+
+    result = minimize(neg_ln_like, gp.get_parameter_vector(), jac=grad_neg_ln_like)
+    assert result.success
+    assert abs(result.fun - 9.225282556043894) < 1e-7
+    assert np.allclose(result.x, [-0.48730733, 0.60407551], atol=2e-4)
+    gp.set_parameter_vector(result.x)
+    assert "{0:.2f}".format(gp.log_likelihood(y)) == "-9.23"
