@@ -20,8 +20,11 @@
 //          multiply by L_jj^-T (left-looking inside the panel, as the launch chain's rows-below stream) -- and the
 //          previous panel's contribution to the next block column, in four pieces as its columns complete;
 //   lo   : everything older than the previous panel, 128 x 128 tiles, k ranges of up to 2048 (the bulk of the flops).
-// crit and hi are claimed only when the task at the head has all its inputs (a compare-and-swap on the head index);
-// lo hands out tickets in order and the holder waits for its inputs, serving crit and hi meanwhile.
+// Every queue is cut into BUCKETS with a gate (a counter that must have reached a value: "L_jj^-1 is there"); inside an open
+// bucket tasks are handed out by a fetch-and-add ticket -- no compare-and-swap chain: the first form claimed only a RUNNABLE
+// head, one claim per ~3.5 us whatever the number of idle workgroups, 8x slower than the launch chain (profiles/r05/
+// dataflow_first_contact.md).  A claimed task whose inputs are not there yet is waited for briefly and then HELD: its owner
+// goes on serving the other queues (one held task per queue and workgroup) and starts it when it becomes runnable.
 //
 // Dependencies are not stored: they follow from a task's fields and three families of monotone counters,
 //   D          diagonal steps finished (L_jj^-1 is readable when D > j),
@@ -50,15 +53,21 @@
 #define DF_NEARF 8           // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time
 #define DF_CHUNK 16          // lo queue: tile columns per task (K = 2048)
 #define DF_NQ 3
+#define DF_SCAN 6            // buckets a claim looks into, beyond the used-up ones
+#define DF_HALVES 0          // 1: the tasks next to the front as 64-row half tiles (measured: a K = 128 task is bound by its eight
+                             //    dependent slab round trips, ~20 us whatever the tile height -- halves only double the task count)
 
 struct DfTask {              // 16 bytes
   uint16_t i, j;             // tile
   uint16_t k0, k1;           // C -= L(i, k0:k1) L(j, k0:k1)^T   (k1 == k0: no update; then k0 = the k steps the tile must have)
   uint8_t half;              // 0, 1: rows [64 half, 64 half + 64) of the tile;  2: the whole tile
-  uint8_t fin;               // then C <- C L_jj^-T (in place; half tiles only)
+  uint8_t fin;               // then C <- C L_jj^-T (in place)
   uint16_t pad[3];
 };
 static_assert(sizeof(DfTask) == 16, "DfTask is one 16-byte load");
+struct DfBucket {            // tasks [start, start + size) of a queue, claimable once cnt[gate_word] >= gate_val
+  uint32_t start, size, gate_word, gate_val;
+};
 
 // counter words (unsigned), hot ones on lines of their own
 #define DF_D 0
@@ -68,20 +77,32 @@ static_assert(sizeof(DfTask) == 16, "DfTask is one 16-byte load");
 #define DF_STAT 192          // [0] tasks run, [1] idle polls (debug)
 #define DF_ROWH 256
 static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
-static inline size_t df_words(int nt) { return df_off_kd(nt) + (size_t)nt * (nt + 1); }
+static inline size_t df_off_next(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }   // per-bucket ticket counters
+static inline size_t df_words(int nt) { return df_off_next(nt) + 4 * (size_t)nt + 8; }       // (three crit buckets and a hi bucket per link, one lo)
 
 // ------------------------------------------------------------------------------------------------ the schedule (host)
 struct DfSchedule {
   std::vector<DfTask> q[DF_NQ];
+  std::vector<DfBucket> b[DF_NQ];
 };
 static void df_build(int nt, DfSchedule& s) {
+  // key: (bucket, order inside the bucket ...)
   typedef std::tuple<int, int, int, int, int, int> Key;
-  std::vector<std::pair<Key, DfTask>> crit, hi, lo;
+  std::vector<std::pair<Key, DfTask>> qs[DF_NQ];
   auto task = [](int i, int j, int k0, int k1, int half, int fin) {
     DfTask t; memset(&t, 0, sizeof(t));
     t.i = (uint16_t)i; t.j = (uint16_t)j; t.k0 = (uint16_t)k0; t.k1 = (uint16_t)k1; t.half = (uint8_t)half; t.fin = (uint8_t)fin;
     return t;
   };
+  // a task next to the front: one whole tile, or its two halves
+  auto near_task = [&](int q, int bucket, int cls, int i, int j, int k0, int k1, int fin) {
+    if (DF_HALVES) { for (int h = 0; h < 2; ++h) qs[q].push_back({Key(bucket, cls, i, j, h, 0), task(i, j, k0, k1, h, fin)}); }
+    else qs[q].push_back({Key(bucket, cls, i, j, 0, 0), task(i, j, k0, k1, 2, fin)});
+  };
+  // crit buckets of link l: 3 l = behind D > l, the multiplies by L_ll^-T of the near rows, then their k = l updates that need
+  // only those; 3 l + 1 = the k = l updates of tile column l + 1, whose B operand L(l+1, l) is the diagonal worker's (gate: its
+  // row counter); 3 l + 2 = step k = l of the NEXT panel's diagonal-block tiles (they also wait for the lo queue: a bucket of
+  // their own, or they would stand in front of this panel's tasks)
   for (int j = 0; j < nt; ++j) {
     const int p = j / DF_PW, q0 = DF_PW * p;
     for (int i = j; i < nt; ++i) {
@@ -91,48 +112,62 @@ static void df_build(int nt, DfSchedule& s) {
       if (p >= 2) {
         const int wend = std::min(DF_PW * (p - 1), kmax);
         for (int k0 = 0; k0 < wend; k0 += DF_CHUNK)
-          lo.push_back({Key(p, j, i, k0, 0, 0), task(i, j, k0, std::min(k0 + DF_CHUNK, wend), 2, 0)});
+          qs[2].push_back({Key(0, p, i < DF_PW * p + DF_NEARF ? 0 : 1, j, i, k0), task(i, j, k0, std::min(k0 + DF_CHUNK, wend), 2, 0)});
       }
       // (2) the previous panel
       if (p >= 1) {
         const int a0 = DF_PW * (p - 1), a1 = std::min(DF_PW * p, kmax);
         if (i < DF_PW * p + DF_NEARF) {
-          for (int k = a0; k < a1; ++k)
-            for (int h = 0; h < 2; ++h) crit.push_back({Key(k, 1, j == k + 1 ? 1 : 0, i, j, h), task(i, j, k, k + 1, h, 0)});
+          for (int k = a0; k < a1; ++k) near_task(0, 3 * k + (j == k + 1 ? 1 : 2), 1, i, j, k, k + 1, 0);
         } else {
           static const int cut[5] = {0, 4, 6, 7, 8};
           for (int c = 0; c < 4; ++c) {
             const int k0 = a0 + cut[c], k1 = std::min(a0 + cut[c + 1], a1);
-            if (k1 > k0) hi.push_back({Key(k1 - 1, 1, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
+            if (k1 > k0) qs[1].push_back({Key(k1 - 1, 1, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
           }
         }
       }
       // (3) inside the panel, eagerly for the rows near the front
       if (kmax > q0 && near_row)
-        for (int k = q0; k < kmax; ++k)
-          for (int h = 0; h < 2; ++h) crit.push_back({Key(k, 1, j == k + 1 ? 1 : 0, i, j, h), task(i, j, k, k + 1, h, 0)});
+        for (int k = q0; k < kmax; ++k) near_task(0, 3 * k + (j == k + 1 ? 1 : 0), 1, i, j, k, k + 1, 0);
       // (4) the multiply by L_jj^-T (rows j + 2 and below; row j + 1 is the diagonal worker's)
       if (i >= j + 2) {
-        if (near_row) {
-          for (int h = 0; h < 2; ++h) crit.push_back({Key(j, 0, 0, i, j, h), task(i, j, j, j, h, 1)});
-        } else {
-          for (int h = 0; h < 2; ++h) hi.push_back({Key(j, 0, i, j, h, 0), task(i, j, kmax > q0 ? q0 : j, j, h, 1)});
+        if (near_row) near_task(0, 3 * j, 0, i, j, j, j, 1);
+        else {
+          // far rows: the in-panel k range and the multiply as ONE task per HALF tile -- a row's eight tasks of a panel follow
+          // one another (36 products), and as whole tiles (23-27 us per product beside a second workgroup on the CU) they took
+          // longer than the diagonal worker needs for the panel: rows finished late, the lo queue behind them stood still
+          for (int h = 0; h < 2; ++h) qs[1].push_back({Key(j, 0, i, j, h, 0), task(i, j, kmax > q0 ? q0 : j, j, h, 1)});
         }
       }
     }
   }
-  std::vector<std::pair<Key, DfTask>>* all[DF_NQ] = {&crit, &hi, &lo};
   for (int q = 0; q < DF_NQ; ++q) {
-    std::stable_sort(all[q]->begin(), all[q]->end(), [](const std::pair<Key, DfTask>& a, const std::pair<Key, DfTask>& b) { return a.first < b.first; });
-    s.q[q].clear();
-    s.q[q].reserve(all[q]->size());
-    for (auto& e : *all[q]) s.q[q].push_back(e.second);
+    std::stable_sort(qs[q].begin(), qs[q].end(), [](const std::pair<Key, DfTask>& a, const std::pair<Key, DfTask>& b) { return a.first < b.first; });
+    s.q[q].clear(); s.b[q].clear();
+    s.q[q].reserve(qs[q].size());
+    int cur = -1;
+    for (auto& e : qs[q]) {
+      const int bk = std::get<0>(e.first);
+      if (bk != cur) {
+        cur = bk;
+        DfBucket B; B.start = (uint32_t)s.q[q].size(); B.size = 0;
+        if (q == 2) { B.gate_word = DF_D; B.gate_val = 0; }                                          // always open
+        else if (q == 1) { B.gate_word = DF_D; B.gate_val = (uint32_t)bk + 1; }                      // D > link
+        else if (bk % 3 != 1) { B.gate_word = DF_D; B.gate_val = (uint32_t)(bk / 3) + 1; }           // D > link
+        else { B.gate_word = DF_ROWH + 2 * (uint32_t)(bk / 3 + 1); B.gate_val = (uint32_t)(bk / 3) + 1; }   // L(l+1, l) published
+        s.b[q].push_back(B);
+      }
+      s.q[q].push_back(e.second);
+      s.b[q].back().size += 1;
+    }
   }
 }
 
 // the schedule of an nt x nt tile matrix, for the replay in tests/test_dataflow_schedule.py (host only, no device needed):
-// counts[q] = tasks of queue q (0 crit, 1 hi, 2 lo); out (when not NULL): rows of 7 ints {queue, i, j, k0, k1, half, fin},
-// queue by queue in claim order, at most max_rows of them
+// counts[q] = tasks of queue q (0 crit, 1 hi, 2 lo); out (when not NULL): rows of 10 ints {queue, i, j, k0, k1, half, fin,
+// bucket, gate word, gate value} queue by queue, bucket by bucket, in ticket order, at most max_rows of them (gate word: 0 = D,
+// 256 + 2 r + h = rowh[r, h])
 extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows) {
   if (nt <= 0 || nt > 4096 || !counts) { gh_set_error("dflow_schedule: bad argument"); return GH_ERR_BAD_ARG; }
   DfSchedule s;
@@ -141,10 +176,14 @@ extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out
   for (int q = 0; q < DF_NQ; ++q) {
     counts[q] = (int32_t)s.q[q].size();
     if (!out) continue;
-    for (const DfTask& t : s.q[q]) {
+    size_t bi = 0;
+    for (size_t x = 0; x < s.q[q].size(); ++x) {
+      const DfTask& t = s.q[q][x];
+      while (bi + 1 < s.b[q].size() && x >= s.b[q][bi + 1].start) ++bi;
       if (r >= max_rows) return GH_OK;
-      int32_t* o = out + 7 * r++;
+      int32_t* o = out + 10 * r++;
       o[0] = q; o[1] = t.i; o[2] = t.j; o[3] = t.k0; o[4] = t.k1; o[5] = t.half; o[6] = t.fin;
+      o[7] = (int32_t)bi; o[8] = (int32_t)s.b[q][bi].gate_word; o[9] = (int32_t)s.b[q][bi].gate_val;
     }
   }
   return GH_OK;
@@ -157,7 +196,9 @@ struct DfArgs {
   long long* info;
   unsigned* cnt;
   const DfTask* tasks[DF_NQ];
-  unsigned count[DF_NQ];
+  const DfBucket* buckets[DF_NQ];
+  unsigned nb[DF_NQ];            // buckets per queue
+  unsigned off_next[DF_NQ];      // cnt + off_next[q] + b: the ticket counter of bucket b of queue q
   unsigned off_kd;
   int nt;
   unsigned long long* trace;     // debugging aid (gh_debug_dflow_trace): [0] = records used, then 4 words per record; NULL: off
@@ -314,7 +355,10 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
   if (s_state < 0) return;
   __syncthreads();
 
-  unsigned ticket = 0xffffffffu;                 // (lane 0) a claimed task of the lo queue that waits for its inputs
+  // (lane 0) per queue: a claimed task that waits for its inputs (index into the queue), or none
+  unsigned held[DF_NQ];
+#pragma unroll
+  for (int q = 0; q < DF_NQ; ++q) held[q] = 0xffffffffu;
   for (;;) {
     if (tid == 0) {
       int st = 0;
@@ -323,35 +367,56 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       for (;;) {
         if (df_ld(cnt + DF_ABORT) != 0u) { st = -1; break; }
         bool anyleft = false;
-#pragma unroll 1
-        for (int q = 0; q < DF_NQ - 1 && st == 0; ++q) {
-          unsigned* const head = cnt + DF_HEAD + 32 * q;
-          unsigned h = df_ld(head);
-          while (h < a.count[q]) {
-            anyleft = true;
-            const DfTask t = a.tasks[q][h];
-            if (!df_ready(a, t)) break;
-            unsigned expect = h;
-            if (__hip_atomic_compare_exchange_strong(head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-              s_task = t; st = 1 + q; break;
+#pragma unroll
+        for (int q = 0; q < DF_NQ; ++q) {
+          if (st != 0) continue;
+          bool fresh = false;
+          if (held[q] == 0xffffffffu) {
+            // claim: from the first bucket that is not used up on, at most DF_SCAN of them, none behind a closed D gate (those
+            // open in order).  crit and hi LOOK before they take a ticket: the next task of the bucket must be runnable -- a
+            // ticket for a task whose inputs are far away would keep its owner from the lo queue (or, held, start late behind
+            // its owner's lo task: the second form of this kernel lost 25 of 37 ms at N = 16384 that way)
+            unsigned* const hint = cnt + DF_HEAD + 32 * q;
+            unsigned bk = df_ld(hint);
+            const unsigned bk0 = bk;
+            bool front = true;                  // every bucket before bk is used up
+            for (int scan = 0; bk < a.nb[q] && scan < DF_SCAN; ++bk) {
+              const DfBucket B = a.buckets[q][bk];
+              unsigned* const next = cnt + a.off_next[q] + bk;
+              const unsigned nx = df_ld(next);
+              if (nx >= B.size) { if (front) __hip_atomic_fetch_max(hint, bk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+              front = false;
+              anyleft = true;
+              ++scan;
+              if (df_ld(cnt + B.gate_word) < B.gate_val) { if (B.gate_word == DF_D) break; continue; }
+              if (q < DF_NQ - 1 && !df_ready(a, a.tasks[q][B.start + nx])) continue;
+              const unsigned tk = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (tk < B.size) { held[q] = B.start + tk; fresh = true; break; }
             }
-            h = expect;
+            (void)bk0;
+          }
+          if (held[q] != 0xffffffffu) {
+            anyleft = true;
+            const DfTask t = a.tasks[q][held[q]];
+            bool ok = df_ready(a, t);
+            if (!ok && fresh && q < DF_NQ - 1) {
+              // just claimed and not runnable: its inputs are tasks of the same link, in flight -- wait a little before
+              // going on with other work (a task that is held while its owner runs a long lo task starts late)
+              const long long w0 = wall_clock64();
+              const long long lim = q == 0 ? 20000 : 5000;                   // 200 us / 50 us
+              while (!ok && wall_clock64() - w0 < lim) {
+                __builtin_amdgcn_s_sleep(4);
+                if (df_ld(cnt + DF_ABORT) != 0u) break;
+                ok = df_ready(a, t);
+              }
+            }
+            if (ok) { s_task = t; held[q] = 0xffffffffu; st = 1 + q; }
           }
         }
         if (st) break;
-        unsigned* const head_lo = cnt + DF_HEAD + 32 * (DF_NQ - 1);
-        if (ticket == 0xffffffffu && df_ld(head_lo) < a.count[DF_NQ - 1]) {
-          const unsigned tk = __hip_atomic_fetch_add(head_lo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (tk < a.count[DF_NQ - 1]) ticket = tk;
-        }
-        if (ticket != 0xffffffffu) {
-          anyleft = true;
-          const DfTask t = a.tasks[DF_NQ - 1][ticket];
-          if (df_ready(a, t)) { s_task = t; ticket = 0xffffffffu; st = DF_NQ; break; }
-        }
-        if (!anyleft) { st = -1; break; }        // nothing left to claim
-        if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
-        if ((++spins & 63u) == 0u && wall_clock64() - t0 > DF_TIMEOUT_TICKS) { df_st(cnt + DF_ABORT, 2u); st = -1; break; }
+        if (!anyleft) { st = -1; break; }        // nothing left to claim, nothing held
+        if (spins < 4) __builtin_amdgcn_s_sleep(16); else if (spins < 16) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(127);
+        if ((++spins & 31u) == 0u && wall_clock64() - t0 > DF_TIMEOUT_TICKS) { df_st(cnt + DF_ABORT, 2u); st = -1; break; }
       }
       if (st > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_state = st;
@@ -385,8 +450,13 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
       }
-      gh_tile64_nt<false>(smem, C, ld, C, ld, a.dinv + (long)t.j * 128 * 128, 128, 128);
-      df_publish(cnt + DF_ROWH + 2 * t.i + t.half, (unsigned)t.j + 1u, nullptr, 0u);
+      if (t.half == 2) {
+        gh_tile128_nt<false>(smem, C, ld, C, ld, a.dinv + (long)t.j * 128 * 128, 128, 128);
+        df_publish(cnt + DF_ROWH + 2 * t.i, (unsigned)t.j + 1u, cnt + DF_ROWH + 2 * t.i + 1, (unsigned)t.j + 1u);
+      } else {
+        gh_tile64_nt<false>(smem, C, ld, C, ld, a.dinv + (long)t.j * 128 * 128, 128, 128);
+        df_publish(cnt + DF_ROWH + 2 * t.i + t.half, (unsigned)t.j + 1u, nullptr, 0u);
+      }
     } else if (t.half == 2) {
       df_publish(kd, t.k1, kd + 1, t.k1);
     } else {
@@ -413,7 +483,9 @@ __global__ void dflow_check_kernel(const unsigned* cnt, long long* info) {
 // ------------------------------------------------------------------------------------------------ host side
 struct DfDeviceSchedule {
   DfTask* d[DF_NQ] = {nullptr, nullptr, nullptr};
+  DfBucket* b[DF_NQ] = {nullptr, nullptr, nullptr};
   unsigned count[DF_NQ] = {0, 0, 0};
+  unsigned nb[DF_NQ] = {0, 0, 0};
 };
 static std::mutex g_df_mutex;
 static std::map<std::pair<int, int>, DfDeviceSchedule> g_df_cache;     // (device, nt): never freed (a few MB per size)
@@ -462,9 +534,12 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
       DfDeviceSchedule n;
       for (int q = 0; q < DF_NQ; ++q) {
         n.count[q] = (unsigned)s.q[q].size();
+        n.nb[q] = (unsigned)s.b[q].size();
         if (s.q[q].empty()) continue;
         GH_HIP(hipMalloc((void**)&n.d[q], s.q[q].size() * sizeof(DfTask)));
         GH_HIP(hipMemcpy(n.d[q], s.q[q].data(), s.q[q].size() * sizeof(DfTask), hipMemcpyHostToDevice));
+        GH_HIP(hipMalloc((void**)&n.b[q], s.b[q].size() * sizeof(DfBucket)));
+        GH_HIP(hipMemcpy(n.b[q], s.b[q].data(), s.b[q].size() * sizeof(DfBucket), hipMemcpyHostToDevice));
       }
       it = g_df_cache.emplace(std::make_pair(dev, nt), n).first;
     }
@@ -478,7 +553,12 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
   }
   DfArgs a;
   a.A = A; a.ld = (long)ld; a.dinv = dinv; a.info = d_info; a.cnt = counters;
-  for (int q = 0; q < DF_NQ; ++q) { a.tasks[q] = ds.d[q]; a.count[q] = ds.count[q]; }
+  unsigned at = (unsigned)df_off_next(nt);
+  for (int q = 0; q < DF_NQ; ++q) {
+    a.tasks[q] = ds.d[q]; a.buckets[q] = ds.b[q]; a.nb[q] = ds.nb[q]; a.off_next[q] = at;
+    at += ds.nb[q];
+  }
+  if ((size_t)at > df_words(nt)) { gh_set_error("dflow: bucket counters overflow"); return GH_ERR_BAD_ARG; }
   a.off_kd = (unsigned)df_off_kd(nt); a.nt = nt;
   a.trace = nullptr; a.trace_cap = 0;
   if (g_df_trace_cap > 0) {

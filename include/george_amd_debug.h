@@ -33,7 +33,8 @@ int gh_microbench_hbm_copy(double* gbps_out);
  * give bit-identical factors. */
 int gh_debug_set_dataflow(int mode);
 /* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q
- * (0 crit, 1 hi, 2 lo); out (nullable): rows of 7 ints {queue, i, j, k0, k1, half, fin} in claim order, at most max_rows */
+ * (0 crit, 1 hi, 2 lo); out (nullable): rows of 10 ints {queue, i, j, k0, k1, half, fin, bucket, gate word, gate value} in
+ * ticket order, at most max_rows */
 int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows);
 /* per-task trace of the dataflow factorisation (single-threaded debugging aid).  capacity >= 0: from now on record up to
  * `capacity` tasks per factorisation (0 = off); out != NULL: first copy the last factorisation's records (4 x uint64 each:

@@ -42,7 +42,7 @@ def summarise(rec, n=None):
         if not m.any():
             continue
         d = (t1[m] - t0[m]) / 100.0
-        steps = np.where(half[m] == 2, 2, 1) * (k1[m] - k0[m]) + fin[m]       # half-tile products of 64 x 128 x 128
+        steps = np.where(half[m] == 2, 2, 1) * (k1[m] - k0[m] + fin[m])       # half-tile products of 64 x 128 x 128
         out.append("%-5s tasks %7d  mean %7.2f  median %7.2f  p90 %7.2f us   us per 64x128x128 product %.2f   busy %.1f ms" %
                    (name, m.sum(), d.mean(), np.median(d), np.percentile(d, 90), d.sum() / max(1, steps.sum()), d.sum() / 1e3))
     if work.any():

@@ -2,8 +2,8 @@
 
 The device kernel stores no dependencies: a task's inputs follow from its fields and three families of counters
 (D, rowh, kd).  This file restates that rule in Python (`ready`), hands the library's queues (gh_debug_dflow_schedule,
-host only) to a pool of simulated workers that claim exactly as the kernel does -- crit and hi by compare-and-swap on
-a runnable head, lo by ticket -- with random task durations, and checks
+host only) to a pool of simulated workers that claim exactly as the kernel does -- a ticket from the first open bucket of
+every queue, one held task per queue and worker -- with random task durations, and checks
 
   * every claim finds its inputs FINAL in the true state (not only in the counters),
   * no two tasks in flight touch the same half tile,
@@ -20,20 +20,27 @@ import pytest
 from george_amd import _native
 
 PW = 8
+SCAN = 6
 
 
 def schedule(nt):
+    """-> per queue: (tasks, buckets); task = (i, j, k0, k1, half, fin); bucket = [start, size, gate_word, gate_val]"""
     lib = _native.lib
     counts = (C.c_int32 * 3)()
     assert lib.gh_debug_dflow_schedule(nt, counts, None, 0) == 0
     tot = sum(counts)
-    out = (C.c_int32 * (7 * max(tot, 1)))()
+    out = (C.c_int32 * (10 * max(tot, 1)))()
     assert lib.gh_debug_dflow_schedule(nt, counts, out, tot) == 0
-    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 7)[:tot]
-    qs = [[], [], []]
+    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 10)[:tot]
+    qs = [([], []) for _ in range(3)]
     for r in rows:
-        qs[r[0]].append(tuple(int(v) for v in r[1:]))
-    assert [len(q) for q in qs] == list(counts)
+        tasks, buckets = qs[r[0]]
+        if r[7] == len(buckets):
+            buckets.append([len(tasks), 0, int(r[8]), int(r[9])])
+        assert r[7] == len(buckets) - 1
+        buckets[-1][1] += 1
+        tasks.append(tuple(int(v) for v in r[1:7]))
+    assert [len(q[0]) for q in qs] == list(counts)
     return qs
 
 
@@ -61,6 +68,13 @@ class Machine:
 
     def halves(self, half):
         return (0, 1) if half == 2 else (half,)
+
+    def word(self, w):
+        """the counter array as the kernel's gates address it: 0 = D, 256 + 2 r + h = rowh[r, h]"""
+        if w == 0:
+            return self.D
+        assert w >= 256 and (w - 256) // 2 < self.nt
+        return self.rowh[(w - 256) // 2][(w - 256) % 2]
 
     # the kernel's df_ready()
     def ready(self, t):
@@ -94,7 +108,7 @@ class Machine:
             for h in hs:
                 assert (i, k, h) in self.final, ("A operand not final", t, k)
         if fin:
-            assert half != 2 and i >= j + 2
+            assert i >= j + 2
             assert k1 == j and (j, j, 2) in self.final, ("L_jj^-1 not there", t)
         new = None
         if self.b:
@@ -162,16 +176,45 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
     qs = schedule(nt)
     m = Machine(nt, b, seed)
     rng = random.Random(seed)
-    heads = [0, 0, 0]
-    tickets = [None] * nworkers      # a claimed lo task waiting for its inputs
-    flight = [None] * nworkers       # (remaining ticks, effects)
-    dj, dphase, dwait = 0, 0, 0      # diagonal worker: step, part, remaining ticks
+    hint = [0, 0, 0]
+    nxt = [[0] * len(q[1]) for q in qs]          # ticket counters
+    held = [[None] * 3 for _ in range(nworkers)]  # per worker and queue: a claimed task waiting for its inputs
+    flight = [None] * nworkers                    # (remaining ticks, effects)
+    dj, dphase, dwait = 0, 0, 0                   # diagonal worker: step, part, remaining ticks
     done_tasks = 0
-    total = sum(len(q) for q in qs)
+    total = sum(len(q[0]) for q in qs)
     stall = 0
+
+    def claim(q):
+        """the kernel's claim: from the first bucket that is not used up on, at most SCAN of them, none behind a closed D
+        gate; crit and hi look at the bucket's next task first and take a ticket only when it is runnable"""
+        tasks, buckets = qs[q]
+        front, scan = True, 0
+        bk = hint[q]
+        while bk < len(buckets) and scan < SCAN:
+            start, size, gw, gv = buckets[bk]
+            if nxt[q][bk] >= size:
+                if front:
+                    hint[q] = max(hint[q], bk + 1)
+                bk += 1
+                continue
+            front = False
+            scan += 1
+            if m.word(gw) < gv:
+                if gw == 0:
+                    break
+                bk += 1
+                continue
+            if q < 2 and not m.ready(tasks[start + nxt[q][bk]]):
+                bk += 1
+                continue
+            tk = nxt[q][bk]
+            nxt[q][bk] += 1
+            return tasks[start + tk]
+        return None
+
     while dj < nt or done_tasks < total:
         progressed = False
-        # diagonal worker
         if dj < nt:
             if dwait > 0:
                 dwait -= 1
@@ -200,26 +243,22 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
                 continue
             if rng.random() < 0.3:       # this worker does not poll in this tick
                 continue
-            got = None
-            for q in (0, 1):
-                if heads[q] < len(qs[q]) and m.ready(qs[q][heads[q]]):
-                    got = qs[q][heads[q]]
-                    heads[q] += 1
-                    break
-            if got is None:
-                if tickets[w] is None and heads[2] < len(qs[2]):
-                    tickets[w] = qs[2][heads[2]]
-                    heads[2] += 1
+            for q in (0, 1, 2):
+                if held[w][q] is None:
+                    held[w][q] = claim(q)
+                    if held[w][q] is not None:
+                        progressed = True
+                if held[w][q] is not None and m.ready(held[w][q]):
+                    flight[w] = (rng.randint(0, max_flight), m.start(held[w][q]))
+                    held[w][q] = None
                     progressed = True
-                if tickets[w] is not None and m.ready(tickets[w]):
-                    got, tickets[w] = tickets[w], None
-            if got is not None:
-                flight[w] = (rng.randint(0, max_flight), m.start(got))
-                progressed = True
+                    break
         stall = 0 if progressed else stall + 1
-        assert stall < 50, ("no forward progress", dj, heads, [len(q) for q in qs], [t for t in tickets if t])
-    assert heads == [len(q) for q in qs] and all(t is None for t in tickets)
-    return m, qs
+        assert stall < 50, ("no forward progress", dj, hint, [[t for t in h if t] for h in held if any(h)][:5])
+    assert all(h == [None] * 3 for h in held)
+    for q in range(3):
+        assert all(nxt[q][bk] >= qs[q][1][bk][1] for bk in range(len(qs[q][1])))
+    return m, [q[0] for q in qs]
 
 
 def check_coverage(nt, m):
@@ -255,13 +294,17 @@ def test_structure_at_product_sizes(nt, workers):
 
 def test_queue_shapes():
     qs = schedule(40)
-    # lo: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns
-    for (i, j, k0, k1, half, fin) in qs[2]:
+    # lo: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns; one bucket, always open
+    assert len(qs[2][1]) == 1 and qs[2][1][0][3] == 0
+    for (i, j, k0, k1, half, fin) in qs[2][0]:
         assert half == 2 and not fin and 0 < k1 - k0 <= 16 and k1 <= PW * (j // PW - 1)
-    # crit: half tiles, one k step or a multiply
-    for (i, j, k0, k1, half, fin) in qs[0]:
-        assert half in (0, 1) and (k1 - k0 == 1 and not fin or k1 == k0 == j and fin)
-    # multiplies by L_jj^-T never on whole tiles, never for the diagonal worker's rows
-    for q in qs:
-        for (i, j, k0, k1, half, fin) in q:
-            assert i >= j and (not fin or (half != 2 and i >= j + 2 and k1 == j))
+    # crit: one k step or a multiply
+    for (i, j, k0, k1, half, fin) in qs[0][0]:
+        assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin)
+    # multiplies by L_jj^-T never for the diagonal worker's rows; gates open in order inside a queue
+    for tasks, buckets in qs:
+        for (i, j, k0, k1, half, fin) in tasks:
+            assert i >= j and (not fin or (i >= j + 2 and k1 == j))
+        d_gates = [b[3] for b in buckets if b[2] == 0]
+        assert d_gates == sorted(d_gates)
+        assert sum(b[1] for b in buckets) == len(tasks)
