@@ -10,21 +10,26 @@
 // is cut into passes does not change a bit: the factor, its diagonal inverses and the log-determinant are
 // bit-identical to factor_lookahead_deep()'s (tests/test_gpu_dataflow.py).
 //
-// Who does what.  Workgroup 0 is the DIAGONAL worker: for j = 0, 1, ...: L_j,j-1 = A_j,j-1 L_j-1,j-1^-T (the
-// sub-diagonal tile), A_jj -= L_j,j-1 L_j,j-1^T, potf2(A_jj) -- the critical path, on a CU of its own (the workgroup
-// that shares its CU leaves at once).  Every other workgroup is a WORKER that takes tasks from three queues, in
-// priority order:
-//   crit : tiles next to the front (rows that the diagonal worker needs within a panel): one k step at a time, as
-//          64-row half tiles; and the multiplies by L_jj^-T of those rows;
-//   hi   : rows far below the front -- per link j ONE task per half tile: the tile's in-panel k range and the
-//          multiply by L_jj^-T (left-looking inside the panel, as the launch chain's rows-below stream) -- and the
-//          previous panel's contribution to the next block column, in four pieces as its columns complete;
-//   lo   : everything older than the previous panel, 128 x 128 tiles, k ranges of up to 2048 (the bulk of the flops).
-// Every queue is cut into BUCKETS with a gate (a counter that must have reached a value: "L_jj^-1 is there"); inside an open
-// bucket tasks are handed out by a fetch-and-add ticket -- no compare-and-swap chain: the first form claimed only a RUNNABLE
-// head, one claim per ~3.5 us whatever the number of idle workgroups, 8x slower than the launch chain (profiles/r05/
-// dataflow_first_contact.md).  A claimed task whose inputs are not there yet is waited for briefly and then HELD: its owner
-// goes on serving the other queues (one held task per queue and workgroup) and starts it when it becomes runnable.
+// Who does what.  One workgroup, a launch of its own, is the DIAGONAL worker: for j = 0, 1, ...: L_j,j-1 = A_j,j-1 L_j-1,j-1^-T
+// (the sub-diagonal tile), A_jj -= L_j,j-1 L_j,j-1^T, potf2(A_jj) -- the critical path, on a CU of its own.  Every other
+// workgroup is a WORKER that takes tasks from five queues (priority order; p = the panel being factored):
+//   q0 : rows of panel p's diagonal block: the multiplies by L_jj^-T and the in-panel updates, one k step at a time;
+//   q1 : the eight rows below them (the next diagonal block): the same, eagerly, and the steps that carry panel p into the
+//        next block column's diagonal-block tiles -- so that those tiles are current when their panel begins;
+//   q2 : rows further down -- per link j ONE task per half tile: the tile's in-panel k range and the multiply by L_jj^-T
+//        (left-looking inside the panel, as the launch chain's rows-below stream);
+//   q3 : the previous panel's contribution to the far tiles of the next block column, in four pieces as its columns complete;
+//   q4 : everything older than the previous panel, 128 x 128 tiles, k ranges of up to 2048 (the bulk of the flops).
+// WHO FINDS THE RUNNABLE TASKS: one more workgroup, the SCANNER (a launch of its own, 512 threads).  A queue is an array of
+// tasks in need order; the scanner's lanes look at a window of each queue (64 + 64 + 128 + 128 + 128 tasks from the queues'
+// low-water marks, every lane checks its task's inputs) and append the runnable ones to the queue's READY LIST -- a plain
+// array as long as the queue, so nothing is ever reused or wraps -- pass after pass, ~4 us each.  A worker polls ONE cache
+// line (the five lists' tails and heads) and takes the first entry of the first non-empty list by compare-and-swap on its
+// head.  Nothing is handed out before it can run, nothing runnable inside a window waits behind something that is not, and an
+// idle worker costs the memory system two loads per poll.  (Forms tried before, profiles/r05/dataflow_*: workers claiming a
+// runnable queue HEAD by compare-and-swap: one claim per 3.5 us, 8x slower than the launch chain; tickets per bucket with
+// waiting owners: runnable tasks found late behind open buckets, 1.2-1.3x; every idle worker scanning the windows itself:
+// 500 x 420 loads per poll, 30x slower.)
 //
 // Dependencies are not stored: they follow from a task's fields and three families of monotone counters,
 //   D          diagonal steps finished (L_jj^-1 is readable when D > j),
@@ -33,9 +38,10 @@
 // written behind an agent-scope release by whoever finishes a task and polled relaxed, followed by ONE agent-scope
 // acquire, by whoever wants to start one (/opt/skills/guides: Guideline 16's recipe, the one the retired persistent
 // panel used bit-identically).  Forward progress: the queues are consistent with one topological order of all tasks
-// (tests/test_dataflow_schedule.py replays them), lo's tickets are claimed in that order, crit and hi only when
-// runnable -- so the earliest unfinished task is always either running or claimable by the next free workgroup, and a
-// workgroup that is not resident has claimed nothing.  Every wait gives up after 2 s and raises the abort word.
+// (tests/test_dataflow_schedule.py replays them); the earliest unfinished task of that order has all its inputs, every task
+// before it in its queue has been handed out, so it sits at its queue's low-water mark, inside the scanner's window -- and a
+// worker that is not resident has taken nothing.  The diagonal worker and the scanner are launched first and the workers'
+// stream waits until both run.  Every wait gives up after 2 s and raises the abort word.
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -52,8 +58,8 @@
 #define DF_NEARX 8           // rows [8 (p + 1), 8 (p + 1) + NEARX) are handled eagerly while panel p is factored
 #define DF_NEARF 8           // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time
 #define DF_CHUNK 16          // lo queue: tile columns per task (K = 2048)
-#define DF_NQ 3
-#define DF_SCAN 6            // buckets a claim looks into, beyond the used-up ones
+#define DF_NQ 5
+#define DF_SCAN_THREADS 512  // the scanner: wavefront 0 -> q0, 1 -> q1, 2-3 -> q2, 4-5 -> q3, 6-7 -> q4
 #define DF_HALVES 0          // 1: the tasks next to the front as 64-row half tiles (measured: a K = 128 task is bound by its eight
                              //    dependent slab round trips, ~20 us whatever the tile height -- halves only double the task count)
 
@@ -65,28 +71,25 @@ struct DfTask {              // 16 bytes
   uint16_t pad[3];
 };
 static_assert(sizeof(DfTask) == 16, "DfTask is one 16-byte load");
-struct DfBucket {            // tasks [start, start + size) of a queue, claimable once cnt[gate_word] >= gate_val
-  uint32_t start, size, gate_word, gate_val;
-};
-
 // counter words (unsigned), hot ones on lines of their own
 #define DF_D 0
 #define DF_ABORT 32
 #define DF_KEY 64
-#define DF_HEAD 96           // + 32 q
-#define DF_STAT 192          // [0] tasks run, [1] idle polls (debug)
-#define DF_ROWH 256
+#define DF_SCANNER 96        // the scanner runs
+#define DF_TAIL 128          // + q: entries of ready list q (written by the scanner); + 8 + q: entries taken (the workers' heads)
+#define DF_DBG 192           // [0] scanner passes, [1] its stage, [2] workers started, [3] workers gone, [4] diagonal worker gone, [5] tasks run, [6] gate passed
+#define DF_ROWH 320
 static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
-static inline size_t df_off_next(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }   // per-bucket ticket counters
-static inline size_t df_words(int nt) { return df_off_next(nt) + 4 * (size_t)nt + 8; }       // (three crit buckets and a hi bucket per link, one lo)
+static inline size_t df_off_lists(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }
+// per task one "handed out" word (the scanner's) and one ready-list slot
+static inline size_t df_words(int nt, size_t ntasks) { return df_off_lists(nt) + 2 * ntasks + 32; }
 
 // ------------------------------------------------------------------------------------------------ the schedule (host)
 struct DfSchedule {
   std::vector<DfTask> q[DF_NQ];
-  std::vector<DfBucket> b[DF_NQ];
+  size_t total() const { size_t n = 0; for (auto& v : q) n += v.size(); return n; }
 };
 static void df_build(int nt, DfSchedule& s) {
-  // key: (bucket, order inside the bucket ...)
   typedef std::tuple<int, int, int, int, int, int> Key;
   std::vector<std::pair<Key, DfTask>> qs[DF_NQ];
   auto task = [](int i, int j, int k0, int k1, int half, int fin) {
@@ -95,79 +98,62 @@ static void df_build(int nt, DfSchedule& s) {
     return t;
   };
   // a task next to the front: one whole tile, or its two halves
-  auto near_task = [&](int q, int bucket, int cls, int i, int j, int k0, int k1, int fin) {
-    if (DF_HALVES) { for (int h = 0; h < 2; ++h) qs[q].push_back({Key(bucket, cls, i, j, h, 0), task(i, j, k0, k1, h, fin)}); }
-    else qs[q].push_back({Key(bucket, cls, i, j, 0, 0), task(i, j, k0, k1, 2, fin)});
+  auto near_task = [&](int q, Key key, int i, int j, int k0, int k1, int fin) {
+    if (DF_HALVES) { for (int h = 0; h < 2; ++h) { std::get<5>(key) = h; qs[q].push_back({key, task(i, j, k0, k1, h, fin)}); } }
+    else qs[q].push_back({key, task(i, j, k0, k1, 2, fin)});
   };
-  // crit buckets of link l: 3 l = behind D > l, the multiplies by L_ll^-T of the near rows, then their k = l updates that need
-  // only those; 3 l + 1 = the k = l updates of tile column l + 1, whose B operand L(l+1, l) is the diagonal worker's (gate: its
-  // row counter); 3 l + 2 = step k = l of the NEXT panel's diagonal-block tiles (they also wait for the lo queue: a bucket of
-  // their own, or they would stand in front of this panel's tasks)
+  // which queue the k = l step / the multiply at link l of a tile in row i belongs to: the row's place below panel l / 8
+  auto rowq = [](int i, int link) { const int p = link / DF_PW; return i < DF_PW * (p + 1) ? 0 : (i < DF_PW * (p + 2) ? 1 : 2); };
   for (int j = 0; j < nt; ++j) {
     const int p = j / DF_PW, q0 = DF_PW * p;
     for (int i = j; i < nt; ++i) {
       const int kmax = std::max(0, i == j ? j - 1 : j);      // the workers' share of the tile's k range: [0, kmax)
-      const bool near_row = i < DF_PW * (p + 1) + DF_NEARX;
-      // (1) panels older than the previous one
+      // (1) panels older than the previous one: the block column's group runs while panel p - 1 is factored (need order)
       if (p >= 2) {
         const int wend = std::min(DF_PW * (p - 1), kmax);
         for (int k0 = 0; k0 < wend; k0 += DF_CHUNK)
-          qs[2].push_back({Key(0, p, i < DF_PW * p + DF_NEARF ? 0 : 1, j, i, k0), task(i, j, k0, std::min(k0 + DF_CHUNK, wend), 2, 0)});
+          qs[4].push_back({Key(p, i < DF_PW * (p + 1) ? 0 : 1, j, i, k0, 0), task(i, j, k0, std::min(k0 + DF_CHUNK, wend), 2, 0)});
       }
-      // (2) the previous panel
+      // (2) the previous panel: eagerly for the tiles of the next diagonal block (q1, their rows are the eight below panel
+      //     p - 1), in four pieces for the far ones (q3)
       if (p >= 1) {
         const int a0 = DF_PW * (p - 1), a1 = std::min(DF_PW * p, kmax);
-        if (i < DF_PW * p + DF_NEARF) {
-          for (int k = a0; k < a1; ++k) near_task(0, 3 * k + (j == k + 1 ? 1 : 2), 1, i, j, k, k + 1, 0);
+        if (i < DF_PW * (p + 1)) {
+          for (int k = a0; k < a1; ++k) near_task(1, Key(k, 1, j == k + 1 ? 1 : 0, i, j, 0), i, j, k, k + 1, 0);
         } else {
           static const int cut[5] = {0, 4, 6, 7, 8};
           for (int c = 0; c < 4; ++c) {
             const int k0 = a0 + cut[c], k1 = std::min(a0 + cut[c + 1], a1);
-            if (k1 > k0) qs[1].push_back({Key(k1 - 1, 1, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
+            if (k1 > k0) qs[3].push_back({Key(k1 - 1, j, i, 0, 0, 0), task(i, j, k0, k1, 2, 0)});
           }
         }
       }
-      // (3) inside the panel, eagerly for the rows near the front
-      if (kmax > q0 && near_row)
-        for (int k = q0; k < kmax; ++k) near_task(0, 3 * k + (j == k + 1 ? 1 : 0), 1, i, j, k, k + 1, 0);
+      // (3) inside the panel: one k step at a time for the rows of this and of the next diagonal block
+      if (kmax > q0 && i < DF_PW * (p + 2))
+        for (int k = q0; k < kmax; ++k) near_task(rowq(i, k), Key(k, 1, j == k + 1 ? 1 : 0, i, j, 0), i, j, k, k + 1, 0);
       // (4) the multiply by L_jj^-T (rows j + 2 and below; row j + 1 is the diagonal worker's)
       if (i >= j + 2) {
-        if (near_row) near_task(0, 3 * j, 0, i, j, j, j, 1);
+        if (i < DF_PW * (p + 2)) near_task(rowq(i, j), Key(j, 0, 0, i, j, 0), i, j, j, j, 1);
         else {
           // far rows: the in-panel k range and the multiply as ONE task per HALF tile -- a row's eight tasks of a panel follow
           // one another (36 products), and as whole tiles (23-27 us per product beside a second workgroup on the CU) they took
-          // longer than the diagonal worker needs for the panel: rows finished late, the lo queue behind them stood still
-          for (int h = 0; h < 2; ++h) qs[1].push_back({Key(j, 0, i, j, h, 0), task(i, j, kmax > q0 ? q0 : j, j, h, 1)});
+          // longer than the diagonal worker needs for the panel: rows finished late, the bulk behind them stood still
+          for (int h = 0; h < 2; ++h) qs[2].push_back({Key(j, i, h, 0, 0, 0), task(i, j, kmax > q0 ? q0 : j, j, h, 1)});
         }
       }
     }
   }
   for (int q = 0; q < DF_NQ; ++q) {
     std::stable_sort(qs[q].begin(), qs[q].end(), [](const std::pair<Key, DfTask>& a, const std::pair<Key, DfTask>& b) { return a.first < b.first; });
-    s.q[q].clear(); s.b[q].clear();
+    s.q[q].clear();
     s.q[q].reserve(qs[q].size());
-    int cur = -1;
-    for (auto& e : qs[q]) {
-      const int bk = std::get<0>(e.first);
-      if (bk != cur) {
-        cur = bk;
-        DfBucket B; B.start = (uint32_t)s.q[q].size(); B.size = 0;
-        if (q == 2) { B.gate_word = DF_D; B.gate_val = 0; }                                          // always open
-        else if (q == 1) { B.gate_word = DF_D; B.gate_val = (uint32_t)bk + 1; }                      // D > link
-        else if (bk % 3 != 1) { B.gate_word = DF_D; B.gate_val = (uint32_t)(bk / 3) + 1; }           // D > link
-        else { B.gate_word = DF_ROWH + 2 * (uint32_t)(bk / 3 + 1); B.gate_val = (uint32_t)(bk / 3) + 1; }   // L(l+1, l) published
-        s.b[q].push_back(B);
-      }
-      s.q[q].push_back(e.second);
-      s.b[q].back().size += 1;
-    }
+    for (auto& e : qs[q]) s.q[q].push_back(e.second);
   }
 }
 
 // the schedule of an nt x nt tile matrix, for the replay in tests/test_dataflow_schedule.py (host only, no device needed):
-// counts[q] = tasks of queue q (0 crit, 1 hi, 2 lo); out (when not NULL): rows of 10 ints {queue, i, j, k0, k1, half, fin,
-// bucket, gate word, gate value} queue by queue, bucket by bucket, in ticket order, at most max_rows of them (gate word: 0 = D,
-// 256 + 2 r + h = rowh[r, h])
+// counts[q] = tasks of queue q (DF_NQ = 5 queues); out (when not NULL): rows of 7 ints {queue, i, j, k0, k1, half, fin}, queue by
+// queue in need order, at most max_rows of them
 extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows) {
   if (nt <= 0 || nt > 4096 || !counts) { gh_set_error("dflow_schedule: bad argument"); return GH_ERR_BAD_ARG; }
   DfSchedule s;
@@ -176,14 +162,10 @@ extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out
   for (int q = 0; q < DF_NQ; ++q) {
     counts[q] = (int32_t)s.q[q].size();
     if (!out) continue;
-    size_t bi = 0;
-    for (size_t x = 0; x < s.q[q].size(); ++x) {
-      const DfTask& t = s.q[q][x];
-      while (bi + 1 < s.b[q].size() && x >= s.b[q][bi + 1].start) ++bi;
+    for (const DfTask& t : s.q[q]) {
       if (r >= max_rows) return GH_OK;
-      int32_t* o = out + 10 * r++;
+      int32_t* o = out + 7 * r++;
       o[0] = q; o[1] = t.i; o[2] = t.j; o[3] = t.k0; o[4] = t.k1; o[5] = t.half; o[6] = t.fin;
-      o[7] = (int32_t)bi; o[8] = (int32_t)s.b[q][bi].gate_word; o[9] = (int32_t)s.b[q][bi].gate_val;
     }
   }
   return GH_OK;
@@ -196,9 +178,9 @@ struct DfArgs {
   long long* info;
   unsigned* cnt;
   const DfTask* tasks[DF_NQ];
-  const DfBucket* buckets[DF_NQ];
-  unsigned nb[DF_NQ];            // buckets per queue
-  unsigned off_next[DF_NQ];      // cnt + off_next[q] + b: the ticket counter of bucket b of queue q
+  unsigned count[DF_NQ];
+  unsigned off_done[DF_NQ];      // cnt + off_done[q] + x: task x of queue q is on its ready list (the scanner's note)
+  unsigned off_list[DF_NQ];      // cnt + off_list[q] + e: entry e of ready list q = task index + 1 (0: not written yet)
   unsigned off_kd;
   int nt;
   unsigned long long* trace;     // debugging aid (gh_debug_dflow_trace): [0] = records used, then 4 words per record; NULL: off
@@ -249,7 +231,7 @@ __device__ __forceinline__ bool df_ready(const DfArgs& a, const DfTask& t) {
 // results of the calling workgroup to memory, then the counters (Guideline 16: plain stores, every wavefront drained,
 // barrier, one lane: agent release, drained again -- inline assembly, the compiler may drop a wait it can prove
 // redundant -- then the relaxed stores)
-__device__ __forceinline__ void df_publish(unsigned* w0, unsigned v0, unsigned* w1, unsigned v1) {
+__device__ __forceinline__ void df_publish(unsigned* cnt, unsigned* w0, unsigned v0, unsigned* w1, unsigned v1) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -280,7 +262,9 @@ __device__ __forceinline__ bool df_wait4(const DfArgs& a, const unsigned* w, uns
     *s_flag = good;
   }
   __syncthreads();
-  const bool r = *s_flag != 0;
+  // (through a scalar register: the compiler must SEE that every lane takes the same way out of the caller's loop, or it
+  //  is free to split the lanes over two loops -- see the workers' loop)
+  const bool r = __builtin_amdgcn_readfirstlane(*s_flag) != 0;
   __syncthreads();
   return r;
 }
@@ -311,11 +295,11 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         if (j > 1) {
           // the workers' share of both tiles: k < j - 1   (kd of (j, j - 1) and (j, j) are four consecutive words)
           const unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)j * (j + 1u) / 2u + (j - 1));
-          if (!df_wait4(a, kd, (unsigned)(j - 1), 4, &s_state)) return;
+          if (!df_wait4(a, kd, (unsigned)(j - 1), 4, &s_state)) { if (tid == 0) df_st(cnt + DF_DBG + 4, 100u + (unsigned)j); return; }
           if (TR) { df_trace(a, tt, j, j, 0, 0, 8, 2, 0); tt = wall_clock64(); }
         }
         gh_tile128_nt<false>(smem, Asub, ld, Asub, ld, dprev, 128, 128);                 // L(j, j-1), in place
-        df_publish(cnt + DF_ROWH + 2 * j, (unsigned)j, cnt + DF_ROWH + 2 * j + 1, (unsigned)j);
+        df_publish(cnt, cnt + DF_ROWH + 2 * j, (unsigned)j, cnt + DF_ROWH + 2 * j + 1, (unsigned)j);
         if (TR) { df_trace(a, tt, j, j - 1, 0, 0, 9, 2, 1); tt = wall_clock64(); }
         // (no barrier: the other wavefronts request the first slab and C while wavefront 0 is in the release)
         gh_tile128_nt<true>(smem, Ajj, ld, Asub, ld, Asub, ld, 128);                     // A_jj -= L(j, j-1) L(j, j-1)^T
@@ -329,9 +313,10 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         if (tid == 0) df_st(cnt + DF_ABORT, 1u);
         return;
       }
-      df_publish(cnt + DF_D, (unsigned)(j + 1), nullptr, 0u);
+      df_publish(cnt, cnt + DF_D, (unsigned)(j + 1), nullptr, 0u);
       if (TR) df_trace(a, tt, j, j, 0, 0, 11, 2, 0);
     }
+    if (tid == 0) df_st(cnt + DF_DBG + 4, 1u);
   }
 }
 
@@ -352,86 +337,72 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
     s_state = (k == mykey) ? -1 : 0;
   }
   __syncthreads();
-  if (s_state < 0) return;
+  if (__builtin_amdgcn_readfirstlane(s_state) < 0) return;
   __syncthreads();
+  if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-  // (lane 0) per queue: a claimed task that waits for its inputs (index into the queue), or none
-  unsigned held[DF_NQ];
-#pragma unroll
-  for (int q = 0; q < DF_NQ; ++q) held[q] = 0xffffffffu;
   for (;;) {
-    if (tid == 0) {
+    if (tid < 64) {
+      // ---- take the first entry of the first non-empty ready list.  The five tails and the five heads share ONE cache line and
+      // the wavefront reads it as one transaction (lane x loads word x): 500 polling workgroups reading ten words each, one load
+      // per word, saturated that line's memory channel and every task on the chip ran 3-4x slower (profiles/r05/dataflow_trace_session_l.log)
+      const int lane = tid;
       int st = 0;
       const long long t0 = wall_clock64();
       unsigned spins = 0;
       for (;;) {
-        if (df_ld(cnt + DF_ABORT) != 0u) { st = -1; break; }
-        bool anyleft = false;
+        const unsigned word = df_ld(cnt + (lane < 16 ? DF_TAIL + lane : DF_ABORT));
+        if (__builtin_amdgcn_readlane(word, 16) != 0u) { st = -1; break; }                      // (lanes >= 16 read the abort word)
+        bool alldone = true;
 #pragma unroll
         for (int q = 0; q < DF_NQ; ++q) {
           if (st != 0) continue;
-          bool fresh = false;
-          if (held[q] == 0xffffffffu) {
-            // claim: from the first bucket that is not used up on, at most DF_SCAN of them, none behind a closed D gate (those
-            // open in order).  crit and hi LOOK before they take a ticket: the next task of the bucket must be runnable -- a
-            // ticket for a task whose inputs are far away would keep its owner from the lo queue (or, held, start late behind
-            // its owner's lo task: the second form of this kernel lost 25 of 37 ms at N = 16384 that way)
-            unsigned* const hint = cnt + DF_HEAD + 32 * q;
-            unsigned bk = df_ld(hint);
-            const unsigned bk0 = bk;
-            bool front = true;                  // every bucket before bk is used up
-            for (int scan = 0; bk < a.nb[q] && scan < DF_SCAN; ++bk) {
-              const DfBucket B = a.buckets[q][bk];
-              unsigned* const next = cnt + a.off_next[q] + bk;
-              const unsigned nx = df_ld(next);
-              if (nx >= B.size) { if (front) __hip_atomic_fetch_max(hint, bk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
-              front = false;
-              anyleft = true;
-              ++scan;
-              if (df_ld(cnt + B.gate_word) < B.gate_val) { if (B.gate_word == DF_D) break; continue; }
-              if (q < DF_NQ - 1 && !df_ready(a, a.tasks[q][B.start + nx])) continue;
-              const unsigned tk = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (tk < B.size) { held[q] = B.start + tk; fresh = true; break; }
+          const unsigned tail = __builtin_amdgcn_readlane(word, q);
+          unsigned h = __builtin_amdgcn_readlane(word, 8 + q);
+          if (h < a.count[q]) alldone = false;
+          while (h < tail) {                                        // (wave-uniform loop; lane 0 acts)
+            unsigned got = 0u, now = h;
+            if (lane == 0) {
+              unsigned expect = h;
+              got = __hip_atomic_compare_exchange_strong(cnt + DF_TAIL + 8 + q, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+              now = expect;
             }
-            (void)bk0;
-          }
-          if (held[q] != 0xffffffffu) {
-            anyleft = true;
-            const DfTask t = a.tasks[q][held[q]];
-            bool ok = df_ready(a, t);
-            if (!ok && fresh && q < DF_NQ - 1) {
-              // just claimed and not runnable: its inputs are tasks of the same link, in flight -- wait a little before
-              // going on with other work (a task that is held while its owner runs a long lo task starts late)
-              const long long w0 = wall_clock64();
-              const long long lim = q == 0 ? 20000 : 5000;                   // 200 us / 50 us
-              while (!ok && wall_clock64() - w0 < lim) {
-                __builtin_amdgcn_s_sleep(4);
-                if (df_ld(cnt + DF_ABORT) != 0u) break;
-                ok = df_ready(a, t);
-              }
+            got = __builtin_amdgcn_readfirstlane(got); now = __builtin_amdgcn_readfirstlane(now);
+            if (got) {
+              unsigned e = 0u;                                      // (the entry was stored before the tail moved past it)
+              for (int tries = 0; tries < 200000 && (e = __builtin_amdgcn_readfirstlane(df_ld(cnt + a.off_list[q] + h))) == 0u; ++tries) __builtin_amdgcn_s_sleep(1);
+              if (e == 0u) { if (lane == 0) df_st(cnt + DF_ABORT, 2u); st = -1; break; }
+              if (lane == 0) s_task = a.tasks[q][e - 1u];
+              st = 1 + q; break;
             }
-            if (ok) { s_task = t; held[q] = 0xffffffffu; st = 1 + q; }
+            h = now;
           }
         }
         if (st) break;
-        if (!anyleft) { st = -1; break; }        // nothing left to claim, nothing held
-        if (spins < 4) __builtin_amdgcn_s_sleep(16); else if (spins < 16) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(127);
-        if ((++spins & 31u) == 0u && wall_clock64() - t0 > DF_TIMEOUT_TICKS) { df_st(cnt + DF_ABORT, 2u); st = -1; break; }
+        if (alldone) { st = -1; break; }           // every task has been taken
+        if (spins < 4) __builtin_amdgcn_s_sleep(16); else if (spins < 16) __builtin_amdgcn_s_sleep(64); else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+        if ((++spins & 63u) == 0u && wall_clock64() - t0 > DF_TIMEOUT_TICKS) { if (lane == 0) df_st(cnt + DF_ABORT, 2u); st = -1; break; }
       }
-      if (st > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      s_state = st;
+      if (st > 0 && lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (lane == 0) s_state = st;
     }
     __syncthreads();
-    if (s_state < 0) return;
+    // The way out of the loop must be UNIFORM for the compiler too: s_state comes from LDS, a per-lane value as far as it knows,
+    // and with a per-lane exit it restructured this loop into two -- the lanes that never enter the block above circling
+    // through the barrier and the task below on their own, lane 0 parked outside for ever: the scanner form's first build
+    // re-ran its first task ~10^5 times per second with the result never published (profiles/r05/dataflow_lane_split.md).
+    const int state = __builtin_amdgcn_readfirstlane(s_state);
+    if (state < 0) { if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     // (the task's fields as SCALARS: every address below is wave-uniform, and the tile functions want their operand bases
     //  in scalar registers -- a buffer descriptor built from a vector register costs a v_readfirstlane per DMA)
     const unsigned* const tw = (const unsigned*)&s_task;
     const unsigned w0 = __builtin_amdgcn_readfirstlane(tw[0]), w1 = __builtin_amdgcn_readfirstlane(tw[1]),
                    w2 = __builtin_amdgcn_readfirstlane(tw[2]);
     struct { unsigned i, j, k0, k1, half, fin; } t = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, w2 & 0xffu, (w2 >> 8) & 0xffu};
-    const int s_q = s_state - 1;
+    const int s_q = state - 1;
     const long long tt = TR ? wall_clock64() : 0;
     __syncthreads();
+    if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int r0 = t.half == 1 ? 64 : 0;
     double* const C = a.A + ((long)t.i * 128 + r0) * ld + (long)t.j * 128;
     unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)t.i * (t.i + 1u) / 2u + t.j);
@@ -442,6 +413,8 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       if (t.half == 2) gh_tile128_nt<true>(smem, C, ld, Ao, ld, Bo, ld, K);
       else gh_tile64_nt<true>(smem, C, ld, Ao, ld, Bo, ld, K);
     }
+    if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 255) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t.fin) {
       if (t.k1 > t.k0) {
         // the rows just written are this product's A operand: stores done, the CU's L1 dropped
@@ -452,17 +425,93 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       }
       if (t.half == 2) {
         gh_tile128_nt<false>(smem, C, ld, C, ld, a.dinv + (long)t.j * 128 * 128, 128, 128);
-        df_publish(cnt + DF_ROWH + 2 * t.i, (unsigned)t.j + 1u, cnt + DF_ROWH + 2 * t.i + 1, (unsigned)t.j + 1u);
+        df_publish(cnt, cnt + DF_ROWH + 2 * t.i, (unsigned)t.j + 1u, cnt + DF_ROWH + 2 * t.i + 1, (unsigned)t.j + 1u);
       } else {
         gh_tile64_nt<false>(smem, C, ld, C, ld, a.dinv + (long)t.j * 128 * 128, 128, 128);
-        df_publish(cnt + DF_ROWH + 2 * t.i + t.half, (unsigned)t.j + 1u, nullptr, 0u);
+        df_publish(cnt, cnt + DF_ROWH + 2 * t.i + t.half, (unsigned)t.j + 1u, nullptr, 0u);
       }
     } else if (t.half == 2) {
-      df_publish(kd, t.k1, kd + 1, t.k1);
+      df_publish(cnt, kd, t.k1, kd + 1, t.k1);
     } else {
-      df_publish(kd + t.half, t.k1, nullptr, 0u);
+      df_publish(cnt, kd + t.half, t.k1, nullptr, 0u);
     }
+    if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (TR) df_trace(a, tt, t.i, t.j, t.k0, t.k1, (unsigned)s_q, t.half, t.fin);
+  }
+}
+
+// The scanner (see the head of this file).  Wavefront -> queue: 0 -> q0, 1 -> q1, 2-3 -> q2, 4-5 -> q3, 6-7 -> q4; lane x of a
+// queue's wavefronts looks at task low[q] + x.  Per pass: inputs of every candidate checked, the runnable ones appended to the
+// queue's ready list in window order (ballot + prefix inside a wavefront, LDS across the two wavefronts of a queue), the tail
+// published behind the entries, the low-water mark moved over the leading handed-out tasks.  Only this workgroup writes the
+// lists, the tails and the notes: plain agent-scope stores, no read-modify-write.
+__global__ __launch_bounds__(DF_SCAN_THREADS) void dflow_scan_kernel(DfArgs a) {
+  __shared__ unsigned s_low[DF_NQ], s_tail[DF_NQ], s_cnt[8], s_lead[8];
+  __shared__ int s_stop;
+  unsigned* const cnt = a.cnt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = wave < 2 ? wave : 2 + (wave - 2) / 2;              // queue of this wavefront
+  const int wfirst = wave < 2 ? wave : 2 + 2 * (q - 2);            // first wavefront of that queue
+  const int x = (wave - wfirst) * 64 + lane;                      // place in the queue's window
+  if (tid < DF_NQ) { s_low[tid] = 0u; s_tail[tid] = 0u; }
+  if (tid == 0) { s_stop = 0; df_st(cnt + DF_SCANNER, 1u); }
+  __syncthreads();
+  long long t_progress = wall_clock64();
+  unsigned passes = 0;
+  for (;;) {
+    if (tid == 0) { df_st(cnt + DF_DBG, ++passes); df_st(cnt + DF_DBG + 1, 1u); }
+    const unsigned low = s_low[q], tail0 = s_tail[q];
+    const unsigned idx = low + (unsigned)x;
+    const bool valid = idx < a.count[q];
+    unsigned* const note = cnt + a.off_done[q] + (valid ? idx : 0u);
+    const unsigned was = valid ? df_ld(note) : 1u;
+    bool ok = false;
+    if (valid && was == 0u) { const DfTask t = a.tasks[q][idx]; ok = df_ready(a, t); }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    const unsigned long long out = __builtin_amdgcn_ballot_w64(ok || (valid && was != 0u));   // handed out after this pass
+    if (lane == 0) {
+      s_cnt[wave] = (unsigned)__builtin_popcountll(m);
+      s_lead[wave] = out == ~0ull ? 64u : (unsigned)__builtin_ctzll(~out);          // leading handed-out tasks of this wavefront's part
+    }
+    __syncthreads();
+    if (tid == 0) df_st(cnt + DF_DBG + 1, 2u);
+    // entries: window order
+    unsigned before = 0u;
+    for (int v = wfirst; v < wave; ++v) before += s_cnt[v];
+    if (ok) {
+      const unsigned pos = tail0 + before + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      df_st(cnt + a.off_list[q] + pos, idx + 1u);
+      df_st(note, 1u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) df_st(cnt + DF_DBG + 1, 3u);
+    if (wave == wfirst && lane == 0) {
+      const int nw = wave < 2 ? 1 : 2;
+      unsigned added = 0u, lead = 0u;
+      bool run = true;
+      for (int v = 0; v < nw; ++v) {
+        added += s_cnt[wfirst + v];
+        if (run) { lead += s_lead[wfirst + v]; run = s_lead[wfirst + v] == 64u; }
+      }
+      if (added) { df_st(cnt + DF_TAIL + q, tail0 + added); s_tail[q] = tail0 + added; }
+      unsigned nl = low + lead;
+      if (nl > a.count[q]) nl = a.count[q];
+      s_low[q] = nl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      bool all = true, moved = false;
+      for (int v = 0; v < 8; ++v) moved = moved || s_cnt[v] != 0u;
+      for (int v = 0; v < DF_NQ; ++v) all = all && s_low[v] >= a.count[v];
+      if (moved) t_progress = wall_clock64();
+      if (all) s_stop = 1;
+      else if (df_ld(cnt + DF_ABORT) != 0u) s_stop = 1;
+      else if (wall_clock64() - t_progress > DF_TIMEOUT_TICKS) { df_st(cnt + DF_ABORT, 2u); s_stop = 1; }
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_stop)) { if (tid == 0) df_st(cnt + DF_DBG + 1, 9u); return; }
+    __builtin_amdgcn_s_sleep(4);
   }
 }
 
@@ -472,7 +521,8 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
 // after 20 ms (the workers then run into their own time-out if the diagonal worker never comes).
 __global__ void dflow_gate_kernel(const unsigned* cnt) {
   const long long t0 = wall_clock64();
-  while (df_ld(cnt + DF_KEY) == 0u && wall_clock64() - t0 < 2000000LL) __builtin_amdgcn_s_sleep(8);
+  while ((df_ld(cnt + DF_KEY) == 0u || df_ld(cnt + DF_SCANNER) == 0u) && wall_clock64() - t0 < 2000000LL) __builtin_amdgcn_s_sleep(8);
+  df_st((unsigned*)cnt + DF_DBG + 6, 1u);
 }
 
 // the time-out of a wait (not a property of the matrix) as an impossible minor index: compute_finish() of gh_chol.hip tells it apart
@@ -482,13 +532,12 @@ __global__ void dflow_check_kernel(const unsigned* cnt, long long* info) {
 
 // ------------------------------------------------------------------------------------------------ host side
 struct DfDeviceSchedule {
-  DfTask* d[DF_NQ] = {nullptr, nullptr, nullptr};
-  DfBucket* b[DF_NQ] = {nullptr, nullptr, nullptr};
-  unsigned count[DF_NQ] = {0, 0, 0};
-  unsigned nb[DF_NQ] = {0, 0, 0};
+  DfTask* d[DF_NQ] = {};
+  unsigned count[DF_NQ] = {};
 };
 static std::mutex g_df_mutex;
 static std::map<std::pair<int, int>, DfDeviceSchedule> g_df_cache;     // (device, nt): never freed (a few MB per size)
+static std::map<int, size_t> g_df_total;                               // nt -> tasks of all queues
 
 // debugging aid: the next factorisations record one line per task (see df_trace); single-threaded use
 static long g_df_trace_cap = 0;
@@ -508,20 +557,28 @@ extern "C" int gh_debug_dflow_trace(int64_t capacity, uint64_t* out, int64_t max
   return GH_OK;
 }
 
-size_t gh_dflow_counter_bytes(int64_t np) { return df_words((int)(np / 128)) * sizeof(unsigned); }
+static size_t df_total_tasks(int nt) {
+  std::lock_guard<std::mutex> lk(g_df_mutex);
+  auto it = g_df_total.find(nt);
+  if (it != g_df_total.end()) return it->second;
+  DfSchedule s;
+  df_build(nt, s);
+  return g_df_total[nt] = s.total();
+}
+size_t gh_dflow_counter_bytes(int64_t np) { const int nt = (int)(np / 128); return df_words(nt, df_total_tasks(nt)) * sizeof(unsigned); }
 
 // factor the np x np matrix at A in place (lower triangle; np a multiple of 128), dinv[j] = L_jj^-1; counters: at least
 // gh_dflow_counter_bytes(np) of device memory that nothing else uses until the streams have passed this call.
 // `st`: the stream the matrix was built on -- the workers' launch goes there; `sd`: a second stream for the diagonal
-// worker's launch (the two must run side by side); ev[2]: two events of the caller.  On return everything is joined
+// worker's launch, `ss`: a third one for the scanner's (the three must run side by side); ev[3]: three events of the caller.  On return everything is joined
 // on `sd` (the diagonal worker finishes last by construction), where the caller continues.
 // ONE dataflow factorisation per device at a time (the caller holds gh_dflow_mutex(device) until it has synchronised):
 // the workers of two of them could fill the chip before either diagonal worker is placed.
 int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* d_info, unsigned* counters,
-                    hipStream_t st, hipStream_t sd, hipEvent_t* ev) {
+                    hipStream_t st, hipStream_t sd, hipStream_t ss, hipEvent_t* ev) {
   const int nt = (int)(np / 128);
   if (np % 128 || nt <= 0 || nt > 4096) { gh_set_error("dflow: np must be a multiple of 128"); return GH_ERR_BAD_ARG; }
-  if (!sd || sd == st || !ev) { gh_set_error("dflow: needs a second stream"); return GH_ERR_BAD_ARG; }
+  if (!sd || sd == st || !ss || ss == st || ss == sd || !ev) { gh_set_error("dflow: needs three streams"); return GH_ERR_BAD_ARG; }
   int dev = 0;
   GH_HIP(hipGetDevice(&dev));
   DfDeviceSchedule ds;
@@ -534,13 +591,11 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
       DfDeviceSchedule n;
       for (int q = 0; q < DF_NQ; ++q) {
         n.count[q] = (unsigned)s.q[q].size();
-        n.nb[q] = (unsigned)s.b[q].size();
         if (s.q[q].empty()) continue;
         GH_HIP(hipMalloc((void**)&n.d[q], s.q[q].size() * sizeof(DfTask)));
         GH_HIP(hipMemcpy(n.d[q], s.q[q].data(), s.q[q].size() * sizeof(DfTask), hipMemcpyHostToDevice));
-        GH_HIP(hipMalloc((void**)&n.b[q], s.b[q].size() * sizeof(DfBucket)));
-        GH_HIP(hipMemcpy(n.b[q], s.b[q].data(), s.b[q].size() * sizeof(DfBucket), hipMemcpyHostToDevice));
       }
+      g_df_total[nt] = s.total();
       it = g_df_cache.emplace(std::make_pair(dev, nt), n).first;
     }
     ds = it->second;
@@ -553,12 +608,14 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
   }
   DfArgs a;
   a.A = A; a.ld = (long)ld; a.dinv = dinv; a.info = d_info; a.cnt = counters;
-  unsigned at = (unsigned)df_off_next(nt);
+  unsigned at = (unsigned)df_off_lists(nt);
+  size_t total = 0;
   for (int q = 0; q < DF_NQ; ++q) {
-    a.tasks[q] = ds.d[q]; a.buckets[q] = ds.b[q]; a.nb[q] = ds.nb[q]; a.off_next[q] = at;
-    at += ds.nb[q];
+    a.tasks[q] = ds.d[q]; a.count[q] = ds.count[q];
+    a.off_done[q] = at; at += ds.count[q];
+    a.off_list[q] = at; at += ds.count[q];
+    total += ds.count[q];
   }
-  if ((size_t)at > df_words(nt)) { gh_set_error("dflow: bucket counters overflow"); return GH_ERR_BAD_ARG; }
   a.off_kd = (unsigned)df_off_kd(nt); a.nt = nt;
   a.trace = nullptr; a.trace_cap = 0;
   if (g_df_trace_cap > 0) {
@@ -566,24 +623,31 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
     GH_HIP(hipMemsetAsync(g_df_trace, 0, sizeof(unsigned long long), st));
     a.trace = g_df_trace; a.trace_cap = (unsigned)g_df_trace_cap;
   }
-  GH_HIP(hipMemsetAsync(counters, 0, df_words(nt) * sizeof(unsigned), st));
+  GH_HIP(hipMemsetAsync(counters, 0, df_words(nt, total) * sizeof(unsigned), st));
   GH_HIP(hipEventRecord(ev[0], st));
   GH_HIP(hipStreamWaitEvent(sd, ev[0], 0));
+  GH_HIP(hipStreamWaitEvent(ss, ev[0], 0));
   if (a.trace) hipLaunchKernelGGL(dflow_diag_kernel<true>, dim3(1), dim3(256), 0, sd, a);
   else hipLaunchKernelGGL(dflow_diag_kernel<false>, dim3(1), dim3(256), 0, sd, a);
   GH_HIP(hipGetLastError());
+  if (total > 0) {
+    hipLaunchKernelGGL(dflow_scan_kernel, dim3(1), dim3(DF_SCAN_THREADS), 0, ss, a);
+    GH_HIP(hipGetLastError());
+  } else GH_HIP(hipMemsetAsync(counters + DF_SCANNER, 0xff, sizeof(unsigned), st));     // (a one-tile matrix: nobody to wait for)
   hipLaunchKernelGGL(dflow_gate_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)counters);
   GH_HIP(hipGetLastError());
-  // two workgroups per CU (64 KiB of LDS each); the diagonal worker's CU takes none (its registers are gone)
+  // two workgroups per CU (64 KiB of LDS each); the diagonal worker's CU takes none (its registers are gone), the scanner's one
   static const int nwork = getenv("GEORGE_AMD_DATAFLOW_WORKERS") ? std::max(1, atoi(getenv("GEORGE_AMD_DATAFLOW_WORKERS"))) : 0;
-  const unsigned grid = (unsigned)(nwork > 0 ? nwork : 2 * ncu - 2);
-  if (ds.count[0] + ds.count[1] + ds.count[2] > 0) {
+  const unsigned grid = (unsigned)(nwork > 0 ? nwork : 2 * ncu - 4);
+  if (total > 0) {
     if (a.trace) hipLaunchKernelGGL(dflow_worker_kernel<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dflow_worker_kernel<false>, dim3(grid), dim3(256), 0, st, a);
     GH_HIP(hipGetLastError());
   }
   GH_HIP(hipEventRecord(ev[1], st));
   GH_HIP(hipStreamWaitEvent(sd, ev[1], 0));
+  GH_HIP(hipEventRecord(ev[2], ss));
+  GH_HIP(hipStreamWaitEvent(sd, ev[2], 0));
   hipLaunchKernelGGL(dflow_check_kernel, dim3(1), dim3(1), 0, sd, (const unsigned*)counters, d_info);
   GH_HIP(hipGetLastError());
   return GH_OK;

@@ -37,13 +37,13 @@ def summarise(rec, n=None):
         out.append("link (potf2 end to potf2 end): mean %.2f median %.2f p90 %.2f max %.2f us" %
                    (link.mean(), np.median(link), np.percentile(link, 90), link.max()))
     work = kind < 8
-    for q, name in ((0, "crit"), (1, "hi"), (2, "lo")):
+    for q, name in ((0, "q0 diag-block rows"), (1, "q1 next-block rows"), (2, "q2 far rows"), (3, "q3 pieces"), (4, "q4 bulk")):
         m = kind == q
         if not m.any():
             continue
         d = (t1[m] - t0[m]) / 100.0
         steps = np.where(half[m] == 2, 2, 1) * (k1[m] - k0[m] + fin[m])       # half-tile products of 64 x 128 x 128
-        out.append("%-5s tasks %7d  mean %7.2f  median %7.2f  p90 %7.2f us   us per 64x128x128 product %.2f   busy %.1f ms" %
+        out.append("%-19s tasks %7d  mean %7.2f  median %7.2f  p90 %7.2f us   us per 64x128x128 product %.2f   busy %.1f ms" %
                    (name, m.sum(), d.mean(), np.median(d), np.percentile(d, 90), d.sum() / max(1, steps.sum()), d.sum() / 1e3))
     if work.any():
         nb = len(np.unique(blk[work]))

@@ -2,8 +2,9 @@
 
 The device kernel stores no dependencies: a task's inputs follow from its fields and three families of counters
 (D, rowh, kd).  This file restates that rule in Python (`ready`), hands the library's queues (gh_debug_dflow_schedule,
-host only) to a pool of simulated workers that claim exactly as the kernel does -- a ticket from the first open bucket of
-every queue, one held task per queue and worker -- with random task durations, and checks
+host only) to the kernel's scanner (windows of 64 / 64 / 128 / 128 / 128 tasks at the queues' low-water marks, runnable tasks appended
+to the queues' ready lists) and a pool of simulated workers that take the first entry of the first non-empty list, with
+random task durations and a scanner that runs at random times, and checks
 
   * every claim finds its inputs FINAL in the true state (not only in the counters),
   * no two tasks in flight touch the same half tile,
@@ -20,27 +21,23 @@ import pytest
 from george_amd import _native
 
 PW = 8
-SCAN = 6
+NQ = 5
+WIN = (64, 64, 128, 128, 128)
 
 
 def schedule(nt):
-    """-> per queue: (tasks, buckets); task = (i, j, k0, k1, half, fin); bucket = [start, size, gate_word, gate_val]"""
+    """-> per queue: list of tasks (i, j, k0, k1, half, fin) in need order"""
     lib = _native.lib
-    counts = (C.c_int32 * 3)()
+    counts = (C.c_int32 * NQ)()
     assert lib.gh_debug_dflow_schedule(nt, counts, None, 0) == 0
     tot = sum(counts)
-    out = (C.c_int32 * (10 * max(tot, 1)))()
+    out = (C.c_int32 * (7 * max(tot, 1)))()
     assert lib.gh_debug_dflow_schedule(nt, counts, out, tot) == 0
-    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 10)[:tot]
-    qs = [([], []) for _ in range(3)]
+    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 7)[:tot]
+    qs = [[] for _ in range(NQ)]
     for r in rows:
-        tasks, buckets = qs[r[0]]
-        if r[7] == len(buckets):
-            buckets.append([len(tasks), 0, int(r[8]), int(r[9])])
-        assert r[7] == len(buckets) - 1
-        buckets[-1][1] += 1
-        tasks.append(tuple(int(v) for v in r[1:7]))
-    assert [len(q[0]) for q in qs] == list(counts)
+        qs[r[0]].append(tuple(int(v) for v in r[1:]))
+    assert [len(q) for q in qs] == list(counts)
     return qs
 
 
@@ -176,41 +173,42 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
     qs = schedule(nt)
     m = Machine(nt, b, seed)
     rng = random.Random(seed)
-    hint = [0, 0, 0]
-    nxt = [[0] * len(q[1]) for q in qs]          # ticket counters
-    held = [[None] * 3 for _ in range(nworkers)]  # per worker and queue: a claimed task waiting for its inputs
+    low = [0] * NQ
+    noted = [[False] * len(q) for q in qs]        # the scanner's "on the ready list" notes
+    ready_list = [[] for _ in range(NQ)]
+    head = [0] * NQ
     flight = [None] * nworkers                    # (remaining ticks, effects)
     dj, dphase, dwait = 0, 0, 0                   # diagonal worker: step, part, remaining ticks
     done_tasks = 0
-    total = sum(len(q[0]) for q in qs)
+    total = sum(len(q) for q in qs)
     stall = 0
 
-    def claim(q):
-        """the kernel's claim: from the first bucket that is not used up on, at most SCAN of them, none behind a closed D
-        gate; crit and hi look at the bucket's next task first and take a ticket only when it is runnable"""
-        tasks, buckets = qs[q]
-        front, scan = True, 0
-        bk = hint[q]
-        while bk < len(buckets) and scan < SCAN:
-            start, size, gw, gv = buckets[bk]
-            if nxt[q][bk] >= size:
-                if front:
-                    hint[q] = max(hint[q], bk + 1)
-                bk += 1
-                continue
-            front = False
-            scan += 1
-            if m.word(gw) < gv:
-                if gw == 0:
+    def scan():
+        """one pass of the scanner"""
+        moved = False
+        for q in range(NQ):
+            lead, run = 0, True
+            for w in range(WIN[q]):
+                x = low[q] + w
+                if x >= len(qs[q]):
                     break
-                bk += 1
-                continue
-            if q < 2 and not m.ready(tasks[start + nxt[q][bk]]):
-                bk += 1
-                continue
-            tk = nxt[q][bk]
-            nxt[q][bk] += 1
-            return tasks[start + tk]
+                if not noted[q][x] and m.ready(qs[q][x]):
+                    noted[q][x] = True
+                    ready_list[q].append(qs[q][x])
+                    moved = True
+                if run and noted[q][x]:
+                    lead += 1
+                else:
+                    run = False
+            low[q] += lead
+            moved = moved or lead > 0
+        return moved
+
+    def take():
+        for q in range(NQ):
+            if head[q] < len(ready_list[q]):
+                head[q] += 1
+                return ready_list[q][head[q] - 1]
         return None
 
     while dj < nt or done_tasks < total:
@@ -241,24 +239,19 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
                     done_tasks += 1
                 progressed = True
                 continue
-            if rng.random() < 0.3:       # this worker does not poll in this tick
+            if rng.random() < 0.3:       # this worker does not look in this tick
                 continue
-            for q in (0, 1, 2):
-                if held[w][q] is None:
-                    held[w][q] = claim(q)
-                    if held[w][q] is not None:
-                        progressed = True
-                if held[w][q] is not None and m.ready(held[w][q]):
-                    flight[w] = (rng.randint(0, max_flight), m.start(held[w][q]))
-                    held[w][q] = None
-                    progressed = True
-                    break
+            t = take()
+            if t is not None:
+                flight[w] = (rng.randint(0, max_flight), m.start(t))
+                progressed = True
+        if rng.random() < 0.6 and scan():
+            progressed = True
         stall = 0 if progressed else stall + 1
-        assert stall < 50, ("no forward progress", dj, hint, [[t for t in h if t] for h in held if any(h)][:5])
-    assert all(h == [None] * 3 for h in held)
-    for q in range(3):
-        assert all(nxt[q][bk] >= qs[q][1][bk][1] for bk in range(len(qs[q][1])))
-    return m, [q[0] for q in qs]
+        assert stall < 50, ("no forward progress", dj, low, [len(q) for q in qs])
+    for q in range(NQ):
+        assert all(noted[q]) and head[q] == len(qs[q])
+    return m, qs
 
 
 def check_coverage(nt, m):
@@ -282,7 +275,7 @@ def test_replay_gives_the_cholesky_factor(nt, workers, seed):
     assert np.allclose(got, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("nt,workers", [(64, 64), (128, 200)])
+@pytest.mark.parametrize("nt,workers", [(64, 48), (100, 120)])
 def test_structure_at_product_sizes(nt, workers):
     m, qs = run(nt, workers, b=0, seed=nt, max_flight=6)
     check_coverage(nt, m)
@@ -294,17 +287,22 @@ def test_structure_at_product_sizes(nt, workers):
 
 def test_queue_shapes():
     qs = schedule(40)
-    # lo: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns; one bucket, always open
-    assert len(qs[2][1]) == 1 and qs[2][1][0][3] == 0
-    for (i, j, k0, k1, half, fin) in qs[2][0]:
+    # q4: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns
+    for (i, j, k0, k1, half, fin) in qs[4]:
         assert half == 2 and not fin and 0 < k1 - k0 <= 16 and k1 <= PW * (j // PW - 1)
-    # crit: one k step or a multiply
-    for (i, j, k0, k1, half, fin) in qs[0][0]:
-        assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin)
-    # multiplies by L_jj^-T never for the diagonal worker's rows; gates open in order inside a queue
-    for tasks, buckets in qs:
+    # q3: the previous panel into far tiles, whole tiles
+    for (i, j, k0, k1, half, fin) in qs[3]:
+        assert half == 2 and not fin and PW * (j // PW - 1) <= k0 < k1 <= PW * (j // PW) and i >= PW * (j // PW + 1)
+    # q0, q1: one k step or a multiply, rows of this / the next diagonal block
+    for q in (0, 1):
+        for (i, j, k0, k1, half, fin) in qs[q]:
+            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin)
+            link = j if fin else k0
+            assert i < PW * (link // PW + 1 + q) + (PW if q == 1 and not fin and j // PW > k0 // PW else 0) or q == 1
+    # q2: far rows, half tiles, the in-panel range and the multiply in one
+    for (i, j, k0, k1, half, fin) in qs[2]:
+        assert half in (0, 1) and fin and k1 == j and i >= PW * (j // PW + 2)
+    # multiplies by L_jj^-T never for the diagonal worker's rows
+    for tasks in qs:
         for (i, j, k0, k1, half, fin) in tasks:
             assert i >= j and (not fin or (i >= j + 2 and k1 == j))
-        d_gates = [b[3] for b in buckets if b[2] == 0]
-        assert d_gates == sorted(d_gates)
-        assert sum(b[1] for b in buckets) == len(tasks)
