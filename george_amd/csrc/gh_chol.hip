@@ -1199,7 +1199,7 @@ extern "C" int gh_debug_set_dataflow(int mode) {
   return prev;
 }
 static bool use_dataflow(const gh_chol* s) {
-  if (use_simple_potf2() || !gh_use_mfma() || s->np < 2 * T || !s->opts.lookahead || !s->st2 || !s->st3 || !s->ev_sync[0]) return false;
+  if (use_simple_potf2() || !gh_use_mfma() || s->np < 2 * T || !s->opts.lookahead || !s->st2 || !s->ev_sync[0]) return false;
   if (g_dataflow >= 0) return g_dataflow == 1;
   static const int env = getenv("GEORGE_AMD_DATAFLOW") ? atoi(getenv("GEORGE_AMD_DATAFLOW")) : -1;
   if (env >= 0) return env != 0;
@@ -1209,7 +1209,7 @@ static int factor_dataflow(gh_chol* s) {
   GH_CHECK(s->dflow.ensure(gh_dflow_counter_bytes(s->np)));
   // one dataflow factorisation per device at a time: held until the caller has synchronised (DflowRelease)
   if (!s->dflow_locked) { gh_dflow_mutex(s->opts.device).lock(); s->dflow_locked = true; }
-  GH_CHECK(gh_dflow_factor(s->A.d(), s->np, s->np, s->dinv.d(), s->d_info, (unsigned*)s->dflow.p, s->st, s->st2, s->st3, s->ev_sync));
+  GH_CHECK(gh_dflow_factor(s->A.d(), s->np, s->np, s->dinv.d(), s->d_info, (unsigned*)s->dflow.p, s->st, s->st2, s->ev_sync));
   s->tail = s->st2;
   return GH_OK;
 }

@@ -20,16 +20,18 @@
 //        (left-looking inside the panel, as the launch chain's rows-below stream);
 //   q3 : the previous panel's contribution to the far tiles of the next block column, in four pieces as its columns complete;
 //   q4 : everything older than the previous panel, 128 x 128 tiles, k ranges of up to 2048 (the bulk of the flops).
-// WHO FINDS THE RUNNABLE TASKS: one more workgroup, the SCANNER (a launch of its own, 512 threads).  A queue is an array of
-// tasks in need order; the scanner's lanes look at a window of each queue (64 + 64 + 128 + 128 + 128 tasks from the queues'
-// low-water marks, every lane checks its task's inputs) and append the runnable ones to the queue's READY LIST -- a plain
-// array as long as the queue, so nothing is ever reused or wraps -- pass after pass, ~4 us each.  A worker polls ONE cache
-// line (the five lists' tails and heads) and takes the first entry of the first non-empty list by compare-and-swap on its
-// head.  Nothing is handed out before it can run, nothing runnable inside a window waits behind something that is not, and an
-// idle worker costs the memory system two loads per poll.  (Forms tried before, profiles/r05/dataflow_*: workers claiming a
-// runnable queue HEAD by compare-and-swap: one claim per 3.5 us, 8x slower than the launch chain; tickets per bucket with
-// waiting owners: runnable tasks found late behind open buckets, 1.2-1.3x; every idle worker scanning the windows itself:
-// 500 x 420 loads per poll, 30x slower.)
+// WHO FINDS THE RUNNABLE TASKS: whoever finishes one.  The host gives every producer -- a task, the diagonal worker's
+// sub-diagonal multiply of step j, its potf2 of step j -- the list of the tasks that read what it writes (its CANDIDATES:
+// the next pass over the same tile, the products that take the finished L tile as an operand, the multiplies that wait for
+// L_jj^-1).  After publishing its counters the producer's 256 threads check their candidates' inputs, one candidate per
+// thread, and append the runnable ones to their queue's READY LIST (a plain array as long as the queue: nothing wraps; a
+// note per task says "already listed").  The producer of a task's LAST input lists it -- at once, with no scan and no
+// window.  A worker polls ONE cache line (the five lists' tails and heads, one wavefront transaction) and takes the first
+// entry of the first non-empty list by compare-and-swap on its head.  (Forms tried before, profiles/r05/dataflow_*: workers
+// claiming a runnable queue HEAD by compare-and-swap: one claim per 3.5 us, 8x slower than the launch chain; tickets per
+// bucket with waiting owners: runnable tasks found late behind open buckets, 1.2-1.3x; every idle worker scanning windows
+// of the queues: 500 x 420 loads per poll, 30x; one scanner workgroup filling the lists: windows that clog behind tasks
+// whose inputs are late and a pass of latency per dependency hop, 3-8x.)
 //
 // Dependencies are not stored: they follow from a task's fields and three families of monotone counters,
 //   D          diagonal steps finished (L_jj^-1 is readable when D > j),
@@ -38,10 +40,10 @@
 // written behind an agent-scope release by whoever finishes a task and polled relaxed, followed by ONE agent-scope
 // acquire, by whoever wants to start one (/opt/skills/guides: Guideline 16's recipe, the one the retired persistent
 // panel used bit-identically).  Forward progress: the queues are consistent with one topological order of all tasks
-// (tests/test_dataflow_schedule.py replays them); the earliest unfinished task of that order has all its inputs, every task
-// before it in its queue has been handed out, so it sits at its queue's low-water mark, inside the scanner's window -- and a
-// worker that is not resident has taken nothing.  The diagonal worker and the scanner are launched first and the workers'
-// stream waits until both run.  Every wait gives up after 2 s and raises the abort word.
+// (tests/test_dataflow_schedule.py replays them); the earliest unfinished task of that order has all its inputs finished,
+// so the producer of its last input has listed it (or is about to) -- and a worker that is not resident has taken nothing.
+// The diagonal worker is launched first and the workers' stream waits until it runs.  Every wait gives up after 2 s and
+// raises the abort word.
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -59,7 +61,6 @@
 #define DF_NEARF 8           // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time
 #define DF_CHUNK 16          // lo queue: tile columns per task (K = 2048)
 #define DF_NQ 5
-#define DF_SCAN_THREADS 512  // the scanner: wavefront 0 -> q0, 1 -> q1, 2-3 -> q2, 4-5 -> q3, 6-7 -> q4
 #define DF_HALVES 0          // 1: the tasks next to the front as 64-row half tiles (measured: a K = 128 task is bound by its eight
                              //    dependent slab round trips, ~20 us whatever the tile height -- halves only double the task count)
 
@@ -75,18 +76,20 @@ static_assert(sizeof(DfTask) == 16, "DfTask is one 16-byte load");
 #define DF_D 0
 #define DF_ABORT 32
 #define DF_KEY 64
-#define DF_SCANNER 96        // the scanner runs
-#define DF_TAIL 128          // + q: entries of ready list q (written by the scanner); + 8 + q: entries taken (the workers' heads)
+#define DF_TAIL 128          // + q: entries of ready list q handed out to producers; + 8 + q: entries taken (the workers' heads)
 #define DF_DBG 192           // [0] scanner passes, [1] its stage, [2] workers started, [3] workers gone, [4] diagonal worker gone, [5] tasks run, [6] gate passed
 #define DF_ROWH 320
 static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
 static inline size_t df_off_lists(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }
-// per task one "handed out" word (the scanner's) and one ready-list slot
+// per task one "listed" note and one ready-list slot
 static inline size_t df_words(int nt, size_t ntasks) { return df_off_lists(nt) + 2 * ntasks + 32; }
 
 // ------------------------------------------------------------------------------------------------ the schedule (host)
 struct DfSchedule {
   std::vector<DfTask> q[DF_NQ];
+  // producers: task g (global index: queue by queue), then the diagonal worker's multiply of step j (total + j), then its potf2
+  // of step j (total + nt + j); cand[cand_ptr[P] .. cand_ptr[P + 1]) = global indices of the tasks that read what P writes
+  std::vector<uint32_t> cand_ptr, cand;
   size_t total() const { size_t n = 0; for (auto& v : q) n += v.size(); return n; }
 };
 static void df_build(int nt, DfSchedule& s) {
@@ -149,6 +152,49 @@ static void df_build(int nt, DfSchedule& s) {
     s.q[q].reserve(qs[q].size());
     for (auto& e : qs[q]) s.q[q].push_back(e.second);
   }
+  // ---- candidates: for every task X and every input of X (df_ready()'s rule), X goes onto the list of that input's producer
+  const size_t G = s.total();
+  std::vector<std::vector<uint32_t>> lists(G + 2 * (size_t)nt);
+  std::map<std::tuple<int, int, int, int>, uint32_t> kd_prod;       // (i, j, half 0|1, value) -> the task that brings the half tile to `value` steps
+  std::map<std::tuple<int, int, int>, uint32_t> fin_prod;           // (i, j, half 0|1) -> the task that makes L(i, j) final
+  {
+    uint32_t g = 0;
+    for (int q = 0; q < DF_NQ; ++q)
+      for (const DfTask& t : s.q[q]) {
+        const int h0 = t.half == 2 ? 0 : t.half, h1 = t.half == 2 ? 1 : t.half;
+        for (int h = h0; h <= h1; ++h) {
+          if (t.fin) fin_prod[std::make_tuple((int)t.i, (int)t.j, h)] = g;
+          else kd_prod[std::make_tuple((int)t.i, (int)t.j, h, (int)t.k1)] = g;
+        }
+        ++g;
+      }
+  }
+  auto final_producer = [&](int r, int c, int h) -> size_t {        // who makes half h of L(r, c) final
+    if (r == c + 1) return G + (size_t)r;                           // the diagonal worker's multiply of step r
+    return fin_prod.at(std::make_tuple(r, c, h));
+  };
+  {
+    uint32_t g = 0;
+    for (int q = 0; q < DF_NQ; ++q)
+      for (const DfTask& t : s.q[q]) {
+        const int h0 = t.half == 2 ? 0 : t.half, h1 = t.half == 2 ? 1 : t.half;
+        std::vector<size_t> prods;
+        if (t.k0 > 0) for (int h = h0; h <= h1; ++h) prods.push_back(kd_prod.at(std::make_tuple((int)t.i, (int)t.j, h, (int)t.k0)));
+        if (t.k1 > t.k0) {
+          const int c = t.k1 - 1;
+          for (int h = 0; h < 2; ++h) prods.push_back(final_producer(t.j, c, h));
+          if (t.i != t.j) for (int h = h0; h <= h1; ++h) prods.push_back(final_producer(t.i, c, h));
+        }
+        if (t.fin) prods.push_back(G + (size_t)nt + t.j);
+        std::sort(prods.begin(), prods.end());
+        prods.erase(std::unique(prods.begin(), prods.end()), prods.end());
+        for (size_t P : prods) lists[P].push_back(g);
+        ++g;
+      }
+  }
+  s.cand_ptr.assign(1, 0u);
+  s.cand.clear();
+  for (auto& l : lists) { s.cand.insert(s.cand.end(), l.begin(), l.end()); s.cand_ptr.push_back((uint32_t)s.cand.size()); }
 }
 
 // the schedule of an nt x nt tile matrix, for the replay in tests/test_dataflow_schedule.py (host only, no device needed):
@@ -171,6 +217,18 @@ extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out
   return GH_OK;
 }
 
+// the candidate lists of the same schedule: ptr (when not NULL) receives total + 2 nt + 1 offsets, cand the entries (at most
+// max_cand); *n_cand = the number of entries
+extern "C" int gh_debug_dflow_candidates(int32_t nt, uint32_t* ptr, uint32_t* cand, int64_t max_cand, int64_t* n_cand) {
+  if (nt <= 0 || nt > 4096 || !n_cand) { gh_set_error("dflow_candidates: bad argument"); return GH_ERR_BAD_ARG; }
+  DfSchedule s;
+  df_build(nt, s);
+  *n_cand = (int64_t)s.cand.size();
+  if (ptr) memcpy(ptr, s.cand_ptr.data(), s.cand_ptr.size() * sizeof(uint32_t));
+  if (cand) memcpy(cand, s.cand.data(), (size_t)std::min<int64_t>(max_cand, (int64_t)s.cand.size()) * sizeof(uint32_t));
+  return GH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
 struct DfArgs {
   double* A; long ld;
@@ -179,7 +237,10 @@ struct DfArgs {
   unsigned* cnt;
   const DfTask* tasks[DF_NQ];
   unsigned count[DF_NQ];
-  unsigned off_done[DF_NQ];      // cnt + off_done[q] + x: task x of queue q is on its ready list (the scanner's note)
+  const uint32_t* cand_ptr;      // candidates of producer P: cand[cand_ptr[P] .. cand_ptr[P + 1])
+  const uint32_t* cand;
+  unsigned qoff[DF_NQ + 1];      // global index of the first task of queue q; qoff[DF_NQ] = all tasks
+  unsigned off_done[DF_NQ];      // cnt + off_done[q] + x: task x of queue q is on its ready list
   unsigned off_list[DF_NQ];      // cnt + off_list[q] + e: entry e of ready list q = task index + 1 (0: not written yet)
   unsigned off_kd;
   int nt;
@@ -239,6 +300,31 @@ __device__ __forceinline__ void df_publish(unsigned* cnt, unsigned* w0, unsigned
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     df_st(w0, v0);
     if (w1) df_st(w1, v1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the counters are out before anybody looks at the candidates
+  }
+}
+
+// After df_publish(): the calling workgroup's threads check the inputs of producer P's candidates, one candidate per thread,
+// and list the runnable ones.  Two producers that finish a task's last two inputs at the same time both find it runnable
+// (each has its own counters out -- waited for -- before it reads the other's); the note's compare-and-swap lets one list it.
+__device__ __forceinline__ void df_list_candidates(const DfArgs& a, unsigned P) {
+  __syncthreads();
+  unsigned* const cnt = a.cnt;
+  const unsigned beg = a.cand_ptr[P], end = a.cand_ptr[P + 1];
+  for (unsigned c = beg + threadIdx.x; c < end; c += blockDim.x) {
+    const unsigned g = a.cand[c];
+    int q = 0;
+#pragma unroll
+    for (int v = 1; v < DF_NQ; ++v) q += g >= a.qoff[v] ? 1 : 0;
+    const unsigned x = g - a.qoff[q];
+    unsigned* const note = cnt + a.off_done[q] + x;
+    if (df_ld(note) != 0u) continue;
+    const DfTask t = a.tasks[q][x];
+    if (!df_ready(a, t)) continue;
+    unsigned expect = 0u;
+    if (!__hip_atomic_compare_exchange_strong(note, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+    const unsigned slot = __hip_atomic_fetch_add(cnt + DF_TAIL + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    df_st(cnt + a.off_list[q] + slot, x + 1u);
   }
 }
 
@@ -300,8 +386,8 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         }
         gh_tile128_nt<false>(smem, Asub, ld, Asub, ld, dprev, 128, 128);                 // L(j, j-1), in place
         df_publish(cnt, cnt + DF_ROWH + 2 * j, (unsigned)j, cnt + DF_ROWH + 2 * j + 1, (unsigned)j);
+        df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)j);
         if (TR) { df_trace(a, tt, j, j - 1, 0, 0, 9, 2, 1); tt = wall_clock64(); }
-        // (no barrier: the other wavefronts request the first slab and C while wavefront 0 is in the release)
         gh_tile128_nt<true>(smem, Ajj, ld, Asub, ld, Asub, ld, 128);                     // A_jj -= L(j, j-1) L(j, j-1)^T
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -314,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         return;
       }
       df_publish(cnt, cnt + DF_D, (unsigned)(j + 1), nullptr, 0u);
+      df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)a.nt + (unsigned)j);
       if (TR) df_trace(a, tt, j, j, 0, 0, 11, 2, 0);
     }
     if (tid == 0) df_st(cnt + DF_DBG + 4, 1u);
@@ -325,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
   __shared__ __attribute__((aligned(1024))) double smem[8192];
   __shared__ DfTask s_task;
   __shared__ int s_state;
+  __shared__ unsigned s_gid;               // global index of the task taken (= its producer number)
   const int tid = threadIdx.x;
   unsigned* const cnt = a.cnt;
   const long ld = a.ld;
@@ -372,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
               unsigned e = 0u;                                      // (the entry was stored before the tail moved past it)
               for (int tries = 0; tries < 200000 && (e = __builtin_amdgcn_readfirstlane(df_ld(cnt + a.off_list[q] + h))) == 0u; ++tries) __builtin_amdgcn_s_sleep(1);
               if (e == 0u) { if (lane == 0) df_st(cnt + DF_ABORT, 2u); st = -1; break; }
-              if (lane == 0) s_task = a.tasks[q][e - 1u];
+              if (lane == 0) { s_task = a.tasks[q][e - 1u]; s_gid = a.qoff[q] + e - 1u; }
               st = 1 + q; break;
             }
             h = now;
@@ -380,7 +468,11 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
         }
         if (st) break;
         if (alldone) { st = -1; break; }           // every task has been taken
-        if (spins < 4) __builtin_amdgcn_s_sleep(16); else if (spins < 16) __builtin_amdgcn_s_sleep(64); else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+#ifndef DF_IDLE_LONG
+#define DF_IDLE_LONG 2
+#endif
+        if (spins < 4) __builtin_amdgcn_s_sleep(16); else if (spins < 16) __builtin_amdgcn_s_sleep(64);
+        else { for (int z = 0; z < DF_IDLE_LONG; ++z) __builtin_amdgcn_s_sleep(127); }
         if ((++spins & 63u) == 0u && wall_clock64() - t0 > DF_TIMEOUT_TICKS) { if (lane == 0) df_st(cnt + DF_ABORT, 2u); st = -1; break; }
       }
       if (st > 0 && lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -435,83 +527,9 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
     } else {
       df_publish(cnt, kd + t.half, t.k1, nullptr, 0u);
     }
+    df_list_candidates(a, __builtin_amdgcn_readfirstlane(s_gid));
     if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (TR) df_trace(a, tt, t.i, t.j, t.k0, t.k1, (unsigned)s_q, t.half, t.fin);
-  }
-}
-
-// The scanner (see the head of this file).  Wavefront -> queue: 0 -> q0, 1 -> q1, 2-3 -> q2, 4-5 -> q3, 6-7 -> q4; lane x of a
-// queue's wavefronts looks at task low[q] + x.  Per pass: inputs of every candidate checked, the runnable ones appended to the
-// queue's ready list in window order (ballot + prefix inside a wavefront, LDS across the two wavefronts of a queue), the tail
-// published behind the entries, the low-water mark moved over the leading handed-out tasks.  Only this workgroup writes the
-// lists, the tails and the notes: plain agent-scope stores, no read-modify-write.
-__global__ __launch_bounds__(DF_SCAN_THREADS) void dflow_scan_kernel(DfArgs a) {
-  __shared__ unsigned s_low[DF_NQ], s_tail[DF_NQ], s_cnt[8], s_lead[8];
-  __shared__ int s_stop;
-  unsigned* const cnt = a.cnt;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = wave < 2 ? wave : 2 + (wave - 2) / 2;              // queue of this wavefront
-  const int wfirst = wave < 2 ? wave : 2 + 2 * (q - 2);            // first wavefront of that queue
-  const int x = (wave - wfirst) * 64 + lane;                      // place in the queue's window
-  if (tid < DF_NQ) { s_low[tid] = 0u; s_tail[tid] = 0u; }
-  if (tid == 0) { s_stop = 0; df_st(cnt + DF_SCANNER, 1u); }
-  __syncthreads();
-  long long t_progress = wall_clock64();
-  unsigned passes = 0;
-  for (;;) {
-    if (tid == 0) { df_st(cnt + DF_DBG, ++passes); df_st(cnt + DF_DBG + 1, 1u); }
-    const unsigned low = s_low[q], tail0 = s_tail[q];
-    const unsigned idx = low + (unsigned)x;
-    const bool valid = idx < a.count[q];
-    unsigned* const note = cnt + a.off_done[q] + (valid ? idx : 0u);
-    const unsigned was = valid ? df_ld(note) : 1u;
-    bool ok = false;
-    if (valid && was == 0u) { const DfTask t = a.tasks[q][idx]; ok = df_ready(a, t); }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-    const unsigned long long out = __builtin_amdgcn_ballot_w64(ok || (valid && was != 0u));   // handed out after this pass
-    if (lane == 0) {
-      s_cnt[wave] = (unsigned)__builtin_popcountll(m);
-      s_lead[wave] = out == ~0ull ? 64u : (unsigned)__builtin_ctzll(~out);          // leading handed-out tasks of this wavefront's part
-    }
-    __syncthreads();
-    if (tid == 0) df_st(cnt + DF_DBG + 1, 2u);
-    // entries: window order
-    unsigned before = 0u;
-    for (int v = wfirst; v < wave; ++v) before += s_cnt[v];
-    if (ok) {
-      const unsigned pos = tail0 + before + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-      df_st(cnt + a.off_list[q] + pos, idx + 1u);
-      df_st(note, 1u);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) df_st(cnt + DF_DBG + 1, 3u);
-    if (wave == wfirst && lane == 0) {
-      const int nw = wave < 2 ? 1 : 2;
-      unsigned added = 0u, lead = 0u;
-      bool run = true;
-      for (int v = 0; v < nw; ++v) {
-        added += s_cnt[wfirst + v];
-        if (run) { lead += s_lead[wfirst + v]; run = s_lead[wfirst + v] == 64u; }
-      }
-      if (added) { df_st(cnt + DF_TAIL + q, tail0 + added); s_tail[q] = tail0 + added; }
-      unsigned nl = low + lead;
-      if (nl > a.count[q]) nl = a.count[q];
-      s_low[q] = nl;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      bool all = true, moved = false;
-      for (int v = 0; v < 8; ++v) moved = moved || s_cnt[v] != 0u;
-      for (int v = 0; v < DF_NQ; ++v) all = all && s_low[v] >= a.count[v];
-      if (moved) t_progress = wall_clock64();
-      if (all) s_stop = 1;
-      else if (df_ld(cnt + DF_ABORT) != 0u) s_stop = 1;
-      else if (wall_clock64() - t_progress > DF_TIMEOUT_TICKS) { df_st(cnt + DF_ABORT, 2u); s_stop = 1; }
-    }
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(s_stop)) { if (tid == 0) df_st(cnt + DF_DBG + 1, 9u); return; }
-    __builtin_amdgcn_s_sleep(4);
   }
 }
 
@@ -521,7 +539,7 @@ __global__ __launch_bounds__(DF_SCAN_THREADS) void dflow_scan_kernel(DfArgs a) {
 // after 20 ms (the workers then run into their own time-out if the diagonal worker never comes).
 __global__ void dflow_gate_kernel(const unsigned* cnt) {
   const long long t0 = wall_clock64();
-  while ((df_ld(cnt + DF_KEY) == 0u || df_ld(cnt + DF_SCANNER) == 0u) && wall_clock64() - t0 < 2000000LL) __builtin_amdgcn_s_sleep(8);
+  while (df_ld(cnt + DF_KEY) == 0u && wall_clock64() - t0 < 2000000LL) __builtin_amdgcn_s_sleep(8);
   df_st((unsigned*)cnt + DF_DBG + 6, 1u);
 }
 
@@ -534,6 +552,8 @@ __global__ void dflow_check_kernel(const unsigned* cnt, long long* info) {
 struct DfDeviceSchedule {
   DfTask* d[DF_NQ] = {};
   unsigned count[DF_NQ] = {};
+  uint32_t* cand_ptr = nullptr;
+  uint32_t* cand = nullptr;
 };
 static std::mutex g_df_mutex;
 static std::map<std::pair<int, int>, DfDeviceSchedule> g_df_cache;     // (device, nt): never freed (a few MB per size)
@@ -570,15 +590,15 @@ size_t gh_dflow_counter_bytes(int64_t np) { const int nt = (int)(np / 128); retu
 // factor the np x np matrix at A in place (lower triangle; np a multiple of 128), dinv[j] = L_jj^-1; counters: at least
 // gh_dflow_counter_bytes(np) of device memory that nothing else uses until the streams have passed this call.
 // `st`: the stream the matrix was built on -- the workers' launch goes there; `sd`: a second stream for the diagonal
-// worker's launch, `ss`: a third one for the scanner's (the three must run side by side); ev[3]: three events of the caller.  On return everything is joined
+// worker's launch (the two must run side by side); ev[2]: two events of the caller.  On return everything is joined
 // on `sd` (the diagonal worker finishes last by construction), where the caller continues.
 // ONE dataflow factorisation per device at a time (the caller holds gh_dflow_mutex(device) until it has synchronised):
 // the workers of two of them could fill the chip before either diagonal worker is placed.
 int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* d_info, unsigned* counters,
-                    hipStream_t st, hipStream_t sd, hipStream_t ss, hipEvent_t* ev) {
+                    hipStream_t st, hipStream_t sd, hipEvent_t* ev) {
   const int nt = (int)(np / 128);
   if (np % 128 || nt <= 0 || nt > 4096) { gh_set_error("dflow: np must be a multiple of 128"); return GH_ERR_BAD_ARG; }
-  if (!sd || sd == st || !ss || ss == st || ss == sd || !ev) { gh_set_error("dflow: needs three streams"); return GH_ERR_BAD_ARG; }
+  if (!sd || sd == st || !ev) { gh_set_error("dflow: needs a second stream"); return GH_ERR_BAD_ARG; }
   int dev = 0;
   GH_HIP(hipGetDevice(&dev));
   DfDeviceSchedule ds;
@@ -595,6 +615,10 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
         GH_HIP(hipMalloc((void**)&n.d[q], s.q[q].size() * sizeof(DfTask)));
         GH_HIP(hipMemcpy(n.d[q], s.q[q].data(), s.q[q].size() * sizeof(DfTask), hipMemcpyHostToDevice));
       }
+      GH_HIP(hipMalloc((void**)&n.cand_ptr, s.cand_ptr.size() * sizeof(uint32_t)));
+      GH_HIP(hipMemcpy(n.cand_ptr, s.cand_ptr.data(), s.cand_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      GH_HIP(hipMalloc((void**)&n.cand, std::max<size_t>(1, s.cand.size()) * sizeof(uint32_t)));
+      if (!s.cand.empty()) GH_HIP(hipMemcpy(n.cand, s.cand.data(), s.cand.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       g_df_total[nt] = s.total();
       it = g_df_cache.emplace(std::make_pair(dev, nt), n).first;
     }
@@ -614,8 +638,11 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
     a.tasks[q] = ds.d[q]; a.count[q] = ds.count[q];
     a.off_done[q] = at; at += ds.count[q];
     a.off_list[q] = at; at += ds.count[q];
+    a.qoff[q] = (unsigned)total;
     total += ds.count[q];
   }
+  a.qoff[DF_NQ] = (unsigned)total;
+  a.cand_ptr = ds.cand_ptr; a.cand = ds.cand;
   a.off_kd = (unsigned)df_off_kd(nt); a.nt = nt;
   a.trace = nullptr; a.trace_cap = 0;
   if (g_df_trace_cap > 0) {
@@ -626,19 +653,14 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
   GH_HIP(hipMemsetAsync(counters, 0, df_words(nt, total) * sizeof(unsigned), st));
   GH_HIP(hipEventRecord(ev[0], st));
   GH_HIP(hipStreamWaitEvent(sd, ev[0], 0));
-  GH_HIP(hipStreamWaitEvent(ss, ev[0], 0));
   if (a.trace) hipLaunchKernelGGL(dflow_diag_kernel<true>, dim3(1), dim3(256), 0, sd, a);
   else hipLaunchKernelGGL(dflow_diag_kernel<false>, dim3(1), dim3(256), 0, sd, a);
   GH_HIP(hipGetLastError());
-  if (total > 0) {
-    hipLaunchKernelGGL(dflow_scan_kernel, dim3(1), dim3(DF_SCAN_THREADS), 0, ss, a);
-    GH_HIP(hipGetLastError());
-  } else GH_HIP(hipMemsetAsync(counters + DF_SCANNER, 0xff, sizeof(unsigned), st));     // (a one-tile matrix: nobody to wait for)
   hipLaunchKernelGGL(dflow_gate_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)counters);
   GH_HIP(hipGetLastError());
-  // two workgroups per CU (64 KiB of LDS each); the diagonal worker's CU takes none (its registers are gone), the scanner's one
+  // two workgroups per CU (64 KiB of LDS each); the diagonal worker's CU takes none (its registers are gone)
   static const int nwork = getenv("GEORGE_AMD_DATAFLOW_WORKERS") ? std::max(1, atoi(getenv("GEORGE_AMD_DATAFLOW_WORKERS"))) : 0;
-  const unsigned grid = (unsigned)(nwork > 0 ? nwork : 2 * ncu - 4);
+  const unsigned grid = (unsigned)(nwork > 0 ? nwork : 2 * ncu - 2);
   if (total > 0) {
     if (a.trace) hipLaunchKernelGGL(dflow_worker_kernel<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dflow_worker_kernel<false>, dim3(grid), dim3(256), 0, st, a);
@@ -646,8 +668,6 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
   }
   GH_HIP(hipEventRecord(ev[1], st));
   GH_HIP(hipStreamWaitEvent(sd, ev[1], 0));
-  GH_HIP(hipEventRecord(ev[2], ss));
-  GH_HIP(hipStreamWaitEvent(sd, ev[2], 0));
   hipLaunchKernelGGL(dflow_check_kernel, dim3(1), dim3(1), 0, sd, (const unsigned*)counters, d_info);
   GH_HIP(hipGetLastError());
   return GH_OK;

@@ -2,9 +2,9 @@
 
 The device kernel stores no dependencies: a task's inputs follow from its fields and three families of counters
 (D, rowh, kd).  This file restates that rule in Python (`ready`), hands the library's queues (gh_debug_dflow_schedule,
-host only) to the kernel's scanner (windows of 64 / 64 / 128 / 128 / 128 tasks at the queues' low-water marks, runnable tasks appended
-to the queues' ready lists) and a pool of simulated workers that take the first entry of the first non-empty list, with
-random task durations and a scanner that runs at random times, and checks
+host only) to the kernel's listing rule (whoever finishes a task checks the inputs of its CANDIDATES -- gh_debug_dflow_candidates --
+and appends the runnable ones to their queue's ready list) and a pool of simulated workers that take the first entry of the
+first non-empty list, with random task durations, and checks
 
   * every claim finds its inputs FINAL in the true state (not only in the counters),
   * no two tasks in flight touch the same half tile,
@@ -22,7 +22,6 @@ from george_amd import _native
 
 PW = 8
 NQ = 5
-WIN = (64, 64, 128, 128, 128)
 
 
 def schedule(nt):
@@ -39,6 +38,18 @@ def schedule(nt):
         qs[r[0]].append(tuple(int(v) for v in r[1:]))
     assert [len(q) for q in qs] == list(counts)
     return qs
+
+
+def candidates(nt, total):
+    lib = _native.lib
+    n = C.c_int64(0)
+    assert lib.gh_debug_dflow_candidates(nt, None, None, 0, C.byref(n)) == 0
+    ptr = (C.c_uint32 * (total + 2 * nt + 1))()
+    cand = (C.c_uint32 * max(1, n.value))()
+    assert lib.gh_debug_dflow_candidates(nt, ptr, cand, n.value, C.byref(n)) == 0
+    ptr, cand = list(ptr), list(cand)[:n.value]
+    assert ptr[0] == 0 and ptr[-1] == n.value
+    return [cand[ptr[p]:ptr[p + 1]] for p in range(total + 2 * nt)]
 
 
 class Machine:
@@ -173,36 +184,27 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
     qs = schedule(nt)
     m = Machine(nt, b, seed)
     rng = random.Random(seed)
-    low = [0] * NQ
-    noted = [[False] * len(q) for q in qs]        # the scanner's "on the ready list" notes
+    flat = [t for q in qs for t in q]             # global task index -> task
+    qof = [q for q in range(NQ) for _ in qs[q]]
+    gid = {}
+    for g, t in enumerate(flat):
+        gid[(qof[g], t)] = g
+    total = len(flat)
+    cands = candidates(nt, total)
+    listed = [False] * total
     ready_list = [[] for _ in range(NQ)]
     head = [0] * NQ
     flight = [None] * nworkers                    # (remaining ticks, effects)
     dj, dphase, dwait = 0, 0, 0                   # diagonal worker: step, part, remaining ticks
     done_tasks = 0
-    total = sum(len(q) for q in qs)
     stall = 0
 
-    def scan():
-        """one pass of the scanner"""
-        moved = False
-        for q in range(NQ):
-            lead, run = 0, True
-            for w in range(WIN[q]):
-                x = low[q] + w
-                if x >= len(qs[q]):
-                    break
-                if not noted[q][x] and m.ready(qs[q][x]):
-                    noted[q][x] = True
-                    ready_list[q].append(qs[q][x])
-                    moved = True
-                if run and noted[q][x]:
-                    lead += 1
-                else:
-                    run = False
-            low[q] += lead
-            moved = moved or lead > 0
-        return moved
+    def list_candidates(producer):
+        """what a producer does after publishing: the runnable ones of its candidates go onto their ready lists"""
+        for g in cands[producer]:
+            if not listed[g] and m.ready(flat[g]):
+                listed[g] = True
+                ready_list[qof[g]].append(g)
 
     def take():
         for q in range(NQ):
@@ -220,10 +222,13 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
             elif dphase == 0:
                 if m.diag_can_start(dj):
                     m.diag_part1(dj)
+                    if dj > 0:
+                        list_candidates(total + dj)
                     dphase, dwait = 1, rng.randint(0, 3)
                     progressed = True
             else:
                 m.diag_part2(dj)
+                list_candidates(total + nt + dj)
                 dj, dphase, dwait = dj + 1, 0, rng.randint(0, 3)
                 progressed = True
         order = list(range(nworkers))
@@ -234,23 +239,22 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
                 if rem > 0:
                     flight[w] = (rem - 1, eff)
                 else:
-                    m.finish(eff)
+                    m.finish(eff[1])
+                    list_candidates(eff[0])
                     flight[w] = None
                     done_tasks += 1
                 progressed = True
                 continue
             if rng.random() < 0.3:       # this worker does not look in this tick
                 continue
-            t = take()
-            if t is not None:
-                flight[w] = (rng.randint(0, max_flight), m.start(t))
+            g = take()
+            if g is not None:
+                assert m.ready(flat[g])                       # nothing is listed before it can run
+                flight[w] = (rng.randint(0, max_flight), (g, m.start(flat[g])))
                 progressed = True
-        if rng.random() < 0.6 and scan():
-            progressed = True
         stall = 0 if progressed else stall + 1
-        assert stall < 50, ("no forward progress", dj, low, [len(q) for q in qs])
-    for q in range(NQ):
-        assert all(noted[q]) and head[q] == len(qs[q])
+        assert stall < 50, ("no forward progress", dj, head, [len(r) for r in ready_list], [len(q) for q in qs])
+    assert all(listed) and [head[q] for q in range(NQ)] == [len(q) for q in qs]
     return m, qs
 
 
