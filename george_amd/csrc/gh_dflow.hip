@@ -77,7 +77,6 @@ static_assert(sizeof(DfTask) == 16, "DfTask is one 16-byte load");
 #define DF_ABORT 32
 #define DF_KEY 64
 #define DF_TAIL 128          // + q: entries of ready list q handed out to producers; + 8 + q: entries taken (the workers' heads)
-#define DF_DBG 192           // [0] scanner passes, [1] its stage, [2] workers started, [3] workers gone, [4] diagonal worker gone, [5] tasks run, [6] gate passed
 #define DF_ROWH 320
 static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
 static inline size_t df_off_lists(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         if (j > 1) {
           // the workers' share of both tiles: k < j - 1   (kd of (j, j - 1) and (j, j) are four consecutive words)
           const unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)j * (j + 1u) / 2u + (j - 1));
-          if (!df_wait4(a, kd, (unsigned)(j - 1), 4, &s_state)) { if (tid == 0) df_st(cnt + DF_DBG + 4, 100u + (unsigned)j); return; }
+          if (!df_wait4(a, kd, (unsigned)(j - 1), 4, &s_state)) return;
           if (TR) { df_trace(a, tt, j, j, 0, 0, 8, 2, 0); tt = wall_clock64(); }
         }
         gh_tile128_nt<false>(smem, Asub, ld, Asub, ld, dprev, 128, 128);                 // L(j, j-1), in place
@@ -403,7 +402,6 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
       df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)a.nt + (unsigned)j);
       if (TR) df_trace(a, tt, j, j, 0, 0, 11, 2, 0);
     }
-    if (tid == 0) df_st(cnt + DF_DBG + 4, 1u);
   }
 }
 
@@ -427,7 +425,6 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_state) < 0) return;
   __syncthreads();
-  if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   for (;;) {
     if (tid < 64) {
@@ -439,8 +436,22 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       const long long t0 = wall_clock64();
       unsigned spins = 0;
       for (;;) {
-        const unsigned word = df_ld(cnt + (lane < 16 ? DF_TAIL + lane : DF_ABORT));
+        unsigned word = df_ld(cnt + (lane < 16 ? DF_TAIL + lane : DF_ABORT));
         if (__builtin_amdgcn_readlane(word, 16) != 0u) { st = -1; break; }                      // (lanes >= 16 read the abort word)
+#ifndef DF_NO_DESYNC
+        {
+          // something is listed: every idle workgroup sees it within a poll period and would fire a compare-and-swap at the same
+          // word.  Wait a pseudo-random 0-2 us and look again: most find the entry gone and never touch the head.
+          bool any = false;
+#pragma unroll
+          for (int q = 0; q < DF_NQ; ++q) any = any || __builtin_amdgcn_readlane(word, 8 + q) < __builtin_amdgcn_readlane(word, q);
+          if (any && spins > 0u) {
+            const unsigned d = (blockIdx.x * 2654435761u + spins * 40503u) >> 27;        // 0 .. 31
+            for (unsigned z = 0; z < d; ++z) __builtin_amdgcn_s_sleep(2);
+            word = df_ld(cnt + (lane < 16 ? DF_TAIL + lane : DF_ABORT));
+          }
+        }
+#endif
         bool alldone = true;
 #pragma unroll
         for (int q = 0; q < DF_NQ; ++q) {
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
     // through the barrier and the task below on their own, lane 0 parked outside for ever: the scanner form's first build
     // re-ran its first task ~10^5 times per second with the result never published (profiles/r05/dataflow_lane_split.md).
     const int state = __builtin_amdgcn_readfirstlane(s_state);
-    if (state < 0) { if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (state < 0) return;
     // (the task's fields as SCALARS: every address below is wave-uniform, and the tile functions want their operand bases
     //  in scalar registers -- a buffer descriptor built from a vector register costs a v_readfirstlane per DMA)
     const unsigned* const tw = (const unsigned*)&s_task;
@@ -494,7 +505,6 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
     const int s_q = state - 1;
     const long long tt = TR ? wall_clock64() : 0;
     __syncthreads();
-    if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int r0 = t.half == 1 ? 64 : 0;
     double* const C = a.A + ((long)t.i * 128 + r0) * ld + (long)t.j * 128;
     unsigned* const kd = cnt + a.off_kd + 2u * ((unsigned)t.i * (t.i + 1u) / 2u + t.j);
@@ -505,8 +515,6 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       if (t.half == 2) gh_tile128_nt<true>(smem, C, ld, Ao, ld, Bo, ld, K);
       else gh_tile64_nt<true>(smem, C, ld, Ao, ld, Bo, ld, K);
     }
-    if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 255) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t.fin) {
       if (t.k1 > t.k0) {
         // the rows just written are this product's A operand: stores done, the CU's L1 dropped
@@ -528,7 +536,9 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       df_publish(cnt, kd + t.half, t.k1, nullptr, 0u);
     }
     df_list_candidates(a, __builtin_amdgcn_readfirstlane(s_gid));
-    if (tid == 0) (void)__hip_atomic_fetch_add(cnt + DF_DBG + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (no debugging counters on this path: four fire-and-forget atomic adds per task on ONE cache line -- 80 per microsecond chip-wide,
+    //  the rate at which a line saturates -- stood in front of every s_waitcnt vmcnt(0) of the publication: every task on the chip
+    //  2-3x slower, sessions j-n of profiles/r05)
     if (TR) df_trace(a, tt, t.i, t.j, t.k0, t.k1, (unsigned)s_q, t.half, t.fin);
   }
 }
@@ -540,7 +550,6 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
 __global__ void dflow_gate_kernel(const unsigned* cnt) {
   const long long t0 = wall_clock64();
   while (df_ld(cnt + DF_KEY) == 0u && wall_clock64() - t0 < 2000000LL) __builtin_amdgcn_s_sleep(8);
-  df_st((unsigned*)cnt + DF_DBG + 6, 1u);
 }
 
 // the time-out of a wait (not a property of the matrix) as an impossible minor index: compute_finish() of gh_chol.hip tells it apart

@@ -38,8 +38,7 @@ for n in [int(a) for a in sys.argv[1:]] or [300, 1100, 2200, 4096]:
             w = list(buf)
             print("STUCK after 6 s: peek rc %d  D %d abort %d key %#x (word 96: %d) tails %s heads %s" %
                   (rc, w[0], w[32], w[64], w[96], w[128:133], w[136:141]), flush=True)
-            print("  scanner passes %d stage %d | workers started %d gone %d | diagonal worker %d | tasks run %d | gate %d | rowh %s | stages: popped %d, update done (lane 0 / lane 255) %d / %d" %
-                  (w[192], w[193], w[194], w[195], w[196], w[197], w[198], w[320:330], w[200], w[201], w[202]), flush=True)
+            print("  rowh %s" % (w[320:330],), flush=True)
             os._exit(4)
         out.append((res[0], time.perf_counter() - t0))
     ok = out[0][0] == out[1][0] == out[2][0]
