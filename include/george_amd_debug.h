@@ -32,22 +32,18 @@ int gh_microbench_hbm_copy(double* gbps_out);
  * launch chain), -1 = by size (the default; GEORGE_AMD_DATAFLOW=0|1 overrides); returns the previous setting.  Both arms
  * give bit-identical factors. */
 int gh_debug_set_dataflow(int mode);
-/* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q, q < 5
- * (gh_dflow.hip: rows of the diagonal block, of the next one, far rows, the previous panel in pieces, the bulk); out (nullable):
- * rows of 7 ints {queue, i, j, k0, k1, half, fin} in need order, at most max_rows */
+/* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q, q < 4
+ * (gh_dflow.hip: crit, next-block steps, hi, lo); out (nullable): rows of 10 ints {queue, i, j, k0, k1, half, fin, bucket,
+ * gate word, gate value} in ticket order, at most max_rows (gate word: 0 = diagonal steps finished, 256 + 2 r + h = final L
+ * tiles of half-row (r, h)) */
 int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows);
-/* the candidate lists of that schedule (who looks at which tasks after finishing): producers = the tasks in the order of
- * gh_debug_dflow_schedule, then the diagonal worker's sub-diagonal multiply of step j (total + j), then its 128 x 128 kernel
- * of step j (total + nt + j); ptr (nullable): total + 2 nt + 1 offsets into cand; cand (nullable): at most max_cand task
- * indices; *n_cand = entries in all */
-int gh_debug_dflow_candidates(int32_t nt, uint32_t* ptr, uint32_t* cand, int64_t max_cand, int64_t* n_cand);
 /* per-task trace of the dataflow factorisation (single-threaded debugging aid).  capacity >= 0: from now on record up to
  * `capacity` tasks per factorisation (0 = off); out != NULL: first copy the last factorisation's records (4 x uint64 each:
- * start and end in 10-ns ticks, i | j << 16 | k0 << 32 | k1 << 48, kind | half << 8 | fin << 16 | workgroup << 32; kind 0-4 =
+ * start and end in 10-ns ticks, i | j << 16 | k0 << 32 | k1 << 48, kind | half << 8 | fin << 16 | workgroup << 32; kind 0-3 =
  * queue, 8-11 = the diagonal worker's wait / multiply / update / 128 x 128 kernel) and their number to *n_out */
 int gh_debug_dflow_trace(int64_t capacity, uint64_t* out, int64_t max_records, int64_t* n_out);
 /* the first n counter words of the handle's dataflow factorisation (gh_dflow.hip: 0 = diagonal steps finished, 32 = abort word,
- * 64 = the diagonal worker runs, 128 + q / 136 + q = entries on / taken from ready list q), read on a stream
+ * 64 = the diagonal worker runs, 96 + 32 q = first bucket of queue q that is not used up), read on a stream
  * of its own: answers while a factorisation is running */
 int gh_debug_dflow_peek(gh_chol* s, uint32_t* out, int32_t n);
 /* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at

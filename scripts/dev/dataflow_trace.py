@@ -37,7 +37,7 @@ def summarise(rec, n=None):
         out.append("link (potf2 end to potf2 end): mean %.2f median %.2f p90 %.2f max %.2f us" %
                    (link.mean(), np.median(link), np.percentile(link, 90), link.max()))
     work = kind < 8
-    for q, name in ((0, "q0 diag-block rows"), (1, "q1 next-block rows"), (2, "q2 far rows"), (3, "q3 pieces"), (4, "q4 bulk")):
+    for q, name in ((0, "crit"), (1, "next-block steps"), (2, "hi"), (3, "lo")):
         m = kind == q
         if not m.any():
             continue

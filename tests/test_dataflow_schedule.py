@@ -2,9 +2,8 @@
 
 The device kernel stores no dependencies: a task's inputs follow from its fields and three families of counters
 (D, rowh, kd).  This file restates that rule in Python (`ready`), hands the library's queues (gh_debug_dflow_schedule,
-host only) to the kernel's listing rule (whoever finishes a task checks the inputs of its CANDIDATES -- gh_debug_dflow_candidates --
-and appends the runnable ones to their queue's ready list) and a pool of simulated workers that take the first entry of the
-first non-empty list, with random task durations, and checks
+host only) to a pool of simulated workers that claim exactly as the kernel does -- a ticket from the first open bucket of
+every queue, one held task per queue and worker -- with random task durations, and checks
 
   * every claim finds its inputs FINAL in the true state (not only in the counters),
   * no two tasks in flight touch the same half tile,
@@ -21,35 +20,29 @@ import pytest
 from george_amd import _native
 
 PW = 8
-NQ = 5
+SCAN = 6
+NQ = 4
 
 
 def schedule(nt):
-    """-> per queue: list of tasks (i, j, k0, k1, half, fin) in need order"""
+    """-> per queue: (tasks, buckets); task = (i, j, k0, k1, half, fin); bucket = [start, size, gate_word, gate_val]"""
     lib = _native.lib
     counts = (C.c_int32 * NQ)()
     assert lib.gh_debug_dflow_schedule(nt, counts, None, 0) == 0
     tot = sum(counts)
-    out = (C.c_int32 * (7 * max(tot, 1)))()
+    out = (C.c_int32 * (10 * max(tot, 1)))()
     assert lib.gh_debug_dflow_schedule(nt, counts, out, tot) == 0
-    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 7)[:tot]
-    qs = [[] for _ in range(NQ)]
+    rows = np.frombuffer(out, dtype=np.int32).reshape(-1, 10)[:tot]
+    qs = [([], []) for _ in range(NQ)]
     for r in rows:
-        qs[r[0]].append(tuple(int(v) for v in r[1:]))
-    assert [len(q) for q in qs] == list(counts)
+        tasks, buckets = qs[r[0]]
+        if r[7] == len(buckets):
+            buckets.append([len(tasks), 0, int(r[8]), int(r[9])])
+        assert r[7] == len(buckets) - 1
+        buckets[-1][1] += 1
+        tasks.append(tuple(int(v) for v in r[1:7]))
+    assert [len(q[0]) for q in qs] == list(counts)
     return qs
-
-
-def candidates(nt, total):
-    lib = _native.lib
-    n = C.c_int64(0)
-    assert lib.gh_debug_dflow_candidates(nt, None, None, 0, C.byref(n)) == 0
-    ptr = (C.c_uint32 * (total + 2 * nt + 1))()
-    cand = (C.c_uint32 * max(1, n.value))()
-    assert lib.gh_debug_dflow_candidates(nt, ptr, cand, n.value, C.byref(n)) == 0
-    ptr, cand = list(ptr), list(cand)[:n.value]
-    assert ptr[0] == 0 and ptr[-1] == n.value
-    return [cand[ptr[p]:ptr[p + 1]] for p in range(total + 2 * nt)]
 
 
 class Machine:
@@ -184,33 +177,41 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
     qs = schedule(nt)
     m = Machine(nt, b, seed)
     rng = random.Random(seed)
-    flat = [t for q in qs for t in q]             # global task index -> task
-    qof = [q for q in range(NQ) for _ in qs[q]]
-    gid = {}
-    for g, t in enumerate(flat):
-        gid[(qof[g], t)] = g
-    total = len(flat)
-    cands = candidates(nt, total)
-    listed = [False] * total
-    ready_list = [[] for _ in range(NQ)]
-    head = [0] * NQ
+    hint = [0] * NQ
+    nxt = [[0] * len(q[1]) for q in qs]          # ticket counters
+    held = [[None] * NQ for _ in range(nworkers)]  # per worker and queue: a claimed task waiting for its inputs
     flight = [None] * nworkers                    # (remaining ticks, effects)
     dj, dphase, dwait = 0, 0, 0                   # diagonal worker: step, part, remaining ticks
     done_tasks = 0
+    total = sum(len(q[0]) for q in qs)
     stall = 0
 
-    def list_candidates(producer):
-        """what a producer does after publishing: the runnable ones of its candidates go onto their ready lists"""
-        for g in cands[producer]:
-            if not listed[g] and m.ready(flat[g]):
-                listed[g] = True
-                ready_list[qof[g]].append(g)
-
-    def take():
-        for q in range(NQ):
-            if head[q] < len(ready_list[q]):
-                head[q] += 1
-                return ready_list[q][head[q] - 1]
+    def claim(q):
+        """the kernel's claim: from the first bucket that is not used up on, at most SCAN of them, none behind a closed D
+        gate; crit and hi look at the bucket's next task first and take a ticket only when it is runnable"""
+        tasks, buckets = qs[q]
+        front, scan = True, 0
+        bk = hint[q]
+        while bk < len(buckets) and scan < SCAN:
+            start, size, gw, gv = buckets[bk]
+            if nxt[q][bk] >= size:
+                if front:
+                    hint[q] = max(hint[q], bk + 1)
+                bk += 1
+                continue
+            front = False
+            scan += 1
+            if m.word(gw) < gv:
+                if gw == 0:
+                    break
+                bk += 1
+                continue
+            if q < NQ - 1 and not m.ready(tasks[start + nxt[q][bk]]):
+                bk += 1
+                continue
+            tk = nxt[q][bk]
+            nxt[q][bk] += 1
+            return tasks[start + tk]
         return None
 
     while dj < nt or done_tasks < total:
@@ -222,13 +223,10 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
             elif dphase == 0:
                 if m.diag_can_start(dj):
                     m.diag_part1(dj)
-                    if dj > 0:
-                        list_candidates(total + dj)
                     dphase, dwait = 1, rng.randint(0, 3)
                     progressed = True
             else:
                 m.diag_part2(dj)
-                list_candidates(total + nt + dj)
                 dj, dphase, dwait = dj + 1, 0, rng.randint(0, 3)
                 progressed = True
         order = list(range(nworkers))
@@ -239,23 +237,29 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
                 if rem > 0:
                     flight[w] = (rem - 1, eff)
                 else:
-                    m.finish(eff[1])
-                    list_candidates(eff[0])
+                    m.finish(eff)
                     flight[w] = None
                     done_tasks += 1
                 progressed = True
                 continue
-            if rng.random() < 0.3:       # this worker does not look in this tick
+            if rng.random() < 0.3:       # this worker does not poll in this tick
                 continue
-            g = take()
-            if g is not None:
-                assert m.ready(flat[g])                       # nothing is listed before it can run
-                flight[w] = (rng.randint(0, max_flight), (g, m.start(flat[g])))
-                progressed = True
+            for q in range(NQ):
+                if held[w][q] is None:
+                    held[w][q] = claim(q)
+                    if held[w][q] is not None:
+                        progressed = True
+                if held[w][q] is not None and m.ready(held[w][q]):
+                    flight[w] = (rng.randint(0, max_flight), m.start(held[w][q]))
+                    held[w][q] = None
+                    progressed = True
+                    break
         stall = 0 if progressed else stall + 1
-        assert stall < 50, ("no forward progress", dj, head, [len(r) for r in ready_list], [len(q) for q in qs])
-    assert all(listed) and [head[q] for q in range(NQ)] == [len(q) for q in qs]
-    return m, qs
+        assert stall < 50, ("no forward progress", dj, hint, [[t for t in h if t] for h in held if any(h)][:5])
+    assert all(h == [None] * NQ for h in held)
+    for q in range(NQ):
+        assert all(nxt[q][bk] >= qs[q][1][bk][1] for bk in range(len(qs[q][1])))
+    return m, [q[0] for q in qs]
 
 
 def check_coverage(nt, m):
@@ -279,7 +283,7 @@ def test_replay_gives_the_cholesky_factor(nt, workers, seed):
     assert np.allclose(got, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("nt,workers", [(64, 48), (100, 120)])
+@pytest.mark.parametrize("nt,workers", [(64, 64), (128, 200)])
 def test_structure_at_product_sizes(nt, workers):
     m, qs = run(nt, workers, b=0, seed=nt, max_flight=6)
     check_coverage(nt, m)
@@ -291,22 +295,18 @@ def test_structure_at_product_sizes(nt, workers):
 
 def test_queue_shapes():
     qs = schedule(40)
-    # q4: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns
-    for (i, j, k0, k1, half, fin) in qs[4]:
-        assert half == 2 and not fin and 0 < k1 - k0 <= 16 and k1 <= PW * (j // PW - 1)
-    # q3: the previous panel into far tiles, whole tiles
-    for (i, j, k0, k1, half, fin) in qs[3]:
-        assert half == 2 and not fin and PW * (j // PW - 1) <= k0 < k1 <= PW * (j // PW) and i >= PW * (j // PW + 1)
-    # q0, q1: one k step or a multiply, rows of this / the next diagonal block
+    # lo: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns; one bucket, always open
+    assert len(qs[3][1]) == 1 and qs[3][1][0][3] == 0
+    for (i, j, k0, k1, half, fin) in qs[3][0]:
+        assert half == 2 and not fin and 0 < k1 - k0 <= PW and k1 <= PW * (j // PW - 1)
+    # crit and the next-block queue: one k step or a multiply
     for q in (0, 1):
-        for (i, j, k0, k1, half, fin) in qs[q]:
-            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin)
-            link = j if fin else k0
-            assert i < PW * (link // PW + 1 + q) + (PW if q == 1 and not fin and j // PW > k0 // PW else 0) or q == 1
-    # q2: far rows, half tiles, the in-panel range and the multiply in one
-    for (i, j, k0, k1, half, fin) in qs[2]:
-        assert half in (0, 1) and fin and k1 == j and i >= PW * (j // PW + 2)
-    # multiplies by L_jj^-T never for the diagonal worker's rows
-    for tasks in qs:
+        for (i, j, k0, k1, half, fin) in qs[q][0]:
+            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin and q == 0)
+    # multiplies by L_jj^-T never for the diagonal worker's rows; gates open in order inside a queue
+    for tasks, buckets in qs:
         for (i, j, k0, k1, half, fin) in tasks:
             assert i >= j and (not fin or (i >= j + 2 and k1 == j))
+        d_gates = [b[3] for b in buckets if b[2] == 0]
+        assert d_gates == sorted(d_gates)
+        assert sum(b[1] for b in buckets) == len(tasks)
