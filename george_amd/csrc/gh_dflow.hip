@@ -51,8 +51,10 @@
 #define DF_PW 8              // panel width in tiles (the launch chain's nb = 1024)
 #define DF_NEARX 8           // rows [8 (p + 1), 8 (p + 1) + NEARX) are handled eagerly while panel p is factored
 #define DF_NEARF 16          // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time (queue 1)
-#define DF_NQ 4
-#define DF_SCAN 6            // buckets a claim looks into, beyond the used-up ones
+#define DF_NQ 5
+#define DF_NPEEK 3           // queues 0 .. 2 hand out a ticket only for a runnable next task; 3 and 4 in order, their owners wait
+#define DF_LO_NEAR 3         // passes of panel q into block columns <= q + DF_LO_NEAR go first (queue 3), the rest after them (queue 4)
+#define DF_SCAN 8            // buckets a claim looks into, beyond the used-up ones
 #define DF_HALVES 0          // 1: the tasks next to the front as 64-row half tiles (measured: a K = 128 task is bound by its eight
                              //    dependent slab round trips, ~20 us whatever the tile height -- halves only double the task count)
 
@@ -100,11 +102,16 @@ static void df_build(int nt, DfSchedule& s) {
   };
   // queue 0 (crit), buckets of link l: 2 l = behind D > l, the multiplies by L_ll^-T of the near rows, then their k = l updates
   // that need only those; 2 l + 1 = the k = l updates of tile column l + 1, whose B operand L(l+1, l) is the diagonal worker's
-  // (gate: its row counter).  Queue 1, the same two buckets per link: step k = l of the tiles of the NEXT block column in the
-  // sixteen rows that will be its near rows -- they also wait for the lo queue, so in a queue of their own, or a bucket of
-  // theirs that stands open would eat the crit queue's scan window (the form before this one: 25 of 37 ms at N = 16384 spent
+  // (gate: its row counter) -- for the rows of the panel's own diagonal block ONLY.  Queue 1, the same two buckets per link:
+  // the same tasks for the eight rows below (the next diagonal block), and step k = l of the tiles of the NEXT block column in
+  // the sixteen rows that will be its near rows.  Those also wait for the lo queues, so in a queue of their own, or a bucket
+  // of theirs that stands open would eat the crit queue's scan window (the form before this one: 25 of 37 ms at N = 16384 spent
   // by the diagonal worker waiting for multiplies that were runnable for 2.5 ms).  Queue 2 (hi): per link the far rows' tasks,
-  // then the far pieces that end there.  Queue 3 (lo): one bucket, always open.
+  // then the far pieces that end there.  Queues 3 and 4 (lo): one bucket each, always open, tickets in order: the passes of
+  // panel q into the next two block columns that still lack it (q + 2, q + 3) before everything further to the right -- the
+  // diagonal worker reaches those columns within two panels, the rest has time.  The tiles of the next diagonal blocks
+  // (rows < 8 p + 16 of block column p) take their old passes through the hi queue instead: few tasks, and the lo queues run
+  // 2-3 ms behind what is runnable when the chip is full -- exactly the tiles the diagonal worker then waits for.
   for (int j = 0; j < nt; ++j) {
     const int p = j / DF_PW, q0 = DF_PW * p;
     for (int i = j; i < nt; ++i) {
@@ -118,7 +125,10 @@ static void df_build(int nt, DfSchedule& s) {
       if (p >= 2) {
         const int wend = std::min(DF_PW * (p - 1), kmax);
         for (int k0 = 0; k0 < wend; k0 += DF_PW)
-          qs[3].push_back({Key(0, k0 / DF_PW, p, i < DF_PW * p + DF_NEARF ? 0 : 1, j, i), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
+          if (i < DF_PW * p + DF_NEARF)      // the next diagonal blocks' tiles: in the hi bucket of the link that ends the panel, behind the far rows' tasks of that link (which make their rows final), ahead of the pieces
+            qs[2].push_back({Key(k0 + DF_PW - 1, 1, p, j, i, 0), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
+          else
+            qs[p - k0 / DF_PW <= DF_LO_NEAR ? 3 : 4].push_back({Key(0, k0 / DF_PW, p, 1, j, i), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
       }
       // (2) the previous panel
       if (p >= 1) {
@@ -129,16 +139,16 @@ static void df_build(int nt, DfSchedule& s) {
           static const int cut[5] = {0, 4, 6, 7, 8};
           for (int c = 0; c < 4; ++c) {
             const int k0 = a0 + cut[c], k1 = std::min(a0 + cut[c + 1], a1);
-            if (k1 > k0) qs[2].push_back({Key(k1 - 1, 1, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
+            if (k1 > k0) qs[2].push_back({Key(k1 - 1, 2, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
           }
         }
       }
       // (3) inside the panel, eagerly for the rows near the front
       if (kmax > q0 && near_row)
-        for (int k = q0; k < kmax; ++k) near_task(0, 2 * k + (j == k + 1 ? 1 : 0), 1, i, j, k, k + 1, 0);
+        for (int k = q0; k < kmax; ++k) near_task(i < DF_PW * (p + 1) ? 0 : 1, 2 * k + (j == k + 1 ? 1 : 0), 1, i, j, k, k + 1, 0);
       // (4) the multiply by L_jj^-T (rows j + 2 and below; row j + 1 is the diagonal worker's)
       if (i >= j + 2) {
-        if (near_row) near_task(0, 2 * j, 0, i, j, j, j, 1);
+        if (near_row) near_task(i < DF_PW * (p + 1) ? 0 : 1, 2 * j, 0, i, j, j, j, 1);
         else {
           // far rows: the in-panel k range and the multiply as ONE task per HALF tile -- a row's eight tasks of a panel follow
           // one another (36 products), and as whole tiles (23-27 us per product beside a second workgroup on the CU) they took
@@ -158,7 +168,7 @@ static void df_build(int nt, DfSchedule& s) {
       if (bk != cur) {
         cur = bk;
         DfBucket B; B.start = (uint32_t)s.q[q].size(); B.size = 0;
-        if (q == 3) { B.gate_word = DF_D; B.gate_val = 0; }                                          // always open
+        if (q >= 3) { B.gate_word = DF_D; B.gate_val = 0; }                                          // always open
         else if (q == 2) { B.gate_word = DF_D; B.gate_val = (uint32_t)bk + 1; }                      // D > link
         else if (bk % 2 == 0) { B.gate_word = DF_D; B.gate_val = (uint32_t)(bk / 2) + 1; }           // D > link
         else { B.gate_word = DF_ROWH + 2 * (uint32_t)(bk / 2 + 1); B.gate_val = (uint32_t)(bk / 2) + 1; }   // L(l+1, l) published
@@ -397,7 +407,10 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
               anyleft = true;
               ++scan;
               if (df_ld(cnt + B.gate_word) < B.gate_val) { if (B.gate_word == DF_D) break; continue; }
-              if (q < DF_NQ - 1 && !df_ready(a, a.tasks[q][B.start + nx])) continue;
+              // (queue 0 -- the diagonal block's own rows -- hands its tickets out blind: its tasks' inputs are always a few
+              //  microseconds away, and an owner that already waits starts the task the moment they are there; with the look,
+              //  every hop of the block's chains waited 100-180 us for a workgroup to come by: profiles/r05/dataflow_critpath_session_u)
+              if (q > 0 && q < DF_NPEEK && !df_ready(a, a.tasks[q][B.start + nx])) continue;
               const unsigned tk = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (tk < B.size) { held[q] = B.start + tk; fresh = true; break; }
             }
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
             anyleft = true;
             const DfTask t = a.tasks[q][held[q]];
             bool ok = df_ready(a, t);
-            if (!ok && fresh && q < DF_NQ - 1) {
+            if (!ok && fresh && q < DF_NPEEK) {
               // just claimed and not runnable: its inputs are tasks of the same link, in flight -- wait a little before
               // going on with other work (a task that is held while its owner runs a long lo task starts late)
               const long long w0 = wall_clock64();

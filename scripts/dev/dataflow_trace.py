@@ -37,7 +37,7 @@ def summarise(rec, n=None):
         out.append("link (potf2 end to potf2 end): mean %.2f median %.2f p90 %.2f max %.2f us" %
                    (link.mean(), np.median(link), np.percentile(link, 90), link.max()))
     work = kind < 8
-    for q, name in ((0, "crit"), (1, "next-block steps"), (2, "hi"), (3, "lo")):
+    for q, name in ((0, "crit"), (1, "next-block steps"), (2, "hi"), (3, "lo near"), (4, "lo far")):
         m = kind == q
         if not m.any():
             continue

@@ -20,8 +20,9 @@ import pytest
 from george_amd import _native
 
 PW = 8
-SCAN = 6
-NQ = 4
+SCAN = 8
+NQ = 5
+NPEEK = 3
 
 
 def schedule(nt):
@@ -206,7 +207,7 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
                     break
                 bk += 1
                 continue
-            if q < NQ - 1 and not m.ready(tasks[start + nxt[q][bk]]):
+            if 0 < q < NPEEK and not m.ready(tasks[start + nxt[q][bk]]):
                 bk += 1
                 continue
             tk = nxt[q][bk]
@@ -294,16 +295,16 @@ def test_structure_at_product_sizes(nt, workers):
 
 
 def test_queue_shapes():
-    qs = schedule(40)
-    # lo: whole tiles, k ranges inside panels older than the previous one, at most 16 tile columns; one bucket, always open
-    assert len(qs[3][1]) == 1 and qs[3][1][0][3] == 0
-    for (i, j, k0, k1, half, fin) in qs[3][0]:
-        assert half == 2 and not fin and 0 < k1 - k0 <= PW and k1 <= PW * (j // PW - 1)
+    qs = schedule(72)
+    # lo (queues 3, 4): whole tiles, one pass per panel older than the previous one; one bucket each, always open
+    assert len(qs[3][1]) == 1 and qs[3][1][0][3] == 0 and len(qs[4][1]) == 1
+    for (i, j, k0, k1, half, fin) in qs[3][0] + qs[4][0]:
+        assert half == 2 and not fin and 0 < k1 - k0 <= PW and k1 <= PW * (j // PW - 1) and i >= PW * (j // PW) + 16
     # crit and the next-block queue: one k step or a multiply
     for q in (0, 1):
         for (i, j, k0, k1, half, fin) in qs[q][0]:
-            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin and q == 0)
-    # multiplies by L_jj^-T never for the diagonal worker's rows; gates open in order inside a queue
+            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin)
+    # multiplies by L_jj^-T never for the diagonal worker's rows; D gates open in order inside a queue
     for tasks, buckets in qs:
         for (i, j, k0, k1, half, fin) in tasks:
             assert i >= j and (not fin or (i >= j + 2 and k1 == j))
