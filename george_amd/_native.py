@@ -106,6 +106,7 @@ SIGNATURES = {
     "gh_debug_set_dataflow": (C.c_int, [C.c_int]),
     "gh_debug_dflow_schedule": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64]),
     "gh_debug_dflow_trace": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)]),
+    "gh_debug_dflow_candidates": (C.c_int, [C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64)]),
     "gh_debug_dflow_peek": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int32]),
     "gh_debug_stream_overlap": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_debug_stream_dispatch": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),

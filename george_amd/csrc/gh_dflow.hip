@@ -52,6 +52,8 @@
 #define DF_NEARX 8           // rows [8 (p + 1), 8 (p + 1) + NEARX) are handled eagerly while panel p is factored
 #define DF_NEARF 16          // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time (queue 1)
 #define DF_NQ 5
+#define DF_AHEAD 24           // tickets of a ready list that may be out beyond its listed entries (workgroups waiting at their slots)
+#define DF_NLIST 2           // queues 0, 1: no buckets, their tasks reach the workers through ready lists (see DfSchedule)
 #define DF_NPEEK 3           // queues 0 .. 2 hand out a ticket only for a runnable next task; 3 and 4 in order, their owners wait
 #define DF_LO_NEAR 3         // passes of panel q into block columns <= q + DF_LO_NEAR go first (queue 3), the rest after them (queue 4)
 #define DF_SCAN 8            // buckets a claim looks into, beyond the used-up ones
@@ -76,15 +78,25 @@ struct DfBucket {            // tasks [start, start + size) of a queue, claimabl
 #define DF_KEY 64
 #define DF_HEAD 96           // + 32 q
 #define DF_STAT 192          // [0] tasks run, [1] idle polls (debug)
+#define DF_TAIL 240           // + q: entries of ready list q handed out to producers; + 8 + q: entries taken (q < DF_NLIST)
 #define DF_ROWH 256
 static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
 static inline size_t df_off_next(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }   // per-bucket ticket counters
-static inline size_t df_words(int nt) { return df_off_next(nt) + 5 * (size_t)nt + 8; }       // (two crit, two next-block and a hi bucket per link, one lo)
+#define DF_LISTED_PER_LINK 320                // bound on the listed tasks (queues 0, 1) per link: checked when the schedule is built
+static inline size_t df_off_notes(int nt) { return df_off_next(nt) + 2 * (size_t)nt + 32; }   // (a hi bucket per link, two lo buckets)
+// per listed task one "listed" note and one ready-list slot
+static inline size_t df_words(int nt) { return df_off_notes(nt) + 2 * (size_t)DF_LISTED_PER_LINK * nt + 64; }
 
 // ------------------------------------------------------------------------------------------------ the schedule (host)
 struct DfSchedule {
   std::vector<DfTask> q[DF_NQ];
-  std::vector<DfBucket> b[DF_NQ];
+  std::vector<DfBucket> b[DF_NQ];          // queues DF_NLIST .. : tickets per bucket
+  // queues 0 .. DF_NLIST - 1 are LISTED: whoever finishes one of their tasks' inputs checks the task and, when it is runnable,
+  // appends it to the queue's ready list.  Producers: task g (global index: queue by queue), then the diagonal worker's
+  // multiply of step j (total + j), then its potf2 of step j (total + nt + j); cand[cand_ptr[P] .. cand_ptr[P + 1]) = global
+  // indices of the listed tasks that read what P writes.
+  std::vector<uint32_t> cand_ptr, cand;
+  size_t total() const { size_t n = 0; for (auto& v : q) n += v.size(); return n; }
 };
 static void df_build(int nt, DfSchedule& s) {
   // key: (bucket, order inside the bucket ...)
@@ -165,6 +177,7 @@ static void df_build(int nt, DfSchedule& s) {
     int cur = -1;
     for (auto& e : qs[q]) {
       const int bk = std::get<0>(e.first);
+      if (q < DF_NLIST) { s.q[q].push_back(e.second); continue; }
       if (bk != cur) {
         cur = bk;
         DfBucket B; B.start = (uint32_t)s.q[q].size(); B.size = 0;
@@ -178,6 +191,49 @@ static void df_build(int nt, DfSchedule& s) {
       s.b[q].back().size += 1;
     }
   }
+  // ---- candidates: every listed task X goes onto the list of each of its inputs' producers (df_ready()'s rule)
+  const size_t G = s.total();
+  std::vector<std::vector<uint32_t>> lists(G + 2 * (size_t)nt);
+  std::map<std::tuple<int, int, int, int>, uint32_t> kd_prod;       // (i, j, half 0|1, value) -> the task that brings the half tile to `value` steps
+  std::map<std::tuple<int, int, int>, uint32_t> fin_prod;           // (i, j, half 0|1) -> the task that makes L(i, j) final
+  {
+    uint32_t g = 0;
+    for (int q = 0; q < DF_NQ; ++q)
+      for (const DfTask& t : s.q[q]) {
+        const int h0 = t.half == 2 ? 0 : t.half, h1 = t.half == 2 ? 1 : t.half;
+        for (int h = h0; h <= h1; ++h) {
+          if (t.fin) fin_prod[std::make_tuple((int)t.i, (int)t.j, h)] = g;
+          else kd_prod[std::make_tuple((int)t.i, (int)t.j, h, (int)t.k1)] = g;
+        }
+        ++g;
+      }
+  }
+  auto final_producer = [&](int r, int c, int h) -> size_t {        // who makes half h of L(r, c) final
+    if (r == c + 1) return G + (size_t)r;                           // the diagonal worker's multiply of step r
+    return fin_prod.at(std::make_tuple(r, c, h));
+  };
+  {
+    uint32_t g = 0;
+    for (int q = 0; q < DF_NLIST; ++q)
+      for (const DfTask& t : s.q[q]) {
+        const int h0 = t.half == 2 ? 0 : t.half, h1 = t.half == 2 ? 1 : t.half;
+        std::vector<size_t> prods;
+        if (t.k0 > 0) for (int h = h0; h <= h1; ++h) prods.push_back(kd_prod.at(std::make_tuple((int)t.i, (int)t.j, h, (int)t.k0)));
+        if (t.k1 > t.k0) {
+          const int c = t.k1 - 1;
+          for (int h = 0; h < 2; ++h) prods.push_back(final_producer(t.j, c, h));
+          if (t.i != t.j) for (int h = h0; h <= h1; ++h) prods.push_back(final_producer(t.i, c, h));
+        }
+        if (t.fin) prods.push_back(G + (size_t)nt + t.j);
+        std::sort(prods.begin(), prods.end());
+        prods.erase(std::unique(prods.begin(), prods.end()), prods.end());
+        for (size_t P : prods) lists[P].push_back(g);
+        ++g;
+      }
+  }
+  s.cand_ptr.assign(1, 0u);
+  s.cand.clear();
+  for (auto& l : lists) { s.cand.insert(s.cand.end(), l.begin(), l.end()); s.cand_ptr.push_back((uint32_t)s.cand.size()); }
 }
 
 // the schedule of an nt x nt tile matrix, for the replay in tests/test_dataflow_schedule.py (host only, no device needed):
@@ -199,9 +255,22 @@ extern "C" int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out
       if (r >= max_rows) return GH_OK;
       int32_t* o = out + 10 * r++;
       o[0] = q; o[1] = t.i; o[2] = t.j; o[3] = t.k0; o[4] = t.k1; o[5] = t.half; o[6] = t.fin;
-      o[7] = (int32_t)bi; o[8] = (int32_t)s.b[q][bi].gate_word; o[9] = (int32_t)s.b[q][bi].gate_val;
+      if (s.b[q].empty()) { o[7] = -1; o[8] = 0; o[9] = 0; }            // a listed queue: no buckets
+      else { o[7] = (int32_t)bi; o[8] = (int32_t)s.b[q][bi].gate_word; o[9] = (int32_t)s.b[q][bi].gate_val; }
     }
   }
+  return GH_OK;
+}
+
+// the candidate lists of the same schedule: ptr (when not NULL) receives total + 2 nt + 1 offsets, cand the entries (at most
+// max_cand); *n_cand = the number of entries
+extern "C" int gh_debug_dflow_candidates(int32_t nt, uint32_t* ptr, uint32_t* cand, int64_t max_cand, int64_t* n_cand) {
+  if (nt <= 0 || nt > 4096 || !n_cand) { gh_set_error("dflow_candidates: bad argument"); return GH_ERR_BAD_ARG; }
+  DfSchedule s;
+  df_build(nt, s);
+  *n_cand = (int64_t)s.cand.size();
+  if (ptr) memcpy(ptr, s.cand_ptr.data(), s.cand_ptr.size() * sizeof(uint32_t));
+  if (cand) memcpy(cand, s.cand.data(), (size_t)std::min<int64_t>(max_cand, (int64_t)s.cand.size()) * sizeof(uint32_t));
   return GH_OK;
 }
 
@@ -215,6 +284,12 @@ struct DfArgs {
   const DfBucket* buckets[DF_NQ];
   unsigned nb[DF_NQ];            // buckets per queue
   unsigned off_next[DF_NQ];      // cnt + off_next[q] + b: the ticket counter of bucket b of queue q
+  unsigned count[DF_NLIST];      // tasks of the listed queues
+  unsigned off_note[DF_NLIST];   // cnt + off_note[q] + x: task x of listed queue q is on its ready list
+  unsigned off_list[DF_NLIST];   // cnt + off_list[q] + e: entry e of ready list q = task index + 1 (0: not written yet)
+  unsigned qoff[DF_NQ + 1];      // global index of the first task of queue q
+  const uint32_t* cand_ptr;      // candidates of producer P: cand[cand_ptr[P] .. cand_ptr[P + 1])
+  const uint32_t* cand;
   unsigned off_kd;
   int nt;
   unsigned long long* trace;     // debugging aid (gh_debug_dflow_trace): [0] = records used, then 4 words per record; NULL: off
@@ -273,6 +348,31 @@ __device__ __forceinline__ void df_publish(unsigned* w0, unsigned v0, unsigned* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     df_st(w0, v0);
     if (w1) df_st(w1, v1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the counters are out before anybody looks at the candidates
+  }
+}
+
+// After df_publish(): the calling workgroup's threads check the inputs of producer P's candidates (tasks of the listed queues
+// that read what P wrote), one candidate per thread, and append the runnable ones to their ready list.  Two producers that
+// finish a task's last two inputs at the same time both find it runnable (each has its own counters out -- waited for --
+// before it reads the other's); the note's compare-and-swap lets one of them list it.
+__device__ __forceinline__ void df_list_candidates(const DfArgs& a, unsigned P) {
+  const unsigned beg = a.cand_ptr[P], end = a.cand_ptr[P + 1];
+  if (beg == end) return;                                       // (uniform)
+  __syncthreads();
+  unsigned* const cnt = a.cnt;
+  for (unsigned c = beg + threadIdx.x; c < end; c += blockDim.x) {
+    const unsigned g = a.cand[c];
+    const int q = g >= a.qoff[1] ? 1 : 0;
+    const unsigned x = g - a.qoff[q];
+    unsigned* const note = cnt + a.off_note[q] + x;
+    if (df_ld(note) != 0u) continue;
+    const DfTask t = a.tasks[q][x];
+    if (!df_ready(a, t)) continue;
+    unsigned expect = 0u;
+    if (!__hip_atomic_compare_exchange_strong(note, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+    const unsigned slot = __hip_atomic_fetch_add(cnt + DF_TAIL + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    df_st(cnt + a.off_list[q] + slot, x + 1u);
   }
 }
 
@@ -334,6 +434,7 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         }
         gh_tile128_nt<false>(smem, Asub, ld, Asub, ld, dprev, 128, 128);                 // L(j, j-1), in place
         df_publish(cnt + DF_ROWH + 2 * j, (unsigned)j, cnt + DF_ROWH + 2 * j + 1, (unsigned)j);
+        df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)j);
         if (TR) { df_trace(a, tt, j, j - 1, 0, 0, 9, 2, 1); tt = wall_clock64(); }
         // (no barrier: the other wavefronts request the first slab and C while wavefront 0 is in the release)
         gh_tile128_nt<true>(smem, Ajj, ld, Asub, ld, Asub, ld, 128);                     // A_jj -= L(j, j-1) L(j, j-1)^T
@@ -348,6 +449,7 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         return;
       }
       df_publish(cnt + DF_D, (unsigned)(j + 1), nullptr, 0u);
+      df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)a.nt + (unsigned)j);
       if (TR) df_trace(a, tt, j, j, 0, 0, 11, 2, 0);
     }
   }
@@ -358,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
   __shared__ __attribute__((aligned(1024))) double smem[8192];
   __shared__ DfTask s_task;
   __shared__ int s_state;
+  __shared__ unsigned s_gid;               // global index of the task taken (= its producer number)
   const int tid = threadIdx.x;
   unsigned* const cnt = a.cnt;
   const long ld = a.ld;
@@ -374,9 +477,11 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
   __syncthreads();
 
   // (lane 0) per queue: a claimed task that waits for its inputs (index into the queue), or none
-  unsigned held[DF_NQ];
+  unsigned held[DF_NQ], tick[DF_NLIST];
 #pragma unroll
   for (int q = 0; q < DF_NQ; ++q) held[q] = 0xffffffffu;
+#pragma unroll
+  for (int q = 0; q < DF_NLIST; ++q) tick[q] = 0xffffffffu;
   for (;;) {
     if (tid == 0) {
       int st = 0;
@@ -385,11 +490,37 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       for (;;) {
         if (df_ld(cnt + DF_ABORT) != 0u) { st = -1; break; }
         bool anyleft = false;
+        // ---- the listed queues first.  Entries are taken by TICKET (a fetch-and-add on the list's head that always succeeds),
+        // up to DF_AHEAD tickets ahead of what is listed: the owner of a ticket polls its own slot -- an address nobody else
+        // looks at -- and starts the task the moment a producer writes it.  (Taking the first entry by compare-and-swap, every
+        // idle workgroup that saw the tail move fired at the same word: hundreds of failed read-modify-writes per listed task on
+        // one memory channel, and every load on the chip that touched that channel queued behind them -- all tasks 2-3x slower,
+        // the more the more workgroups were idle: profiles/r05/dataflow_ab_session_n.log, _w.log.)
 #pragma unroll
-        for (int q = 0; q < DF_NQ; ++q) {
+        for (int q = 0; q < DF_NLIST; ++q) {
+          if (st != 0) continue;
+          if (tick[q] == 0xffffffffu) {
+            const unsigned tail = df_ld(cnt + DF_TAIL + q), h = df_ld(cnt + DF_TAIL + 8 + q);
+            if (h < a.count[q]) anyleft = true;
+            if (h < a.count[q] && h < tail + DF_AHEAD) {
+              const unsigned tk = __hip_atomic_fetch_add(cnt + DF_TAIL + 8 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (tk < a.count[q]) tick[q] = tk;
+            }
+          }
+          if (tick[q] != 0xffffffffu) {
+            anyleft = true;
+            const unsigned e = df_ld(cnt + a.off_list[q] + tick[q]);
+            if (e != 0u) { s_task = a.tasks[q][e - 1u]; s_gid = a.qoff[q] + e - 1u; tick[q] = 0xffffffffu; st = 1 + q; }
+          }
+        }
+        // (a workgroup that waits for a listed entry takes no new bucket tickets: the entry would start late behind a 200-us
+        //  pass; what it holds from before it still runs when that becomes runnable -- others may be waiting for it)
+        const bool waiting = tick[0] != 0xffffffffu || tick[1] != 0xffffffffu;
+#pragma unroll
+        for (int q = DF_NLIST; q < DF_NQ; ++q) {
           if (st != 0) continue;
           bool fresh = false;
-          if (held[q] == 0xffffffffu) {
+          if (held[q] == 0xffffffffu && !waiting) {
             // claim: from the first bucket that is not used up on, at most DF_SCAN of them, none behind a closed D gate (those
             // open in order).  crit and hi LOOK before they take a ticket: the next task of the bucket must be runnable -- a
             // ticket for a task whose inputs are far away would keep its owner from the lo queue (or, held, start late behind
@@ -407,10 +538,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
               anyleft = true;
               ++scan;
               if (df_ld(cnt + B.gate_word) < B.gate_val) { if (B.gate_word == DF_D) break; continue; }
-              // (queue 0 -- the diagonal block's own rows -- hands its tickets out blind: its tasks' inputs are always a few
-              //  microseconds away, and an owner that already waits starts the task the moment they are there; with the look,
-              //  every hop of the block's chains waited 100-180 us for a workgroup to come by: profiles/r05/dataflow_critpath_session_u)
-              if (q > 0 && q < DF_NPEEK && !df_ready(a, a.tasks[q][B.start + nx])) continue;
+              if (q < DF_NPEEK && !df_ready(a, a.tasks[q][B.start + nx])) continue;
               const unsigned tk = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (tk < B.size) { held[q] = B.start + tk; fresh = true; break; }
             }
@@ -424,14 +552,14 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
               // just claimed and not runnable: its inputs are tasks of the same link, in flight -- wait a little before
               // going on with other work (a task that is held while its owner runs a long lo task starts late)
               const long long w0 = wall_clock64();
-              const long long lim = q == 0 ? 20000 : 5000;                   // 200 us / 50 us
+              const long long lim = 5000;                                     // 50 us
               while (!ok && wall_clock64() - w0 < lim) {
                 __builtin_amdgcn_s_sleep(4);
                 if (df_ld(cnt + DF_ABORT) != 0u) break;
                 ok = df_ready(a, t);
               }
             }
-            if (ok) { s_task = t; held[q] = 0xffffffffu; st = 1 + q; }
+            if (ok) { s_task = t; s_gid = a.qoff[q] + held[q]; held[q] = 0xffffffffu; st = 1 + q; }
           }
         }
         if (st) break;
@@ -488,6 +616,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
     } else {
       df_publish(kd + t.half, t.k1, nullptr, 0u);
     }
+    df_list_candidates(a, __builtin_amdgcn_readfirstlane(s_gid));
     if (TR) df_trace(a, tt, t.i, t.j, t.k0, t.k1, (unsigned)s_q, t.half, t.fin);
   }
 }
@@ -508,10 +637,12 @@ __global__ void dflow_check_kernel(const unsigned* cnt, long long* info) {
 
 // ------------------------------------------------------------------------------------------------ host side
 struct DfDeviceSchedule {
-  DfTask* d[DF_NQ] = {nullptr, nullptr, nullptr};
-  DfBucket* b[DF_NQ] = {nullptr, nullptr, nullptr};
-  unsigned count[DF_NQ] = {0, 0, 0};
-  unsigned nb[DF_NQ] = {0, 0, 0};
+  DfTask* d[DF_NQ] = {};
+  DfBucket* b[DF_NQ] = {};
+  unsigned count[DF_NQ] = {};
+  unsigned nb[DF_NQ] = {};
+  uint32_t* cand_ptr = nullptr;
+  uint32_t* cand = nullptr;
 };
 static std::mutex g_df_mutex;
 static std::map<std::pair<int, int>, DfDeviceSchedule> g_df_cache;     // (device, nt): never freed (a few MB per size)
@@ -564,9 +695,15 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
         if (s.q[q].empty()) continue;
         GH_HIP(hipMalloc((void**)&n.d[q], s.q[q].size() * sizeof(DfTask)));
         GH_HIP(hipMemcpy(n.d[q], s.q[q].data(), s.q[q].size() * sizeof(DfTask), hipMemcpyHostToDevice));
+        if (s.b[q].empty()) continue;
         GH_HIP(hipMalloc((void**)&n.b[q], s.b[q].size() * sizeof(DfBucket)));
         GH_HIP(hipMemcpy(n.b[q], s.b[q].data(), s.b[q].size() * sizeof(DfBucket), hipMemcpyHostToDevice));
       }
+      if (s.q[0].size() + s.q[1].size() > (size_t)DF_LISTED_PER_LINK * nt) { gh_set_error("dflow: more listed tasks than the counter buffer holds"); return GH_ERR_BAD_ARG; }
+      GH_HIP(hipMalloc((void**)&n.cand_ptr, s.cand_ptr.size() * sizeof(uint32_t)));
+      GH_HIP(hipMemcpy(n.cand_ptr, s.cand_ptr.data(), s.cand_ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      GH_HIP(hipMalloc((void**)&n.cand, std::max<size_t>(1, s.cand.size()) * sizeof(uint32_t)));
+      if (!s.cand.empty()) GH_HIP(hipMemcpy(n.cand, s.cand.data(), s.cand.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       it = g_df_cache.emplace(std::make_pair(dev, nt), n).first;
     }
     ds = it->second;
@@ -580,11 +717,21 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
   DfArgs a;
   a.A = A; a.ld = (long)ld; a.dinv = dinv; a.info = d_info; a.cnt = counters;
   unsigned at = (unsigned)df_off_next(nt);
+  unsigned total = 0;
   for (int q = 0; q < DF_NQ; ++q) {
     a.tasks[q] = ds.d[q]; a.buckets[q] = ds.b[q]; a.nb[q] = ds.nb[q]; a.off_next[q] = at;
     at += ds.nb[q];
+    a.qoff[q] = total; total += ds.count[q];
   }
-  if ((size_t)at > df_words(nt)) { gh_set_error("dflow: bucket counters overflow"); return GH_ERR_BAD_ARG; }
+  a.qoff[DF_NQ] = total;
+  if ((size_t)at > df_off_notes(nt)) { gh_set_error("dflow: bucket counters overflow"); return GH_ERR_BAD_ARG; }
+  at = (unsigned)df_off_notes(nt);
+  for (int q = 0; q < DF_NLIST; ++q) {
+    a.count[q] = ds.count[q];
+    a.off_note[q] = at; at += ds.count[q];
+    a.off_list[q] = at; at += ds.count[q];
+  }
+  a.cand_ptr = ds.cand_ptr; a.cand = ds.cand;
   a.off_kd = (unsigned)df_off_kd(nt); a.nt = nt;
   a.trace = nullptr; a.trace_cap = 0;
   if (g_df_trace_cap > 0) {
@@ -603,7 +750,7 @@ int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* 
   // two workgroups per CU (64 KiB of LDS each); the diagonal worker's CU takes none (its registers are gone)
   static const int nwork = getenv("GEORGE_AMD_DATAFLOW_WORKERS") ? std::max(1, atoi(getenv("GEORGE_AMD_DATAFLOW_WORKERS"))) : 0;
   const unsigned grid = (unsigned)(nwork > 0 ? nwork : 2 * ncu - 2);
-  if (ds.count[0] + ds.count[1] + ds.count[2] > 0) {
+  if (total > 0) {
     if (a.trace) hipLaunchKernelGGL(dflow_worker_kernel<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dflow_worker_kernel<false>, dim3(grid), dim3(256), 0, st, a);
     GH_HIP(hipGetLastError());

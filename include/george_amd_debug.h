@@ -32,11 +32,16 @@ int gh_microbench_hbm_copy(double* gbps_out);
  * launch chain), -1 = by size (the default; GEORGE_AMD_DATAFLOW=0|1 overrides); returns the previous setting.  Both arms
  * give bit-identical factors. */
 int gh_debug_set_dataflow(int mode);
-/* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q, q < 4
- * (gh_dflow.hip: crit, next-block steps, hi, lo); out (nullable): rows of 10 ints {queue, i, j, k0, k1, half, fin, bucket,
+/* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q
+ * (gh_dflow.hip: crit, next-block steps, hi, lo near, lo far; q < 5); out (nullable): rows of 10 ints {queue, i, j, k0, k1, half, fin, bucket,
  * gate word, gate value} in ticket order, at most max_rows (gate word: 0 = diagonal steps finished, 256 + 2 r + h = final L
  * tiles of half-row (r, h)) */
 int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows);
+/* the candidate lists of that schedule (queues 0 and 1 have no buckets: whoever finishes one of their tasks' inputs appends the
+ * task to the queue's ready list): producers = all tasks in the order of gh_debug_dflow_schedule, then the diagonal worker's
+ * sub-diagonal multiply of step j (total + j), then its 128 x 128 kernel of step j (total + nt + j); ptr (nullable): total +
+ * 2 nt + 1 offsets into cand; cand (nullable): at most max_cand task indices (of queues 0, 1); *n_cand = entries in all */
+int gh_debug_dflow_candidates(int32_t nt, uint32_t* ptr, uint32_t* cand, int64_t max_cand, int64_t* n_cand);
 /* per-task trace of the dataflow factorisation (single-threaded debugging aid).  capacity >= 0: from now on record up to
  * `capacity` tasks per factorisation (0 = off); out != NULL: first copy the last factorisation's records (4 x uint64 each:
  * start and end in 10-ns ticks, i | j << 16 | k0 << 32 | k1 << 48, kind | half << 8 | fin << 16 | workgroup << 32; kind 0-3 =

@@ -2,8 +2,9 @@
 
 The device kernel stores no dependencies: a task's inputs follow from its fields and three families of counters
 (D, rowh, kd).  This file restates that rule in Python (`ready`), hands the library's queues (gh_debug_dflow_schedule,
-host only) to a pool of simulated workers that claim exactly as the kernel does -- a ticket from the first open bucket of
-every queue, one held task per queue and worker -- with random task durations, and checks
+host only) to a pool of simulated workers that claim exactly as the kernel does -- queues 0 and 1 through ready lists that
+whoever finishes a task's input fills (gh_debug_dflow_candidates), the others by a ticket from the first open
+bucket, one held task per queue and worker -- with random task durations, and checks
 
   * every claim finds its inputs FINAL in the true state (not only in the counters),
   * no two tasks in flight touch the same half tile,
@@ -23,6 +24,7 @@ PW = 8
 SCAN = 8
 NQ = 5
 NPEEK = 3
+NLIST = 2
 
 
 def schedule(nt):
@@ -37,6 +39,9 @@ def schedule(nt):
     qs = [([], []) for _ in range(NQ)]
     for r in rows:
         tasks, buckets = qs[r[0]]
+        if r[7] < 0:
+            tasks.append(tuple(int(v) for v in r[1:7]))
+            continue
         if r[7] == len(buckets):
             buckets.append([len(tasks), 0, int(r[8]), int(r[9])])
         assert r[7] == len(buckets) - 1
@@ -44,6 +49,18 @@ def schedule(nt):
         tasks.append(tuple(int(v) for v in r[1:7]))
     assert [len(q[0]) for q in qs] == list(counts)
     return qs
+
+
+def candidates(nt, total):
+    lib = _native.lib
+    n = C.c_int64(0)
+    assert lib.gh_debug_dflow_candidates(nt, None, None, 0, C.byref(n)) == 0
+    ptr = (C.c_uint32 * (total + 2 * nt + 1))()
+    cand = (C.c_uint32 * max(1, n.value))()
+    assert lib.gh_debug_dflow_candidates(nt, ptr, cand, n.value, C.byref(n)) == 0
+    ptr, cand = list(ptr), list(cand)[:n.value]
+    assert ptr[0] == 0 and ptr[-1] == n.value
+    return [cand[ptr[p]:ptr[p + 1]] for p in range(total + 2 * nt)]
 
 
 class Machine:
@@ -181,11 +198,32 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
     hint = [0] * NQ
     nxt = [[0] * len(q[1]) for q in qs]          # ticket counters
     held = [[None] * NQ for _ in range(nworkers)]  # per worker and queue: a claimed task waiting for its inputs
-    flight = [None] * nworkers                    # (remaining ticks, effects)
+    flight = [None] * nworkers                    # (remaining ticks, producer index, effects)
     dj, dphase, dwait = 0, 0, 0                   # diagonal worker: step, part, remaining ticks
     done_tasks = 0
     total = sum(len(q[0]) for q in qs)
     stall = 0
+    qoff = [0]
+    for q in range(NQ):
+        qoff.append(qoff[-1] + len(qs[q][0]))
+    gid = {}
+    for q in range(NQ):
+        for x, t in enumerate(qs[q][0]):
+            gid[(q, x)] = qoff[q] + x
+    cands = candidates(nt, total)
+    listed = [[False] * len(qs[q][0]) for q in range(NLIST)]
+    ready_list = [[] for _ in range(NLIST)]
+    head = [0] * NLIST
+
+    def list_candidates(producer):
+        """what a producer does after publishing: the runnable ones of its candidates go onto their ready lists"""
+        for g in cands[producer]:
+            q = 1 if g >= qoff[1] else 0
+            assert g < qoff[NLIST]
+            x = g - qoff[q]
+            if not listed[q][x] and m.ready(qs[q][0][x]):
+                listed[q][x] = True
+                ready_list[q].append(x)
 
     def claim(q):
         """the kernel's claim: from the first bucket that is not used up on, at most SCAN of them, none behind a closed D
@@ -207,12 +245,12 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
                     break
                 bk += 1
                 continue
-            if 0 < q < NPEEK and not m.ready(tasks[start + nxt[q][bk]]):
+            if q < NPEEK and not m.ready(tasks[start + nxt[q][bk]]):
                 bk += 1
                 continue
             tk = nxt[q][bk]
             nxt[q][bk] += 1
-            return tasks[start + tk]
+            return start + tk
         return None
 
     while dj < nt or done_tasks < total:
@@ -224,41 +262,59 @@ def run(nt, nworkers, b=0, seed=0, max_flight=12):
             elif dphase == 0:
                 if m.diag_can_start(dj):
                     m.diag_part1(dj)
+                    if dj > 0:
+                        list_candidates(total + dj)
                     dphase, dwait = 1, rng.randint(0, 3)
                     progressed = True
             else:
                 m.diag_part2(dj)
+                list_candidates(total + nt + dj)
                 dj, dphase, dwait = dj + 1, 0, rng.randint(0, 3)
                 progressed = True
         order = list(range(nworkers))
         rng.shuffle(order)
         for w in order:
             if flight[w] is not None:
-                rem, eff = flight[w]
+                rem, prod, eff = flight[w]
                 if rem > 0:
-                    flight[w] = (rem - 1, eff)
+                    flight[w] = (rem - 1, prod, eff)
                 else:
                     m.finish(eff)
+                    list_candidates(prod)
                     flight[w] = None
                     done_tasks += 1
                 progressed = True
                 continue
             if rng.random() < 0.3:       # this worker does not poll in this tick
                 continue
-            for q in range(NQ):
+            started = False
+            for q in range(NLIST):       # the ready lists first
+                if head[q] < len(ready_list[q]):
+                    x = ready_list[q][head[q]]
+                    head[q] += 1
+                    assert m.ready(qs[q][0][x])
+                    flight[w] = (rng.randint(0, max_flight), gid[(q, x)], m.start(qs[q][0][x]))
+                    progressed = started = True
+                    break
+            if started:
+                continue
+            for q in range(NLIST, NQ):
                 if held[w][q] is None:
                     held[w][q] = claim(q)
                     if held[w][q] is not None:
                         progressed = True
-                if held[w][q] is not None and m.ready(held[w][q]):
-                    flight[w] = (rng.randint(0, max_flight), m.start(held[w][q]))
+                if held[w][q] is not None and m.ready(qs[q][0][held[w][q]]):
+                    x = held[w][q]
+                    flight[w] = (rng.randint(0, max_flight), gid[(q, x)], m.start(qs[q][0][x]))
                     held[w][q] = None
                     progressed = True
                     break
         stall = 0 if progressed else stall + 1
         assert stall < 50, ("no forward progress", dj, hint, [[t for t in h if t] for h in held if any(h)][:5])
     assert all(h == [None] * NQ for h in held)
-    for q in range(NQ):
+    for q in range(NLIST):
+        assert all(listed[q]) and head[q] == len(qs[q][0])
+    for q in range(NLIST, NQ):
         assert all(nxt[q][bk] >= qs[q][1][bk][1] for bk in range(len(qs[q][1])))
     return m, [q[0] for q in qs]
 
@@ -310,4 +366,5 @@ def test_queue_shapes():
             assert i >= j and (not fin or (i >= j + 2 and k1 == j))
         d_gates = [b[3] for b in buckets if b[2] == 0]
         assert d_gates == sorted(d_gates)
-        assert sum(b[1] for b in buckets) == len(tasks)
+        assert (not buckets) or sum(b[1] for b in buckets) == len(tasks)
+    assert not qs[0][1] and not qs[1][1] and qs[2][1]            # queues 0, 1 are listed, the others have buckets
