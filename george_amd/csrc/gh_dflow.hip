@@ -78,7 +78,7 @@ struct DfBucket {            // tasks [start, start + size) of a queue, claimabl
 #define DF_KEY 64
 #define DF_HEAD 96           // + 32 q
 #define DF_STAT 192          // [0] tasks run, [1] idle polls (debug)
-#define DF_TAIL 240           // + q: entries of ready list q handed out to producers; + 8 + q: entries taken (q < DF_NLIST)
+#define DF_TAIL 240           // + q: entries of ready list q handed out to producers; + 4 + q: tasks of queue q kept by their producers (never listed); + 8 + q: tickets taken (q < DF_NLIST)
 #define DF_ROWH 256
 static inline size_t df_off_kd(int nt) { return DF_ROWH + (size_t)((2 * nt + 31) / 32) * 32; }
 static inline size_t df_off_next(int nt) { return df_off_kd(nt) + (size_t)((nt * (nt + 1) + 31) / 32) * 32; }   // per-bucket ticket counters
@@ -231,6 +231,20 @@ static void df_build(int nt, DfSchedule& s) {
         ++g;
       }
   }
+  // order: a producer keeps the FIRST runnable candidate of its list for itself (see df_list_candidates) -- the one that
+  // continues its own row's chain: same row first, then the nearest column
+  {
+    std::vector<const DfTask*> flat;
+    for (int q = 0; q < DF_NQ; ++q) for (const DfTask& t : s.q[q]) flat.push_back(&t);
+    for (size_t P = 0; P < lists.size(); ++P) {
+      const int prow = P < G ? (int)flat[P]->i : -1;
+      std::stable_sort(lists[P].begin(), lists[P].end(), [&](uint32_t x, uint32_t y) {
+        const DfTask &a = *flat[x], &b = *flat[y];
+        const int ka = (int)a.i == prow ? 0 : 1, kb = (int)b.i == prow ? 0 : 1;
+        return std::make_tuple(ka, (int)a.j, (int)a.i, (int)a.k0) < std::make_tuple(kb, (int)b.j, (int)b.i, (int)b.k0);
+      });
+    }
+  }
   s.cand_ptr.assign(1, 0u);
   s.cand.clear();
   for (auto& l : lists) { s.cand.insert(s.cand.end(), l.begin(), l.end()); s.cand_ptr.push_back((uint32_t)s.cand.size()); }
@@ -356,23 +370,49 @@ __device__ __forceinline__ void df_publish(unsigned* w0, unsigned v0, unsigned* 
 // that read what P wrote), one candidate per thread, and append the runnable ones to their ready list.  Two producers that
 // finish a task's last two inputs at the same time both find it runnable (each has its own counters out -- waited for --
 // before it reads the other's); the note's compare-and-swap lets one of them list it.
-__device__ __forceinline__ void df_list_candidates(const DfArgs& a, unsigned P) {
+// `keep` (LDS, or NULL): the workgroup keeps the first runnable candidate of the list for itself instead of listing it -- its
+// own row's next task, by the order the host gave the list; *keep = its global index + 1, or 0.
+__device__ __forceinline__ void df_list_candidates(const DfArgs& a, unsigned P, unsigned* keep) {
   const unsigned beg = a.cand_ptr[P], end = a.cand_ptr[P + 1];
-  if (beg == end) return;                                       // (uniform)
+  if (keep && threadIdx.x == 0) *keep = 0xffffffffu;
+  if (beg == end) { if (keep) { __syncthreads(); if (threadIdx.x == 0) *keep = 0u; __syncthreads(); } return; }     // (uniform)
   __syncthreads();
   unsigned* const cnt = a.cnt;
-  for (unsigned c = beg + threadIdx.x; c < end; c += blockDim.x) {
-    const unsigned g = a.cand[c];
-    const int q = g >= a.qoff[1] ? 1 : 0;
-    const unsigned x = g - a.qoff[q];
-    unsigned* const note = cnt + a.off_note[q] + x;
-    if (df_ld(note) != 0u) continue;
-    const DfTask t = a.tasks[q][x];
-    if (!df_ready(a, t)) continue;
-    unsigned expect = 0u;
-    if (!__hip_atomic_compare_exchange_strong(note, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-    const unsigned slot = __hip_atomic_fetch_add(cnt + DF_TAIL + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    df_st(cnt + a.off_list[q] + slot, x + 1u);
+  for (unsigned c0 = beg; c0 < end; c0 += blockDim.x) {
+    const unsigned c = c0 + threadIdx.x;
+    bool mine = false;
+    unsigned g = 0, x = 0;
+    int q = 0;
+    if (c < end) {
+      g = a.cand[c];
+      q = g >= a.qoff[1] ? 1 : 0;
+      x = g - a.qoff[q];
+      unsigned* const note = cnt + a.off_note[q] + x;
+      if (df_ld(note) == 0u) {
+        const DfTask t = a.tasks[q][x];
+        if (df_ready(a, t)) {
+          unsigned expect = 0u;
+          mine = __hip_atomic_compare_exchange_strong(note, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (keep && c0 == beg) {                                     // (uniform) the first round decides what stays here
+      if (mine) __hip_atomic_fetch_min(keep, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __syncthreads();
+      if (mine && *keep == c) {                                   // kept: not listed -- one list slot less will ever be written
+        mine = false;
+        (void)__hip_atomic_fetch_add(cnt + DF_TAIL + 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (mine) {
+      const unsigned slot = __hip_atomic_fetch_add(cnt + DF_TAIL + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      df_st(cnt + a.off_list[q] + slot, x + 1u);
+    }
+  }
+  if (keep) {
+    __syncthreads();
+    if (threadIdx.x == 0) *keep = *keep == 0xffffffffu ? 0u : a.cand[*keep] + 1u;
+    __syncthreads();
   }
 }
 
@@ -434,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         }
         gh_tile128_nt<false>(smem, Asub, ld, Asub, ld, dprev, 128, 128);                 // L(j, j-1), in place
         df_publish(cnt + DF_ROWH + 2 * j, (unsigned)j, cnt + DF_ROWH + 2 * j + 1, (unsigned)j);
-        df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)j);
+        df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)j, nullptr);
         if (TR) { df_trace(a, tt, j, j - 1, 0, 0, 9, 2, 1); tt = wall_clock64(); }
         // (no barrier: the other wavefronts request the first slab and C while wavefront 0 is in the release)
         gh_tile128_nt<true>(smem, Ajj, ld, Asub, ld, Asub, ld, 128);                     // A_jj -= L(j, j-1) L(j, j-1)^T
@@ -449,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void dflow_diag_kernel(DfArgs a) {
         return;
       }
       df_publish(cnt + DF_D, (unsigned)(j + 1), nullptr, 0u);
-      df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)a.nt + (unsigned)j);
+      df_list_candidates(a, a.qoff[DF_NQ] + (unsigned)a.nt + (unsigned)j, nullptr);
       if (TR) df_trace(a, tt, j, j, 0, 0, 11, 2, 0);
     }
   }
@@ -461,10 +501,12 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
   __shared__ DfTask s_task;
   __shared__ int s_state;
   __shared__ unsigned s_gid;               // global index of the task taken (= its producer number)
+  __shared__ unsigned s_keep;              // the candidate this workgroup kept for itself after its last task (global index + 1), or 0
   const int tid = threadIdx.x;
   unsigned* const cnt = a.cnt;
   const long ld = a.ld;
   const unsigned mykey = df_cu_key();
+  if (tid == 0) s_keep = 0u;
   if (tid == 0) {
     // the workgroup that shares the diagonal worker's CU leaves (its matrix instructions would halve potf2's rate);
     // its key is there within microseconds of its launch -- bounded anyway (~0.5 ms)
@@ -490,6 +532,12 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
       for (;;) {
         if (df_ld(cnt + DF_ABORT) != 0u) { st = -1; break; }
         bool anyleft = false;
+        if (s_keep != 0u) {                                     // the next task of the row this workgroup just worked on
+          const unsigned g = s_keep - 1u;
+          const int q = g >= a.qoff[1] ? 1 : 0;
+          s_task = a.tasks[q][g - a.qoff[q]]; s_gid = g; s_keep = 0u; st = 1 + q;
+          break;
+        }
         // ---- the listed queues first.  Entries are taken by TICKET (a fetch-and-add on the list's head that always succeeds),
         // up to DF_AHEAD tickets ahead of what is listed: the owner of a ticket polls its own slot -- an address nobody else
         // looks at -- and starts the task the moment a producer writes it.  (Taking the first entry by compare-and-swap, every
@@ -501,16 +549,18 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
           if (st != 0) continue;
           if (tick[q] == 0xffffffffu) {
             const unsigned tail = df_ld(cnt + DF_TAIL + q), h = df_ld(cnt + DF_TAIL + 8 + q);
-            if (h < a.count[q]) anyleft = true;
-            if (h < a.count[q] && h < tail + DF_AHEAD) {
+            const unsigned lim = a.count[q] - df_ld(cnt + DF_TAIL + 4 + q);            // slots that can still be written
+            if (h < lim) anyleft = true;
+            if (h < lim && h < tail + DF_AHEAD) {
               const unsigned tk = __hip_atomic_fetch_add(cnt + DF_TAIL + 8 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (tk < a.count[q]) tick[q] = tk;
+              if (tk < lim) tick[q] = tk;
             }
           }
           if (tick[q] != 0xffffffffu) {
-            anyleft = true;
             const unsigned e = df_ld(cnt + a.off_list[q] + tick[q]);
-            if (e != 0u) { s_task = a.tasks[q][e - 1u]; s_gid = a.qoff[q] + e - 1u; tick[q] = 0xffffffffu; st = 1 + q; }
+            if (e != 0u) { anyleft = true; s_task = a.tasks[q][e - 1u]; s_gid = a.qoff[q] + e - 1u; tick[q] = 0xffffffffu; st = 1 + q; }
+            else if (tick[q] + df_ld(cnt + DF_TAIL + 4 + q) >= a.count[q]) tick[q] = 0xffffffffu;   // as many tasks were KEPT by their producers as slots lie behind this one: it stays empty
+            else anyleft = true;
           }
         }
         // (a workgroup that waits for a listed entry takes no new bucket tickets: the entry would start late behind a 200-us
@@ -616,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
     } else {
       df_publish(kd + t.half, t.k1, nullptr, 0u);
     }
-    df_list_candidates(a, __builtin_amdgcn_readfirstlane(s_gid));
+    df_list_candidates(a, __builtin_amdgcn_readfirstlane(s_gid), &s_keep);
     if (TR) df_trace(a, tt, t.i, t.j, t.k0, t.k1, (unsigned)s_q, t.half, t.fin);
   }
 }
