@@ -52,7 +52,7 @@
 #define DF_NEARX 8           // rows [8 (p + 1), 8 (p + 1) + NEARX) are handled eagerly while panel p is factored
 #define DF_NEARF 16          // tiles of block column p in rows < 8 p + NEARF take panel p - 1 one column at a time (queue 1)
 #define DF_NQ 5
-#define DF_AHEAD 24           // tickets of a ready list that may be out beyond its listed entries (workgroups waiting at their slots)
+#define DF_AHEAD 8            // tickets of a ready list that may be out beyond its listed entries (workgroups waiting at their slots)
 #define DF_NLIST 2           // queues 0, 1: no buckets, their tasks reach the workers through ready lists (see DfSchedule)
 #define DF_NPEEK 3           // queues 0 .. 2 hand out a ticket only for a runnable next task; 3 and 4 in order, their owners wait
 #define DF_LO_NEAR 3         // passes of panel q into block columns <= q + DF_LO_NEAR go first (queue 3), the rest after them (queue 4)
@@ -137,10 +137,13 @@ static void df_build(int nt, DfSchedule& s) {
       if (p >= 2) {
         const int wend = std::min(DF_PW * (p - 1), kmax);
         for (int k0 = 0; k0 < wend; k0 += DF_PW)
-          if (i < DF_PW * p + DF_NEARF)      // the next diagonal blocks' tiles: in the hi bucket of the link that ends the panel, behind the far rows' tasks of that link (which make their rows final), ahead of the pieces
-            qs[2].push_back({Key(k0 + DF_PW - 1, 1, p, j, i, 0), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
-          else
-            qs[p - k0 / DF_PW <= DF_LO_NEAR ? 3 : 4].push_back({Key(0, k0 / DF_PW, p, 1, j, i), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
+          if (i < DF_PW * p + DF_NEARF)      // the next diagonal blocks' tiles: LISTED (queue 1) -- they run the moment their rows are final through the panel
+            qs[1].push_back({Key(k0 + DF_PW - 1, 2, 0, i, j, 0), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
+          else {
+            // (inside a panel's group: the rows of the next few diagonal blocks first -- they are the first to become near rows)
+            const int q_ = k0 / DF_PW, soon = i / DF_PW <= q_ + 4 ? 0 : 1;
+            qs[p - q_ <= DF_LO_NEAR ? 3 : 4].push_back({Key(0, q_, soon, p, j, i), task(i, j, k0, std::min(k0 + DF_PW, wend), 2, 0)});
+          }
       }
       // (2) the previous panel
       if (p >= 1) {
@@ -151,7 +154,7 @@ static void df_build(int nt, DfSchedule& s) {
           static const int cut[5] = {0, 4, 6, 7, 8};
           for (int c = 0; c < 4; ++c) {
             const int k0 = a0 + cut[c], k1 = std::min(a0 + cut[c + 1], a1);
-            if (k1 > k0) qs[2].push_back({Key(k1 - 1, 2, j, i, 0, 0), task(i, j, k0, k1, 2, 0)});
+            if (k1 > k0) qs[2].push_back({Key(k1 - 1, 2, i / DF_PW <= p + 2 ? 0 : 1, j, i, 0), task(i, j, k0, k1, 2, 0)});
           }
         }
       }
@@ -520,6 +523,9 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
 
   // (lane 0) per queue: a claimed task that waits for its inputs (index into the queue), or none
   unsigned held[DF_NQ], tick[DF_NLIST];
+  bool lo_done[DF_NQ - DF_NPEEK];
+#pragma unroll
+  for (int q = 0; q < DF_NQ - DF_NPEEK; ++q) lo_done[q] = false;
 #pragma unroll
   for (int q = 0; q < DF_NQ; ++q) held[q] = 0xffffffffu;
 #pragma unroll
@@ -544,23 +550,31 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
         // idle workgroup that saw the tail move fired at the same word: hundreds of failed read-modify-writes per listed task on
         // one memory channel, and every load on the chip that touched that channel queued behind them -- all tasks 2-3x slower,
         // the more the more workgroups were idle: profiles/r05/dataflow_ab_session_n.log, _w.log.)
+        {
+          // (all the words of both lists in one batch: the loads are independent, the round trip is paid once)
+          unsigned tl[DF_NLIST], hd[DF_NLIST], kp[DF_NLIST], sl[DF_NLIST];
 #pragma unroll
-        for (int q = 0; q < DF_NLIST; ++q) {
-          if (st != 0) continue;
-          if (tick[q] == 0xffffffffu) {
-            const unsigned tail = df_ld(cnt + DF_TAIL + q), h = df_ld(cnt + DF_TAIL + 8 + q);
-            const unsigned lim = a.count[q] - df_ld(cnt + DF_TAIL + 4 + q);            // slots that can still be written
-            if (h < lim) anyleft = true;
-            if (h < lim && h < tail + DF_AHEAD) {
-              const unsigned tk = __hip_atomic_fetch_add(cnt + DF_TAIL + 8 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (tk < lim) tick[q] = tk;
-            }
+          for (int q = 0; q < DF_NLIST; ++q) {
+            tl[q] = df_ld(cnt + DF_TAIL + q); hd[q] = df_ld(cnt + DF_TAIL + 8 + q); kp[q] = df_ld(cnt + DF_TAIL + 4 + q);
+            sl[q] = tick[q] != 0xffffffffu ? df_ld(cnt + a.off_list[q] + tick[q]) : 0u;
           }
-          if (tick[q] != 0xffffffffu) {
-            const unsigned e = df_ld(cnt + a.off_list[q] + tick[q]);
-            if (e != 0u) { anyleft = true; s_task = a.tasks[q][e - 1u]; s_gid = a.qoff[q] + e - 1u; tick[q] = 0xffffffffu; st = 1 + q; }
-            else if (tick[q] + df_ld(cnt + DF_TAIL + 4 + q) >= a.count[q]) tick[q] = 0xffffffffu;   // as many tasks were KEPT by their producers as slots lie behind this one: it stays empty
-            else anyleft = true;
+#pragma unroll
+          for (int q = 0; q < DF_NLIST; ++q) {
+            if (st != 0) continue;
+            const unsigned lim = a.count[q] - kp[q];                                  // slots that can still be written
+            if (tick[q] == 0xffffffffu) {
+              if (hd[q] < lim) anyleft = true;
+              if (hd[q] < lim && hd[q] < tl[q] + DF_AHEAD) {
+                const unsigned tk = __hip_atomic_fetch_add(cnt + DF_TAIL + 8 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk < lim) { tick[q] = tk; sl[q] = df_ld(cnt + a.off_list[q] + tk); }
+              }
+            }
+            if (tick[q] != 0xffffffffu) {
+              const unsigned e = sl[q];
+              if (e != 0u) { anyleft = true; s_task = a.tasks[q][e - 1u]; s_gid = a.qoff[q] + e - 1u; tick[q] = 0xffffffffu; st = 1 + q; }
+              else if (tick[q] >= lim) tick[q] = 0xffffffffu;   // as many tasks were KEPT by their producers as slots lie behind this one: it stays empty
+              else anyleft = true;
+            }
           }
         }
         // (a workgroup that waits for a listed entry takes no new bucket tickets: the entry would start late behind a 200-us
@@ -570,6 +584,15 @@ __global__ __launch_bounds__(256, 2) void dflow_worker_kernel(DfArgs a) {
         for (int q = DF_NLIST; q < DF_NQ; ++q) {
           if (st != 0) continue;
           bool fresh = false;
+          if (q >= DF_NPEEK) {
+            // the lo queues: ONE bucket, always open, tickets in order -- no hint, no gate, no look: a fetch-and-add
+            if (held[q] == 0xffffffffu && !waiting && !lo_done[q - DF_NPEEK]) {
+              const unsigned size = a.qoff[q + 1] - a.qoff[q];
+              const unsigned tk = size ? __hip_atomic_fetch_add(cnt + a.off_next[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : size;
+              if (tk < size) { held[q] = tk; fresh = true; } else lo_done[q - DF_NPEEK] = true;
+            }
+            if (!lo_done[q - DF_NPEEK]) anyleft = true;
+          } else
           if (held[q] == 0xffffffffu && !waiting) {
             // claim: from the first bucket that is not used up on, at most DF_SCAN of them, none behind a closed D gate (those
             // open in order).  crit and hi LOOK before they take a ticket: the next task of the bucket must be runnable -- a

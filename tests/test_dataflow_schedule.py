@@ -356,10 +356,11 @@ def test_queue_shapes():
     assert len(qs[3][1]) == 1 and qs[3][1][0][3] == 0 and len(qs[4][1]) == 1
     for (i, j, k0, k1, half, fin) in qs[3][0] + qs[4][0]:
         assert half == 2 and not fin and 0 < k1 - k0 <= PW and k1 <= PW * (j // PW - 1) and i >= PW * (j // PW) + 16
-    # crit and the next-block queue: one k step or a multiply
+    # crit and the next-block queue: one k step or a multiply; the next-block queue also has the old panels' passes into the
+    # next diagonal blocks' tiles
     for q in (0, 1):
         for (i, j, k0, k1, half, fin) in qs[q][0]:
-            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin)
+            assert (k1 - k0 == 1 and not fin) or (k1 == k0 == j and fin) or (q == 1 and not fin and k1 - k0 == PW and k1 <= PW * (j // PW - 1) and i < PW * (j // PW) + 16)
     # multiplies by L_jj^-T never for the diagonal worker's rows; D gates open in order inside a queue
     for tasks, buckets in qs:
         for (i, j, k0, k1, half, fin) in tasks:
