@@ -231,8 +231,8 @@ def hodlr_level_ranks(ranks):
 def hodlr_report(n, local_rank, steps=10, warmup=3, cpu_n=32768):
     """BASELINE config C4 for the N = 1 line: time, per-level ranks, footprint roofline, CPU sample."""
     job = HodlrJob(n, local_rank)
-    elapsed, ll = run_timed(job, steps, warmup, lambda: None)
-    sec = elapsed / steps
+    ts_, ll = run_steps(job, steps, warmup)
+    sec = float(np.mean(ts_))
     ranks = job.ranks()
     job.close()
     lv = hodlr_level_ranks(ranks)
@@ -259,7 +259,7 @@ def hodlr_report(n, local_rank, steps=10, warmup=3, cpu_n=32768):
     if hits:
         measured = json.load(open(hits[-1]))["bytes_per_step"]
     out = {"workload": "N=%d 1-D ExpSquared, HODLRSolver(tol=1e-10, min_size=100, seed=42): compute()+log_likelihood()" % n,
-           "seconds_per_step": sec, "steps": steps, "log_likelihood": ll, "rank_per_level": lv, "rank_total": rtot,
+           "seconds_per_step": sec, "per_step_s": spread(ts_), "steps": steps, "log_likelihood": ll, "rank_per_level": lv, "rank_total": rtot,
            "roofline": {"kernel": "whole HODLR compute()+log_likelihood() (ACA, leaf / core factorisation, Woodbury sweeps)",
                         "bound": "hbm", "achieved": foot / sec * 1e-9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": foot / sec * 1e-9 / PEAK_HBM_GBS, "traffic": measured if measured is not None else streamed,
@@ -554,9 +554,13 @@ def compact_line(out):
     a = cfg.get("also_configs1_N16384")
     if a:
         also["configs1_N16384"] = {"ms": a["seconds_per_step"] * 1e3, "tflops": a["value_tflops"], "frac": a["frac_of_fp64_mfma_peak"]}
+        if "per_step_s" in a:
+            also["configs1_N16384"]["ms_min_med_max"] = [a["per_step_s"][k] * 1e3 for k in ("min", "median", "max")]
     a = cfg.get("also_C4")
     if a and "seconds_per_step" in a:
-        also["C4_hodlr_N262144"] = {"ms": a["seconds_per_step"] * 1e3, "rank_per_level": a.get("rank_per_level"),
+        also["C4_hodlr_N262144"] = {"ms": a["seconds_per_step"] * 1e3,
+                                    "ms_min_med_max": [a["per_step_s"][k] * 1e3 for k in ("min", "median", "max")] if "per_step_s" in a else None,
+                                    "rank_per_level": a.get("rank_per_level"),
                                     "roofline": {k: a["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
                                                                                    "algorithmic_bytes", "streamed_bytes", "achieved_streamed")
                                                  if k in a["roofline"]},
@@ -582,6 +586,12 @@ def compact_line(out):
     a = cfg.get("also_C3_matern32")
     if a:
         also["C3_matern32"] = {"s": a["seconds_per_step"], "tflops": a["value_tflops"]}
+    a = cfg.get("also_other_grid")
+    if a:
+        also["other_grid"] = {k: a[k] for k in ("grid", "seconds_per_step", "value_tflops", "error") if k in a}
+    a = cfg.get("also_dataflow")
+    if a:
+        also["dataflow_arm"] = a
     a = cfg.get("also_curve")
     if a:
         also["reference_plot_sizes"] = [[r["solver"].split("(")[0], r["n"], r["seconds"], r["reference_plot_seconds"]] for r in a["rows"]]
@@ -591,7 +601,7 @@ def compact_line(out):
     if isinstance(par, dict):
         line["parity"] = {"bound": par.get("bound"), "ok": par.get("ok"),
                           "rel": {k: v["rel"] for k, v in par.items() if isinstance(v, dict) and "rel" in v}}
-    for k in ("rccl_ranks_seen", "timeline_rank0_ms", "abi_form"):
+    for k in ("rccl_ranks_seen", "timeline_rank0_ms", "abi_form", "links"):
         if k in out:
             line[k] = out[k]
     if "rccl" in out:
@@ -711,6 +721,74 @@ def run_timed(job, steps, warmup, barrier):
     return time.perf_counter() - t0, ll
 
 
+def run_steps(job, steps, warmup):
+    """The secondary legs of the line: every step timed on its own (synchronised on both sides), so that the line can carry
+    min / median / max and a slow box or a first-touch step shows as such.  -> (list of seconds, last value)"""
+    import torch
+    v = None
+    for _ in range(warmup):
+        v = job.step()
+    ts = []
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v = job.step()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return ts, v
+
+
+def spread(ts):
+    return {"min": float(np.min(ts)), "median": float(np.median(ts)), "max": float(np.max(ts)), "n": len(ts)}
+
+
+def link_probe(dist, device, world, rank, panel_bytes):
+    """Before the timed steps of an N > 1 run: what the links give, so that the line itself checks the assumptions of
+    profiles/r04/scale_model.md -- (i) one-way rate of ONE busy link (rank 0 -> each peer in turn), (ii) per-link rate with all
+    N - 1 links of every rank busy (each rank sends to every other rank at once), (iii) bus bandwidth of the bulk all-gather at
+    the first step's panel size.  Works on any backend (the launcher self-test runs it over gloo)."""
+    import torch
+    nbytes = int(min(64 << 20, max(1 << 20, panel_bytes)))
+    n = nbytes // 8
+    sync = (lambda: torch.cuda.synchronize()) if device != "cpu" else (lambda: None)
+    buf = torch.ones(n, dtype=torch.float64, device=device)
+    rx = [torch.empty(n, dtype=torch.float64, device=device) for _ in range(world)]
+    out = {"bytes": nbytes}
+
+    def timed(fn, reps=3):
+        fn()
+        sync(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync(); dist.barrier()
+        return (time.perf_counter() - t0) / reps
+
+    one = []
+    for peer in range(1, world):
+        def f(peer=peer):
+            if rank == 0:
+                dist.send(buf, dst=peer)
+            elif rank == peer:
+                dist.recv(rx[0], src=0)
+        one.append(nbytes / timed(f) * 1e-9)
+    out["one_link_GBs"] = {"min": min(one), "median": float(np.median(one)), "max": max(one)}
+
+    def all_links():
+        ops = []
+        for d in range(1, world):
+            ops.append(dist.P2POp(dist.isend, buf, (rank + d) % world))
+            ops.append(dist.P2POp(dist.irecv, rx[d], (rank - d) % world))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    t = timed(all_links)
+    out["all_links_busy_GBs_per_link"] = nbytes / t * 1e-9
+    gat = torch.empty(n * world, dtype=torch.float64, device=device)
+    t = timed(lambda: dist.all_gather_into_tensor(gat, buf))
+    out["allgather_busbw_GBs"] = nbytes * (world - 1) / t * 1e-9
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -812,6 +890,13 @@ def main():
         job = DenseJob(args.n, args.nb, local_rank, profile=True, lookahead=not args.no_lookahead, kernel=args.kernel)
         barrier = lambda: None
 
+    links = None
+    if world > 1 and not args.no_extra:
+        import torch.distributed as dist
+        try:
+            links = link_probe(dist, "cpu" if selftest else "cuda", world, rank, args.n * job.nb * 8 // world)
+        except Exception as e:                                    # (a backend without all_gather_into_tensor / batched p2p: say so)
+            links = {"error": repr(e)[:200]}
     elapsed, ll = run_timed(job, args.steps, args.warmup, barrier)
     if world > 1:
         import torch.distributed as dist
@@ -837,6 +922,25 @@ def main():
             t3 = torch.tensor([e3], dtype=torch.float64, device=t.device)
             dist.all_reduce(t3, op=dist.ReduceOp.MAX)
             c3 = (float(t3.item()), ll3)
+        # the OTHER grid on the same ranks: the default is N x 1 (whole tile rows per rank, chosen on the evidence of a replay
+        # model, profiles/r04/scale_model.md), north_star words it 2-D block-cyclic -- one warm-up + one timed step of
+        # 'square' (1x2 / 2x2 / 2x4), or of N x 1 when --grid asked for something else, so that ONE hardware run adjudicates
+        other = None
+        if not args.no_extra and world in (2, 4, 8):
+            og = "square" if not args.grid else ""
+            try:
+                job.set_kernel(args.kernel)
+                j2 = DistributedDenseJob(args.n, args.nb, local_rank, make_inputs, kernel=make_kernel, kernel_name=args.kernel, ops=ops,
+                                         grid=og or None)
+                j2.step()
+                eo, llo = run_timed(j2, 1, 0, barrier)
+                to = torch.tensor([eo], dtype=torch.float64, device=t.device)
+                dist.all_reduce(to, op=dist.ReduceOp.MAX)
+                other = {"grid": "%dx%d" % j2.chol_grid(), "seconds_per_step": float(to.item()),
+                         "value_tflops": flops_alg(args.n) / float(to.item()) * 1e-12, "log_likelihood": llo, "steps": 1}
+                del j2
+            except Exception as e:
+                other = {"error": repr(e)[:200]}
 
     if world > 1:
         # every rank's RCCL banner (C stdio) out BEFORE rank 0 prints the line, so that the line is last
@@ -901,6 +1005,13 @@ def main():
                 if g3 is not None:
                     parity["C3_matern32"] = {"n": args.n, "ll_gpu": c3[1], "ll_ref": g3[0], "rel": abs(c3[1] - g3[0]) / abs(g3[0]),
                                              "ref": "tests/golden/large.json[%s]" % g3[1]}
+            if other is not None:
+                out["config"]["also_other_grid"] = other
+                if "log_likelihood" in other:
+                    parity["other_grid"] = {"n": args.n, "ll_gpu": other["log_likelihood"], "ll_ref": ll,
+                                            "rel": abs(other["log_likelihood"] - ll) / abs(ll), "ref": "the default grid, same ranks"}
+            if links is not None:
+                out["links"] = links
             out["parity"] = parity
             out["parity"]["bound"] = 1e-6
             out["parity"]["ok"] = all(v["rel"] <= 1e-6 for v in parity.values() if isinstance(v, dict))
@@ -999,12 +1110,34 @@ def main():
                             "of x / yerr / y and the Python facade inside; `value` itself has the inputs resident in HBM"}
                 if args.n != 16384:
                     j2 = DenseJob(16384, args.nb, local_rank, profile=False)
-                    e2, ll2 = run_timed(j2, 5, 2, lambda: None)
-                    j2.close()
+                    ts2, ll2 = run_steps(j2, 7, 2)
+                    e2 = float(np.mean(ts2)) * 5
                     out["config"]["also_configs1_N16384"] = {
                         "seconds_per_step": e2 / 5, "value_tflops": flops_alg(16384) / (e2 / 5) * 1e-12,
                         "frac_of_fp64_mfma_peak": flops_alg(16384) / (e2 / 5) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
-                        "log_likelihood": ll2}
+                        "log_likelihood": ll2, "per_step_s": spread(ts2)}
+                    # the opt-in arm of the factorisation (GEORGE_AMD_DATAFLOW=1: one persistent launch of tile tasks,
+                    # george_amd/csrc/gh_dflow.hip) at the same sizes, same handle type, bits compared
+                    try:
+                        df = {}
+                        for nd in (8192, 16384):
+                            jc = j2 if nd == 16384 else DenseJob(nd, args.nb, local_rank, profile=False)
+                            tc, llc = (ts2, ll2) if nd == 16384 else run_steps(jc, 7, 2)
+                            prev = j2.N.lib.gh_debug_set_dataflow(1)
+                            try:
+                                jd = DenseJob(nd, args.nb, local_rank, profile=False)
+                                td, lld = run_steps(jd, 7, 2)
+                                jd.close()
+                            finally:
+                                j2.N.lib.gh_debug_set_dataflow(prev)
+                            if jc is not j2:
+                                jc.close()
+                            df["N%d" % nd] = {"launch_chain_ms": float(np.median(tc)) * 1e3, "dataflow_ms": float(np.median(td)) * 1e3,
+                                              "same_bits": bool(lld == llc)}
+                        out["config"]["also_dataflow"] = df
+                    except Exception as e:
+                        out["config"]["also_dataflow"] = {"error": repr(e)[:160]}
+                    j2.close()
                     g2 = golden_ll(16384)
                     if g2 is not None:
                         parity["configs1"] = {"n": 16384, "ll_gpu": ll2, "ll_ref": g2[0], "rel": abs(ll2 - g2[0]) / abs(g2[0])}

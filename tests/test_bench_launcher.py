@@ -53,6 +53,11 @@ def test_gpus_2_launches_two_ranks_and_prints_one_line(tmp_path):
     p = d["parity"]
     assert p["ok"] and p["rel"]["headline"] <= 1e-9 and p["rel"]["ranks_agree"] == 0.0
     assert "C3_matern32" in d["also"]                        # configs[2]'s kernel on the same workspace
+    # one run adjudicates the grid: the other grid timed on the same ranks, the links probed before the timed steps
+    assert d["also"]["other_grid"]["grid"] == "1x2" and d["also"]["other_grid"]["seconds_per_step"] > 0
+    assert p["rel"]["other_grid"] <= 1e-9
+    lk = d["links"]
+    assert lk["one_link_GBs"]["min"] > 0 and lk["all_links_busy_GBs_per_link"] > 0 and lk["allgather_busbw_GBs"] > 0
     full = json.load(open(detail))                           # the full record behind the line
     assert len(full["rccl"]["members"]) == 2 and full["parity"]["ranks_agree"]["spread"] == 0.0
     assert "also_C3_matern32" in full["config"]
