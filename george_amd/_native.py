@@ -61,7 +61,7 @@ class gh_hodlr_mgpu_opts(C.Structure):
 
 
 GH_MGPU_RCCL, GH_MGPU_COPY = 0, 1
-GH_MGPU_PLAIN_CYCLIC, GH_MGPU_CHAIN_ONLY, GH_MGPU_TRACE = 1, 2, 4
+GH_MGPU_PLAIN_CYCLIC, GH_MGPU_CHAIN_ONLY, GH_MGPU_TRACE, GH_MGPU_ONE_COMM = 1, 2, 4, 8
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -157,6 +157,7 @@ SIGNATURES = {
     "gh_mgpu_compute": (C.c_int, [_vp, _vp, _dp, _i64, _i32, _dp, C.POINTER(C.c_double)]),
     "gh_mgpu_info": (_i64, [_vp]),
     "gh_mgpu_grid": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gh_mgpu_comm_mode": (C.c_int, [_vp]),
     "gh_mgpu_dot_solve": (C.c_int, [_vp, _dp, C.POINTER(C.c_double)]),
     "gh_mgpu_solve": (C.c_int, [_vp, _dp, _i64, _dp]),
     "gh_mgpu_owner": (C.c_int, [_vp, _i64, _i64]),

@@ -638,6 +638,16 @@ double dispatch_wait_ms(hipStream_t big, hipStream_t small) {
   return ms;
 }
 }  // namespace
+// do kernels of `a` and `b` (streams of the current device) dispatch side by side?  (gh_mgpu.hip: two communicators at once)
+bool gh_streams_dispatch_independently(hipStream_t a, hipStream_t b) {
+  if (!a || !b || a == b) return false;
+  hipLaunchKernelGGL(place_spin_kernel, dim3(1), dim3(64), 0, a, 0LL);          // (queues are made at first use)
+  hipLaunchKernelGGL(place_spin_kernel, dim3(1), dim3(64), 0, b, 0LL);
+  (void)hipDeviceSynchronize();
+  const bool ok = dispatch_wait_ms(a, b) <= 0.3 && dispatch_wait_ms(b, a) <= 0.3;
+  (void)hipGetLastError();
+  return ok;
+}
 bool gh_shared_main_crowded(int device) {
   std::lock_guard<std::mutex> lk(g_ss_mu);
   auto it = g_ss.find(device);

@@ -156,6 +156,9 @@ void gh_prime_device(int device);
 // measured when the process-wide streams of `device` were made: does the main stream share a dispatcher with the chain,
 // rows-below or near stream?  (gh_chol.hip, factor_lookahead_deep: where a look-ahead factorisation is joined)
 bool gh_shared_main_crowded(int device);
+// do one-workgroup kernels of one stream complete while a grid far larger than the chip runs on the other, both ways round?
+// (streams of the current device; ~8 ms)
+bool gh_streams_dispatch_independently(hipStream_t a, hipStream_t b);
 hipStream_t gh_shared_masked_stream(int device, int reserve_cus);
 bool gh_use_mfma();               // false when GEORGE_AMD_NO_MFMA=1 (VALU validation path)
 

@@ -639,7 +639,10 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   // (operands the LDS-DMA path cannot take -- an odd leading dimension or a base that is not 16-byte aligned; none of
   //  the solver's own calls -- go through the plain-VALU kernel)
 #define GH_GEMM_LAUNCH(AK, BKM) hipLaunchKernelGGL((gemm_f64_valu<AK, BKM>), grid, block, 0, st, g)
-  const bool dma = mode == 1 && h.lda % 2 == 0 && h.ldb % 2 == 0 &&
+  // (... or a row pitch so large that the lane's byte offset inside a slab -- up to 127 rows x ld x 8 bytes, the 32-bit
+  //  voffset of buffer_load ... lds -- would pass 2^31: ld >= 2 M doubles, sixteen times the largest matrix that fits in HBM)
+  constexpr int64_t GH_DMA_MAX_LD = ((1LL << 31) - 4096) / (128 * 8);
+  const bool dma = mode == 1 && h.lda % 2 == 0 && h.ldb % 2 == 0 && h.lda <= GH_DMA_MAX_LD && h.ldb <= GH_DMA_MAX_LD &&
                    ((uintptr_t)h.A % 16) == 0 && ((uintptr_t)h.B % 16) == 0;
 #define GH_DMA_LAUNCH(AK, BKM)                                                                            \
   do {                                                                                                   \

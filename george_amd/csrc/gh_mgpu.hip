@@ -65,6 +65,7 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  bool shared_device_ok = false;   // the loaded library is the test stand-in: ranks may share a device
   std::string why;
 };
 Rccl g_rccl;
@@ -74,9 +75,16 @@ bool rccl_load() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (g_rccl.ok) return true;
   if (g_rccl.lib == nullptr) {
+    // GEORGE_AMD_RCCL_LIB=<path>: that library instead (tests/mock_rccl: a stand-in that checks every send against its
+    // receive on virtual ranks; a library that exports ncclMockSharedDeviceOk lifts "one rank per device")
+    if (const char* env = getenv("GEORGE_AMD_RCCL_LIB")) {
+      g_rccl.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+      if (!g_rccl.lib) { g_rccl.why = std::string("GEORGE_AMD_RCCL_LIB: ") + (dlerror() ? dlerror() : "?"); return false; }
+      g_rccl.shared_device_ok = dlsym(g_rccl.lib, "ncclMockSharedDeviceOk") != nullptr;
+    }
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (g_rccl.lib) break;
+      g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!g_rccl.lib) { g_rccl.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "?"); return false; }
   }
@@ -143,7 +151,9 @@ struct gh_mgpu {
   Group world;
   ncclComm_t comms[MG_MAX_DEV], comms_b[MG_MAX_DEV];       // chain / bulk communicators
   bool have_comms = false, have_comms_b = false;
+  bool one_comm = false;           // the bulk gather shares the chain's stream and communicator (gh_mgpu_create: why)
   std::atomic<int> abort{0};
+  std::atomic<int> dead{0};        // mg_drain gave up on a stream: kernels may still run, nothing is synchronised or freed any more
   std::mutex turn;                 // trace mode: one rank's compute phase at a time (contention-free durations on virtual devices)
   bool computed = false;
   double logdet = 0.0;
@@ -152,6 +162,7 @@ struct gh_mgpu {
   int prow(int i) const { if (!snake) return i % Pr; const int t = i % (2 * Pr); return t < Pr ? t : 2 * Pr - 1 - t; }
   int pcol(int j) const { return j % Pc; }
   ~gh_mgpu() {
+    if (dead.load()) return;       // (see mg_drain)
     for (auto& r : ranks) {
       (void)hipSetDevice(r.dev);
       for (hipStream_t q : {r.st, r.sp, r.sg}) if (q) (void)hipStreamSynchronize(q);
@@ -184,6 +195,31 @@ inline int local_index(const std::vector<int>& v, int g) {            // positio
 }
 inline int first_at_least(const std::vector<int>& v, int g) { return (int)(std::lower_bound(v.begin(), v.end(), g) - v.begin()); }
 inline int mg_aborted() { gh_set_error("multi-GPU solve aborted (another rank failed)"); return GH_ERR_HIP; }
+
+// ---- the end of a factorisation: wait for a stream, but not for ever.  With RCCL the transfer kernels of two ranks wait
+//      for each other ON THE DEVICE; should they ever do so crosswise (gh_mgpu_create: two communicators in flight) no HIP
+//      call returns an error -- the streams just never drain.  GEORGE_AMD_MGPU_TIMEOUT_S (default 900; 0: wait for ever)
+//      bounds the wait; past it the solver is marked dead (its device memory is abandoned: nothing can be freed under
+//      kernels that still run) and the caller gets an error that names the way out.
+int mg_drain(gh_mgpu* h, MRank& r, hipStream_t q) {
+  static const double limit = [] { const char* e = getenv("GEORGE_AMD_MGPU_TIMEOUT_S"); return e ? atof(e) : 900.0; }();
+  if (limit <= 0.0 || h->opts.transport != GH_MGPU_RCCL || h->W == 1) { GH_HIP(hipStreamSynchronize(q)); return GH_OK; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spin = 0;; ++spin) {
+    const hipError_t e = hipStreamQuery(q);
+    if (e == hipSuccess) return GH_OK;
+    if (e != hipErrorNotReady) { GH_HIP(e); }
+    if (h->dead.load()) break;
+    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(spin > 20000 ? 1000 : 50));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+  }
+  (void)hipGetLastError();
+  h->dead.store(1);
+  gh_set_error("multi-GPU factorisation: a stream of rank %d (device %d) did not drain within %g s%s; this solver is dead -- make a new one "
+               "(GH_MGPU_ONE_COMM / one_comm=True keeps one communicator in flight at a time)", r.rank, r.dev, limit,
+               h->one_comm ? "" : " with the chain and the bulk gather on two communicators");
+  return GH_ERR_HIP;
+}
 
 // ---- broadcast of `count` doubles at `buf` (same address role on every member) from global rank `root`;
 //      `cs`: the communicator set (chain or bulk) -- calls on one set are issued in the same order by every member
@@ -468,7 +504,10 @@ int rank_factor(gh_mgpu* h, MRank& r) {
   // P(k), bulk part, on stream sg: tile row j of the panel for my tile columns j > k+1, held (after the row transfer)
   // by process row prow(j); ends with "the whole column panel is here" (ev_panel[buf])
   auto gather = [&](int k, int buf) -> int {
-    hipStream_t sg = r.sg;
+    // (one_comm: the bulk gather goes out on the CHAIN's stream and communicator, after the chain's transfers of the step, in
+    //  program order -- the same on every rank; see gh_mgpu_create)
+    hipStream_t sg = h->one_comm ? r.sp : r.sg;
+    ncclComm_t* const bulk_comms = h->one_comm ? h->comms : h->comms_b;
     GH_HIP(hipStreamWaitEvent(sg, r.ev_fast[buf], 0));
     if (k < nt - 1 && !h->chain_only) {
       const int li0 = first_at_least(r.rows, k + 1);
@@ -486,7 +525,7 @@ int rank_factor(gh_mgpu* h, MRank& r) {
             if (r.pr == spr)
               GH_HIP(hipMemcpyAsync(pj, wrow + (long)(local_index(r.rows, j) - li0) * nb * nb, (size_t)nb * nb * sizeof(double),
                                     hipMemcpyDeviceToDevice, sg));
-            if (Pr > 1) GH_CHECK(mg_bcast(h, r, h->colg[r.pc], pj, (size_t)nb * nb, grank(h, spr, r.pc), sg, h->comms_b));
+            if (Pr > 1) GH_CHECK(mg_bcast(h, r, h->colg[r.pc], pj, (size_t)nb * nb, grank(h, spr, r.pc), sg, bulk_comms));
           }
           return mg_group_end(h);
         }));
@@ -555,9 +594,7 @@ int rank_factor(gh_mgpu* h, MRank& r) {
   double ld_part = 0.0;
   GH_HIP(hipMemcpyAsync(&info, r.d_info, sizeof(long long), hipMemcpyDeviceToHost, r.st));
   GH_HIP(hipMemcpyAsync(&ld_part, r.scal.d(), sizeof(double), hipMemcpyDeviceToHost, r.st));
-  GH_HIP(hipStreamSynchronize(r.st));
-  GH_HIP(hipStreamSynchronize(r.sp));
-  GH_HIP(hipStreamSynchronize(r.sg));
+  for (hipStream_t q : {r.st, r.sp, r.sg}) GH_CHECK(mg_drain(h, r, q));
   r.info = info; r.logdet = ld_part;
   return GH_OK;
 }
@@ -723,7 +760,7 @@ extern "C" int gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out) {
   const int W = opts->n_dev;
   for (int i = 0; i < W; ++i) {
     if (opts->devices[i] < 0 || opts->devices[i] >= ndev_box) { gh_set_error("devices[%d] = %d: this box has %d", i, opts->devices[i], ndev_box); return GH_ERR_BAD_ARG; }
-    if (opts->transport == GH_MGPU_RCCL)
+    if (opts->transport == GH_MGPU_RCCL && !(getenv("GEORGE_AMD_RCCL_LIB") && rccl_load() && g_rccl.shared_device_ok))
       for (int j = 0; j < i; ++j)
         if (opts->devices[j] == opts->devices[i]) { gh_set_error("device %d listed twice: RCCL needs one rank per device (GH_MGPU_COPY accepts virtual devices)", opts->devices[i]); return GH_ERR_BAD_ARG; }
   }
@@ -765,6 +802,21 @@ extern "C" int gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out) {
     } else {
       h->comms_b[0] = h->comms[0];                               // (a world of one never transfers)
     }
+    // TWO communicators are driven at once (chain(k+2) on sp, the bulk gather of step k+1 on sg) and nothing orders them
+    // across ranks: if sp and sg share a hardware queue on one rank and not on another, rank A may dispatch the gather's
+    // transfer kernel in front of the chain's while rank B does the opposite -- each then waits for the peer's kernel that is
+    // queued behind the other: a hang (the multi-communicator hazard of the NCCL documentation).  So: on every rank, does a
+    // one-workgroup kernel on sg complete while a long grid runs on sp, and the other way round (the probe of gh_chol.hip)?
+    // If not on ANY rank -- or GH_MGPU_ONE_COMM asks for it -- the gather goes out on sp with the chain's communicator, in
+    // program order, the same on every rank.  (What it costs: the gather of step k+1 no longer overlaps the chain of k+2.)
+    h->one_comm = (opts->flags & GH_MGPU_ONE_COMM) != 0;
+    if (W > 1 && !h->one_comm) {
+      for (int i = 0; i < W && !h->one_comm; ++i) {
+        MRank& r = h->ranks[i];
+        if (hipSetDevice(r.dev) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (!gh_streams_dispatch_independently(r.sp, r.sg)) h->one_comm = true;
+      }
+    }
     // self-check of both communicators: all-reduce of (rank + 1) must give W (W + 1) / 2 on every rank
     for (ncclComm_t* cs : {h->comms, h->comms_b}) {
       std::vector<double> got(W, 0.0);
@@ -788,7 +840,11 @@ extern "C" int gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out) {
 
 extern "C" void gh_mgpu_destroy(gh_mgpu* h) { delete h; }
 extern "C" int64_t gh_mgpu_info(const gh_mgpu* h) { return h ? h->info : 0; }
-extern "C" int gh_mgpu_grid(const gh_mgpu* h, int32_t* pr, int32_t* pc, int32_t* nb) {
+extern "C" int gh_mgpu_comm_mode(const gh_mgpu* h) {
+  if (!h) return -1;
+  return h->opts.transport != GH_MGPU_RCCL ? 0 : (h->one_comm ? 1 : 2);
+}
+int gh_mgpu_grid(const gh_mgpu* h, int32_t* pr, int32_t* pc, int32_t* nb) {
   if (!h) { gh_set_error("null solver"); return GH_ERR_BAD_ARG; }
   if (pr) *pr = h->Pr;
   if (pc) *pc = h->Pc;
@@ -804,6 +860,7 @@ extern "C" int gh_mgpu_compute(gh_mgpu* h, gh_kernel* k, const double* x, int64_
                                double* logdet_out) {
   if (!h || !k || !x || !yerr || n <= 0) { gh_set_error("bad argument to compute"); return GH_ERR_BAD_ARG; }
   if (ndim != k->ndim) { gh_set_error("dimension mismatch"); return GH_ERR_DIM; }
+  if (h->dead.load()) { gh_set_error("this multi-GPU solver timed out earlier (mg_drain) and is dead: make a new one"); return GH_ERR_HIP; }
   h->computed = false; h->info = 0;
   h->n = n; h->ndim = ndim;
   h->nb = h->opts.nb > 0 ? h->opts.nb : (n >= 24576 ? 1024 : 512);
@@ -851,7 +908,7 @@ extern "C" int gh_mgpu_get_trace(const gh_mgpu* h, double* out, int64_t max_rows
   if (!h || !n_rows) { gh_set_error("null argument"); return GH_ERR_BAD_ARG; }
   const int64_t have = (int64_t)h->trace_rows.size() / 5;
   *n_rows = have;
-  if (out) memcpy(out, h->trace_rows.data(), (size_t)std::min(have, max_rows) * 5 * sizeof(double));
+  if (out && max_rows > 0) memcpy(out, h->trace_rows.data(), (size_t)std::min(have, max_rows) * 5 * sizeof(double));
   return GH_OK;
 }
 

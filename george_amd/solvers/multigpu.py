@@ -22,7 +22,8 @@ __all__ = ["MultiGPUSolver", "MultiGPUHODLRSolver"]
 
 class MultiGPUSolver(object):
 
-    def __init__(self, kernel, devices=None, nb=0, grid=None, transport="rccl", plain_cyclic=False, chain_only=False, trace=False):
+    def __init__(self, kernel, devices=None, nb=0, grid=None, transport="rccl", plain_cyclic=False, chain_only=False, trace=False,
+                 one_comm=False):
         self.kernel = kernel
         if devices is None:
             devices = list(range(max(int(N.lib.gh_device_count()), 1)))
@@ -35,7 +36,7 @@ class MultiGPUSolver(object):
         self.grid = tuple(grid) if grid is not None else (0, 0)
         self.transport = transport
         self.flags = ((N.GH_MGPU_PLAIN_CYCLIC if plain_cyclic else 0) | (N.GH_MGPU_CHAIN_ONLY if chain_only else 0) |
-                      (N.GH_MGPU_TRACE if trace else 0))
+                      (N.GH_MGPU_TRACE if trace else 0) | (N.GH_MGPU_ONE_COMM if one_comm else 0))
         self._handle = None
         self._dk = None
         self._computed = False
@@ -85,6 +86,11 @@ class MultiGPUSolver(object):
         pr, pc, nb = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         N.check(N.lib.gh_mgpu_grid(self._ensure_handle(), C.byref(pr), C.byref(pc), C.byref(nb)))
         return pr.value, pc.value, nb.value
+
+    def comm_mode(self):
+        """2: chain and bulk gather on their own RCCL communicators; 1: one communicator (``one_comm=True``, or chosen by
+        gh_mgpu_create because two streams of a rank did not dispatch independently); 0: transport "copy" """
+        return int(N.lib.gh_mgpu_comm_mode(self._ensure_handle()))
 
     def compute(self, x, yerr):
         """basic.py:51-70.  ``yerr`` already contains the white noise (gp.py:330)."""
@@ -186,6 +192,8 @@ class MultiGPUSolver(object):
             N.check(N.lib.gh_mgpu_predict(h, dk.handle, N.ptr(r), N.ptr(xs), m, N.ptr(mu), None, None))
             Kxs = kernel.get_value(xs, self._x_host)
             cov = kernel.get_value(xs) - np.dot(Kxs, self.apply_inverse(np.ascontiguousarray(Kxs.T)))
+            if var is not None:
+                var[:] = np.diag(cov)
             return mu, var, cov
         cov = np.empty((m, m)) if return_cov else None
         N.check(N.lib.gh_mgpu_predict(h, dk.handle, N.ptr(r), N.ptr(xs), m, N.ptr(mu), N.ptr(var), N.ptr(cov)))

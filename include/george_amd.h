@@ -260,9 +260,12 @@ enum {
   GH_MGPU_PLAIN_CYCLIC = 1,  /* pc == 1: tile row I on rank I mod pr instead of the snake order                    */
   GH_MGPU_CHAIN_ONLY   = 2,  /* timing aid: skip every trailing update except block column k+1 and the bulk gather
                                 -- what is left is the critical chain; results are meaningless, NOT_PD is not raised */
-  GH_MGPU_TRACE        = 4   /* record (rank, step, phase, ms, flops or bytes) of every phase: gh_mgpu_get_trace.  With
+  GH_MGPU_TRACE        = 4,  /* record (rank, step, phase, ms, flops or bytes) of every phase: gh_mgpu_get_trace.  With
                                 GH_MGPU_COPY the compute phases of all ranks run one at a time and to completion, so
                                 that virtual devices sharing one GPU give the durations of a rank alone on its GPU  */
+  GH_MGPU_ONE_COMM     = 8   /* GH_MGPU_RCCL: the bulk gather on the chain's stream and communicator (one communicator in
+                                flight at a time) -- chosen by itself when the two streams of a rank do not dispatch
+                                independently (gh_mgpu_comm_mode tells which)                                         */
 };
 typedef struct gh_mgpu_opts {
   int32_t n_dev;             /* 1..16 */
@@ -270,7 +273,7 @@ typedef struct gh_mgpu_opts {
   int32_t pr, pc;            /* process grid, pr * pc == n_dev; 0, 0: n_dev x 1 (whole tile rows per rank) */
   int32_t nb;                /* tile edge, multiple of 128; 0: 1024 from N = 24576 up, else 512 */
   int32_t transport;         /* GH_MGPU_RCCL | GH_MGPU_COPY */
-  int32_t flags;             /* GH_MGPU_PLAIN_CYCLIC | GH_MGPU_CHAIN_ONLY | GH_MGPU_TRACE */
+  int32_t flags;             /* GH_MGPU_PLAIN_CYCLIC | GH_MGPU_CHAIN_ONLY | GH_MGPU_TRACE | GH_MGPU_ONE_COMM */
   int32_t reserved[3];
 } gh_mgpu_opts;
 int  gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out);      /* communicators + an all-reduce self-check */
@@ -281,6 +284,7 @@ int  gh_mgpu_compute(gh_mgpu* h, gh_kernel* k, const double* x, int64_t n, int32
                      const double* yerr, double* logdet_out);
 int64_t gh_mgpu_info(const gh_mgpu* h);
 int  gh_mgpu_grid(const gh_mgpu* h, int32_t* pr, int32_t* pc, int32_t* nb);
+int  gh_mgpu_comm_mode(const gh_mgpu* h);   /* 2: chain and bulk gather on their own communicators; 1: GH_MGPU_ONE_COMM; 0: GH_MGPU_COPY */
 int  gh_mgpu_owner(const gh_mgpu* h, int64_t tile_row, int64_t tile_col);              /* rank that holds tile (I, J); -1 on bad arguments */
 /* all of the following take HOST pointers; every right-hand side of a call is swept together (chunks of 2048 columns) */
 int  gh_mgpu_dot_solve(gh_mgpu* h, const double* y, double* out);                     /* basic.py:89-102 */

@@ -9,7 +9,15 @@ the test box:
   tests/test_gpu_fullsize.py): factorisation, the sweeps with one and many right-hand sides, apply_sqrt,
   get_inverse, predict; the chain-only and trace modes behind profiles/r04/scale_model.md.
 
-What this cannot cover is RCCL between two physical devices; see DESIGN.md section 7."""
+With GEORGE_AMD_TEST_VIRTUAL_TRANSPORT=rccl and GEORGE_AMD_RCCL_LIB=tests/mock_rccl/libmock_rccl.so (what
+tests/test_gpu_mgpu_mock_rccl.py does in a child process) every virtual-device case below runs through the RCCL
+branch of the driver instead -- ncclSend / ncclRecv / groups -- against a stand-in library that pairs every send
+with its receive and fails on a count, type, peer or ordering mismatch or an operation nobody answers.
+
+What this cannot cover is RCCL's own transport between two physical devices; see DESIGN.md section 7."""
+import ctypes
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +25,10 @@ import zoo
 from george_amd import kernels, GP, BasicSolver, MultiGPUSolver
 
 pytestmark = pytest.mark.gpu
+
+VIRTUAL = os.environ.get("GEORGE_AMD_TEST_VIRTUAL_TRANSPORT", "copy")        # transport of the virtual-device cases
+MOCK = os.environ.get("GEORGE_AMD_RCCL_LIB") if VIRTUAL == "rccl" else None
+ONE_COMM = bool(int(os.environ.get("GEORGE_AMD_TEST_ONE_COMM", "0")))
 
 
 def _case(n, ndim=1):
@@ -33,21 +45,23 @@ def _case(n, ndim=1):
 
 @pytest.mark.parametrize("devices,transport,n,nb,grid", [
     ([0], "rccl", 2500, 512, None),
-    ([0], "copy", 1000, 128, None),
-    ([0, 0], "copy", 2500, 256, None),
-    ([0, 0, 0, 0], "copy", 3000, 256, None),
-    ([0, 0, 0, 0], "copy", 1700, 128, (2, 2)),
-    ([0, 0, 0, 0], "copy", 1700, 128, (1, 4)),
-    ([0] * 8, "copy", 4100, 256, None),
-    ([0] * 8, "copy", 4100, 256, (2, 4)),
-    ([0] * 8, "copy", 2600, 128, (4, 2)),
-    ([0] * 6, "copy", 2900, 128, (2, 3)),
-    ([0] * 3, "copy", 2000, 128, None),
+    ([0], VIRTUAL, 1000, 128, None),
+    ([0, 0], VIRTUAL, 2500, 256, None),
+    ([0, 0, 0, 0], VIRTUAL, 3000, 256, None),
+    ([0, 0, 0, 0], VIRTUAL, 1700, 128, (2, 2)),
+    ([0, 0, 0, 0], VIRTUAL, 1700, 128, (1, 4)),
+    ([0] * 8, VIRTUAL, 4100, 256, None),
+    ([0] * 8, VIRTUAL, 4100, 256, (2, 4)),
+    ([0] * 8, VIRTUAL, 2600, 128, (4, 2)),
+    ([0] * 6, VIRTUAL, 2900, 128, (2, 3)),
+    ([0] * 3, VIRTUAL, 2000, 128, None),
 ])
 def test_sharded_solver_matches_single_gpu(devices, transport, n, nb, grid):
     kernel, X, yerr, y, d = _case(n)
-    s = MultiGPUSolver(kernel, devices=devices, nb=nb, grid=grid, transport=transport)
+    s = MultiGPUSolver(kernel, devices=devices, nb=nb, grid=grid, transport=transport, one_comm=ONE_COMM)
     s.compute(X, yerr)
+    mode = s.comm_mode()
+    assert (mode == 0) if transport == "copy" else (mode == 1 if ONE_COMM else mode in (1, 2))
     pr, pc, nb_used = s.grid_shape()
     assert pr * pc == len(devices) and nb_used == nb
     if grid is None:
@@ -77,7 +91,7 @@ def test_sharded_solver_matches_single_gpu(devices, transport, n, nb, grid):
 
 def test_sharded_solver_through_gp_and_3d():
     kernel, X, yerr, y, d = _case(2000, ndim=3)
-    gp = GP(kernel, solver=MultiGPUSolver, devices=[0, 0, 0, 0], transport="copy", nb=256)
+    gp = GP(kernel, solver=MultiGPUSolver, devices=[0, 0, 0, 0], transport=VIRTUAL, nb=256)
     gp.compute(X, yerr)
     ref = GP(kernel)
     ref.compute(X, yerr)
@@ -99,7 +113,7 @@ def test_sharded_solver_through_gp_and_3d():
 def test_whole_protocol_on_the_sharded_factor(devices, grid, nb, n):
     """basic.py:72-121 and gp.py:482-545 as tile sweeps: many right-hand sides at once, apply_sqrt, get_inverse, predict"""
     kernel, X, yerr, y, d = _case(n)
-    s = MultiGPUSolver(kernel, devices=devices, transport="copy", nb=nb, grid=grid)
+    s = MultiGPUSolver(kernel, devices=devices, transport=VIRTUAL, nb=nb, grid=grid)
     s.compute(X, yerr)
     rng = np.random.RandomState(5)
     B = rng.randn(n, 131)                                        # not a multiple of anything
@@ -134,7 +148,7 @@ def test_whole_protocol_on_the_sharded_factor(devices, grid, nb, n):
 def test_chain_only_and_trace_modes():
     """the two timing aids behind profiles/r04/scale_model.md: the trace leaves the numbers alone, chain-only does not raise"""
     kernel, X, yerr, y, d = _case(3000)
-    s = MultiGPUSolver(kernel, devices=[0] * 4, transport="copy", nb=256, trace=True)
+    s = MultiGPUSolver(kernel, devices=[0] * 4, transport=VIRTUAL, nb=256, trace=True)
     s.compute(X, yerr)
     assert abs(s.log_determinant - d.log_determinant) <= 1e-11 * abs(d.log_determinant)
     tr = s.trace()
@@ -144,7 +158,7 @@ def test_chain_only_and_trace_modes():
     potrf = tr[tr[:, 2] == 0]
     assert len(potrf) == nt and sorted(potrf[:, 1].astype(int)) == list(range(nt))             # one diagonal tile per step ...
     assert [int(r_) for r_ in potrf[np.argsort(potrf[:, 1]), 0]] == [s.owner(k, k) for k in range(nt)]     # ... on its owner
-    c = MultiGPUSolver(kernel, devices=[0] * 4, transport="copy", nb=256, chain_only=True, trace=True)
+    c = MultiGPUSolver(kernel, devices=[0] * 4, transport=VIRTUAL, nb=256, chain_only=True, trace=True)
     c.compute(X, yerr)                                           # (garbage numbers, no exception)
     assert not c.computed
     with pytest.raises(RuntimeError):
@@ -156,7 +170,7 @@ def test_sharded_solver_errors():
     x = np.linspace(0, 3, 700)
     bad = kernels.CosineKernel(log_period=0.0)                              # singular without noise
     for devices in ([0], [0, 0, 0, 0]):
-        s = MultiGPUSolver(bad, devices=devices, transport="copy", nb=128)
+        s = MultiGPUSolver(bad, devices=devices, transport=VIRTUAL, nb=128)
         with pytest.raises(np.linalg.LinAlgError):
             s.compute(x[:, None], np.zeros(700))
         assert not s.computed
@@ -166,12 +180,35 @@ def test_sharded_solver_errors():
         s.kernel = 1.0 * kernels.ExpSquaredKernel(1.0)
         s.compute(x[:, None], 0.1 * np.ones(700))
         assert s.computed and np.isfinite(s.log_determinant)
-    s = MultiGPUSolver(1.0 * kernels.ExpSquaredKernel(1.0, ndim=2), devices=[0, 0], transport="copy")
+    s = MultiGPUSolver(1.0 * kernels.ExpSquaredKernel(1.0, ndim=2), devices=[0, 0], transport=VIRTUAL)
     with pytest.raises(RuntimeError):
         s.compute(x[:, None], 0.1)                                           # dimension mismatch
+    if MOCK is None:
+        with pytest.raises(ValueError):
+            MultiGPUSolver(bad, devices=[0, 0], transport="rccl").compute(x[:, None], 0.1)      # RCCL: one rank per device
     with pytest.raises(ValueError):
-        MultiGPUSolver(bad, devices=[0, 0], transport="rccl").compute(x[:, None], 0.1)      # RCCL: one rank per device
+        MultiGPUSolver(bad, devices=[0, 0, 0], grid=(2, 2), transport=VIRTUAL).compute(x[:, None], 0.1)
     with pytest.raises(ValueError):
-        MultiGPUSolver(bad, devices=[0, 0, 0], grid=(2, 2), transport="copy").compute(x[:, None], 0.1)
-    with pytest.raises(ValueError):
-        MultiGPUSolver(bad, devices=[97], transport="copy").compute(x[:, None], 0.1)
+        MultiGPUSolver(bad, devices=[97], transport=VIRTUAL).compute(x[:, None], 0.1)
+
+
+@pytest.mark.skipif(MOCK is None, reason="only under the stand-in RCCL library (tests/test_gpu_mgpu_mock_rccl.py)")
+def test_stand_in_paired_every_operation():
+    """runs LAST in this module: what the stand-in library saw over all the cases above"""
+    lib = ctypes.CDLL(MOCK)                                      # (the handle gh_mgpu.hip opened: same path, same library)
+    st = (ctypes.c_longlong * 8)()
+    lib.mock_rccl_stats(st)
+    sets, pairs, nbytes, reduces, errors, pending, biggest, groups = list(st)
+    msg = ctypes.create_string_buffer(1024)
+    lib.mock_rccl_last_error(msg, 1024)
+    assert errors == 0, msg.value
+    assert pending == 0
+    assert sets >= 20 and pairs > 1000 and nbytes > 100e6 and reduces >= sets and groups > 100 and biggest >= 2
+    mode = MultiGPUSolver(1.0 * kernels.ExpSquaredKernel(1.0), devices=[0, 0], transport="rccl", one_comm=ONE_COMM).comm_mode()
+    line = ("stand-in RCCL: %d communicator sets, %d matched pairs, %.2f GB, %d all-reduces, %d groups (largest %d operations), "
+            "0 errors, 0 left over; communicators in flight per rank: %d" % (sets, pairs, nbytes / 1e9, reduces, groups, biggest, mode))
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "mock_rccl_stats_one_comm%d.txt" % int(ONE_COMM)), "w") as f:
+            f.write(line + "\n")
