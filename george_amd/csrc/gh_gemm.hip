@@ -24,6 +24,10 @@
 
 #include "gh_gemm_tile.h"
 
+#ifndef GH_GEMM_SP_DEFAULT
+#define GH_GEMM_SP_DEFAULT 1
+#endif
+
 struct GemmDev {
   double* C; long ldc;
   const double* A; long lda;
@@ -320,6 +324,105 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same kernel for k-major x k-major operands with the slab loop SOFTWARE-PIPELINED by half a slab (round 5).
+// In gemm_f64_mfma_dma a wavefront leaves the end-of-slab barrier, issues its 16 ds_read_b128 and can start the first matrix
+// instruction of the slab only when the first of them are back: ~300 cycles of a 4128-cycle slab in which this wavefront feeds
+// nothing to the matrix pipe ("the 16 ds_read_b128 in front of each slab's first MFMA").  Here the barrier sits
+// in the MIDDLE of a slab's 64 matrix instructions:
+//     top of slab t     : read the second half of slab t's fragments (k-steps 2, 3) -- they land under k-steps 0, 1,
+//                         whose fragments were read half a slab ago;
+//     k-steps 0, 1      : 32 matrix instructions;
+//     barrier           : every wavefront has read all of slab t (buffer t & 1 is free) and its DMA pieces of slab t + 1 are in;
+//     DMA of slab t + 2 into buffer t & 1; read the FIRST half of slab t + 1's fragments (k-steps 0, 1) into the registers
+//                         k-steps 0, 1 of slab t have just released -- they land under k-steps 2, 3 of slab t;
+//     k-steps 2, 3      : 32 matrix instructions.
+// No matrix instruction waits for an LDS read issued less than 32 matrix instructions (~2000 cycles) earlier, no extra registers
+// (the halves alternate), the same two LDS buffers, a DMA has a full slab to land as before.  Every accumulator still adds k-steps
+// 0, 1, 2, 3 of slab 0, 1, ... in this order: the bits are those of gemm_f64_mfma_dma.
+// The fragment reads are inline asm: hipcc orders every LDS read it can see behind a vmcnt(0) once an LDS-DMA has been issued
+// (it cannot tell the buffers apart), which would put the DMA's whole latency in front of the reads that follow it.  The waits
+// are therefore written by hand: LDS reads return in order, `s_waitcnt lgkmcnt(8)` = "all but the 8 youngest are back"; the
+// wait statements name the registers they guard as in/out operands so the compiler keeps every consumer behind them.
+typedef double v2d __attribute__((ext_vector_type(2)));
+#define GH_SP_READ8(x0, x1, x2, x3, y0, y1, y2, y3, pa, pb, BO)                                                     \
+  asm volatile("ds_read_b128 %0, %8 offset:%10\n\tds_read_b128 %1, %8 offset:%11\n\t"                               \
+               "ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %8 offset:%13\n\t"                               \
+               "ds_read_b128 %4, %9 offset:%10\n\tds_read_b128 %5, %9 offset:%11\n\t"                               \
+               "ds_read_b128 %6, %9 offset:%12\n\tds_read_b128 %7, %9 offset:%13"                                   \
+               : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)               \
+               : "v"(pa), "v"(pb), "n"((BO)), "n"((BO) + 2048), "n"((BO) + 4096), "n"((BO) + 6144))
+#define GH_SP_WAIT(cnt, x0, x1, x2, x3, y0, y1, y2, y3)                                                             \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                        \
+               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3))
+#define GH_SP_MFMA(x, y, c)                                                                                         \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i_][c], y[j_][c], acc[i_][j_], 0, 0, 0);
+template <bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma_sp(GemmDev g) {
+  // ONE array: the asm reads take the buffers' byte offsets as immediates (A0 | A1 | B0 | B1, 16 KiB each)
+  __shared__ __attribute__((aligned(1024))) double sm[4 * BM * BK];
+  double* const sA0 = sm; double* const sA1 = sm + BM * BK;
+  double* const sB0 = sm + 2 * BM * BK; double* const sB1 = sm + 3 * BM * BK;
+  int tm, tn;
+  if (!tile_of(g, tm, tn)) return;
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  const long row0 = (long)tm * BM, col0 = (long)tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  v4d acc[4][4];
+  const long nk = g.K / BK;                            // even, >= 2 (the launcher's condition)
+  DmaOperand<true> oa, ob;
+  oa.init(g.A, g.lda, row0, 0, wave, lane, wm);
+  ob.init(g.B, g.ldb, col0, 0, wave, lane, wn);
+  const int dst = wave * 4 * 128;
+  // LDS byte addresses of this lane's fragment pieces in buffer 0: half q of the row (16 i + fr) is piece off2[q] of its image
+  const unsigned lbase = (unsigned)(unsigned long)(gh_lds_void*)sm;
+  const unsigned pa0 = lbase + (unsigned)(oa.f0 + oa.off2[0]) * 8u, pa1 = lbase + (unsigned)(oa.f0 + oa.off2[1]) * 8u;
+  const unsigned pb0 = lbase + 2u * BM * BK * 8u + (unsigned)(ob.f0 + ob.off2[0]) * 8u;
+  const unsigned pb1 = lbase + 2u * BM * BK * 8u + (unsigned)(ob.f0 + ob.off2[1]) * 8u;
+  constexpr int B1 = BM * BK * 8;                      // byte offset of buffer 1 of either operand
+  v2d a01[4], b01[4], a23[4], b23[4];                  // [16-row group]: .x / .y = the even / odd k-step of the half
+
+  GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0)
+  gemm_init_acc(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
+  __syncthreads();
+  GH_DMA_ISSUE(oa, sA1) GH_DMA_ISSUE(ob, sB1)
+  GH_SP_READ8(a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3], pa0, pb0, 0);
+  for (long kt = 0; kt < nk; kt += 2) {
+    const bool more = kt + 2 < nk;
+    // ---- slab kt (buffer 0)
+    GH_SP_READ8(a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3], pa1, pb1, 0);
+    GH_SP_WAIT(8, a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3]);
+    GH_SP_MFMA(a01, b01, 0) GH_SP_MFMA(a01, b01, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    GH_SP_WAIT(0, a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3]);
+    __syncthreads();                                   // (vmcnt(0): my pieces of slab kt + 1; everybody is done with buffer 0)
+    if (more) { GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0) }
+    GH_SP_READ8(a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3], pa0, pb0, B1);
+    __builtin_amdgcn_sched_barrier(0);
+    GH_SP_MFMA(a23, b23, 0) GH_SP_MFMA(a23, b23, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- slab kt + 1 (buffer 1)
+    GH_SP_READ8(a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3], pa1, pb1, B1);
+    GH_SP_WAIT(8, a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3]);
+    GH_SP_MFMA(a01, b01, 0) GH_SP_MFMA(a01, b01, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    GH_SP_WAIT(0, a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3]);
+    if (more) {
+      __syncthreads();
+      if (kt + 3 < nk) { GH_DMA_ISSUE(oa, sA1) GH_DMA_ISSUE(ob, sB1) }
+      GH_SP_READ8(a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3], pa0, pb0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    GH_SP_MFMA(a23, b23, 0) GH_SP_MFMA(a23, b23, 1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  gemm_epilogue(g, acc, row0 + wm * 64, col0 + wn * 64, fr, fk);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 64x64-tile variant for launches that cannot fill the chip anyway (the GEMMs inside the panel
 // chain: <= 128 tiles of 128x128, K = 128..1024).  A 128x128x128 tile is 512 MFMAs per wavefront
 // = 15 us on its one CU no matter how idle the other 255 are; four times as many workgroups of a
@@ -608,6 +711,20 @@ extern "C" int gh_debug_set_mfma(int mode) {
   return prev;
 }
 
+// the half-slab software-pipelined form of the k-major x k-major kernel (gemm_f64_mfma_dma_sp): 1 = on for every launch it
+// can take (the default: 1.3 - 2.6 % faster on every shape of the factorisation, 72.4 TFLOP/s on the SYRK shape and 75.5 at
+// K = 4096, profiles/r05/gemm_sp_ab.md), 0 = off.  GEORGE_AMD_GEMM_SP / gh_debug_set_gemm_sp; same bits either way.
+static int g_gemm_sp = -1;
+static int gemm_sp_mode() {
+  if (g_gemm_sp < 0) { const char* e = getenv("GEORGE_AMD_GEMM_SP"); g_gemm_sp = e ? (atoi(e) != 0) : GH_GEMM_SP_DEFAULT; }
+  return g_gemm_sp;
+}
+extern "C" int gh_debug_set_gemm_sp(int mode) {
+  const int prev = gemm_sp_mode();
+  g_gemm_sp = mode < 0 ? GH_GEMM_SP_DEFAULT : (mode != 0);
+  return prev;
+}
+
 int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   if (h.M <= 0 || h.N <= 0) return GH_OK;
   if (h.M % BM || h.N % BN || h.K % BK) { gh_set_error("gemm: sizes must be multiples of the tile (%ld %ld %ld)", (long)h.M, (long)h.N, (long)h.K); return GH_ERR_BAD_ARG; }
@@ -679,6 +796,10 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
       q.nblk = h.lower ? 4 * g.nblk : (long)q.tiles_m * q.tiles_n;
       hipLaunchKernelGGL(gemm_f64_mfma_dma64<2>, dim3((unsigned)q.nblk), block, 0, st, q);
     }
+  }
+  else if (dma && h.a_km && h.b_km && gemm_sp_mode() && !h.klo_max && !h.khi_col && !h.khi_row && h.K % (2 * BK) == 0) {
+    if (h.lower) hipLaunchKernelGGL(gemm_f64_mfma_dma_sp<true>, grid, block, 0, st, g);
+    else         hipLaunchKernelGGL(gemm_f64_mfma_dma_sp<false>, grid, block, 0, st, g);
   }
   else if (dma && h.a_km && h.b_km)   GH_DMA_LAUNCH(true, true);
   else if (dma && h.a_km && !h.b_km)  GH_DMA_LAUNCH(true, false);

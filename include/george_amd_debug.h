@@ -20,6 +20,9 @@ int gh_microbench_mfma_f64(double* tflops_out);
  * MFMA lane maps on the device), anything else = v_mfma_f64_16x16x4 with LDS-DMA operand staging
  * (default); returns the previous setting. */
 int gh_debug_set_mfma(int mode);
+/* the k-major x k-major GEMM kernel with its slab loop software-pipelined by half a slab (gemm_f64_mfma_dma_sp): 1 on, 0 off,
+ * -1 the build's default; returns the previous mode.  Same bits either way (tests/test_gpu_gemm.py).  GEORGE_AMD_GEMM_SP. */
+int gh_debug_set_gemm_sp(int mode);
 /* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */

@@ -1,0 +1,7 @@
+#!/bin/bash
+# full -m gpu suite, smoke, then the default bench line
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout -s KILL 120 python scripts/dev/dataflow_smoke.py > gpurun_out/suite_smoke.log 2>&1; echo "smoke rc=$?"
+timeout -s KILL 900 python -X faulthandler -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/suite_gpu.log 2>&1; echo "suite rc=$?"; tail -5 gpurun_out/suite_gpu.log
+timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/suite_entry_smoke.log 2>&1; echo "entry smoke rc=$?"; tail -2 gpurun_out/suite_entry_smoke.log
+timeout -s KILL 600 python bench.py > gpurun_out/bench_default.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench_default.log | cut -c1-3000

@@ -293,3 +293,33 @@ def test_staircase_gemm(group_rows, widths, K):
     bad = (C.c_int64 * 2)(256, 128)
     assert N.lib.gh_dev_gemm_nt_stair(c.data_ptr(), c.stride(0), a.data_ptr(), K, b.data_ptr(), K, 128, 2, bad, K, None) != 0
     assert N.lib.gh_dev_gemm_nt_stair(c.data_ptr(), c.stride(0), a.data_ptr(), K, b.data_ptr(), K, 100, 1, w, K, None) != 0
+
+
+@pytest.mark.parametrize("m,n,k,lower,alpha,beta", [(256, 384, 32, False, -1.0, 1.0), (640, 640, 1024, True, -1.0, 1.0), (128, 128, 64, False, 1.0, 0.0),
+                                                    (1024, 128, 128, False, -1.0, 1.0), (2048, 2048, 96, True, -1.0, 1.0),
+                                                    (4224, 4224, 1024, True, -1.0, 1.0), (512, 640, 4096, False, 2.5, -0.5),
+                                                    (384, 256, 48, False, -1.0, 1.0)])
+def test_half_slab_pipelined_kernel_gives_the_same_bits(m, n, k, lower, alpha, beta):
+    """gemm_f64_mfma_dma_sp (the k-major x k-major kernel with the barrier in the middle of a slab, the default) against
+    gemm_f64_mfma_dma (gh_debug_set_gemm_sp(0)): every accumulator adds the same k-steps in the same order -- identical
+    results, bit for bit; k = 48: a shape the pipelined form does not take (odd number of slabs) runs the old kernel in
+    both modes"""
+    from george_amd import _native as N
+    rng = np.random.RandomState(m + n + k)
+    A = rng.randn(m, k)
+    B = A if lower else rng.randn(n, k)
+    C0 = rng.randn(m, n)
+    outs = []
+    try:
+        for mode in (0, 1):
+            N.lib.gh_debug_set_gemm_sp(mode)
+            a, c = _dev(A), _dev(C0)
+            b = a if lower else _dev(B)
+            _gemm(c, a, b, m, n, k, alpha, beta, FLAGS["LOWER"] if lower else 0, k, k, n)
+            outs.append(c.cpu().numpy())
+    finally:
+        N.lib.gh_debug_set_gemm_sp(-1)
+    mask = np.kron(np.tril(np.ones((m // 128, n // 128))), np.ones((128, 128))).astype(bool) if lower else np.ones((m, n), bool)
+    assert np.array_equal(outs[0][mask], outs[1][mask])
+    want = beta * C0 + alpha * (A @ B.T)
+    assert np.abs(outs[1] - want)[mask].max() <= 1e-13 * max(1.0, np.abs(A @ B.T).max())
