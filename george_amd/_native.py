@@ -104,6 +104,7 @@ SIGNATURES = {
     "gh_microbench_hbm_copy": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
     "gh_debug_set_gemm_sp": (C.c_int, [C.c_int]),
+    "gh_debug_set_hodlr_passes": (C.c_int, [C.c_int]),
     "gh_debug_set_dataflow": (C.c_int, [C.c_int]),
     "gh_debug_dflow_schedule": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64]),
     "gh_debug_dflow_trace": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)]),

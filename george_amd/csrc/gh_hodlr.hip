@@ -953,6 +953,166 @@ __global__ __launch_bounds__(256) void hodlr_sum_narrow_kernel(const double* P, 
     Tsum[((long)node * 2 * R + row) * Cp + threadIdx.x] = t;
   }
 }
+// ---- round 5: the narrow solve (C <= 8 right-hand sides: every log-likelihood) in fewer, better-shaped launches.
+// Round 4's solve of C4 (N = 262144, one right-hand side) was 45 launches, 0.57 ms: the leaf kernel walked 32 rows per
+// wavefront with one exposed HBM round trip each (110 us for 268 MB), the per-chunk reduce kept R of every 32 lanes busy in a
+// serial walk over the chunk's rows (21 us per level for 8 MB), and each level paid four dispatches.
+//
+// X rows of a leaf <- K_leaf^-1 X rows, thread = OUTPUT ROW: K^-1 is symmetric, so row i of the product is the sum over k of
+// column i of row k -- every load of a wavefront is one contiguous 512-byte piece of row k, no reduction across lanes, and
+// eight rows' loads are in flight per thread.  The rows k are split over 256 / (padded leaf size) thread groups whose partial
+// sums are added in a fixed order.  (K^-1 = L^-T L^-1 is symmetric up to rounding: its (i, k) and (k, i) entries may differ
+// in the last bit, as may the sum order from the row form -- the results agree to rounding, tests/test_gpu_hodlr.py.)
+__global__ __launch_bounds__(256) void hodlr_mv_leaf_sym_kernel(const MMJob* jobs, const double* Kinv, long pitch, double* X, long ldx,
+                                                                long xcol0, int C) {
+  __shared__ double xs[256 * MV_C];
+  __shared__ double part[256 * MV_C];
+  const MMJob job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, n = job.m;
+  for (int e = tid; e < n * C; e += 256) xs[(e / C) * MV_C + (e % C)] = X[(long)(job.b_row + e / C) * ldx + xcol0 + (e % C)];
+  __syncthreads();
+  const int S = n <= 64 ? 4 : (n <= 128 ? 2 : 1), per_row = 256 / S;
+  const int i = tid % per_row, sidx = tid / per_row;
+  const int kper = (n + S - 1) / S, k_lo = sidx * kper, k_hi = min(n, k_lo + kper);
+  double acc[MV_C];
+#pragma unroll
+  for (int c = 0; c < MV_C; ++c) acc[c] = 0.0;
+  if (i < n) {
+    const double* col = Kinv + job.a_off + i;
+    int k = k_lo;
+    for (; k + 8 <= k_hi; k += 8) {
+      double a[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] = col[(long)(k + q) * pitch];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int c = 0; c < MV_C; ++c) if (c < C) acc[c] += a[q] * xs[(k + q) * MV_C + c];
+    }
+    for (; k < k_hi; ++k) {
+      const double a = col[(long)k * pitch];
+#pragma unroll
+      for (int c = 0; c < MV_C; ++c) if (c < C) acc[c] += a * xs[k * MV_C + c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MV_C; ++c) part[tid * MV_C + c] = acc[c];
+  __syncthreads();
+  if (sidx == 0 && i < n) {
+    for (int c = 0; c < C; ++c) {
+      double v = part[i * MV_C + c];
+      for (int q = 1; q < S; ++q) v += part[(q * per_row + i) * MV_C + c];
+      X[(long)(job.o_row + i) * ldx + xcol0 + c] = v;
+    }
+  }
+}
+// One pass over the rows of a chunk for TWO neighbouring levels of the sweep (either part may be absent):
+//   update (level l):   X(rows, c) -= sum_k U_l(row, k) T_l(b_row + k, c)                  [hodlr_mv_update_kernel]
+//   reduce (level l'):  P[(o_row + r) Cp + c] = sum_rows V_l'(row, r) X(row, c)             [hodlr_mv_reduce_kernel]
+// l' is the next shallower level with a positive rank and the SAME chunks (HLevel::chunk_geom): what the reduce reads is what
+// the update has just written, kept in LDS.  Reduce: wavefront w takes the columns r = w, w + 4, ... of V, lane = row (and
+// row + 64), one wavefront sum per (r, c) -- all lanes busy whatever R is, every load issued before the first sum.
+__global__ __launch_bounds__(256) void hodlr_mv_updred_kernel(const MMJob* ujobs, const double* U, long u_rs, const double* T,
+                                                              const MMJob* rjobs, const double* V, int R2, double* P,
+                                                              long Cp, double* X, long ldx, long xcol0, int C) {
+  __shared__ double ts[32 * MV_C];
+  __shared__ double xs[128 * MV_C];
+  __shared__ double us[128 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int row0, m;
+  // the reduce's V values first (they do not depend on the update): wavefront w, columns r = w + 4 q, rows lane and lane + 64
+  double v0[8], v1[8];
+  MMJob rj = {0, 0, 0, 0, 0};
+  if (rjobs) {
+    rj = rjobs[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = wave + 4 * q;
+      v0[q] = (r < R2 && lane < rj.kd) ? V[rj.a_off + (long)lane * R2 + r] : 0.0;
+      v1[q] = (r < R2 && lane + 64 < rj.kd) ? V[rj.a_off + (long)(lane + 64) * R2 + r] : 0.0;
+    }
+  }
+  if (ujobs) {
+    const MMJob job = ujobs[blockIdx.x];
+    row0 = job.o_row; m = job.m;
+    double xold[MV_C];                                // (requested with everything else: one round trip for the whole update)
+    if (tid < m) {
+#pragma unroll
+      for (int c = 0; c < MV_C; ++c) xold[c] = c < C ? X[(long)(row0 + tid) * ldx + xcol0 + c] : 0.0;
+    }
+    for (int e = tid; e < job.kd * C; e += 256) ts[(e / C) * MV_C + (e % C)] = T[(long)(job.b_row + e / C) * Cp + (e % C)];
+    // the chunk's rows of U_l through LDS, all 256 threads, element e = (row, k) with k fastest: consecutive lanes read the kd
+    // contiguous doubles of a row, then the next row (U is row-major with pitch u_rs here: one thread per row reading its kd
+    // values in turn was 64 scattered 8-byte requests per load instruction)
+    const int kd = job.kd;
+    for (int e = tid; e < m * kd; e += 256) { const int r_ = e / kd, k_ = e - r_ * kd; us[r_ * 33 + k_] = U[job.a_off + (long)r_ * u_rs + k_]; }
+    __syncthreads();
+    if (tid < m) {
+      double acc[MV_C];
+#pragma unroll
+      for (int c = 0; c < MV_C; ++c) acc[c] = 0.0;
+      for (int k = 0; k < kd; ++k) {
+        const double u = us[tid * 33 + k];
+#pragma unroll
+        for (int c = 0; c < MV_C; ++c) acc[c] += u * ts[k * MV_C + c];
+      }
+      double* xr = X + (long)(row0 + tid) * ldx + xcol0;
+#pragma unroll
+      for (int c = 0; c < MV_C; ++c)
+        if (c < C) { const double v = xold[c] - acc[c]; xr[c] = v; xs[tid * MV_C + c] = v; }
+    }
+  } else {
+    row0 = rj.b_row; m = rj.kd;
+    for (int e = tid; e < m * C; e += 256) xs[(e / C) * MV_C + (e % C)] = X[(long)(row0 + e / C) * ldx + xcol0 + (e % C)];
+  }
+  if (!rjobs) return;
+  __syncthreads();
+  const bool k0 = lane < m, k1 = lane + 64 < m;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = wave + 4 * q;
+    if (r >= R2) break;                              // (uniform)
+    for (int c = 0; c < C; ++c) {
+      double t = v0[q] * (k0 ? xs[lane * MV_C + c] : 0.0);
+      t += v1[q] * (k1 ? xs[(lane + 64) * MV_C + c] : 0.0);
+      t = hw_wave_sum(t);
+      if (lane == 0) P[(long)(rj.o_row + r) * Cp + c] = t;
+    }
+  }
+}
+// Per node: Tsum = the chunk partials of each half added up (as hodlr_sum_narrow_kernel: 32 slices, then the slice sums in
+// order), then Tout = S^-1 Tsum, the 2R x 2R core inverse times 2R x C, in the same workgroup (hodlr.h:247-252).
+__global__ __launch_bounds__(256) void hodlr_mv_summm_kernel(const double* P, const int* crange, int R, long Cp, int C, const double* Sinv,
+                                                             double* Tout) {
+  __shared__ double sl[32][MV_C];
+  __shared__ double tsum[64 * MV_C];
+  const int node = blockIdx.x, n2 = 2 * R;
+  const int c = threadIdx.x & 7, sidx = threadIdx.x >> 3;
+  for (int row = 0; row < n2; ++row) {
+    const int half = row < R ? 1 : 0, k = row < R ? row : row - R;
+    const int cb = crange[(node * 2 + half) * 2], ce = crange[(node * 2 + half) * 2 + 1];
+    const int per = (ce - cb + 31) / 32;
+    const int lo = cb + sidx * per, hi = lo + per < ce ? lo + per : ce;
+    double v = 0.0;
+    if (c < C) for (int ch = lo; ch < hi; ++ch) v += P[((long)ch * R + k) * Cp + c];
+    sl[sidx][c] = v;
+    __syncthreads();
+    if (threadIdx.x < MV_C) {
+      double t = 0.0;
+      for (int q = 0; q < 32; ++q) t += sl[q][threadIdx.x];
+      tsum[row * MV_C + threadIdx.x] = threadIdx.x < C ? t : 0.0;
+    }
+    __syncthreads();
+  }
+  const double* S = Sinv + (long)node * n2 * n2;
+  for (int e = threadIdx.x; e < n2 * MV_C; e += 256) {
+    const int i = e >> 3, cc = e & 7;
+    if (cc >= C) continue;
+    double t = 0.0;
+    for (int k = 0; k < n2; ++k) t += S[i * n2 + k] * tsum[k * MV_C + cc];
+    Tout[((long)node * n2 + i) * Cp + cc] = t;
+  }
+}
 // Tsum[node][0:R] = sum of the partials of its half-1 chunks, [R:2R] = half-0 chunks (hodlr.h:247-249)
 // blockDim = 64 x NS: NS threads per column each add a contiguous slice of the node's chunks, the first
 // then adds the NS slice sums in order (fixed order: reproducible).  The top levels have up to N/256
@@ -1033,6 +1193,7 @@ struct HLevel {
   // The job tables depend on the tree and on (R, off, Rtot) only: inside an optimiser loop neither
   // changes from one compute() to the next, and re-uploading them (~9 small copies per level, each a
   // host round trip) was ~1 ms of the 12 ms of a C4 compute.
+  std::vector<int> chunk_geom;      // (row0, rows) of every chunk in order: two levels with the same list can share a pass over the rows
   bool nodes_up = false;
   int tab_R = -1, tab_off = -1, gj_R = -1;
   long tab_Rtot = -1;
@@ -1090,7 +1251,10 @@ struct gh_hodlr {
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   GhBuf d_leaf_prod;
   GhBuf d_aca_segs, d_aca_segs1, d_compact_segs;
-  GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (solves) and its column map
+  double* pin = nullptr;         // pinned host block for the results compute() brings back (log|det| of every block, flags)
+  size_t pin_doubles = 0;
+  GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (wide solves: ensure_ul) and its column map
+  bool ul_valid = false;
   long col_Rtot = -1;
   std::vector<int> col_sig;
   GhBuf ld_all, flags;           // log|det| of every factored block of a compute(); [0] Gauss-Jordan failure, [2..3] leaf info
@@ -1142,6 +1306,7 @@ extern "C" void gh_hodlr_destroy(gh_hodlr* h) {
   if (h->st_b) (void)hipStreamSynchronize(h->st_b);
   if (h->st_c) (void)hipStreamSynchronize(h->st_c);
   if (h->st_d) (void)hipStreamSynchronize(h->st_d);
+  if (h->pin) (void)hipHostFree(h->pin);
   delete h;
 }
 
@@ -1189,10 +1354,18 @@ __device__ __forceinline__ void hodlr_stage_rows(double* Xs, int xp, const doubl
 // kernel took this as 16384 workgroups of one 32 x 64 tile each into a scratch copy (every U row staged four times,
 // every K^-1 slab twice) plus a copy back: 505 + 57 us of the C4 sweep for 0.6 GB of traffic.
 // Wavefront w: row tiles 2w, 2w+1 (16 rows each) x all CT column tiles.
+// rjobs != nullptr (round 5): the chunk products V^T X of the deepest level with a positive rank -- whose chunks are the
+// leaves -- are formed here too, from the result tiles while they are in registers (see hodlr_updred_kernel: the result
+// layout is the B operand layout of hodlr_red_kernel's k-steps, same order, same bits), saving that level's pass over U.
 template <int CT>
 __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ Kinv,
-                                                               double* __restrict__ X, long ldx, long xcol0, int C) {
-  constexpr int XP = 16 * CT + 1;
+                                                               double* __restrict__ X, long ldx, long xcol0, int C,
+                                                               const MMJob* __restrict__ rjobs = nullptr, const double* __restrict__ V2 = nullptr,
+                                                               int R2 = 0, double* __restrict__ P = nullptr, long ldp = 0) {
+  // (no padding column: at CT = 5 the image is then exactly 80 KiB and TWO workgroups share a CU's 160 KiB -- with 81 columns
+  //  it was 83 KiB, one workgroup = one wavefront per SIMD and nothing to hide the A operand's HBM latency behind; the price is
+  //  a two-way bank conflict between the lane groups fk and fk + 2 of a B fragment read)
+  constexpr int XP = 16 * CT;
   __shared__ double Xs[128 * XP];
   typedef double la_v4d __attribute__((ext_vector_type(4)));
   const MMJob job = jobs[blockIdx.x];
@@ -1207,12 +1380,15 @@ __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __re
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[i][j] = (la_v4d){0.0, 0.0, 0.0, 0.0};
-  const double* const ka = Kinv + job.a_off + (long)(32 * wave + fr) * 128 + fk;
+  // A operand: K^-1(row 32 wave + 16 i + fr, k = 4 kk + fk), read as its mirror image K^-1(k, row) -- the leaf inverse is
+  // symmetric (up to the last bit) and in this form the 16 lanes fr of a load are 128 contiguous bytes of row k instead of
+  // 16 rows x 8 bytes (round 5: 208 -> see profiles/r05/hodlr_passes.md)
+  const double* const ka = Kinv + job.a_off + (long)fk * 128 + 32 * wave + fr;
 #pragma unroll 1
   for (int k0 = 0; k0 < 32; k0 += 8) {
     double a[8][2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { a[q][0] = ka[4 * (k0 + q)]; a[q][1] = ka[16 * 128 + 4 * (k0 + q)]; }
+    for (int q = 0; q < 8; ++q) { a[q][0] = ka[(long)(4 * (k0 + q)) * 128]; a[q][1] = ka[(long)(4 * (k0 + q)) * 128 + 16]; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const double* const bp = Xs + (4 * (k0 + q) + fk) * XP + fr;
@@ -1236,6 +1412,45 @@ __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __re
       for (int j = 0; j < CT; ++j)
         if (16 * j + fr < C) xb[(long)row * ldx + 16 * j + fr] = acc[i][j][r];
     }
+  if (!rjobs) return;                             // (uniform)
+  const MMJob rj = rjobs[blockIdx.x];
+  la_v4d acc2[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc2[j] = (la_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {                   // k-step q = 4 i + r: rows 32 wave + 16 i + 4 r + fk
+    const int row = 4 * (8 * wave + q) + fk;
+    const double a2 = (fr < R2 && row < rj.kd) ? V2[rj.a_off + (long)row * R2 + fr] : 0.0;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      if (j >= ct) continue;
+      // (what hodlr_red_kernel would read back from its LDS image of X: zero outside the leaf's rows and the C columns)
+      const double bv = (row < job.m && 16 * j + fr < C) ? acc[q >> 2][j][q & 3] : 0.0;
+      acc2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bv, acc2[j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                // (every wavefront is done with Xs)
+  double* const part = Xs;                        // [3][CT][4][64]
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(((wave - 1) * CT + j) * 4 + r) * 64 + lane] = acc2[j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = fk + 4 * r, c = 16 * j + fr;
+        if (k < R2 && c < C) {
+          const double v = ((acc2[j][r] + part[((0 * CT + j) * 4 + r) * 64 + lane]) + part[((1 * CT + j) * 4 + r) * 64 + lane]) +
+                           part[((2 * CT + j) * 4 + r) * 64 + lane];
+          P[(long)(rj.o_row + k) * ldp + c] = v;
+        }
+      }
+  }
 }
 
 // The per-chunk products V_l^T U of the factorisation sweep (R <= 16 columns of V, <= 128 rows of a chunk, C <= 16 CT
@@ -1354,6 +1569,113 @@ __global__ __launch_bounds__(256) void hodlr_upd_kernel(const MMJob* __restrict_
       }
   }
 }
+// hodlr_upd_kernel for level l and hodlr_red_kernel for the next shallower level l' in ONE pass over a chunk's rows of U
+// (round 5).  The reduce of l' reads columns [0, off_l' + R_l') = [0, off_l) of U -- exactly what the update of l has just
+// written: here the updated tiles go to HBM and into the LDS image the reduce multiplies from, and the sweep reads U once
+// per level instead of twice (C4: upd<4> 52 us + red<4> 66 us per level, both HBM-bound).  The update's arithmetic is
+// hodlr_upd_kernel's, the reduce multiplies the same doubles hodlr_red_kernel would have staged from HBM, in the same order:
+// bit-identical to the two launches.  Needs the two levels' chunks to be the same rows (HLevel::chunk_geom).
+template <int CT>
+__global__ __launch_bounds__(256) void hodlr_updred_kernel(const MMJob* __restrict__ ujobs, const double* __restrict__ A, long a_rs,
+                                                           const double* __restrict__ B, long ldb, double* __restrict__ O, long ldo, int C,
+                                                           const MMJob* __restrict__ rjobs, const double* __restrict__ V2, int R2,
+                                                           double* __restrict__ P, long ldp) {
+  __shared__ double part[3 * CT * 4 * 64];
+  typedef double uk_v4d __attribute__((ext_vector_type(4)));
+  const MMJob job = ujobs[blockIdx.x];
+  const MMJob rj = rjobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int R = job.kd, nkk = (R + 3) >> 2;                             // (uniform; every one of the CT column tiles is computed:
+  // columns >= C are zero on both sides, and a `tile j < ceil(C / 16)` test in front of each matrix instruction made hipcc keep
+  // both versions of every accumulator -- 256 VGPRs at CT = 4)
+  // the reduce's A operand (V_l'^T: this wavefront's eight k steps, q = 4 i + r <-> rows 32 wave + 16 i + 4 r + fk), requested
+  // first: it lands under the update
+  double a2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = 4 * (8 * wave + q) + fk;
+    a2[q] = (fr < R2 && row < rj.kd) ? V2[rj.a_off + (long)row * R2 + fr] : 0.0;
+  }
+  double b[4][CT];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int k = 4 * kk + fk, c = 16 * j + fr;
+      b[kk][j] = (k < R && c < C) ? B[(long)(job.b_row + k) * ldb + c] : 0.0;
+    }
+  double* const ob = O + (long)job.o_row * ldo;
+  uk_v4d acc2[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc2[j] = (uk_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    uk_v4d acc[CT];
+    const bool live = 32 * wave + 16 * i < job.m;                      // (uniform)
+    // (one 16-row tile at a time, fenced: with both tiles' loads hoisted to the top hipcc needs 256 VGPRs at CT = 4 -- two
+    //  wavefronts per SIMD for a kernel that lives on memory latency, 127-136 us per level against 52 + 66 for the two launches)
+    double a[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int row = 32 * wave + 16 * i + fr, k = 4 * kk + fk;
+      a[kk] = (row < job.m && k < R) ? -A[job.a_off + (long)row * a_rs + k] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * i + fk + 4 * r, c = 16 * j + fr;
+        acc[j][r] = (live && row < job.m && c < C) ? ob[(long)row * ldo + c] : 0.0;
+      }
+    if (live) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk >= nkk) continue;
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk][j], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * wave + 16 * i + fk + 4 * r, c = 16 * j + fr;
+          if (row < job.m && c < C) ob[(long)row * ldo + c] = acc[j][r];
+        }
+    }
+    // The reduce, straight from the registers: the update's result layout (lane (fr, fk), register r of tile j = row 4 r + fk,
+    // column 16 j + fr of this 16-row tile) IS the matrix instruction's B operand layout for the k-step over rows 4 r .. 4 r + 3
+    // (B[k = fk][n = fr]) -- hodlr_red_kernel stages exactly these values through LDS and reads them back into this position.
+    // Same k-steps in the same order (q = 4 i + r) on the same wavefront: the same bits.
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+        acc2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[4 * i + r], acc[j][r], acc2[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(((wave - 1) * CT + j) * 4 + r) * 64 + lane] = acc2[j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = fk + 4 * r, c = 16 * j + fr;
+        if (k < R2 && c < C) {
+          const double v = ((acc2[j][r] + part[((0 * CT + j) * 4 + r) * 64 + lane]) + part[((1 * CT + j) * 4 + r) * 64 + lane]) +
+                           part[((2 * CT + j) * 4 + r) * 64 + lane];
+          P[(long)(rj.o_row + k) * ldp + c] = v;
+        }
+      }
+  }
+}
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
                      const double* B, long ldb, long b_col0, double* O, long ldo, long o_col0, int C, bool subtract, int mtiles = 1);
 static int launch_red(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const double* V, const double* B, long ldb, long b_col0,
@@ -1394,6 +1716,31 @@ static int launch_upd(gh_hodlr* h, const MMJob* jobs, int njobs, int R, const do
   return GH_OK;
 }
 
+static int hodlr_passes();
+// update of level `L` (columns [0, C) of U, C = L->off) + reduce of level `nx` over the same columns in one pass; false when
+// the pair cannot share a pass (the caller then launches the two kernels)
+static bool updred_possible(const HLevel* L, const HLevel* nx, int C, int cpass) {
+  return (hodlr_passes() & 2) && nx && !nx->top && !L->top && L->R <= 16 && nx->R <= 16 && C > 0 && C <= 128 && HCH == 128 &&
+         nx->off + nx->R == C && C <= cpass && nx->chunk_geom == L->chunk_geom && !L->chunk_geom.empty();
+}
+static int launch_updred(gh_hodlr* h, const HLevel* L, const HLevel* nx, const double* A, long a_rs, const double* B, long ldb,
+                         double* O, long ldo, int C, const double* V2, double* P, long ldp) {
+  const MMJob* uj = (const MMJob*)L->d_upd_jobs.p;
+  const MMJob* rj = (const MMJob*)nx->d_red_jobs.p;
+#define GH_UR_LAUNCH(CT) hipLaunchKernelGGL(hodlr_updred_kernel<CT>, dim3(L->nchunks), dim3(256), 0, h->st, uj, A, a_rs, B, ldb, O, ldo, C, rj, V2, nx->R, P, ldp)
+  switch ((C + 15) / 16) {
+    case 1: GH_UR_LAUNCH(1); break;
+    case 2: GH_UR_LAUNCH(2); break;
+    case 3: GH_UR_LAUNCH(3); break;
+    case 4: GH_UR_LAUNCH(4); break;
+    case 5: GH_UR_LAUNCH(5); break;
+    default: GH_UR_LAUNCH(8); break;
+  }
+#undef GH_UR_LAUNCH
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+
 // mtiles: 32-row tiles of a job handled by ONE workgroup (the update passes: 4, i.e. a whole 128-row
 // chunk -- 8192 workgroups of one tiny tile each spent their 50 us on being dispatched)
 static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const double* A, long a_rs, long a_cs,
@@ -1408,10 +1755,37 @@ static int launch_mm(gh_hodlr* h, const MMJob* jobs, int njobs, int max_m, const
   return GH_OK;
 }
 
+// level-major copy UL of the final U (every level's columns contiguous: what the wide solves' tile kernel wants), made on demand
+static int ensure_ul(gh_hodlr* h) {
+  if (h->ul_valid || h->Rtot <= 0) return GH_OK;
+  const long n = h->n, Rtot = h->Rtot;
+  hipStream_t st = h->st;
+  GH_CHECK(h->UL.ensure((size_t)n * Rtot * sizeof(double)));
+  std::vector<long> colbase(Rtot);
+  std::vector<int> colld(Rtot);
+  for (auto* L : h->levels)
+    for (int kk = 0; kk < L->R; ++kk) { colbase[L->off + kk] = (long)n * L->off + kk; colld[L->off + kk] = L->R; }
+  // (cached like the job tables: same ranks, same map)
+  bool same = h->col_Rtot == Rtot && h->col_sig.size() == h->levels.size();
+  for (size_t q = 0; same && q < h->levels.size(); ++q) same = h->col_sig[q] == h->levels[q]->R;
+  if (!same) {
+    GH_CHECK(upload(h->d_colbase, colbase, st));
+    GH_CHECK(upload(h->d_colld, colld, st));
+    h->col_Rtot = Rtot;
+    h->col_sig.clear();
+    for (auto* L : h->levels) h->col_sig.push_back(L->R);
+  }
+  hipLaunchKernelGGL(hodlr_relayout_kernel, dim3(2048), dim3(256), 0, st, h->UA.d(), (long)n, (int)Rtot,
+                     (const long*)h->d_colbase.p, (const int*)h->d_colld.p, h->UL.d());
+  GH_HIP(hipGetLastError());
+  h->ul_valid = true;
+  return GH_OK;
+}
 // X[:, xcol0 : xcol0+C] <- (level lv)^-1 applied (hodlr.h:244-253 for every node of the level)
 // (U == nullptr: the level-major copy UL is used -- solves; else the row-major UA with pitch ldu)
 static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, int C, const double* U, long ldu) {
   if (L->R == 0 || C <= 0) return GH_OK;
+  if (!U) GH_CHECK(ensure_ul(h));
   const int R = L->R, nn = (int)L->node_ids.size();
   const double* Vl = h->VA.d() + (long)h->n * L->off;
   if (C <= MV_C && R <= 32) {
@@ -1456,7 +1830,11 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
   return GH_OK;
 }
 // X rows of every leaf <- K_leaf^-1 X
-static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
+// red / red_done: the sweep's first call -- form the chunk products of level `red` over the same columns in the same pass when
+// its chunks are the leaves (then *red_done = true and the caller skips that level's reduce)
+static int hodlr_passes();
+static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C, const HLevel* red = nullptr, bool* red_done = nullptr) {
+  if (red_done) *red_done = false;
   if (C <= 0) return GH_OK;
   if (C <= MV_C && h->max_leaf <= 256) {
     hipLaunchKernelGGL(hodlr_mv_leaf_kernel, dim3((unsigned)h->leaves.size()), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p,
@@ -1466,6 +1844,22 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
   }
   if (h->leaf_pitch == 128 && h->max_leaf <= 128) {
     // one workgroup per leaf, in place; column passes of <= 128 (80 where that covers the rest: less LDS, fewer MFMAs)
+    bool fuse = (hodlr_passes() & 2) && red && red_done && C <= 128 && xcol0 == 0 && red->R > 0 && red->R <= 16 && !red->top &&
+                red->off + red->R == C && C <= h->cpass && red->chunk_geom.size() == 2 * h->leaves.size();
+    for (size_t q = 0; fuse && q < h->leaves.size(); ++q)
+      fuse = red->chunk_geom[2 * q] == h->leaves[q].start && red->chunk_geom[2 * q + 1] == h->leaves[q].size;
+    if (fuse) {
+      const unsigned nl = (unsigned)h->leaves.size();
+      const MMJob* rj = (const MMJob*)red->d_red_jobs.p;
+      const double* V2 = h->VA.d() + (long)h->n * red->off;
+      if (C <= 80) hipLaunchKernelGGL(hodlr_leaf_apply_kernel<5>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0, C,
+                                      rj, V2, red->R, h->P.d(), (long)h->cpass);
+      else hipLaunchKernelGGL(hodlr_leaf_apply_kernel<8>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0, C,
+                              rj, V2, red->R, h->P.d(), (long)h->cpass);
+      GH_HIP(hipGetLastError());
+      *red_done = true;
+      return GH_OK;
+    }
     for (int cp = 0; cp < C;) {
       const int cw = std::min(128, C - cp);
       const unsigned nl = (unsigned)h->leaves.size();
@@ -1488,7 +1882,60 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C) {
   return GH_OK;
 }
 // full solve on X (n x C): leaves, then levels bottom-up (hodlr.h:107-114)
+// GEORGE_AMD_HODLR_PASSES / gh_debug_set_hodlr_passes: bit 0 = the narrow solve in shared passes (round 5), bit 1 = the
+// factorisation sweep's update of level l and reduce of the next level in one pass over U; default: both
+static int g_hodlr_passes = -1;
+static int hodlr_passes() {
+  if (g_hodlr_passes < 0) { const char* e = getenv("GEORGE_AMD_HODLR_PASSES"); g_hodlr_passes = e ? atoi(e) & 3 : 3; }
+  return g_hodlr_passes;
+}
+extern "C" int gh_debug_set_hodlr_passes(int mask) {
+  const int prev = hodlr_passes();
+  g_hodlr_passes = mask < 0 ? 3 : (mask & 3);
+  return prev;
+}
+// the narrow solve: leaves (symmetric form), then per level "sum + core product" and ONE pass over the rows that applies this
+// level's update and forms the next level's chunk products (separate passes where the two levels' chunks differ)
+static int solve_narrow(gh_hodlr* h, double* X, long ldx, int C) {
+  hipLaunchKernelGGL(hodlr_mv_leaf_sym_kernel, dim3((unsigned)h->leaves.size()), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p,
+                     h->leaf_inv.d(), (long)h->leaf_pitch, X, ldx, 0L, C);
+  std::vector<HLevel*> Ls;
+  for (int l = (int)h->levels.size() - 1; l >= 0; --l) if (h->levels[l]->R > 0) Ls.push_back(h->levels[l]);
+  const long Cp = h->cpass;
+  auto pass = [&](HLevel* up, HLevel* red) {
+    HLevel* g = up ? up : red;
+    hipLaunchKernelGGL(hodlr_mv_updred_kernel, dim3(g->nchunks), dim3(256), 0, h->st,
+                       up ? (const MMJob*)up->d_upd_jobs.p : (const MMJob*)nullptr, up ? h->UA.d() + up->off : (const double*)nullptr,
+                       (long)h->Rtot, (const double*)h->Tout.d(),
+                       red ? (const MMJob*)red->d_red_jobs.p : (const MMJob*)nullptr, red ? h->VA.d() + (long)h->n * red->off : (const double*)nullptr,
+                       red ? red->R : 0, h->P.d(), Cp, X, ldx, 0L, C);
+  };
+  if (!Ls.empty()) pass(nullptr, Ls[0]);
+  for (size_t i = 0; i < Ls.size(); ++i) {
+    HLevel* L = Ls[i];
+    // (one workgroup per node adds the partials of ALL 2R rows: fine while a half has <= 64 chunks -- the deep levels, many nodes;
+    //  the few nodes of the top levels have up to N / 256 chunks per half and keep one workgroup per (node, row) + the product)
+    const int nn = (int)L->node_ids.size();
+    if ((long)L->nchunks <= 128L * nn) {
+      hipLaunchKernelGGL(hodlr_mv_summm_kernel, dim3((unsigned)nn), dim3(256), 0, h->st, h->P.d(), (const int*)L->d_crange.p, L->R, Cp, C,
+                         (const double*)L->sinv.d(), h->Tout.d());
+    } else {
+      hipLaunchKernelGGL(hodlr_sum_narrow_kernel, dim3(nn, 2 * L->R), dim3(256), 0, h->st, h->P.d(), (const int*)L->d_crange.p, L->R, Cp, C, h->Tsum.d());
+      GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * L->R, L->sinv.d(), 2 * L->R, 1, h->Tsum.d(), Cp, 0, h->Tout.d(), Cp, 0, C, false));
+    }
+    HLevel* nx = i + 1 < Ls.size() ? Ls[i + 1] : nullptr;
+    if (nx && nx->chunk_geom == L->chunk_geom) pass(L, nx);
+    else { pass(L, nullptr); if (nx) pass(nullptr, nx); }
+  }
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
 static int solve_all(gh_hodlr* h, double* X, long ldx, int C) {
+  if ((hodlr_passes() & 1) && C <= MV_C && h->max_leaf <= 256 && h->sub.depth == 0) {
+    bool ok = true;
+    for (auto* L : h->levels) ok = ok && !L->top && L->R <= 32 && (L->R == 0 || !L->chunk_geom.empty());
+    if (ok) return solve_narrow(h, X, ldx, C);
+  }
   GH_CHECK(apply_leaves(h, X, ldx, 0, C));
   for (int l = (int)h->levels.size() - 1; l >= 0; --l)
     GH_CHECK(apply_level(h, h->levels[l], X, ldx, 0, C, nullptr, 0));
@@ -2185,6 +2632,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       smul[q] = {(long)q * 4 * R * R, q * 2 * R, q * 2 * R, 2 * R, 2 * R};
     }
     L->nchunks = (int)chunks.size();
+    L->chunk_geom.clear();
+    for (const Chunk& c : chunks) { L->chunk_geom.push_back(c.row0); L->chunk_geom.push_back(c.nrows); }
     h->max_chunks = std::max(h->max_chunks, L->nchunks);
     GH_CHECK(upload(L->d_chunks, chunks, st));
     GH_CHECK(upload(L->d_crange, crange, st));
@@ -2219,7 +2668,12 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   mark("work arrays, leaf stage enqueued");
 
   // ---- factorisation sweep (hodlr.h:75-103, level-batched): leaves into every U, then levels bottom-up
-  if (h->Rtot > 0) GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot));
+  bool red_ready = false;                            // the chunk products of the next level to be processed are in P already
+  if (h->Rtot > 0) {
+    const HLevel* deepest = nullptr;
+    for (int q = nlev - 1; q >= 0 && !deepest; --q) if (h->levels[q]->R > 0) deepest = h->levels[q];
+    GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot, deepest, &red_ready));
+  }
   std::vector<size_t> top_ld(l0, (size_t)-1);        // where in ld_all the core of pseudo-level l put its log|det|
   bool local_done = (l0 == 0);
   for (int l = nlev - 1; l >= 0; --l) {
@@ -2259,8 +2713,11 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     const int Call = L->off + R;
     const bool merged = Call <= h->cpass;
     if (merged) {
-      GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
-                          h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
+      // (red_ready: the deeper level's update pass has already formed this level's chunk products -- hodlr_updred_kernel)
+      if (!red_ready)
+        GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
+                            h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
+      red_ready = false;
       hipLaunchKernelGGL(hodlr_sum_kernel, dim3(nn, 2 * R), dim3(64 * SUM_NS), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, Call, h->Tsum.d());
       GH_HIP(hipGetLastError());
     } else {
@@ -2284,38 +2741,38 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // (Tsum already holds V_l^T U[:, 0:off]: core product and update only)
       GH_CHECK(launch_mm(h, (const MMJob*)L->d_smul_jobs.p, nn, 2 * R, L->sinv.d(), 2 * R, 1,
                          h->Tsum.d(), h->cpass, 0, h->Tout.d(), h->cpass, 0, L->off, false));
-      GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
-                          h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
+      const HLevel* nx = nullptr;
+      for (int q = l - 1; q >= 0 && !nx; --q) if (h->levels[q]->R > 0) nx = h->levels[q];
+      if (updred_possible(L, nx, L->off, h->cpass)) {
+        GH_CHECK(launch_updred(h, L, nx, h->UA.d() + L->off, Rtot, h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off,
+                               h->VA.d() + (long)n * nx->off, h->P.d(), h->cpass));
+        red_ready = true;
+      } else {
+        GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
+                            h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
+      }
     } else {
       GH_CHECK(apply_level(h, L, h->UA.d(), Rtot, 0, L->off, h->UA.d(), Rtot));
     }
   }
-  // level-major copy of the final U for the solves
-  if (h->Rtot > 0) {
-    GH_CHECK(h->UL.ensure((size_t)n * Rtot * sizeof(double)));
-    std::vector<long> colbase(Rtot);
-    std::vector<int> colld(Rtot);
-    for (auto* L : h->levels)
-      for (int kk = 0; kk < L->R; ++kk) { colbase[L->off + kk] = (long)n * L->off + kk; colld[L->off + kk] = L->R; }
-    // (cached like the job tables: same ranks, same map)
-    bool same = h->col_Rtot == Rtot && h->col_sig.size() == h->levels.size();
-    for (size_t q = 0; same && q < h->levels.size(); ++q) same = h->col_sig[q] == h->levels[q]->R;
-    if (!same) {
-      GH_CHECK(upload(h->d_colbase, colbase, st));
-      GH_CHECK(upload(h->d_colld, colld, st));
-      h->col_Rtot = Rtot;
-      h->col_sig.clear();
-      for (auto* L : h->levels) h->col_sig.push_back(L->R);
-    }
-    hipLaunchKernelGGL(hodlr_relayout_kernel, dim3(2048), dim3(256), 0, st, h->UA.d(), (long)n, (int)Rtot,
-                       (const long*)h->d_colbase.p, (const int*)h->d_colld.p, h->UL.d());
-    GH_HIP(hipGetLastError());
+  // (the level-major copy of the final U that the WIDE solves multiply from is made when one of them asks for it -- ensure_ul;
+  //  the narrow solve of a log-likelihood reads the row-major U: 90 us of every C4 step for a copy nothing read)
+  h->ul_valid = false;
+  // (into PINNED host memory: a copy to pageable memory is staged and waited for inside the call -- two of them were ~45 us
+  //  between the last kernel and the return)
+  const size_t nld = std::max<size_t>(n_blocks, 1);
+  if (h->pin_doubles < nld + 2) {
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr; h->pin_doubles = 0;
+    GH_HIP(hipHostMalloc((void**)&h->pin, (nld + 2 + 1024) * sizeof(double), hipHostMallocDefault));
+    h->pin_doubles = nld + 2 + 1024;
   }
-  std::vector<double> ld_host(std::max<size_t>(n_blocks, 1), 0.0);
+  double* const ld_host = h->pin;
   int fl[4] = {0, 0, 0, 0};
-  GH_HIP(hipMemcpyAsync(ld_host.data(), h->ld_all.p, std::max<size_t>(n_blocks, 1) * sizeof(double), hipMemcpyDeviceToHost, st));
-  GH_HIP(hipMemcpyAsync(fl, h->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipMemcpyAsync(ld_host, h->ld_all.p, nld * sizeof(double), hipMemcpyDeviceToHost, st));
+  GH_HIP(hipMemcpyAsync(ld_host + nld, h->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   GH_HIP(hipStreamSynchronize(st));
+  memcpy(fl, ld_host + nld, 4 * sizeof(int));
   long long leaf_info = 0;
   memcpy(&leaf_info, fl + 2, sizeof(long long));
   if (leaf_info != 0) { gh_set_error("HODLR: a leaf block is not positive definite"); return GH_ERR_NOT_PD; }
@@ -2354,10 +2811,11 @@ extern "C" int gh_hodlr_dot_solve(gh_hodlr* h, const double* y, double* out) {
   GH_CHECK(h->rhs.ensure((size_t)h->n * sizeof(double)));
   GH_CHECK(h->work.ensure((size_t)h->n * sizeof(double)));
   GH_CHECK(gh_to_device(h->rhs.d(), y, (size_t)h->n, h->st));
-  GH_CHECK(gh_to_device(h->work.d(), y, (size_t)h->n, h->st));
+  const double* yd = y;                              // (a device-resident y is read where it is)
+  if (!gh_is_device_ptr(y)) { GH_CHECK(gh_to_device(h->work.d(), y, (size_t)h->n, h->st)); yd = h->work.d(); }
   GH_CHECK(solve_all(h, h->rhs.d(), 1, 1));
   GH_CHECK(h->dotp.ensure(256 * sizeof(double)));
-  hipLaunchKernelGGL(hodlr_dot_kernel, dim3(256), dim3(256), 0, h->st, h->work.d(), h->rhs.d(), (long)h->n, h->dotp.d());
+  hipLaunchKernelGGL(hodlr_dot_kernel, dim3(256), dim3(256), 0, h->st, yd, h->rhs.d(), (long)h->n, h->dotp.d());
   hipLaunchKernelGGL(hodlr_dot_kernel, dim3(1), dim3(256), 0, h->st, h->dotp.d(), (const double*)nullptr, 256L, h->scal.d());
   GH_HIP(hipGetLastError());
   double v = 0.0;

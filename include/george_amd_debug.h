@@ -23,6 +23,11 @@ int gh_debug_set_mfma(int mode);
 /* the k-major x k-major GEMM kernel with its slab loop software-pipelined by half a slab (gemm_f64_mfma_dma_sp): 1 on, 0 off,
  * -1 the build's default; returns the previous mode.  Same bits either way (tests/test_gpu_gemm.py).  GEORGE_AMD_GEMM_SP. */
 int gh_debug_set_gemm_sp(int mode);
+/* HODLR passes that serve two levels at once (round 5): bit 0 = the narrow solve (update of level l + chunk products of the
+ * next level in one pass over the rows, "sum + core product" in one launch, symmetric leaf product), bit 1 = the factorisation
+ * sweep's update of level l + reduce of the next level in one pass over U; -1: the default (both); returns the previous mask.
+ * GEORGE_AMD_HODLR_PASSES. */
+int gh_debug_set_hodlr_passes(int mask);
 /* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */
