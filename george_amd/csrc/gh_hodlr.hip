@@ -598,6 +598,14 @@ __global__ __launch_bounds__(128) void hodlr_leaf_logdet_kernel(const double* Lf
   if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * v;
 }
 
+// the same for a 256 x 256 slot factored as 2 x 2 blocks of 128 (both diagonal blocks hold their factors)
+__global__ __launch_bounds__(256) void hodlr_leaf_logdet256_kernel(const double* Lf, double* out) {
+  __shared__ double sh[8];
+  const double* slot = Lf + (long)blockIdx.x * 256 * 256;
+  const double v = hw_block_sum(log(slot[threadIdx.x * 257]), sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * v;
+}
+
 // Batched in-place inverse by Gauss-Jordan with partial (row) pivoting; one workgroup per matrix
 // (row-major n x n at base + offs[b]).  logdet[b] = sum log|pivot|.  scratch: n doubles + n ints
 // per matrix at sc_off[b].  When the launch provides dynamic LDS (`lds_doubles` >= n * (n|1) + n) the
@@ -1017,7 +1025,8 @@ __global__ __launch_bounds__(256) void hodlr_mv_updred_kernel(const MMJob* ujobs
                                                               long Cp, double* X, long ldx, long xcol0, int C) {
   __shared__ double ts[32 * MV_C];
   __shared__ double xs[128 * MV_C];
-  __shared__ double us[128 * 33];
+  extern __shared__ double us[];                     // [128][up]: the chunk's rows of U_l; up = 17 or 33 (the launch sizes it: 17 KiB
+                                                     // instead of 33 lets all 2048 workgroups of a C4 level be resident at once)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int row0, m;
   // the reduce's V values first (they do not depend on the update): wavefront w, columns r = w + 4 q, rows lane and lane + 64
@@ -1044,15 +1053,15 @@ __global__ __launch_bounds__(256) void hodlr_mv_updred_kernel(const MMJob* ujobs
     // the chunk's rows of U_l through LDS, all 256 threads, element e = (row, k) with k fastest: consecutive lanes read the kd
     // contiguous doubles of a row, then the next row (U is row-major with pitch u_rs here: one thread per row reading its kd
     // values in turn was 64 scattered 8-byte requests per load instruction)
-    const int kd = job.kd;
-    for (int e = tid; e < m * kd; e += 256) { const int r_ = e / kd, k_ = e - r_ * kd; us[r_ * 33 + k_] = U[job.a_off + (long)r_ * u_rs + k_]; }
+    const int kd = job.kd, up = kd <= 16 ? 17 : 33;
+    for (int e = tid; e < m * kd; e += 256) { const int r_ = e / kd, k_ = e - r_ * kd; us[r_ * up + k_] = U[job.a_off + (long)r_ * u_rs + k_]; }
     __syncthreads();
     if (tid < m) {
       double acc[MV_C];
 #pragma unroll
       for (int c = 0; c < MV_C; ++c) acc[c] = 0.0;
       for (int k = 0; k < kd; ++k) {
-        const double u = us[tid * 33 + k];
+        const double u = us[tid * up + k];
 #pragma unroll
         for (int c = 0; c < MV_C; ++c) acc[c] += u * ts[k * MV_C + c];
       }
@@ -1904,7 +1913,8 @@ static int solve_narrow(gh_hodlr* h, double* X, long ldx, int C) {
   const long Cp = h->cpass;
   auto pass = [&](HLevel* up, HLevel* red) {
     HLevel* g = up ? up : red;
-    hipLaunchKernelGGL(hodlr_mv_updred_kernel, dim3(g->nchunks), dim3(256), 0, h->st,
+    const size_t lds = up ? (size_t)128 * (up->R <= 16 ? 17 : 33) * sizeof(double) : 0;
+    hipLaunchKernelGGL(hodlr_mv_updred_kernel, dim3(g->nchunks), dim3(256), lds, h->st,
                        up ? (const MMJob*)up->d_upd_jobs.p : (const MMJob*)nullptr, up ? h->UA.d() + up->off : (const double*)nullptr,
                        (long)h->Rtot, (const double*)h->Tout.d(),
                        red ? (const MMJob*)red->d_red_jobs.p : (const MMJob*)nullptr, red ? h->VA.d() + (long)h->n * red->off : (const double*)nullptr,
@@ -2072,6 +2082,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // The leaf stage (build, batched Cholesky + inverse, K^-1 = L^-T L^-1: 1.4 ms at C4) depends on
   // nothing the ACA produces, so it is issued on the second stream under the ACA of the top levels.
   GhPooledBuf linv;                              // (lives until the final synchronisation: two streams touch it)
+  GhPooledBuf lstk, l22b, lwk;                   // (the 129..256-row leaf path's work blocks: as linv)
   bool leaves_done = false;
   auto leaf_stage = [&](hipStream_t st) -> int {
     struct StreamSwap { gh_hodlr* h; hipStream_t keep; ~StreamSwap() { h->st = keep; } } swap_guard{h, h->st};
@@ -2107,6 +2118,60 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     }
     GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
     h->leaf_pitch = 128;
+  } else if (h->max_leaf <= 256 && !getenv("GEORGE_AMD_HODLR_LEAF_GJ")) {
+    // Leaves of 129 .. 256 rows -- the reference's tree stops splitting below 2 min_size, so with min_size = 100 most problem
+    // sizes have leaves of up to 199 rows (N = 50000: 256 leaves of 195 / 196) -- went through the pivoted Gauss-Jordan in place
+    // in HBM: 14 of the 17 ms of a step at N = 50000 (round 5 profile).  Same recipe as above on 256 x 256 identity-padded slots,
+    // as 2 x 2 blocks of 128 with the batched kernels there are:  L11 = chol(A11);  W = L21^T = L11^-1 A12;  A22 -= W^T W;
+    // L22 = chol(A22);  L^-1 = [[L11^-1, 0], [X, L22^-1]],  X = -L22^-1 L21 L11^-1;  K^-1 = L^-T L^-1 block by block
+    // (the full symmetric matrix is stored: the products read rows and, by symmetry, columns).
+    const int nl = (int)h->leaves.size();
+    const size_t slot = (size_t)256 * 256, blk = (size_t)128 * 128;
+    GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
+    GH_CHECK(lstk.ensure(nl * 2 * blk * sizeof(double)));        // per leaf [L11^-1; X']  (256 x 128), X' = L22^-1 L21 L11^-1 = -X
+    GH_CHECK(l22b.ensure(nl * blk * sizeof(double)));            // L22^-1
+    GH_CHECK(lwk.ensure(nl * 2 * blk * sizeof(double)));         // W, then T = L21 L11^-1
+    long long* d_info = (long long*)((int*)h->flags.p + 2);
+    if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
+    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 16), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
+                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 256);
+    GH_HIP(hipGetLastError());
+    double* const S = h->leaf_inv.d();
+    // job tables (uploaded once per tree): a_off / b_row / o_row of leaf i for each of the nine products
+    enum { J_W = 0, J_A22, J_T, J_X, J_K11, J_K21, J_K22, J_K12, J_N };
+    std::vector<MMJob> jb((size_t)J_N * nl), jobs(nl);
+    for (int i = 0; i < nl; ++i) {
+      jb[(size_t)J_W * nl + i]   = {(long)(i * 2 * blk), i * 256, i * 256, 128, 128};                 // W = L11^-1 (lstk rows 0..127) x A12
+      jb[(size_t)J_A22 * nl + i] = {(long)(i * 2 * blk), i * 256, i * 256 + 128, 128, 128};           // A22 -= W^T W     (A: lwk, transposed)
+      jb[(size_t)J_T * nl + i]   = {(long)(i * 2 * blk), i * 256, i * 256 + 128, 128, 128};           // T = W^T L11^-1   (A: lwk transposed, B: lstk, O: lwk rows 128..)
+      jb[(size_t)J_X * nl + i]   = {(long)(i * blk), i * 256 + 128, i * 256 + 128, 128, 128};         // X' = L22^-1 T    (B: lwk rows 128.., O: lstk rows 128..)
+      jb[(size_t)J_K11 * nl + i] = {(long)(i * 2 * blk), i * 256, i * 256, 128, 256};                 // K11 = [L11^-1; X']^T [L11^-1; X']
+      jb[(size_t)J_K21 * nl + i] = {(long)(i * blk), i * 256 + 128, i * 256 + 128, 128, 128};         // K21 = -L22^-T X'   (A: l22b transposed, B: lstk rows 128..)
+      jb[(size_t)J_K22 * nl + i] = {(long)(i * blk), i * 128, i * 256 + 128, 128, 128};               // K22 = L22^-T L22^-1
+      jb[(size_t)J_K12 * nl + i] = {(long)(i * 2 * blk + blk), i * 128, i * 256, 128, 128};           // K12 = -X'^T L22^-1 (A: lstk rows 128.. transposed, B: l22b)
+      jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
+    }
+    if (!h->leaf_tab_up) {
+      GH_CHECK(upload(h->d_leaf_prod, jb, st));
+      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+      h->leaf_tab_up = true;
+    }
+    const MMJob* const J = (const MMJob*)h->d_leaf_prod.p;
+    GH_CHECK(gh_launch_potf2_batched(S, 256, (int64_t)slot, lstk.d(), (int64_t)(2 * blk), d_info, nl, st));                       // L11 (in place), L11^-1
+    GH_CHECK(launch_mm(h, J + (size_t)J_W * nl, nl, 128, lstk.d(), 128, 1, S, 256, 128, lwk.d(), 128, 0, 128, false));
+    GH_CHECK(launch_mm(h, J + (size_t)J_A22 * nl, nl, 128, lwk.d(), 1, 128, lwk.d(), 128, 0, S, 256, 128, 128, true));
+    GH_CHECK(gh_launch_potf2_batched(S + 128 * 256 + 128, 256, (int64_t)slot, l22b.d(), (int64_t)blk, d_info, nl, st));           // L22, L22^-1
+    hipLaunchKernelGGL(hodlr_leaf_logdet256_kernel, dim3(nl), dim3(256), 0, st, (const double*)S, h->ld_all.d() + ld_at);
+    ld_at += nl;
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipMemsetAsync(S, 0, nl * slot * sizeof(double), st));                                     // (both factors have been used: K21 and K12 are formed by subtraction)
+    GH_CHECK(launch_mm(h, J + (size_t)J_T * nl, nl, 128, lwk.d(), 1, 128, lstk.d(), 128, 0, lwk.d(), 128, 0, 128, false));
+    GH_CHECK(launch_mm(h, J + (size_t)J_X * nl, nl, 128, l22b.d(), 128, 1, lwk.d(), 128, 0, lstk.d(), 128, 0, 128, false));
+    GH_CHECK(launch_mm(h, J + (size_t)J_K11 * nl, nl, 128, lstk.d(), 1, 128, lstk.d(), 128, 0, S, 256, 0, 128, false));
+    GH_CHECK(launch_mm(h, J + (size_t)J_K21 * nl, nl, 128, l22b.d(), 1, 128, lstk.d(), 128, 0, S, 256, 0, 128, true));
+    GH_CHECK(launch_mm(h, J + (size_t)J_K22 * nl, nl, 128, l22b.d(), 1, 128, l22b.d(), 128, 0, S, 256, 128, 128, false));
+    GH_CHECK(launch_mm(h, J + (size_t)J_K12 * nl, nl, 128, lstk.d(), 1, 128, l22b.d(), 128, 0, S, 256, 128, 128, true));
+    h->leaf_pitch = 256;
   } else {
   {
     const int nl = (int)h->leaves.size();

@@ -294,19 +294,77 @@ def test_hodlr_not_positive_definite_leaf(leaf_gj):
     """A leaf block that is not positive definite must surface as LinAlgError (what GP.compute
     catches, gp.py:356) from the batched-Cholesky leaf path; the Gauss-Jordan path (general leaves)
     only fails on exactly singular blocks, so there the answer just has to be finite or an error."""
-    n = 512 if not leaf_gj else 600                      # leaves of 128 rows (Cholesky path) / 150 rows (Gauss-Jordan)
+    n = 512 if not leaf_gj else 600                      # leaves of 128 rows / 150 rows (2 x 2 blocked Cholesky, or Gauss-Jordan on request)
     x = np.linspace(0, 3, n)[:, None]
     k = kernels.CosineKernel(log_period=0.0)             # rank-2 kernel: every leaf is singular
-    s = HODLRSolver(k, tol=1e-10)
-    if not leaf_gj:
-        with pytest.raises(np.linalg.LinAlgError):
-            s.compute(x, np.zeros(n))
-        assert not s.computed
-    else:
+    for env in ([None] if not leaf_gj else [None, "1"]):
+        if env:
+            os.environ["GEORGE_AMD_HODLR_LEAF_GJ"] = env
         try:
-            s.compute(x, np.zeros(n))
-        except (np.linalg.LinAlgError, RuntimeError):
-            assert not s.computed
+            s = HODLRSolver(k, tol=1e-10)
+            if env is None:
+                with pytest.raises(np.linalg.LinAlgError):
+                    s.compute(x, np.zeros(n))
+                assert not s.computed
+            else:
+                try:
+                    s.compute(x, np.zeros(n))
+                except (np.linalg.LinAlgError, RuntimeError):
+                    assert not s.computed
+        finally:
+            os.environ.pop("GEORGE_AMD_HODLR_LEAF_GJ", None)
+
+
+@pytest.mark.parametrize("n", [3000, 1560, 10000])
+def test_blocked_cholesky_leaves_match_gauss_jordan_and_dense(n):
+    """leaves of 129 .. 256 rows (n = 3000: 187 / 188 rows; 1560: 195; 10000: 156 / 157): the 2 x 2 blocked Cholesky path on
+    256 x 256 slots (round 5) against the pivoted Gauss-Jordan it replaces (GEORGE_AMD_HODLR_LEAF_GJ=1) and the dense solver"""
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    X = x[:, None]
+    got = {}
+    for env in (None, "1"):
+        if env:
+            os.environ["GEORGE_AMD_HODLR_LEAF_GJ"] = env
+        try:
+            s = HODLRSolver(kernel, tol=1e-12)
+            s.compute(X, yerr)
+            got[env] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(np.stack([y, np.cos(x)], axis=1)))
+        finally:
+            os.environ.pop("GEORGE_AMD_HODLR_LEAF_GJ", None)
+    a, b = got[None], got["1"]
+    assert abs(a[0] - b[0]) <= 1e-11 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-9 * abs(b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8 * np.abs(b[2]).max())
+    if n <= 3000:
+        d = BasicSolver(kernel)
+        d.compute(X, yerr)
+        assert abs(a[0] - d.log_determinant) <= 1e-9 * abs(d.log_determinant)
+        assert abs(a[1] - d.dot_solve(y)) <= 1e-7 * abs(d.dot_solve(y))
+
+
+@pytest.mark.parametrize("n", [4096, 16384, 3000])
+def test_shared_passes_match_separate_launches(n):
+    """gh_debug_set_hodlr_passes: the sweep's update + next level's reduce in one pass (and the deepest level's reduce inside the
+    leaf product) multiply the same doubles in the same order as the separate launches -- the log-determinant and the factors
+    are IDENTICAL; the narrow solve's passes change the order of a few sums -- agreement to rounding.  n = 4096, 16384: leaves
+    of 128 rows, every pass shared; n = 3000: chunks differ from level to level, the sweep falls back to separate launches."""
+    from george_amd import _native as N
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    got = {}
+    try:
+        for mask in (0, 2, 1, 3):
+            N.lib.gh_debug_set_hodlr_passes(mask)
+            s = HODLRSolver(kernel, tol=1e-10)
+            s.compute(x[:, None], yerr)
+            got[mask] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(y))
+    finally:
+        N.lib.gh_debug_set_hodlr_passes(-1)
+    assert got[2][0] == got[0][0] and got[3][0] == got[0][0] and got[1][0] == got[0][0]
+    assert got[2][1] == got[0][1] and np.array_equal(got[2][2], got[0][2])            # the sweep: same bits
+    for m in (1, 3):
+        assert abs(got[m][1] - got[0][1]) <= 1e-12 * abs(got[0][1])
+        np.testing.assert_allclose(got[m][2], got[0][2], rtol=0, atol=1e-11 * np.abs(got[0][2]).max())
 
 
 def test_parked_handles_are_bounded_and_reused():
