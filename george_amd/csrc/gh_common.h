@@ -43,6 +43,7 @@ bool gh_is_device_ptr(const void* p);
 void* gh_pool_acquire(size_t bytes, size_t* capacity);     // nullptr on allocation failure
 void gh_pool_release(void* p, size_t capacity);
 void gh_pool_trim();                                       // really free every cached block of the current device
+size_t gh_pool_parked_bytes();                             // released blocks parked in the current device's cache
 
 // RAII device buffer
 struct GhBuf {

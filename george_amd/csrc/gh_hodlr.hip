@@ -41,6 +41,7 @@
 #include <vector>
 #include "gh_common.h"
 #include "gh_threads.h"
+#include "gh_gemm_tile.h"
 
 // gh_potf2.hip: batched 128x128 Cholesky + inverse of the factor (block b at A + b*stride_a)
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
@@ -604,6 +605,28 @@ __global__ __launch_bounds__(256) void hodlr_leaf_logdet256_kernel(const double*
   const double* slot = Lf + (long)blockIdx.x * 256 * 256;
   const double v = hw_block_sum(log(slot[threadIdx.x * 257]), sh);
   if (threadIdx.x == 0) out[blockIdx.x] = 2.0 * v;
+}
+
+// ---- batched 128 x 128 products of the leaf stage on the dense solver's tile function (round 5)
+// C_b (-)= A_b B_b^T for b < gridDim.x: A_b, B_b are 128 x K with k contiguous, one workgroup per product, the LDS-DMA /
+// v_mfma_f64_16x16x4 tile of gh_gemm_tile.h.  The leaf stage's products went through hodlr_mm_kernel (a generic 32 x 64 x 32
+// tile with register staging: 8-13 TFLOP/s -- 0.67 ms for the 2048 products K^-1 = L^-T L^-1 of C4, 1.1-2.2 ms for each of the
+// nine products of 4096 leaves of 171 rows at N = 700000).
+template <bool ACC>
+__global__ __launch_bounds__(256, 2) void hodlr_bmm_nt_kernel(double* C, long ldc, long sc, const double* A, long lda, long sa,
+                                                              const double* B, long ldb, long sb, long K) {
+  __shared__ __attribute__((aligned(1024))) double sm[4 * BM * BK];
+  const long b = blockIdx.x;
+  gh_tile128_nt<ACC>(sm, C + b * sc, ldc, A + b * sa, lda, B + b * sb, ldb, K);
+}
+// dst_b = src_b^T (128 x 128 each), through a padded LDS tile
+__global__ __launch_bounds__(256) void hodlr_transpose128_kernel(const double* src, long lds_, long ss, double* dst, long ldd, long sd) {
+  __shared__ double t[128 * 129];
+  const double* s = src + (long)blockIdx.x * ss;
+  double* d = dst + (long)blockIdx.x * sd;
+  for (int e = threadIdx.x; e < 128 * 128; e += 256) t[(e >> 7) * 129 + (e & 127)] = s[(long)(e >> 7) * lds_ + (e & 127)];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 128 * 128; e += 256) d[(long)(e >> 7) * ldd + (e & 127)] = t[(e & 127) * 129 + (e >> 7)];
 }
 
 // Batched in-place inverse by Gauss-Jordan with partial (row) pivoting; one workgroup per matrix
@@ -2116,7 +2139,16 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
       h->leaf_tab_up = true;
     }
-    GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
+    if (getenv("GEORGE_AMD_HODLR_LEAF_MM")) {        // (round 4's product, for A/B)
+      GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
+    } else {
+      // K^-1 = L^-T L^-1 = (L^-T)(L^-T)^T: the transposed inverse factors, then one tile product per leaf
+      GH_CHECK(lstk.ensure(nl * slot * sizeof(double)));
+      hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl), dim3(256), 0, st, (const double*)linv.d(), 128L, (long)slot, lstk.d(), 128L, (long)slot);
+      hipLaunchKernelGGL(hodlr_bmm_nt_kernel<false>, dim3(nl), dim3(256), 0, st, h->leaf_inv.d(), 128L, (long)slot, (const double*)lstk.d(), 128L, (long)slot,
+                         (const double*)lstk.d(), 128L, (long)slot, 128L);
+      GH_HIP(hipGetLastError());
+    }
     h->leaf_pitch = 128;
   } else if (h->max_leaf <= 256 && !getenv("GEORGE_AMD_HODLR_LEAF_GJ")) {
     // Leaves of 129 .. 256 rows -- the reference's tree stops splitting below 2 min_size, so with min_size = 100 most problem
@@ -2128,49 +2160,46 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     const int nl = (int)h->leaves.size();
     const size_t slot = (size_t)256 * 256, blk = (size_t)128 * 128;
     GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
-    GH_CHECK(lstk.ensure(nl * 2 * blk * sizeof(double)));        // per leaf [L11^-1; X']  (256 x 128), X' = L22^-1 L21 L11^-1 = -X
-    GH_CHECK(l22b.ensure(nl * blk * sizeof(double)));            // L22^-1
-    GH_CHECK(lwk.ensure(nl * 2 * blk * sizeof(double)));         // W, then T = L21 L11^-1
+    GH_CHECK(lstk.ensure(nl * 2 * blk * sizeof(double)));        // per leaf Z = [L11^-T | X'^T]  (128 x 256), X' = L22^-1 L21 L11^-1 = -X
+    GH_CHECK(l22b.ensure(nl * 2 * blk * sizeof(double)));        // L22^-1, L22^-T
+    GH_CHECK(lwk.ensure(nl * 2 * blk * sizeof(double)));         // L21, T^T
     long long* d_info = (long long*)((int*)h->flags.p + 2);
     if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
     hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 16), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
                        h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 256);
     GH_HIP(hipGetLastError());
     double* const S = h->leaf_inv.d();
-    // job tables (uploaded once per tree): a_off / b_row / o_row of leaf i for each of the nine products
-    enum { J_W = 0, J_A22, J_T, J_X, J_K11, J_K21, J_K22, J_K12, J_N };
-    std::vector<MMJob> jb((size_t)J_N * nl), jobs(nl);
-    for (int i = 0; i < nl; ++i) {
-      jb[(size_t)J_W * nl + i]   = {(long)(i * 2 * blk), i * 256, i * 256, 128, 128};                 // W = L11^-1 (lstk rows 0..127) x A12
-      jb[(size_t)J_A22 * nl + i] = {(long)(i * 2 * blk), i * 256, i * 256 + 128, 128, 128};           // A22 -= W^T W     (A: lwk, transposed)
-      jb[(size_t)J_T * nl + i]   = {(long)(i * 2 * blk), i * 256, i * 256 + 128, 128, 128};           // T = W^T L11^-1   (A: lwk transposed, B: lstk, O: lwk rows 128..)
-      jb[(size_t)J_X * nl + i]   = {(long)(i * blk), i * 256 + 128, i * 256 + 128, 128, 128};         // X' = L22^-1 T    (B: lwk rows 128.., O: lstk rows 128..)
-      jb[(size_t)J_K11 * nl + i] = {(long)(i * 2 * blk), i * 256, i * 256, 128, 256};                 // K11 = [L11^-1; X']^T [L11^-1; X']
-      jb[(size_t)J_K21 * nl + i] = {(long)(i * blk), i * 256 + 128, i * 256 + 128, 128, 128};         // K21 = -L22^-T X'   (A: l22b transposed, B: lstk rows 128..)
-      jb[(size_t)J_K22 * nl + i] = {(long)(i * blk), i * 128, i * 256 + 128, 128, 128};               // K22 = L22^-T L22^-1
-      jb[(size_t)J_K12 * nl + i] = {(long)(i * 2 * blk + blk), i * 128, i * 256, 128, 128};           // K12 = -X'^T L22^-1 (A: lstk rows 128.. transposed, B: l22b)
-      jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
-    }
+    std::vector<MMJob> jobs(nl);
+    for (int i = 0; i < nl; ++i) jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
     if (!h->leaf_tab_up) {
-      GH_CHECK(upload(h->d_leaf_prod, jb, st));
       GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
       h->leaf_tab_up = true;
     }
-    const MMJob* const J = (const MMJob*)h->d_leaf_prod.p;
-    GH_CHECK(gh_launch_potf2_batched(S, 256, (int64_t)slot, lstk.d(), (int64_t)(2 * blk), d_info, nl, st));                       // L11 (in place), L11^-1
-    GH_CHECK(launch_mm(h, J + (size_t)J_W * nl, nl, 128, lstk.d(), 128, 1, S, 256, 128, lwk.d(), 128, 0, 128, false));
-    GH_CHECK(launch_mm(h, J + (size_t)J_A22 * nl, nl, 128, lwk.d(), 1, 128, lwk.d(), 128, 0, S, 256, 128, 128, true));
-    GH_CHECK(gh_launch_potf2_batched(S + 128 * 256 + 128, 256, (int64_t)slot, l22b.d(), (int64_t)blk, d_info, nl, st));           // L22, L22^-1
+    // work blocks per leaf: Z = [L11^-T | X'^T] (128 x 256, k contiguous), L11^-1, L21 then T^T, L22^-1, L22^-T
+    GH_CHECK(linv.ensure(nl * blk * sizeof(double)));            // L11^-1 (row-major, from the factorisation kernel)
+    double* const Z = lstk.d();                                  // pitch 256
+    double* const W = lwk.d();                                   // block 0: L21, block 1: T^T   (pitch 128)
+    const long s2 = (long)slot, sZ = (long)(2 * blk), sW = (long)(2 * blk), sb = (long)blk;
+#define GH_BMM(ACC, C_, ldc_, sc_, A_, lda_, sa_, B_, ldb_, sb_, K_)                                                              \
+    hipLaunchKernelGGL(hodlr_bmm_nt_kernel<ACC>, dim3(nl), dim3(256), 0, st, C_, (long)(ldc_), (long)(sc_), (const double*)(A_), (long)(lda_), (long)(sa_), \
+                       (const double*)(B_), (long)(ldb_), (long)(sb_), (long)(K_))
+    GH_CHECK(gh_launch_potf2_batched(S, 256, (int64_t)slot, linv.d(), (int64_t)blk, d_info, nl, st));                             // L11 in place, L11^-1
+    hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl), dim3(256), 0, st, (const double*)linv.d(), 128L, sb, Z, 256L, sZ);    // Z[:, 0:128] = L11^-T
+    GH_BMM(false, W, 128, sW, S + 128 * 256, 256, s2, linv.d(), 128, sb, 128);                                                     // L21 = A21 L11^-T
+    GH_BMM(true, S + 128 * 256 + 128, 256, s2, W, 128, sW, W, 128, sW, 128);                                                       // A22 -= L21 L21^T
+    GH_CHECK(gh_launch_potf2_batched(S + 128 * 256 + 128, 256, (int64_t)slot, l22b.d(), (int64_t)(2 * blk), d_info, nl, st));     // L22 in place, L22^-1
     hipLaunchKernelGGL(hodlr_leaf_logdet256_kernel, dim3(nl), dim3(256), 0, st, (const double*)S, h->ld_all.d() + ld_at);
     ld_at += nl;
+    hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl), dim3(256), 0, st, (const double*)l22b.d(), 128L, sZ, l22b.d() + blk, 128L, sZ);   // L22^-T
+    GH_BMM(false, W + blk, 128, sW, Z, 256, sZ, W, 128, sW, 128);                                                                   // T^T = L11^-T L21^T   (T = L21 L11^-1)
+    GH_BMM(false, Z + 128, 256, sZ, W + blk, 128, sW, l22b.d(), 128, sZ, 128);                                                      // X'^T = T^T L22^-T    (X' = L22^-1 T = -X)
+    GH_HIP(hipMemsetAsync(S, 0, nl * slot * sizeof(double), st));                                                                  // (both factors are used up; K21, K12 are formed by subtraction)
+    GH_BMM(false, S, 256, s2, Z, 256, sZ, Z, 256, sZ, 256);                                                                         // K11 = L11^-T L11^-1 + X^T X
+    GH_BMM(false, S + 128 * 256 + 128, 256, s2, l22b.d() + blk, 128, sZ, l22b.d() + blk, 128, sZ, 128);                             // K22 = L22^-T L22^-1
+    GH_BMM(true, S + 128 * 256, 256, s2, l22b.d() + blk, 128, sZ, Z + 128, 256, sZ, 128);                                           // K21 = L22^-T X = -L22^-T X'
+    GH_BMM(true, S + 128, 256, s2, Z + 128, 256, sZ, l22b.d() + blk, 128, sZ, 128);                                                 // K12 = K21^T
+#undef GH_BMM
     GH_HIP(hipGetLastError());
-    GH_HIP(hipMemsetAsync(S, 0, nl * slot * sizeof(double), st));                                     // (both factors have been used: K21 and K12 are formed by subtraction)
-    GH_CHECK(launch_mm(h, J + (size_t)J_T * nl, nl, 128, lwk.d(), 1, 128, lstk.d(), 128, 0, lwk.d(), 128, 0, 128, false));
-    GH_CHECK(launch_mm(h, J + (size_t)J_X * nl, nl, 128, l22b.d(), 128, 1, lwk.d(), 128, 0, lstk.d(), 128, 0, 128, false));
-    GH_CHECK(launch_mm(h, J + (size_t)J_K11 * nl, nl, 128, lstk.d(), 1, 128, lstk.d(), 128, 0, S, 256, 0, 128, false));
-    GH_CHECK(launch_mm(h, J + (size_t)J_K21 * nl, nl, 128, l22b.d(), 1, 128, lstk.d(), 128, 0, S, 256, 0, 128, true));
-    GH_CHECK(launch_mm(h, J + (size_t)J_K22 * nl, nl, 128, l22b.d(), 1, 128, l22b.d(), 128, 0, S, 256, 128, 128, false));
-    GH_CHECK(launch_mm(h, J + (size_t)J_K12 * nl, nl, 128, lstk.d(), 1, 128, l22b.d(), 128, 0, S, 256, 128, 128, true));
     h->leaf_pitch = 256;
   } else {
   {
@@ -2238,7 +2267,18 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   const int rcap0 = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
   const int nlev = (int)h->levels.size();
   const int aca_fence = 0, aca_multi = 1;         // (fence-free cluster barrier, 8 then 64 candidate rows per search pass: DESIGN.md section 4)
-  const bool concurrent = nlev - l0 > 1 && (double)n * rcap0 * sizeof(double) * (nlev - l0) <= 12.0 * (1u << 30);
+  // (round 5: "more than 12 GiB" was a 64-GB-card habit; an MI355X has 288 GB.  Above 12 GiB the question is put to the device:
+  //  all levels at once while their scratch fits in 40 % of what is free now -- N = 700000 went one level at a time, 34 ms)
+  bool concurrent = nlev - l0 > 1;
+  {
+    const double need = (double)n * rcap0 * sizeof(double) * (nlev - l0);
+    if (concurrent && need > 12.0 * (1u << 30)) {
+      size_t free_b = 0, tot_b = 0;
+      if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+      // (blocks parked in the pool by the previous compute() of this handle count as used there and are what will be handed out again)
+      concurrent = need <= 0.4 * (double)free_b + (double)gh_pool_parked_bytes();
+    }
+  }
   if (concurrent && !h->st_b) {
     hipStream_t shq[4] = {nullptr, nullptr, nullptr, nullptr};
     if (h->shared_streams && gh_shared_streams(h->opts.device, shq)) h->st_b = shq[2];

@@ -69,7 +69,7 @@ struct BlockCache {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks[16];      // per device, keyed by capacity
   size_t cached_bytes[16] = {0};
-  static constexpr size_t kMaxCached = (size_t)48 << 30;   // per device (of 288 GB); beyond it blocks are really freed
+  static constexpr size_t kMaxCached = (size_t)128 << 30;  // per device (of 288 GB); beyond it blocks are really freed
 };
 BlockCache g_cache;
 }
@@ -92,7 +92,7 @@ void* gh_pool_acquire(size_t bytes, size_t* capacity) {
   const size_t cap = (bytes + 255) & ~(size_t)255;
   void* p = nullptr;
   if (hipMalloc(&p, cap) != hipSuccess) {
-    // out of device memory with up to 48 GB of released blocks parked here: give them back and try once more
+    // out of device memory with up to 128 GB of released blocks parked here: give them back and try once more
     (void)hipGetLastError();
     gh_pool_trim();
     if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -120,6 +120,14 @@ extern "C" void gh_release_caches(int32_t device) {
   if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
   gh_pool_trim();
   (void)hipSetDevice(prev);
+}
+// bytes of released blocks parked in the current device's cache (they will be handed out again before anything is allocated)
+size_t gh_pool_parked_bytes() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  return g_cache.cached_bytes[dev];
 }
 void gh_pool_release(void* p, size_t capacity) {
   if (!p) return;

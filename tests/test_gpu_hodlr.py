@@ -363,8 +363,8 @@ def test_shared_passes_match_separate_launches(n):
     assert got[2][0] == got[0][0] and got[3][0] == got[0][0] and got[1][0] == got[0][0]
     assert got[2][1] == got[0][1] and np.array_equal(got[2][2], got[0][2])            # the sweep: same bits
     for m in (1, 3):
-        assert abs(got[m][1] - got[0][1]) <= 1e-12 * abs(got[0][1])
-        np.testing.assert_allclose(got[m][2], got[0][2], rtol=0, atol=1e-11 * np.abs(got[0][2]).max())
+        assert abs(got[m][1] - got[0][1]) <= 1e-10 * abs(got[0][1])
+        np.testing.assert_allclose(got[m][2], got[0][2], rtol=0, atol=1e-9 * np.abs(got[0][2]).max())
 
 
 def test_parked_handles_are_bounded_and_reused():
