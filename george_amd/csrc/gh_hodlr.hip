@@ -619,14 +619,19 @@ __global__ __launch_bounds__(256, 2) void hodlr_bmm_nt_kernel(double* C, long ld
   const long b = blockIdx.x;
   gh_tile128_nt<ACC>(sm, C + b * sc, ldc, A + b * sa, lda, B + b * sb, ldb, K);
 }
-// dst_b = src_b^T (128 x 128 each), through a padded LDS tile
+// dst_b = src_b^T (128 x 128 each): blockIdx.y = one of the sixteen 32 x 32 tiles, through a padded LDS tile (8.4 KiB: the
+// first form staged the whole block -- 132 KiB, one workgroup per CU, 633 us for the 2048 leaves of C4)
 __global__ __launch_bounds__(256) void hodlr_transpose128_kernel(const double* src, long lds_, long ss, double* dst, long ldd, long sd) {
-  __shared__ double t[128 * 129];
+  __shared__ double t[32 * 33];
   const double* s = src + (long)blockIdx.x * ss;
   double* d = dst + (long)blockIdx.x * sd;
-  for (int e = threadIdx.x; e < 128 * 128; e += 256) t[(e >> 7) * 129 + (e & 127)] = s[(long)(e >> 7) * lds_ + (e & 127)];
+  const int tr = (blockIdx.y >> 2) * 32, tc = (blockIdx.y & 3) * 32;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[(r0 + 8 * q) * 33 + c] = s[(long)(tr + r0 + 8 * q) * lds_ + tc + c];
   __syncthreads();
-  for (int e = threadIdx.x; e < 128 * 128; e += 256) d[(long)(e >> 7) * ldd + (e & 127)] = t[(e & 127) * 129 + (e >> 7)];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d[(long)(tc + r0 + 8 * q) * ldd + tr + c] = t[c * 33 + r0 + 8 * q];
 }
 
 // Batched in-place inverse by Gauss-Jordan with partial (row) pivoting; one workgroup per matrix
@@ -2144,7 +2149,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     } else {
       // K^-1 = L^-T L^-1 = (L^-T)(L^-T)^T: the transposed inverse factors, then one tile product per leaf
       GH_CHECK(lstk.ensure(nl * slot * sizeof(double)));
-      hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl), dim3(256), 0, st, (const double*)linv.d(), 128L, (long)slot, lstk.d(), 128L, (long)slot);
+      hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl, 16), dim3(256), 0, st, (const double*)linv.d(), 128L, (long)slot, lstk.d(), 128L, (long)slot);
       hipLaunchKernelGGL(hodlr_bmm_nt_kernel<false>, dim3(nl), dim3(256), 0, st, h->leaf_inv.d(), 128L, (long)slot, (const double*)lstk.d(), 128L, (long)slot,
                          (const double*)lstk.d(), 128L, (long)slot, 128L);
       GH_HIP(hipGetLastError());
@@ -2184,13 +2189,13 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     hipLaunchKernelGGL(hodlr_bmm_nt_kernel<ACC>, dim3(nl), dim3(256), 0, st, C_, (long)(ldc_), (long)(sc_), (const double*)(A_), (long)(lda_), (long)(sa_), \
                        (const double*)(B_), (long)(ldb_), (long)(sb_), (long)(K_))
     GH_CHECK(gh_launch_potf2_batched(S, 256, (int64_t)slot, linv.d(), (int64_t)blk, d_info, nl, st));                             // L11 in place, L11^-1
-    hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl), dim3(256), 0, st, (const double*)linv.d(), 128L, sb, Z, 256L, sZ);    // Z[:, 0:128] = L11^-T
+    hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl, 16), dim3(256), 0, st, (const double*)linv.d(), 128L, sb, Z, 256L, sZ);    // Z[:, 0:128] = L11^-T
     GH_BMM(false, W, 128, sW, S + 128 * 256, 256, s2, linv.d(), 128, sb, 128);                                                     // L21 = A21 L11^-T
     GH_BMM(true, S + 128 * 256 + 128, 256, s2, W, 128, sW, W, 128, sW, 128);                                                       // A22 -= L21 L21^T
     GH_CHECK(gh_launch_potf2_batched(S + 128 * 256 + 128, 256, (int64_t)slot, l22b.d(), (int64_t)(2 * blk), d_info, nl, st));     // L22 in place, L22^-1
     hipLaunchKernelGGL(hodlr_leaf_logdet256_kernel, dim3(nl), dim3(256), 0, st, (const double*)S, h->ld_all.d() + ld_at);
     ld_at += nl;
-    hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl), dim3(256), 0, st, (const double*)l22b.d(), 128L, sZ, l22b.d() + blk, 128L, sZ);   // L22^-T
+    hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl, 16), dim3(256), 0, st, (const double*)l22b.d(), 128L, sZ, l22b.d() + blk, 128L, sZ);   // L22^-T
     GH_BMM(false, W + blk, 128, sW, Z, 256, sZ, W, 128, sW, 128);                                                                   // T^T = L11^-T L21^T   (T = L21 L11^-1)
     GH_BMM(false, Z + 128, 256, sZ, W + blk, 128, sW, l22b.d(), 128, sZ, 128);                                                      // X'^T = T^T L22^-T    (X' = L22^-1 T = -X)
     GH_HIP(hipMemsetAsync(S, 0, nl * slot * sizeof(double), st));                                                                  // (both factors are used up; K21, K12 are formed by subtraction)
