@@ -1019,7 +1019,7 @@ def main():
             if ms > 0:
                 ach = fl / (ms * 1e-3) * 1e-12
                 out["roofline"] = {
-                    "kernel": "gemm_f64_mfma_dma<k-major, k-major, full> (rank 0's trailing tile updates; one event pair per "
+                    "kernel": "gemm_f64_mfma_dma_sp<full> (k-major x k-major; rank 0's trailing tile updates; one event pair per "
                               "update sweep, its tile-column GEMMs fanned over 3 streams)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "launches": calls,
@@ -1035,7 +1035,7 @@ def main():
                 # over the timed steps.  rocprofv3's average duration of the same kernel must agree
                 # (profiles/r04/kernel_trace_N65536_*.md).
                 out["roofline"] = {
-                    "kernel": "gemm_f64_mfma_dma<k-major, k-major, lower> (trailing SYRK A22 -= L21 L21^T, one wide launch per panel)",
+                    "kernel": "gemm_f64_mfma_dma_sp<lower> (k-major x k-major; trailing SYRK A22 -= L21 L21^T, one wide launch per panel)",
                     "bound": "mfma", "achieved": ach_syrk, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach_syrk / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                     "launches": nl, "avg_launch_ms": p.ms_trailing / nl,

@@ -1483,7 +1483,7 @@ extern "C" int gh_chol_dot_solve(gh_chol* s, const double* y, double* out) {
 // columns [0, (j+1)*128) only, so every product is clipped to those columns.
 static int trsm_multi(gh_chol* s, double* B, int64_t rp, bool forward, bool backward, bool tri = false) {
   // (tiles per super-block; measured at N = 32768 with 4096 right-hand sides, both sweeps: 2 -> 167 ms, 4 -> 158.5,
-  //  8 -> 151.6, 16 -> 149.5; no difference at N = 8192.  GEORGE_AMD_TRSM_SB overrides)
+  //  8 -> 151.6, 16 -> 149.5; no difference at N = 8192; the switch that overrode it went in round 4)
   const int64_t SB = 8;
   const int64_t np = s->np, nt = np / T;
   const double* L = s->A.d();

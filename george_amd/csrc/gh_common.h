@@ -143,7 +143,7 @@ int gh_launch_gemm(const GhGemm& g, hipStream_t st);
 // Why shared: HIP maps streams onto a few hardware queues; every further handle with streams of its
 // own moved the others' onto different queues and a dense compute() at N <= 16384 ran 20-40 % slower
 // with a second handle (or two application streams) alive (scripts/dev/queue_pattern.py) -- and a
-// CU-masked stream takes ~1 s to create.  GEORGE_AMD_PRIVATE_STREAMS restores per-handle streams.
+// CU-masked stream takes ~1 s to create.  (Per-handle streams were an environment switch until round 4.)
 bool gh_shared_streams(int device, hipStream_t q[4]);
 // Once per device and process, BEFORE the library creates its first stream there: one empty kernel on the null stream
 // and a device synchronisation.  Measured (scripts/dev/no_torch_step.py, stream_order_probe.py): when this library's

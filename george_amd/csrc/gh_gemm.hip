@@ -16,7 +16,7 @@
 // The operand path is gemm_f64_mfma_dma: global -> LDS by global_load_lds_dwordx4, XOR-swizzled image
 // (the register-staged predecessor and the 4x4x4-4b instruction form are retired: scripts/dev/arms/);
 // gemm_f64_valu is a plain-VALU kernel with the same semantics that cross-checks the MFMA lane maps
-// on the device (GEORGE_AMD_MFMA_MODE=0 / gh_debug_set_mfma(0)).
+// on the device (GEORGE_AMD_NO_MFMA=1 / gh_debug_set_mfma(0)).
 #include <stdlib.h>
 #include <algorithm>
 #include "gh_common.h"

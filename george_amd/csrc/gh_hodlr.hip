@@ -146,7 +146,7 @@ __device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoc
   // agent-scope atomic stores (aca_st), and s_waitcnt makes every lane's stores complete before the
   // arrival is counted.  __threadfence() here writes this XCD's L2 back at every barrier -- three
   // per ACA step, 128 workgroups: 60 us per barrier, 2.8 of the 7 ms of ACA time at N = 262144.
-  // (GEORGE_AMD_HODLR_FENCE=1 restores it.)
+  // (The `fence` argument restores it; its environment switch went in round 4.)
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2439,7 +2439,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       continue;
     }
     // cluster size: as many workgroups per node as keep the whole grid resident (nodes * G <= 256)
-    // and leave every thread `ept` columns (GEORGE_AMD_HODLR_EPT; measured at C4: 2 -> 12.5 ms,
+    // and leave every thread `ept` columns (measured at C4 with a switch that went in round 4: 2 -> 12.5 ms,
     // 4 -> 13.1, 8 -> 14.1, 16 -> 16.0: the step is bound by per-thread memory latency, not by the
     // barriers, so more and smaller workgroups win)
     int G = 1;

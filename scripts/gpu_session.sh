@@ -1,5 +1,7 @@
 #!/bin/bash
-# full -m gpu suite, smoke, then the default bench line
+# One gpurun call, the way round 5's sessions were written: a smoke run first, every step under its own `timeout -s KILL`
+# (shorter than the call's limit: a hang must cost its own step, not the call), everything to gpurun_out/.
+#   /usr/local/graft/bin/gpurun --timeout 2000 -- 'bash scripts/gpu_session.sh'
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout -s KILL 120 python scripts/dev/dataflow_smoke.py > gpurun_out/suite_smoke.log 2>&1; echo "smoke rc=$?"
 timeout -s KILL 900 python -X faulthandler -m pytest tests -x -q -m gpu -p no:cacheprovider > gpurun_out/suite_gpu.log 2>&1; echo "suite rc=$?"; tail -5 gpurun_out/suite_gpu.log
