@@ -31,7 +31,8 @@ def main():
             "select d.grid_size_x / d.workgroup_size_x, d.end - d.start, s.kernel_name "
             "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
             "where s.kernel_name like '%gemm_f64_mfma%'"))
-        is_tr = lambda grid, name: "dmaILb1ELb1ELb1EE" in name and grid >= tmin * (tmin + 1) // 2
+        # (round 5: the k-major x k-major launches are gemm_f64_mfma_dma_sp<LOWER>)
+        is_tr = lambda grid, name: ("dmaILb1ELb1ELb1EE" in name or "dma_spILb1EE" in name) and grid >= tmin * (tmin + 1) // 2
         tr = [dur for grid, dur, name in g if is_tr(grid, name)]
         ot = [dur for grid, dur, name in g if not is_tr(grid, name)]
         out.write("\n`gemm_f64_mfma*` dispatches by role (trailing update <=> the LOWER instantiation with a grid of "

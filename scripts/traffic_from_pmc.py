@@ -40,7 +40,7 @@ def collect(db, counter, grids):
     q = ("select d.dispatch_id, d.grid_size_x/256, d.end-d.start, e.value from rocpd_pmc_event e "
          "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
          "join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
-         "where s.kernel_name like '%gemm_f64_mfma_dmaILb1ELb1ELb1EE%' and p.name = ?")
+         "where (s.kernel_name like '%gemm_f64_mfma_dmaILb1ELb1ELb1EE%' or s.kernel_name like '%gemm_f64_mfma_dma_spILb1EE%') and p.name = ?")
     per = {}
     for did, g, dt, v in cur.execute(q, (counter,)):
         if g in grids and g > 36:
