@@ -343,21 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma(GemmDev g) {
 // (it cannot tell the buffers apart), which would put the DMA's whole latency in front of the reads that follow it.  The waits
 // are therefore written by hand: LDS reads return in order, `s_waitcnt lgkmcnt(8)` = "all but the 8 youngest are back"; the
 // wait statements name the registers they guard as in/out operands so the compiler keeps every consumer behind them.
-typedef double v2d __attribute__((ext_vector_type(2)));
-#define GH_SP_READ8(x0, x1, x2, x3, y0, y1, y2, y3, pa, pb, BO)                                                     \
-  asm volatile("ds_read_b128 %0, %8 offset:%10\n\tds_read_b128 %1, %8 offset:%11\n\t"                               \
-               "ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %8 offset:%13\n\t"                               \
-               "ds_read_b128 %4, %9 offset:%10\n\tds_read_b128 %5, %9 offset:%11\n\t"                               \
-               "ds_read_b128 %6, %9 offset:%12\n\tds_read_b128 %7, %9 offset:%13"                                   \
-               : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)               \
-               : "v"(pa), "v"(pb), "n"((BO)), "n"((BO) + 2048), "n"((BO) + 4096), "n"((BO) + 6144))
-#define GH_SP_WAIT(cnt, x0, x1, x2, x3, y0, y1, y2, y3)                                                             \
-  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                        \
-               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3))
-#define GH_SP_MFMA(x, y, c)                                                                                         \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                  \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
-      acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i_][c], y[j_][c], acc[i_][j_], 0, 0, 0);
+// (v2d, GH_SP_READ8 / GH_SP_WAIT / GH_SP_MFMA: gh_gemm_tile.h -- gh_tile128_nt runs the same loop)
 template <bool LOWER>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma_dma_sp(GemmDev g) {
   // ONE array: the asm reads take the buffers' byte offsets as immediates (A0 | A1 | B0 | B1, 16 KiB each)

@@ -98,6 +98,27 @@ struct DmaOperand {
 
 
 // ---------------------------------------------------------------------------------------------
+// The pieces of the half-slab software-pipelined slab loop (gemm_f64_mfma_dma_sp in gh_gemm.hip explains it): fragment reads as
+// inline asm (hipcc would order them behind a vmcnt(0) once an LDS-DMA is in flight), hand-written counted waits that name the
+// registers they guard, and one k-step of 16 matrix instructions.  LDS byte offsets are immediates: buffers A0 | A1 | B0 | B1
+// of 16 KiB each behind ONE base address.
+typedef double v2d __attribute__((ext_vector_type(2)));
+#define GH_SP_READ8(x0, x1, x2, x3, y0, y1, y2, y3, pa, pb, BO)                                                     \
+  asm volatile("ds_read_b128 %0, %8 offset:%10\n\tds_read_b128 %1, %8 offset:%11\n\t"                               \
+               "ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %8 offset:%13\n\t"                               \
+               "ds_read_b128 %4, %9 offset:%10\n\tds_read_b128 %5, %9 offset:%11\n\t"                               \
+               "ds_read_b128 %6, %9 offset:%12\n\tds_read_b128 %7, %9 offset:%13"                                   \
+               : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)               \
+               : "v"(pa), "v"(pb), "n"((BO)), "n"((BO) + 2048), "n"((BO) + 4096), "n"((BO) + 6144))
+#define GH_SP_WAIT(cnt, x0, x1, x2, x3, y0, y1, y2, y3)                                                             \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                        \
+               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3))
+#define GH_SP_MFMA(x, y, c)                                                                                         \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i_][c], y[j_][c], acc[i_][j_], 0, 0, 0);
+
+// ---------------------------------------------------------------------------------------------
 // One 128 x 128 tile on the calling 256-thread workgroup:  ACC: C -= A B^T (accumulators start from -C, store-only
 // write-back), else C = A B^T (C may be A: every slab of A has been read when the first element of C is stored).
 // A, B: 128 x K, k contiguous (lda, ldb even, bases 16-byte aligned), K a multiple of 16.  sm: 8192 doubles of LDS, 1 KiB
@@ -165,6 +186,92 @@ __device__ __forceinline__ void gh_tile128_nt(double* sm, double* C, long ldc, c
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+  }
+  const double alpha = ACC ? -1.0 : 1.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* const crow = cbase + (long)(i * 16 + 4 * r) * ldc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][r];
+    }
+}
+
+// gh_tile128_nt_sp: the same tile with the half-slab pipelined loop of gemm_f64_mfma_dma_sp (same k-steps in the same order: same
+// bits; K a multiple of 32).  Used by the HODLR leaf stage's batched products (one tile per workgroup).  NOT by the dataflow
+// factorisation's persistent workers: inlined there (beside the task loop, with spills) the first attempt faulted on the GPU
+// (round 5, `Memory access fault` in dataflow_smoke, while the batched kernel with the same function was correct) and there
+// was no GPU time left to find out why -- the dataflow keeps round 4's loop.
+template <bool ACC>
+__device__ __forceinline__ void gh_tile128_nt_sp(double* sm, double* C, long ldc, const double* A, long lda,
+                                              const double* B, long ldb, long K) {
+  double* const sA0 = sm; double* const sA1 = sm + BM * BK;
+  double* const sB0 = sm + 2 * BM * BK; double* const sB1 = sm + 2 * BM * BK + BN * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  v4d acc[4][4];
+  const long nk = K / BK;
+  DmaOperand<true> oa, ob;
+  oa.init(A, lda, 0, 0, wave, lane, wm);
+  ob.init(B, ldb, 0, 0, wave, lane, wn);
+  const int dst = wave * 4 * 128;
+  GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0)
+  double* const cbase = C + (long)(wm * 64 + fk) * ldc + wn * 64 + fr;
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = -1.0 * cbase[(long)(i * 16 + 4 * r) * ldc + j * 16];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+  {
+    // the half-slab pipelined loop of gemm_f64_mfma_dma_sp (round 5; an EVEN number of slabs): same k-steps in the same order, same bits
+    const unsigned lbase = (unsigned)(unsigned long)(gh_lds_void*)sm;
+    const unsigned pa0 = lbase + (unsigned)(oa.f0 + oa.off2[0]) * 8u, pa1 = lbase + (unsigned)(oa.f0 + oa.off2[1]) * 8u;
+    const unsigned pb0 = lbase + 2u * BM * BK * 8u + (unsigned)(ob.f0 + ob.off2[0]) * 8u;
+    const unsigned pb1 = lbase + 2u * BM * BK * 8u + (unsigned)(ob.f0 + ob.off2[1]) * 8u;
+    constexpr int B1 = BM * BK * 8;
+    v2d a01[4], b01[4], a23[4], b23[4];
+    GH_DMA_ISSUE(oa, sA1) GH_DMA_ISSUE(ob, sB1)
+    GH_SP_READ8(a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3], pa0, pb0, 0);
+    for (long kt = 0; kt < nk; kt += 2) {
+      const bool more = kt + 2 < nk;
+      GH_SP_READ8(a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3], pa1, pb1, 0);
+      GH_SP_WAIT(8, a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3]);
+      GH_SP_MFMA(a01, b01, 0) GH_SP_MFMA(a01, b01, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      GH_SP_WAIT(0, a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3]);
+      __syncthreads();
+      if (more) { GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0) }
+      GH_SP_READ8(a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3], pa0, pb0, B1);
+      __builtin_amdgcn_sched_barrier(0);
+      GH_SP_MFMA(a23, b23, 0) GH_SP_MFMA(a23, b23, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      GH_SP_READ8(a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3], pa1, pb1, B1);
+      GH_SP_WAIT(8, a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3]);
+      GH_SP_MFMA(a01, b01, 0) GH_SP_MFMA(a01, b01, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      GH_SP_WAIT(0, a23[0], a23[1], a23[2], a23[3], b23[0], b23[1], b23[2], b23[3]);
+      // (also behind the LAST slab: the contract -- every wavefront has passed a barrier after its last read of sm --
+      //  is what lets the caller's next tile start its DMA at once)
+      __syncthreads();
+      if (more) {
+        if (kt + 3 < nk) { GH_DMA_ISSUE(oa, sA1) GH_DMA_ISSUE(ob, sB1) }
+        GH_SP_READ8(a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3], pa0, pb0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      GH_SP_MFMA(a23, b23, 0) GH_SP_MFMA(a23, b23, 1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   const double alpha = ACC ? -1.0 : 1.0;
 #pragma unroll

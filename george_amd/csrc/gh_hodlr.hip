@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void hodlr_bmm_nt_kernel(double* C, long ld
                                                               const double* B, long ldb, long sb, long K) {
   __shared__ __attribute__((aligned(1024))) double sm[4 * BM * BK];
   const long b = blockIdx.x;
-  gh_tile128_nt<ACC>(sm, C + b * sc, ldc, A + b * sa, lda, B + b * sb, ldb, K);
+  gh_tile128_nt_sp<ACC>(sm, C + b * sc, ldc, A + b * sa, lda, B + b * sb, ldb, K);
 }
 // dst_b = src_b^T (128 x 128 each): blockIdx.y = one of the sixteen 32 x 32 tiles, through a padded LDS tile (8.4 KiB: the
 // first form staged the whole block -- 132 KiB, one workgroup per CU, 633 us for the 2048 leaves of C4)
