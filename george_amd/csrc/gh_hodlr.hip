@@ -815,6 +815,94 @@ __global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long*
   if (lane == 0) logdet[b] = ld;
 }
 
+// The same inverse with ONE WORKGROUP per matrix, its columns dealt over the four wavefronts (column c on wavefront c & 3): for
+// the levels with few nodes, where gj_small_kernel leaves one wavefront to walk all n pivots x n columns alone -- 42-46 us for each
+// of the three 24..30-row cores at the top of C4's tree, 13-17 us for the 10..14-row ones below them.  The owner of column k
+// finds the pivot and puts the column and the pivot row's index in LDS (double-buffered: one barrier per pivot); every
+// wavefront then updates its own columns with exactly gj_small_kernel's operations -- a column's arithmetic does not depend
+// on which wavefront holds it: the same bits.
+template <int NMAX>
+__global__ __launch_bounds__(256) void gj_small4_kernel(double* base, const long* offs, const int* sizes, int nb,
+                                                        double* logdet, int* fail, const double* tsum, long Cp, int R) {
+  constexpr int CW = NMAX / 4;
+  __shared__ double fcol[2][64];
+  __shared__ int sp[2];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  const int n = __builtin_amdgcn_readfirstlane(sizes[b]);
+  double* const M = base + offs[b];
+  const bool row = lane < n;
+  double m[CW];
+  if (tsum) {
+    const double* const tr = tsum + ((long)b * n + lane) * Cp;
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+      const int c = 4 * q + w;
+      double v = (lane == c) ? 1.0 : 0.0;
+      if (row && c < n) {
+        if (lane < R && c >= R) v = tr[c - R];
+        else if (lane >= R && c < R) v = tr[c];
+      }
+      m[q] = (row && c < n) ? v : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < CW; ++q) { const int c = 4 * q + w; m[q] = (row && c < n) ? M[(long)lane * n + c] : 0.0; }
+  }
+  bool used = false, bad = false;
+  int myk = 0, pcw[CW];
+  double ld = 0.0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    if (k < n && !bad) {                          // (uniform over the workgroup: `bad` is set by all wavefronts together)
+      const int buf = k & 1, own = k & 3, qk = k >> 2;
+      if (w == own) {
+        const bool cand = row && !used;
+        const unsigned key = cand ? (unsigned)__double2hiint(fabs(m[qk])) : 0u;
+        const unsigned rm = gj_row_max_u32(key);
+        const unsigned mx = max((unsigned)__builtin_amdgcn_readlane((int)rm, 0), (unsigned)__builtin_amdgcn_readlane((int)rm, 16));
+        const unsigned long long who = __builtin_amdgcn_ballot_w64(cand && key == mx);
+        const int p = (int)__builtin_ctzll(who | (1ull << 63));
+        const double pv = gj_bcast(m[qk], p);
+        fcol[buf][lane] = m[qk];
+        if (lane == 0) sp[buf] = (who == 0ull || !(fabs(pv) > 0.0)) ? -1 : p;
+      }
+      __syncthreads();
+      const int p = __builtin_amdgcn_readfirstlane(sp[buf]);
+      if (p < 0) { bad = true; }
+      else {
+        const double f = fcol[buf][lane];
+        const double pv = fcol[buf][p];
+        if (lane == p) { used = true; myk = k; }
+        ld += log(fabs(pv));
+        const double rinv = 1.0 / pv;
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const int c = 4 * q + w;
+          if (c == k) pcw[q] = p;
+          if (c != k && c < n) {
+            const double pr = gj_bcast(m[q], p) * rinv;
+            m[q] = (lane == p) ? pr : fma(-f, pr, m[q]);
+          }
+        }
+        if (w == own) m[qk] = (lane == p) ? rinv : -f * rinv;
+      }
+    }
+  }
+  if (bad) {
+    if (threadIdx.x == 0) { atomicExch(fail, b + 1); logdet[b] = 0.0; }
+    return;
+  }
+  if (row) {
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+      const int c = 4 * q + w;
+      if (c < n) M[(long)myk * n + pcw[q]] = m[q];
+    }
+  }
+  if (threadIdx.x == 0) logdet[b] = ld;
+}
+
 // =============================================================== batched small dense products
 // O(job rows, 0:C) (=|-=) A_job (m x kd) * B(job rows, 0:C); A element (r, k) at
 // A[a_off + r*a_rs + k*a_cs]; B row b_row+k at B[(b_row+k)*ldb + b_col0 + c].
@@ -2003,6 +2091,12 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
   }
   int nmax = 0;
   for (int v : sizes) nmax = std::max(nmax, v);
+  if (nmax <= 32 && nb <= 64 && !getenv("GEORGE_AMD_HODLR_GJ1")) {   // few cores (the top levels): a workgroup per matrix, columns over its four wavefronts
+    if (nmax <= 16) hipLaunchKernelGGL(gj_small4_kernel<16>, dim3(nb), dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
+    else hipLaunchKernelGGL(gj_small4_kernel<32>, dim3(nb), dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+  }
   if (nmax <= 32) {                  // the Woodbury cores: one wavefront per matrix
     const dim3 grid((unsigned)((nb + 3) / 4));
     if (nmax <= 8) hipLaunchKernelGGL(gj_small_kernel<8>, grid, dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);

@@ -329,12 +329,15 @@ def test_blocked_cholesky_leaves_match_gauss_jordan_and_dense(n):
         try:
             s = HODLRSolver(kernel, tol=1e-12)
             s.compute(X, yerr)
-            got[env] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(np.stack([y, np.cos(x)], axis=1)))
+            wide = np.stack([np.cos((q + 1) * x) for q in range(20)], axis=1)      # 20 right-hand sides: the tile-kernel path, leaf pitch 256
+            got[env] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(np.stack([y, np.cos(x)], axis=1)), s.apply_inverse(wide))
         finally:
             os.environ.pop("GEORGE_AMD_HODLR_LEAF_GJ", None)
     a, b = got[None], got["1"]
     assert abs(a[0] - b[0]) <= 1e-11 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-9 * abs(b[1])
     np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8 * np.abs(b[2]).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=0, atol=1e-8 * np.abs(b[3]).max())
+    np.testing.assert_allclose(a[3][:, 0], s.apply_inverse(np.cos(x)), rtol=0, atol=1e-8 * np.abs(a[3][:, 0]).max())   # wide against narrow
     if n <= 3000:
         d = BasicSolver(kernel)
         d.compute(X, yerr)
