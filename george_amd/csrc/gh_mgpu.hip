@@ -47,6 +47,7 @@
 #include <thread>
 #include "gh_common.h"
 #include "gh_threads.h"
+#include "../../include/george_amd_debug.h"
 #include <rccl/rccl.h>            // types and enums only: every function is resolved with dlsym
 
 #define T GH_TILE

@@ -258,11 +258,8 @@ enum {
 };
 enum {
   GH_MGPU_PLAIN_CYCLIC = 1,  /* pc == 1: tile row I on rank I mod pr instead of the snake order                    */
-  GH_MGPU_CHAIN_ONLY   = 2,  /* timing aid: skip every trailing update except block column k+1 and the bulk gather
-                                -- what is left is the critical chain; results are meaningless, NOT_PD is not raised */
-  GH_MGPU_TRACE        = 4,  /* record (rank, step, phase, ms, flops or bytes) of every phase: gh_mgpu_get_trace.  With
-                                GH_MGPU_COPY the compute phases of all ranks run one at a time and to completion, so
-                                that virtual devices sharing one GPU give the durations of a rank alone on its GPU  */
+  /* (2 and 4 are the timing aids GH_MGPU_CHAIN_ONLY / GH_MGPU_TRACE: include/george_amd_debug.h -- a chain-only compute()
+   *  returns GH_OK with numbers that mean nothing, which has no place among the drop-in's flags)                          */
   GH_MGPU_ONE_COMM     = 8   /* GH_MGPU_RCCL: the bulk gather on the chain's stream and communicator (one communicator in
                                 flight at a time) -- chosen by itself when the two streams of a rank do not dispatch
                                 independently (gh_mgpu_comm_mode tells which)                                         */
@@ -273,7 +270,7 @@ typedef struct gh_mgpu_opts {
   int32_t pr, pc;            /* process grid, pr * pc == n_dev; 0, 0: n_dev x 1 (whole tile rows per rank) */
   int32_t nb;                /* tile edge, multiple of 128; 0: 1024 from N = 24576 up, else 512 */
   int32_t transport;         /* GH_MGPU_RCCL | GH_MGPU_COPY */
-  int32_t flags;             /* GH_MGPU_PLAIN_CYCLIC | GH_MGPU_CHAIN_ONLY | GH_MGPU_TRACE | GH_MGPU_ONE_COMM */
+  int32_t flags;             /* GH_MGPU_PLAIN_CYCLIC | GH_MGPU_ONE_COMM (| the timing aids of george_amd_debug.h) */
   int32_t reserved[3];
 } gh_mgpu_opts;
 int  gh_mgpu_create(const gh_mgpu_opts* opts, gh_mgpu** out);      /* communicators + an all-reduce self-check */
@@ -295,13 +292,6 @@ int  gh_mgpu_get_inverse(gh_mgpu* h, double* out /* n*n */);                    
  * var / cov may be NULL; cov is offered for m <= 2048 */
 int  gh_mgpu_predict(gh_mgpu* h, gh_kernel* k, const double* r /* n: y - mean */, const double* xs, int64_t m,
                      double* mu /* m */, double* var /* m or NULL */, double* cov /* m*m or NULL */);
-/* GH_MGPU_TRACE: rows of 5 doubles (rank, step k, phase, milliseconds, flops or bytes) of the last compute();
- * phases: 0 potrf, 1 column TRSM (+ pack), 2 update of block column k+1, 3 the rest of the trailing update,
- * 4 L_kk transfer, 5 row-panel transfer, 6 panel tile k+1 sent ahead, 7 column-panel gather, 8 kernel-matrix build
- * (step -1).  *n_rows = rows
- * recorded (out may be NULL to ask for the count). */
-int  gh_mgpu_get_trace(const gh_mgpu* h, double* out, int64_t max_rows, int64_t* n_rows);
-
 /* --------------------------------------------------- HODLR solver, tree split over several GPUs
  * hodlr::Node (include/george/hodlr.h:29-254) with the top log2(n_dev) levels of the tree shared and the
  * n_dev sub-trees below them -- independent of each other (hodlr.h:75-103: a node's factorisation touches

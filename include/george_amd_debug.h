@@ -70,6 +70,22 @@ int gh_microbench_suite(double* out, int n);
  * wavefronts per SIMD, out[3] = the best, out[4..6] = milliseconds; n >= 8. */
 int gh_microbench_mfma_f64_ceiling(double* out, int n);
 
+/* Timing aids of the sharded dense solver (gh_mgpu_opts.flags, beside the public GH_MGPU_PLAIN_CYCLIC = 1 and GH_MGPU_ONE_COMM = 8):
+ * what profiles/r04/scale_model.md was measured with. */
+enum {
+  GH_MGPU_CHAIN_ONLY   = 2,  /* skip every trailing update except block column k+1 and the bulk gather -- what is left is the
+                                critical chain; the results mean nothing (compute() still returns GH_OK), NOT_PD is not raised */
+  GH_MGPU_TRACE        = 4   /* record (rank, step, phase, ms, flops or bytes) of every phase: gh_mgpu_get_trace.  With
+                                GH_MGPU_COPY the compute phases of all ranks run one at a time and to completion, so
+                                that virtual devices sharing one GPU give the durations of a rank alone on its GPU  */
+};
+/* GH_MGPU_TRACE: rows of 5 doubles (rank, step k, phase, milliseconds, flops or bytes) of the last compute();
+ * phases: 0 potrf, 1 column TRSM (+ pack), 2 update of block column k+1, 3 the rest of the trailing update,
+ * 4 L_kk transfer, 5 row-panel transfer, 6 panel tile k+1 sent ahead, 7 column-panel gather, 8 kernel-matrix build
+ * (step -1).  *n_rows = rows
+ * recorded (out may be NULL to ask for the count). */
+int  gh_mgpu_get_trace(const gh_mgpu* h, double* out, int64_t max_rows, int64_t* n_rows);
+
 #ifdef __cplusplus
 }
 #endif
