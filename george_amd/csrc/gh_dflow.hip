@@ -23,7 +23,7 @@
 // Every queue is cut into BUCKETS with a gate (a counter that must have reached a value: "L_jj^-1 is there"); inside an open
 // bucket tasks are handed out by a fetch-and-add ticket -- no compare-and-swap chain: the first form claimed only a RUNNABLE
 // head, one claim per ~3.5 us whatever the number of idle workgroups, 8x slower than the launch chain (profiles/r05/
-// dataflow_first_contact.md).  A claimed task whose inputs are not there yet is waited for briefly and then HELD: its owner
+// dataflow.md, session a).  A claimed task whose inputs are not there yet is waited for briefly and then HELD: its owner
 // goes on serving the other queues (one held task per queue and workgroup) and starts it when it becomes runnable.
 //
 // Dependencies are not stored: they follow from a task's fields and three families of monotone counters,

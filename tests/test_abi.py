@@ -185,3 +185,23 @@ def test_split_layout_rejects_a_leaf_above_the_split():
         N.check(N.lib.gh_hodlr_mgpu_layout(700, 8, 100, row0, nrows, None, 0, ctypes.byref(nl)))     # level 2: 175 points, half 87
     with pytest.raises(ValueError):
         N.check(N.lib.gh_hodlr_mgpu_layout(4096, 3, 100, row0, nrows, None, 0, ctypes.byref(nl)))
+
+
+def test_stand_in_rccl_exports_what_gh_mgpu_binds():
+    """tests/mock_rccl/libmock_rccl.so (test infrastructure of tests/test_gpu_mgpu_mock_rccl.py, built by __graft_entry__.build()):
+    the eight entry points george_amd/csrc/gh_mgpu.hip resolves with dlsym, the marker that lifts "one rank per device", and
+    the two read-outs; and the product library exposes which communicator mode a sharded solver runs in."""
+    path = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+    assert os.path.exists(path), "run __graft_entry__.build()"
+    lib = ctypes.CDLL(path)
+    src = open(os.path.join(ROOT, "george_amd", "csrc", "gh_mgpu.hip")).read()
+    bound = re.findall(r'MG_SYM\([A-Za-z]+, "(nccl[A-Za-z]+)"\)', src)
+    assert sorted(bound) == sorted(["ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
+                                    "ncclAllReduce", "ncclGetErrorString"])
+    for name in bound + ["ncclMockSharedDeviceOk", "mock_rccl_stats", "mock_rccl_last_error"]:
+        assert hasattr(lib, name), name
+    st = (ctypes.c_longlong * 8)()
+    lib.mock_rccl_stats(st)
+    assert list(st) == [0] * 8                                   # nothing has run: no HIP call is made by loading it
+    from george_amd import _native
+    assert "gh_mgpu_comm_mode" in _native.SIGNATURES and _native.GH_MGPU_ONE_COMM == 8
