@@ -200,9 +200,12 @@ __device__ __forceinline__ void gh_tile128_nt(double* sm, double* C, long ldc, c
 
 // gh_tile128_nt_sp: the same tile with the half-slab pipelined loop of gemm_f64_mfma_dma_sp (same k-steps in the same order: same
 // bits; K a multiple of 32).  Used by the HODLR leaf stage's batched products (one tile per workgroup).  NOT by the dataflow
-// factorisation's persistent workers: inlined there (beside the task loop, with spills) the first attempt faulted on the GPU
-// (round 5, `Memory access fault` in dataflow_smoke, while the batched kernel with the same function was correct) and there
-// was no GPU time left to find out why -- the dataflow keeps round 4's loop.
+// factorisation's persistent workers: inlined there the first attempt faulted on the GPU (round 5, `Memory access fault` in
+// dataflow_smoke, while the batched kernel with the same function is correct).  The probable cause: those kernels SPILL (256
+// VGPRs + 128-156 bytes of scratch), and an inline-asm LDS read's destination is, to the compiler, written when the asm is
+// issued -- it may spill that value at once and hand the register to something else (an address, say) while the hardware still
+// owes it the data.  A kernel without spills never does that (gemm_f64_mfma_dma_sp, hodlr_bmm_nt_kernel: 208-236 VGPRs, no
+// scratch).  Until the workers fit their registers, the dataflow keeps round 4's loop.
 template <bool ACC>
 __device__ __forceinline__ void gh_tile128_nt_sp(double* sm, double* C, long ldc, const double* A, long lda,
                                               const double* B, long ldb, long K) {
