@@ -276,7 +276,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       }
       __syncthreads();
       const int lane = tid & 63, wave = tid >> 6;
-      for (int c = wave; c < NC; c += 8) {
+      for (int c = wave; c < NC; c += (nt >> 6)) {
         const int i = sh.cand_i[c];
         double* cw = sh.coef + wave * 32;
         __builtin_amdgcn_wave_barrier();              // (the previous candidate's reads of cw are done)
@@ -564,16 +564,29 @@ __global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, GhFast f
                                         const double* yerr, const LeafDesc* leaves, double* Lf, int pitch) {
   const LeafDesc lf = leaves[blockIdx.x];
   if (pitch > 0) {
+    // (round 5) the leaf's coordinates and noise through LDS first: with both points of every element fetched from global
+    // memory inside the loop a thread's eight elements were eight dependent round trips -- 750-860 us for the 2048 leaves of
+    // C4 (45 G elements/s; the dense build evaluates 700 G/s), the longest piece of the leaf chain and, through it, of the
+    // whole first phase of a step.  Same evaluator, same ordered arguments: same bits.
+    __shared__ double xs[256 * 8];
+    __shared__ double es[256];
+    const bool in_lds = nd <= 8 && lf.size <= 256;
+    if (in_lds) {
+      for (int t = threadIdx.x; t < lf.size * nd; t += blockDim.x) xs[t] = x[(long)lf.start * nd + t];
+      for (int t = threadIdx.x; t < lf.size; t += blockDim.x) es[t] = yerr[lf.start + t];
+      __syncthreads();
+    }
+    const double* const xb = in_lds ? (const double*)xs : x + (long)lf.start * nd;
     double* slot = Lf + (long)blockIdx.x * pitch * pitch;
     for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < pitch * pitch; e += gridDim.y * blockDim.x) {
       const int r = e / pitch, c = e % pitch;
       double v = (r == c) ? 1.0 : 0.0;
       if (r < lf.size && c < lf.size) {
         const int lo = r < c ? r : c, hi = r < c ? c : r;
-        const double* pa = x + (long)(lf.start + lo) * nd;
-        const double* pb = x + (long)(lf.start + hi) * nd;
+        const double* pa = xb + (long)lo * nd;
+        const double* pb = xb + (long)hi * nd;
         v = fast.ok ? gh_fast_value(fast, pa, pb) : gh_eval_value(prog, n_prog, pa, pb);
-        if (r == c) { const double e2 = yerr[lf.start + r]; v += e2 * e2; }
+        if (r == c) { const double e2 = in_lds ? es[r] : yerr[lf.start + r]; v += e2 * e2; }
       }
       slot[e] = v;
     }
@@ -2434,7 +2447,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     return GH_OK;
   };
   // all clustered levels `cl` as ONE launch of at most 256 workgroups (al[l].G already balanced)
-  auto enqueue_fused = [&](const std::vector<int>& cl, int rc, hipStream_t sx, GhBuf& segbuf) -> int {
+  auto enqueue_fused = [&](const std::vector<int>& cl, int rc, hipStream_t sx, GhBuf& segbuf, int threads = ACA_THREADS) -> int {
     std::vector<AcaSeg> segs;
     int wg = 0;
     bool ones_only = true;                                 // (one-workgroup nodes only: the launch carries the LDS mirrors)
@@ -2454,7 +2467,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     }
     GH_CHECK(upload(segbuf, segs, sx));
 #define GH_ACA_LAUNCH(F)                                                                                          \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(ACA_THREADS), ones_only ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),    \
+    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(threads), ones_only ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),    \
                        k->fast, ndim, h->x.d(), (const LvlNode*)nullptr, (double*)nullptr, (long)n, rc, (int*)nullptr, \
                        (int*)nullptr, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, 0,                     \
                        1, (unsigned*)nullptr, (double*)nullptr, pstride, (int*)nullptr, (int*)nullptr, aca_multi, aca_fence, \
@@ -2629,6 +2642,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         std::sort(ones.begin(), ones.end());
         GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));
         if (h->st_d) GH_HIP(hipStreamWaitEvent(h->st_d, h->ev_b, 0));
+        // (round 5, measured and left out -- HISTORY.md: the leaf chain first and this launch behind it: +1.5 %; the levels with
+        //  blocks of <= 256 rows as a launch of their own with 256 / 128 / 64 threads per workgroup: 0 / +2.4 / +8 %.  The three
+        //  pieces of this phase are bound by what they ask of the chip together, not by their order or their shapes.)
         GH_CHECK(enqueue_fused(ones, rcap0, h->st_b, h->d_aca_segs1));
         GH_CHECK(leaf_stage(h->st_c));
         GH_HIP(hipEventRecord(h->ev_c, h->st_c));
