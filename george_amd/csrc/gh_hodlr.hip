@@ -240,6 +240,19 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   const long long dbg_t0 = wall_clock64();
   int dbg_passes = 0;
 #endif
+  bool have_sel = false;                               // clusters: the next candidate row has been drawn and published already
+  auto draw_row = [&]() {                              // (workgroup 0, thread 0 of the cluster) hodlr.h:159-176: a random unused row
+    st += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const int k = (int)(z % (unsigned long long)remaining);
+    int pick;
+    if (lperm) { pick = sh.lidx[k]; sh.lidx[k] = sh.lidx[remaining - 1]; }
+    else { pick = idx[row0 + k]; idx[row0 + k] = idx[row0 + remaining - 1]; }
+    if (sw) __hip_atomic_store(sel + node, pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else sel[node] = pick;
+  };
   while (rank < max_rank) {
     // ---- choose a random unused row with a non-negligible residual (hodlr.h:159-191)
     bool got = false;
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     // 0.75 + 0.6 ms; after the first pass without a hit the batch grows to 64.  Same result as the
     // one-by-one search: the candidates are drawn in the same order, the first that passes wins,
     // and the draws after it are undone (row permutation and generator state restored).
-    while (multi && lperm && remaining > 0 && rank <= 32) {
+    while ((multi & 1) && lperm && remaining > 0 && rank <= 32) {
       int NC = remaining < batch ? remaining : batch;
       if (rank + NC > rcap) NC = rcap - rank;
       if (NC < 1) break;
@@ -338,21 +351,13 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       got = true;
       break;
     }
-    while (!got && remaining > 0) {
-      if (g == 0 && tid == 0) {
-        st += 0x9E3779B97F4A7C15ull;
-        unsigned long long z = st;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z ^= z >> 31;
-        const int k = (int)(z % (unsigned long long)remaining);
-        int pick;
-        if (lperm) { pick = sh.lidx[k]; sh.lidx[k] = sh.lidx[remaining - 1]; }
-        else { pick = idx[row0 + k]; idx[row0 + k] = idx[row0 + remaining - 1]; }
-        if (sw) __hip_atomic_store(sel + node, pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else sel[node] = pick;
+    while (!got && (have_sel || remaining > 0)) {
+      if (!have_sel) {
+        if (g == 0 && tid == 0) draw_row();
+        --remaining;
+        if (!aca_barrier(bar, G, epoch, fail, fence)) return;                         // B1: row chosen
       }
-      --remaining;
-      if (!aca_barrier(bar, G, epoch, fail, fence)) return;                           // B1: row chosen
+      have_sel = false;
       const int i = (G == 1) ? sel[node] : aca_ldi(sel + node);
       for (int k = tid; k < rank; k += nt) sh.coef[k] = aca_ld(Tcm + (long)k * N + row0 + i);   // U(i, 0:rank)
       __syncthreads();
@@ -460,8 +465,17 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
       }
     }
     if (G > 1) {
+      // (round 5) the NEXT step's first candidate row is drawn here and published with this barrier: the draw depends on the
+      // generator and the row permutation alone, not on the norms, every member has read the current `sel` before it arrived at
+      // B2, and a draw made in vain (the block converges below) changes nothing that is read again -- same draws in the same
+      // order, one cluster barrier per step fewer (two instead of three)
+      if ((multi & 2) && remaining > 0) {
+        if (g == 0 && tid == 0) draw_row();
+        --remaining;
+        have_sel = true;
+      }
       if (tid == 0) { aca_st(mypart + 3, un2, true); aca_st(mypart + 4, vn2, true); }     // (slots 0-2 may still be read by a slow member)
-      if (!aca_barrier(bar, G, epoch, fail, fence)) return;                           // B3: norms
+      if (!aca_barrier(bar, G, epoch, fail, fence)) return;                           // B3: norms (+ the next row)
       {
         double pu = 0.0, pv = 0.0;
         if (tid < G) { pu = aca_ld(allpart + (long)tid * pstride + 3); pv = aca_ld(allpart + (long)tid * pstride + 4); }
@@ -2378,7 +2392,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   const bool user_cap = h->opts.max_rank > 0;
   const int rcap0 = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
   const int nlev = (int)h->levels.size();
-  const int aca_fence = 0, aca_multi = 1;         // (fence-free cluster barrier, 8 then 64 candidate rows per search pass: DESIGN.md section 4)
+  const int aca_fence = 0, aca_multi = getenv("GEORGE_AMD_HODLR_ACA_3BAR") ? 1 : 3;   // bit 0: batched candidate search (one-workgroup nodes); bit 1: clusters draw the next row before the norms barrier         // (fence-free cluster barrier, 8 then 64 candidate rows per search pass: DESIGN.md section 4)
   // (round 5: "more than 12 GiB" was a 64-GB-card habit; an MI355X has 288 GB.  Above 12 GiB the question is put to the device:
   //  all levels at once while their scratch fits in 40 % of what is free now -- N = 700000 went one level at a time, 34 ms)
   bool concurrent = nlev - l0 > 1;
