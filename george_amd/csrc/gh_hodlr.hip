@@ -1197,7 +1197,19 @@ __global__ __launch_bounds__(256) void hodlr_mv_updred_kernel(const MMJob* ujobs
     // contiguous doubles of a row, then the next row (U is row-major with pitch u_rs here: one thread per row reading its kd
     // values in turn was 64 scattered 8-byte requests per load instruction)
     const int kd = job.kd, up = kd <= 16 ? 17 : 33;
-    for (int e = tid; e < m * kd; e += 256) { const int r_ = e / kd, k_ = e - r_ * kd; us[r_ * up + k_] = U[job.a_off + (long)r_ * u_rs + k_]; }
+    for (int e0 = tid; e0 < m * kd; e0 += 8 * 256) {           // eight loads in flight per thread (a rolled loop waits for each in turn)
+      double uv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + 256 * q, r_ = e / kd, k_ = e - r_ * kd;
+        uv[q] = e < m * kd ? U[job.a_off + (long)r_ * u_rs + k_] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + 256 * q, r_ = e / kd, k_ = e - r_ * kd;
+        if (e < m * kd) us[r_ * up + k_] = uv[q];
+      }
+    }
     __syncthreads();
     if (tid < m) {
       double acc[MV_C];
