@@ -589,9 +589,6 @@ def compact_line(out):
     a = cfg.get("also_other_grid")
     if a:
         also["other_grid"] = {k: a[k] for k in ("grid", "seconds_per_step", "value_tflops", "error") if k in a}
-    a = cfg.get("also_dataflow")
-    if a:
-        also["dataflow_arm"] = a
     a = cfg.get("also_curve")
     if a:
         also["reference_plot_sizes"] = [[r["solver"].split("(")[0], r["n"], r["seconds"], r["reference_plot_seconds"]] for r in a["rows"]]
@@ -1116,27 +1113,6 @@ def main():
                         "seconds_per_step": e2 / 5, "value_tflops": flops_alg(16384) / (e2 / 5) * 1e-12,
                         "frac_of_fp64_mfma_peak": flops_alg(16384) / (e2 / 5) * 1e-12 / PEAK_FP64_MFMA_TFLOPS,
                         "log_likelihood": ll2, "per_step_s": spread(ts2)}
-                    # the opt-in arm of the factorisation (GEORGE_AMD_DATAFLOW=1: one persistent launch of tile tasks,
-                    # george_amd/csrc/gh_dflow.hip) at the same sizes, same handle type, bits compared
-                    try:
-                        df = {}
-                        for nd in (8192, 16384):
-                            jc = j2 if nd == 16384 else DenseJob(nd, args.nb, local_rank, profile=False)
-                            tc, llc = (ts2, ll2) if nd == 16384 else run_steps(jc, 7, 2)
-                            prev = j2.N.lib.gh_debug_set_dataflow(1)
-                            try:
-                                jd = DenseJob(nd, args.nb, local_rank, profile=False)
-                                td, lld = run_steps(jd, 7, 2)
-                                jd.close()
-                            finally:
-                                j2.N.lib.gh_debug_set_dataflow(prev)
-                            if jc is not j2:
-                                jc.close()
-                            df["N%d" % nd] = {"launch_chain_ms": float(np.median(tc)) * 1e3, "dataflow_ms": float(np.median(td)) * 1e3,
-                                              "same_bits": bool(lld == llc)}
-                        out["config"]["also_dataflow"] = df
-                    except Exception as e:
-                        out["config"]["also_dataflow"] = {"error": repr(e)[:160]}
                     j2.close()
                     g2 = golden_ll(16384)
                     if g2 is not None:

@@ -100,16 +100,13 @@ SIGNATURES = {
     "gh_last_error": (C.c_char_p, []),
     "gh_version": (C.c_char_p, []),
     "gh_release_caches": (None, [C.c_int32]),
+    "gh_set_cache_limit": (None, [C.c_int64]),
     "gh_microbench_mfma_f64": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_microbench_hbm_copy": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
     "gh_debug_set_gemm_sp": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_passes": (C.c_int, [C.c_int]),
-    "gh_debug_set_dataflow": (C.c_int, [C.c_int]),
-    "gh_debug_dflow_schedule": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64]),
-    "gh_debug_dflow_trace": (C.c_int, [C.c_int64, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)]),
-    "gh_debug_dflow_candidates": (C.c_int, [C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64)]),
-    "gh_debug_dflow_peek": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int32]),
+    "gh_debug_set_hodlr_leaf_gj": (C.c_int, [C.c_int]),
     "gh_debug_stream_overlap": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_debug_stream_dispatch": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gh_microbench_suite": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

@@ -21,16 +21,10 @@
 #include <algorithm>
 #include <chrono>
 #include "gh_common.h"
+#include "gh_spin.h"
 #include "../../include/george_amd_debug.h"
 
 #define T 128                 // tile edge
-// sizes that take the dataflow factorisation by default (Np = N rounded up to 128); see use_dataflow()
-#ifndef GH_DATAFLOW_MIN_NP
-#define GH_DATAFLOW_MIN_NP (1L << 40)
-#endif
-#ifndef GH_DATAFLOW_MAX_NP
-#define GH_DATAFLOW_MAX_NP 24576
-#endif
 #define LP 129                // LDS row pitch of the potf2 tile (odd -> conflict-free columns)
 
 // ============================================================= potf2 + inverse
@@ -326,24 +320,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_fwd_chain_direct(const dou
       // lane (one request; every waiting workgroup hammering all 128 was the L2 queue as the critical path), and only the
       // next two in line poll the whole block at once.
       const int dist = b - j;
-      const long long t0 = wall_clock64();
-      unsigned spins = 0;
+      GhSpin spin(fail);                                  // (gh_spin.h: the 2-s give-up and the abort word)
       bool ok = true;
       if (dist > 2) {
         while (!chain_ready(__hip_atomic_load(z + (long)j * T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);   // 0 .. 8k cycles
-          if ((++spins & 63u) == 0u) {
-            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-            if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }   // 100 MHz ticks: 2 s
-          }
+          if (!spin.keep_waiting(63u)) { ok = false; break; }
         }
       }
       double2 zj = ld_coherent2(z + (long)j * T + 2 * lane);
       while (ok && !__all(chain_ready(zj.x) && chain_ready(zj.y))) {
-        if ((++spins & 1023u) == 0u) {
-          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }
-        }
+        if (!spin.keep_waiting(1023u)) { ok = false; break; }
         zj = ld_coherent2(z + (long)j * T + 2 * lane);
       }
       if (!ok && lane == 0) gave_up = 1;
@@ -437,24 +424,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void trsv_bwd_chain_direct(const dou
   for (int j = nt - 1; j > b; --j) {
     if (wave == 0) {
       const int dist = j - b;
-      const long long t0 = wall_clock64();
-      unsigned spins = 0;
+      GhSpin spin(fail);
       bool ok = true;
       if (dist > 2) {
         while (!chain_ready(__hip_atomic_load(x + (long)j * T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           for (int q = dist > 64 ? 16 : dist >> 2; q > 0; --q) __builtin_amdgcn_s_sleep(8);
-          if ((++spins & 63u) == 0u) {
-            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-            if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }
-          }
+          if (!spin.keep_waiting(63u)) { ok = false; break; }
         }
       }
       double2 xj = ld_coherent2(x + (long)j * T + 2 * lane);
       while (ok && !__all(chain_ready(xj.x) && chain_ready(xj.y))) {
-        if ((++spins & 1023u) == 0u) {
-          if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-          if (wall_clock64() - t0 > 200000000LL) { atomicExch(fail, 1); ok = false; break; }
-        }
+        if (!spin.keep_waiting(1023u)) { ok = false; break; }
         xj = ld_coherent2(x + (long)j * T + 2 * lane);
       }
       if (!ok && lane == 0) gave_up = 1;
@@ -561,7 +541,6 @@ struct gh_chol {
   hipStream_t tail = nullptr;            // where the last factor() ended: the stream on which its results are complete in stream order
 
 
-  bool dflow_locked = false;             // this handle holds gh_dflow_mutex(device): a dataflow factorisation is in flight
   int mask_reserved = -1;                // CUs st_mask leaves out (-1: not created yet, 0: creation failed)
   hipEvent_t ev_xfer = nullptr;
   hipEvent_t ev_sync[3] = {nullptr, nullptr, nullptr};
@@ -570,7 +549,7 @@ struct gh_chol {
   bool computed = false;
   int64_t info = 0;
   double logdet = 0.0;
-  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain, dflow;
+  GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
   long long* d_info = nullptr;           // = (long long*)(scal + 2): the failure word lives beside the scalars (set in compute_enqueue)
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
@@ -669,8 +648,7 @@ bool gh_shared_streams(int device, hipStream_t q[4]) {
     // Does the main stream share a dispatcher with one of the panel streams?  (Which queues end up together depends on how
     // many the process made before: never in a process that made none, with the rows-below stream after five application
     // streams, with the chain stream after six.)  Decides where a look-ahead factorisation is joined: factor_lookahead_deep.
-    // (GEORGE_AMD_JOIN=main|chain decides by itself: nothing to measure then)
-    if (ss.q[0] && ss.q[1] && ss.q[2] && ss.q[3] && !getenv("GEORGE_AMD_JOIN")) {
+    if (ss.q[0] && ss.q[1] && ss.q[2] && ss.q[3]) {
       for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(place_spin_kernel, dim3(1), dim3(64), 0, ss.q[i], 0LL);   // (queues are made at first use)
       (void)hipDeviceSynchronize();
       for (int i = 1; i < 4 && !ss.main_crowded; ++i)
@@ -1166,9 +1144,8 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   // In the placement a process gets that made no queues before, the main stream shares its dispatcher with the CU-masked
   // stream only, and there the join on the main stream is the faster one (N = 8192: 7.0 vs 7.3 ms, same box): the chain
   // join is used when the main stream was FOUND to share a dispatcher with a panel stream when the set was made
-  // (gh_shared_main_crowded), and always with streams of the handle's own.  GEORGE_AMD_JOIN=main|chain forces one.
-  static const char* const join_env = getenv("GEORGE_AMD_JOIN");
-  const bool join_on_chain = join_env ? join_env[0] == 'c' : (!s->shared_streams || gh_shared_main_crowded(s->opts.device));
+  // (gh_shared_main_crowded), and always with streams of the handle's own.
+  const bool join_on_chain = !s->shared_streams || gh_shared_main_crowded(s->opts.device);
   if (sm != s->st && join_on_chain) {
     GH_HIP(hipEventRecord(s->ev_sync[2], sn));
     GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[2], 0));
@@ -1190,60 +1167,19 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
   return GH_OK;
 }
 
+#ifndef GH_LOOKAHEAD_DEPTH
+#define GH_LOOKAHEAD_DEPTH 1
+#endif
 static int lookahead_depth(const gh_chol* s) {
-  static const int forced = getenv("GEORGE_AMD_LOOKAHEAD_DEPTH") ? atoi(getenv("GEORGE_AMD_LOOKAHEAD_DEPTH")) : -1;
-  if (forced >= 1) return forced;
   // depth 1 in this formulation (block column j+1 updated on the chain stream itself, the wide SYRK
   // alone on the main stream) beats the older scheme (block column on the main stream, depth "0") by
   // 7-12 % from N = 4096 to 16384 and is level with it above; deeper windows lose (size sweep in
-  // profiles/r02/lookahead_depth_sweep.md): the narrow GEMMs of the window compete with the potf2 chain
-  return 1;
-}
-
-// The tile-level dataflow factorisation (gh_dflow.hip): ONE persistent launch on the main stream instead of the launch
-// chain.  -1: by size (GEORGE_AMD_DATAFLOW=0|1 overrides), 0 / 1: forced (gh_debug_set_dataflow, tests and A/B runs).
-static int g_dataflow = -1;
-extern "C" int gh_debug_set_dataflow(int mode) {
-  const int prev = g_dataflow;
-  g_dataflow = mode < 0 ? -1 : (mode ? 1 : 0);
-  return prev;
-}
-static bool use_dataflow(const gh_chol* s) {
-  if (use_simple_potf2() || !gh_use_mfma() || s->np < 2 * T || !s->opts.lookahead || !s->st2 || !s->ev_sync[0]) return false;
-  if (g_dataflow >= 0) return g_dataflow == 1;
-  static const int env = getenv("GEORGE_AMD_DATAFLOW") ? atoi(getenv("GEORGE_AMD_DATAFLOW")) : -1;
-  if (env >= 0) return env != 0;
-  return s->np >= GH_DATAFLOW_MIN_NP && s->np < GH_DATAFLOW_MAX_NP;
-}
-static int factor_dataflow(gh_chol* s) {
-  GH_CHECK(s->dflow.ensure(gh_dflow_counter_bytes(s->np)));
-  // one dataflow factorisation per device at a time: held until the caller has synchronised (DflowRelease)
-  if (!s->dflow_locked) { gh_dflow_mutex(s->opts.device).lock(); s->dflow_locked = true; }
-  GH_CHECK(gh_dflow_factor(s->A.d(), s->np, s->np, s->dinv.d(), s->d_info, (unsigned*)s->dflow.p, s->st, s->st2, s->ev_sync));
-  s->tail = s->st2;
-  return GH_OK;
-}
-// in every function that calls compute_enqueue(): releases the device's dataflow lock when the function returns (it has
-// synchronised by then, or failed before anything was launched)
-struct DflowRelease {
-  gh_chol* s;
-  explicit DflowRelease(gh_chol* h) : s(h) {}
-  ~DflowRelease() { if (s && s->dflow_locked) { s->dflow_locked = false; gh_dflow_mutex(s->opts.device).unlock(); } }
-};
-
-// debugging aid: the first `n` counter words of the handle's dataflow factorisation, read on a stream of its own (works while
-// the factorisation's kernels are still running -- or stuck)
-extern "C" int gh_debug_dflow_peek(gh_chol* s, uint32_t* out, int32_t n) {
-  if (!s || !out || n <= 0 || !s->dflow.p || (size_t)n * 4 > s->dflow.bytes) { gh_set_error("dflow_peek: nothing to read"); return GH_ERR_BAD_ARG; }
-  static hipStream_t peek = nullptr;
-  if (!peek) GH_HIP(hipStreamCreateWithFlags(&peek, hipStreamNonBlocking));
-  GH_HIP(hipMemcpyAsync(out, s->dflow.p, (size_t)n * 4, hipMemcpyDeviceToHost, peek));
-  GH_HIP(hipStreamSynchronize(peek));
-  return GH_OK;
+  // profiles/r02/lookahead_depth_sweep.md): the narrow GEMMs of the window compete with the potf2 chain.
+  // (-DGH_LOOKAHEAD_DEPTH=<d> builds the deeper windows for an A/B; an environment switch until round 5)
+  return GH_LOOKAHEAD_DEPTH;
 }
 
 static int factor(gh_chol* s) {
-  if (use_dataflow(s)) return factor_dataflow(s);
   struct Guard { bool prev; Guard(bool v) : prev(t_gemm_small_lds) { t_gemm_small_lds = v; } ~Guard() { t_gemm_small_lds = prev; } }
       guard(s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
   // (a matrix of ONE panel has nothing to look ahead to: on the main stream it saves the two cross-stream hand-overs,
@@ -1362,11 +1298,6 @@ static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long 
     }
     for (size_t i : s->ev_panel) { GH_HIP(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b)); s->prof.ms_panel += ms; }
   }
-  if (info_host == GH_DFLOW_TIMEOUT_INFO) {
-    s->info = 0;
-    gh_set_error("the dataflow factorisation gave up waiting for a tile (2 s): GEORGE_AMD_DATAFLOW=0 selects the launch chain");
-    return GH_ERR_HIP;
-  }
   if (info_host != 0) {
     s->info = info_host;
     gh_set_error("%lld-th leading minor of the array is not positive definite", info_host);
@@ -1381,7 +1312,6 @@ static int compute_finish(gh_chol* s, const ComputeCtx& c, double ld_host, long 
 extern "C" int gh_chol_compute(gh_chol* s, gh_kernel* k, const double* x, int64_t n, int32_t ndim,
                                const double* yerr, double* logdet_out) {
   ComputeCtx c;
-  DflowRelease dfr(s);
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
   hipStream_t st = s->tail;                             // (the stream the factorisation ended on: compute_enqueue)
   double back[3] = {0.0, 0.0, 0.0};                     // [0] log-det, [1] (quadratic form), [2] the failure word's bits
@@ -1698,7 +1628,6 @@ extern "C" int gh_chol_objective(gh_chol* s, gh_kernel* k, const double* x, int6
   if (!r || !logdet || !quad) { gh_set_error("bad argument to objective"); return GH_ERR_BAD_ARG; }
   if (grad && !which) { gh_set_error("objective: gradient requested without a parameter mask"); return GH_ERR_BAD_ARG; }
   ComputeCtx c;
-  DflowRelease dfr(s);
   GH_CHECK(compute_enqueue(s, k, x, n, ndim, yerr, c));
   hipStream_t st = s->st;
   if (s->tail && s->tail != st && s->ev_sync[1]) {      // (the solves and the gradient run on the main stream: it joins here)

@@ -163,12 +163,3 @@ bool gh_streams_dispatch_independently(hipStream_t a, hipStream_t b);
 hipStream_t gh_shared_masked_stream(int device, int reserve_cus);
 bool gh_use_mfma();               // false when GEORGE_AMD_NO_MFMA=1 (VALU validation path)
 
-// gh_dflow.hip: the factorisation of an np x np matrix (np a multiple of 128, lower triangle, in place) as ONE persistent
-// launch of tile tasks; dinv[j] = L_jj^-1.  `counters`: gh_dflow_counter_bytes(np) of device memory that belongs to the
-// call until the streams have passed it; st: the stream A was built on, sd: a second one (the diagonal worker's launch),
-// on which everything is joined.  A wait that gave up (2 s) leaves GH_DFLOW_TIMEOUT_INFO in *d_info.  One at a time per device.
-#define GH_DFLOW_TIMEOUT_INFO (-77LL)
-size_t gh_dflow_counter_bytes(int64_t np);
-std::mutex& gh_dflow_mutex(int device);
-int gh_dflow_factor(double* A, int64_t ld, int64_t np, double* dinv, long long* d_info, unsigned* counters,
-                    hipStream_t st, hipStream_t sd, hipEvent_t* ev /* two */);

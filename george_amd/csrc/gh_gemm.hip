@@ -699,10 +699,10 @@ extern "C" int gh_debug_set_mfma(int mode) {
 
 // the half-slab software-pipelined form of the k-major x k-major kernel (gemm_f64_mfma_dma_sp): 1 = on for every launch it
 // can take (the default: 1.3 - 2.6 % faster on every shape of the factorisation, 72.4 TFLOP/s on the SYRK shape and 75.5 at
-// K = 4096, profiles/r05/gemm_sp_ab.md), 0 = off.  GEORGE_AMD_GEMM_SP / gh_debug_set_gemm_sp; same bits either way.
+// K = 4096, profiles/r05/gemm_sp_ab.md), 0 = off.  gh_debug_set_gemm_sp (the bit-compare test and A/B scripts); same bits either way.
 static int g_gemm_sp = -1;
 static int gemm_sp_mode() {
-  if (g_gemm_sp < 0) { const char* e = getenv("GEORGE_AMD_GEMM_SP"); g_gemm_sp = e ? (atoi(e) != 0) : GH_GEMM_SP_DEFAULT; }
+  if (g_gemm_sp < 0) g_gemm_sp = GH_GEMM_SP_DEFAULT;
   return g_gemm_sp;
 }
 extern "C" int gh_debug_set_gemm_sp(int mode) {

@@ -1,12 +1,11 @@
 // gh_gemm_tile.h -- device-side pieces of the fp64 MFMA GEMM family that more than one translation unit uses:
 // the LDS-DMA operand path of gh_gemm.hip's kernels (XOR-swizzled slab images, the k assignment every k-major x k-major
-// product shares) and, built from it, one-tile products as DEVICE FUNCTIONS for kernels whose workgroups take tile tasks
-// one after the other (gh_dflow.hip, the tile-level dataflow factorisation).
+// product shares) and, built from it, a one-tile product as a DEVICE FUNCTION (gh_tile128_nt_sp: the HODLR leaf stage's
+// batched products, gh_hodlr.hip).
 //
-// A tile's bits must not depend on which kernel computed it (tests compare schedules bit for bit): gh_tile128_nt follows
-// gemm_f64_mfma_dma<true, true, .> slab for slab and instruction for instruction, gh_tile64_nt follows
-// gemm_f64_mfma_dma64<4>; accumulators start from -C and the write-back is -acc (exact), so any split of K into
-// consecutive multiples of 16 gives the same sums as one pass over all of K.
+// A tile's bits must not depend on which kernel computed it: gh_tile128_nt_sp follows gemm_f64_mfma_dma_sp slab for slab and
+// instruction for instruction; accumulators start from -C and the write-back is -acc (exact).  (gh_tile128_nt / gh_tile64_nt,
+// the round-4 loop as device functions for the retired dataflow factorisation: scripts/dev/arms/dataflow_r05/.)
 #pragma once
 #include "gh_common.h"
 
@@ -121,91 +120,15 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------
 // One 128 x 128 tile on the calling 256-thread workgroup:  ACC: C -= A B^T (accumulators start from -C, store-only
 // write-back), else C = A B^T (C may be A: every slab of A has been read when the first element of C is stored).
-// A, B: 128 x K, k contiguous (lda, ldb even, bases 16-byte aligned), K a multiple of 16.  sm: 8192 doubles of LDS, 1 KiB
+// A, B: 128 x K, k contiguous (lda, ldb even, bases 16-byte aligned), K a multiple of 32.  sm: 8192 doubles of LDS, 1 KiB
 // aligned.  Every wavefront must have passed a barrier since its last read of sm; on return all stores have been ISSUED
 // (not waited for) and every wavefront has passed the loop's last barrier.
-template <bool ACC>
-__device__ __forceinline__ void gh_tile128_nt(double* sm, double* C, long ldc, const double* A, long lda,
-                                              const double* B, long ldb, long K) {
-  double* const sA0 = sm; double* const sA1 = sm + BM * BK;
-  double* const sB0 = sm + 2 * BM * BK; double* const sB1 = sm + 2 * BM * BK + BN * BK;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-  v4d acc[4][4];
-  const long nk = K / BK;
-  DmaOperand<true> oa, ob;
-  oa.init(A, lda, 0, 0, wave, lane, wm);
-  ob.init(B, ldb, 0, 0, wave, lane, wn);
-  const int dst = wave * 4 * 128;
-  if (nk > 0) { GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0) }
-  double* const cbase = C + (long)(wm * 64 + fk) * ldc + wn * 64 + fr;
-  if (ACC) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j][r] = -1.0 * cbase[(long)(i * 16 + 4 * r) * ldc + j * 16];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-  }
-  __syncthreads();
-  for (long kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    const double* const ca = cur ? sA1 : sA0;
-    const double* const cb = cur ? sB1 : sB0;
-    double a[4][4], b[4][4];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { const double2 v = oa.frag2(ca, q, i); a[2 * q][i] = v.x; a[2 * q + 1][i] = v.y; }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const double2 v = ob.frag2(cb, q, j); b[2 * q][j] = v.x; b[2 * q + 1][j] = v.y; }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      if (cur) { GH_DMA_ISSUE(oa, sA0) GH_DMA_ISSUE(ob, sB0) }
-      else     { GH_DMA_ISSUE(oa, sA1) GH_DMA_ISSUE(ob, sB1) }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 1; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-  const double alpha = ACC ? -1.0 : 1.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double* const crow = cbase + (long)(i * 16 + 4 * r) * ldc;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][r];
-    }
-}
-
-// gh_tile128_nt_sp: the same tile with the half-slab pipelined loop of gemm_f64_mfma_dma_sp (same k-steps in the same order: same
-// bits; K a multiple of 32).  Used by the HODLR leaf stage's batched products (one tile per workgroup).  NOT by the dataflow
-// factorisation's persistent workers: inlined there the first attempt faulted on the GPU (round 5, `Memory access fault` in
-// dataflow_smoke, while the batched kernel with the same function is correct).  The probable cause: those kernels SPILL (256
-// VGPRs + 128-156 bytes of scratch), and an inline-asm LDS read's destination is, to the compiler, written when the asm is
-// issued -- it may spill that value at once and hand the register to something else (an address, say) while the hardware still
-// owes it the data.  A kernel without spills never does that (gemm_f64_mfma_dma_sp, hodlr_bmm_nt_kernel: 208-236 VGPRs, no
-// scratch).  Until the workers fit their registers, the dataflow keeps round 4's loop.
+// gh_tile128_nt_sp: the half-slab pipelined loop of gemm_f64_mfma_dma_sp (same k-steps in the same order: same bits).
+// THE INVARIANT (enforced by the build: check_kernels.py): a kernel that inlines this function must not use
+// scratch memory.  An inline-asm LDS read's destination is, to the compiler, written when the asm is issued -- under register
+// pressure it stores that value to scratch at once (tests/kernel_gate/spilled_variant.hip shows exactly that: scratch_store of
+// the destinations in front of the s_waitcnt) while the hardware still owes the register its data.  Round 5 met this as a
+// `Memory access fault` when the function was inlined into the spilling workers of the (since retired) dataflow factorisation.
 template <bool ACC>
 __device__ __forceinline__ void gh_tile128_nt_sp(double* sm, double* C, long ldc, const double* A, long lda,
                                               const double* B, long ldb, long K) {
@@ -275,6 +198,9 @@ __device__ __forceinline__ void gh_tile128_nt_sp(double* sm, double* C, long ldc
       GH_SP_MFMA(a23, b23, 0) GH_SP_MFMA(a23, b23, 1)
       __builtin_amdgcn_sched_barrier(0);
     }
+    // (a loop that never ran -- K = 0 -- would leave the prologue's eight reads outstanding while the epilogue reuses their
+    //  registers; after a loop that did run nothing is outstanding and this costs nothing.  Found by check_kernels.py.)
+    GH_SP_WAIT(0, a01[0], a01[1], a01[2], a01[3], b01[0], b01[1], b01[2], b01[3]);
   }
   const double alpha = ACC ? -1.0 : 1.0;
 #pragma unroll
@@ -285,97 +211,4 @@ __device__ __forceinline__ void gh_tile128_nt_sp(double* sm, double* C, long ldc
 #pragma unroll
       for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][r];
     }
-}
-
-// The same for a 64 x 128 tile (2 x 2 wavefronts of 32 x 64): the tasks next to the factorisation's critical path, where
-// a tile's latency counts and not the chip's throughput.  C may be A (whole rows belong to the workgroup).
-// sm: 6144 doubles of LDS, 1 KiB aligned.
-template <bool ACC>
-__device__ __forceinline__ void gh_tile64_nt(double* sm, double* C, long ldc, const double* A, long lda,
-                                             const double* B, long ldb, long K) {
-  double* const sA0 = sm; double* const sA1 = sm + 64 * BK;
-  double* const sB0 = sm + 2 * 64 * BK; double* const sB1 = sm + 2 * 64 * BK + 128 * BK;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-  const long nk = K / BK;
-  const double* ga[2];
-  const double* gb[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wave * 16 + i * 8 + (lane >> 3);
-    ga[i] = A + (long)r * lda + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + (lane >> 3);
-    gb[i] = B + (long)r * ldb + (((lane & 7) ^ ((r >> 1) & 7)) * 2);
-  }
-  const int sw = (fr >> 1) & 7;
-  int offk[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) offk[kk] = GH_KM_OFFK(kk, fk, sw);
-  const int rowA = (wm * 32 + fr) * BK, rowB = (wn * 64 + fr) * BK;
-  const int dstA = wave * 2 * 128, dstB = wave * 4 * 128;
-#define GH_T64_ISSUE(bufA, bufB)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-    __builtin_amdgcn_global_load_lds((gh_glb_void*)ga[i], (gh_lds_void*)((bufA) + dstA + i * 128), 16, 0, 0); \
-    ga[i] += BK;                                                                                           \
-  }                                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-    __builtin_amdgcn_global_load_lds((gh_glb_void*)gb[i], (gh_lds_void*)((bufB) + dstB + i * 128), 16, 0, 0); \
-    gb[i] += BK;                                                                                           \
-  }
-  v4d acc[2][4];
-  double* const cbase = C + (long)(wm * 32 + fk) * ldc + wn * 64 + fr;
-  if (nk > 0) { GH_T64_ISSUE(sA0, sB0) }
-  if (ACC) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j][r] = -1.0 * cbase[(long)(i * 16 + 4 * r) * ldc + j * 16];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-  }
-  __syncthreads();
-  for (long kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    const double* const pa = (cur ? sA1 : sA0) + rowA;
-    const double* const pb = (cur ? sB1 : sB0) + rowB;
-    double a[4][2], b[4][4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[kk][i] = pa[i * 16 * BK + offk[kk]];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[kk][j] = pb[j * 16 * BK + offk[kk]];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      if (cur) { GH_T64_ISSUE(sA0, sB0) } else { GH_T64_ISSUE(sA1, sB1) }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-#undef GH_T64_ISSUE
-  const double alpha = ACC ? -1.0 : 1.0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cbase[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
 }

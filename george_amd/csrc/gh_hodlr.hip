@@ -42,6 +42,7 @@
 #include "gh_common.h"
 #include "gh_threads.h"
 #include "gh_gemm_tile.h"
+#include "gh_spin.h"
 
 // gh_potf2.hip: batched 128x128 Cholesky + inverse of the factor (block b at A + b*stride_a)
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
@@ -153,11 +154,11 @@ __device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoc
     if (fence) __threadfence();
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = (unsigned)G * (epoch + 1u);
-    const long long t0 = wall_clock64();
+    GhSpin spin(fail);                                      // (gh_spin.h: the 2-s give-up and the abort word)
     int good = 1;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > 200000000LL || aca_ldi(fail)) { good = 0; break; }     // 100 MHz ticks: 2 s
+      if (!spin.keep_waiting(0u)) { good = 0; break; }
     }
     if (!good) atomicExch(fail, 1);
     // (no acquire fence: everything another cluster member wrote is read with agent-scope atomic
@@ -2046,12 +2047,20 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C, con
   return GH_OK;
 }
 // full solve on X (n x C): leaves, then levels bottom-up (hodlr.h:107-114)
-// GEORGE_AMD_HODLR_PASSES / gh_debug_set_hodlr_passes: bit 0 = the narrow solve in shared passes (round 5), bit 1 = the
+// gh_debug_set_hodlr_passes (A/B in one process, tests): bit 0 = the narrow solve in shared passes (round 5), bit 1 = the
 // factorisation sweep's update of level l and reduce of the next level in one pass over U; default: both
 static int g_hodlr_passes = -1;
 static int hodlr_passes() {
-  if (g_hodlr_passes < 0) { const char* e = getenv("GEORGE_AMD_HODLR_PASSES"); g_hodlr_passes = e ? atoi(e) & 3 : 3; }
+  if (g_hodlr_passes < 0) g_hodlr_passes = 3;
   return g_hodlr_passes;
+}
+// 1: leaves of 129 .. 256 rows through the pivoted Gauss-Jordan in place (the path every leaf of more than 256 rows takes)
+// instead of the 2 x 2 blocked Cholesky: validation arm, tests/test_gpu_hodlr.py
+static int g_hodlr_leaf_gj = 0;
+extern "C" int gh_debug_set_hodlr_leaf_gj(int on) {
+  const int prev = g_hodlr_leaf_gj;
+  g_hodlr_leaf_gj = on ? 1 : 0;
+  return prev;
 }
 extern "C" int gh_debug_set_hodlr_passes(int mask) {
   const int prev = hodlr_passes();
@@ -2130,7 +2139,7 @@ static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& o
   }
   int nmax = 0;
   for (int v : sizes) nmax = std::max(nmax, v);
-  if (nmax <= 32 && nb <= 64 && !getenv("GEORGE_AMD_HODLR_GJ1")) {   // few cores (the top levels): a workgroup per matrix, columns over its four wavefronts
+  if (nmax <= 32 && nb <= 64) {   // few cores (the top levels): a workgroup per matrix, columns over its four wavefronts
     if (nmax <= 16) hipLaunchKernelGGL(gj_small4_kernel<16>, dim3(nb), dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
     else hipLaunchKernelGGL(gj_small4_kernel<32>, dim3(nb), dim3(256), 0, h->st, base, (const long*)d_offs.p, (const int*)d_sizes.p, nb, d_logdet, (int*)h->flags.p, tsum, (long)h->cpass, tsum_R);
     GH_HIP(hipGetLastError());
@@ -2277,9 +2286,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
       h->leaf_tab_up = true;
     }
-    if (getenv("GEORGE_AMD_HODLR_LEAF_MM")) {        // (round 4's product, for A/B)
-      GH_CHECK(launch_mm(h, (const MMJob*)h->d_leaf_prod.p, nl, 128, linv.d(), 1, 128, linv.d(), 128, 0, h->leaf_inv.d(), 128, 0, 128, false));
-    } else {
+    {
       // K^-1 = L^-T L^-1 = (L^-T)(L^-T)^T: the transposed inverse factors, then one tile product per leaf
       GH_CHECK(lstk.ensure(nl * slot * sizeof(double)));
       hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl, 16), dim3(256), 0, st, (const double*)linv.d(), 128L, (long)slot, lstk.d(), 128L, (long)slot);
@@ -2288,7 +2295,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       GH_HIP(hipGetLastError());
     }
     h->leaf_pitch = 128;
-  } else if (h->max_leaf <= 256 && !getenv("GEORGE_AMD_HODLR_LEAF_GJ")) {
+  } else if (h->max_leaf <= 256 && !g_hodlr_leaf_gj) {
     // Leaves of 129 .. 256 rows -- the reference's tree stops splitting below 2 min_size, so with min_size = 100 most problem
     // sizes have leaves of up to 199 rows (N = 50000: 256 leaves of 195 / 196) -- went through the pivoted Gauss-Jordan in place
     // in HBM: 14 of the 17 ms of a step at N = 50000 (round 5 profile).  Same recipe as above on 256 x 256 identity-padded slots,
@@ -2404,7 +2411,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   const bool user_cap = h->opts.max_rank > 0;
   const int rcap0 = user_cap ? h->opts.max_rank : std::min(256, RANK_CAP);
   const int nlev = (int)h->levels.size();
-  const int aca_fence = 0, aca_multi = getenv("GEORGE_AMD_HODLR_ACA_3BAR") ? 1 : 3;   // bit 0: batched candidate search (one-workgroup nodes); bit 1: clusters draw the next row before the norms barrier         // (fence-free cluster barrier, 8 then 64 candidate rows per search pass: DESIGN.md section 4)
+  const int aca_fence = 0, aca_multi = 3;   // bit 0: batched candidate search (one-workgroup nodes); bit 1: clusters draw the next row before the norms barrier         // (fence-free cluster barrier, 8 then 64 candidate rows per search pass: DESIGN.md section 4)
   // (round 5: "more than 12 GiB" was a 64-GB-card habit; an MI355X has 288 GB.  Above 12 GiB the question is put to the device:
   //  all levels at once while their scratch fits in 40 % of what is free now -- N = 700000 went one level at a time, 34 ms)
   bool concurrent = nlev - l0 > 1;

@@ -69,7 +69,7 @@ struct BlockCache {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks[16];      // per device, keyed by capacity
   size_t cached_bytes[16] = {0};
-  static constexpr size_t kMaxCached = (size_t)128 << 30;  // per device (of 288 GB); beyond it blocks are really freed
+  size_t max_cached = (size_t)128 << 30;             // per device (of 288 GB); beyond it blocks are really freed (gh_set_cache_limit)
 };
 BlockCache g_cache;
 }
@@ -121,6 +121,30 @@ extern "C" void gh_release_caches(int32_t device) {
   gh_pool_trim();
   (void)hipSetDevice(prev);
 }
+// The block cache parks up to 128 GB of released blocks per device and gives them back to the driver only when one of THIS
+// library's allocations fails -- another allocator in the process (torch, RCCL) cannot make it do so.  A process that shares
+// the device with one sets a smaller limit here (bytes per device; 0 = cache nothing); blocks above the new limit go now.
+extern "C" void gh_set_cache_limit(int64_t bytes) {
+  int ndev = 0, prev = 0;
+  (void)hipGetDevice(&prev);
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+  std::vector<std::pair<int, void*>> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.max_cached = bytes > 0 ? (size_t)bytes : 0;
+    for (int d = 0; d < 16; ++d) {
+      auto& m = g_cache.free_blocks[d];
+      while (g_cache.cached_bytes[d] > g_cache.max_cached && !m.empty()) {
+        auto it = std::prev(m.end());                   // largest first
+        g_cache.cached_bytes[d] -= it->first;
+        drop.emplace_back(d, it->second);
+        m.erase(it);
+      }
+    }
+  }
+  for (auto& q : drop) { if (q.first < ndev && hipSetDevice(q.first) == hipSuccess) (void)hipFree(q.second); }
+  if (!drop.empty()) (void)hipSetDevice(prev);
+}
 // bytes of released blocks parked in the current device's cache (they will be handed out again before anything is allocated)
 size_t gh_pool_parked_bytes() {
   int dev = 0;
@@ -136,7 +160,7 @@ void gh_pool_release(void* p, size_t capacity) {
   dev &= 15;
   {
     std::lock_guard<std::mutex> lk(g_cache.mu);
-    if (g_cache.cached_bytes[dev] + capacity <= BlockCache::kMaxCached) {
+    if (g_cache.cached_bytes[dev] + capacity <= g_cache.max_cached) {
       g_cache.free_blocks[dev].emplace(capacity, p);
       g_cache.cached_bytes[dev] += capacity;
       return;

@@ -125,6 +125,7 @@ struct MRank {
   GhBuf A, dinv, Lkk, wrow[2], colp[2], nxt[2], x, yerr, scal, flags;
   GhBuf zc, xr, wk, part, red, rhs, acc;                   // sweeps: Z for my tile columns, X for my tile rows, work tile, partial, reduce slots
   long long* d_info = nullptr;
+  double* h_back = nullptr;        // pinned, 2 doubles: [0] the failure word's bits, [1] this rank's log-det part (end of a factorisation)
   std::vector<int> rows, cols;     // global tile rows / columns this rank owns, ascending
   int rc = GH_OK;
   std::string err;
@@ -171,6 +172,7 @@ struct gh_mgpu {
                        &r.flags, &r.zc, &r.xr, &r.wk, &r.part, &r.red, &r.rhs, &r.acc}) b->release();
       if (r.kern.d_nodes) { (void)hipFree(r.kern.d_nodes); r.kern.d_nodes = nullptr; }
       if (r.d_info) (void)hipFree(r.d_info);
+      if (r.h_back) (void)hipHostFree(r.h_back);
       for (hipEvent_t e : {r.ev_ready, r.ev_done, r.ev_fast[0], r.ev_fast[1], r.ev_panel[0], r.ev_panel[1], r.ev_bcol, r.ev_rest}) if (e) (void)hipEventDestroy(e);
       for (hipEvent_t e : r.ev_pool) (void)hipEventDestroy(e);
       for (hipStream_t q : {r.sg, r.sp, r.st}) if (q) (void)hipStreamDestroy(q);
@@ -401,6 +403,7 @@ int rank_setup(gh_mgpu* h, MRank& r, const gh_kernel* k, const double* x, const 
   GH_CHECK(r.scal.ensure(64 * sizeof(double)));
   GH_CHECK(r.flags.ensure((size_t)(nb / T + 2) * sizeof(unsigned)));
   if (!r.d_info) GH_HIP(hipMalloc((void**)&r.d_info, sizeof(long long)));
+  if (!r.h_back) GH_HIP(hipHostMalloc((void**)&r.h_back, 2 * sizeof(double), hipHostMallocDefault));
   GH_CHECK(gh_to_device(r.x.d(), x, (size_t)n * h->ndim, r.st));
   GH_CHECK(gh_to_device(r.yerr.d(), yerr, (size_t)n, r.st));
   GH_HIP(hipMemsetAsync(r.d_info, 0, sizeof(long long), r.st));
@@ -591,12 +594,18 @@ int rank_factor(gh_mgpu* h, MRank& r) {
     GH_HIP(hipStreamWaitEvent(r.st, r.ev_panel[buf], 0));        // the whole column panel of step k
     if (!h->chain_only) GH_CHECK(update(k, buf, k + 2, (int)nt - 1, false));
   }
+  // Drain FIRST, copy afterwards.  A device-to-host copy into pageable memory blocks inside hipMemcpyAsync until the stream
+  // has reached it (the HODLR solver's pinned result block exists for that reason), so with the copies in front the rank
+  // thread sat in the copy -- not in mg_drain's bounded poll -- in exactly the crossed-communicator hang the time-out is
+  // for, and a drain that gave up returned with copies still aimed at this stack frame.  Now: the bounded drains of the
+  // chain and gather streams, then of the main stream, then two small copies into a PINNED block that lives in the rank.
+  for (hipStream_t q : {r.sp, r.sg, r.st}) GH_CHECK(mg_drain(h, r, q));
+  GH_HIP(hipMemcpyAsync(r.h_back, r.d_info, sizeof(long long), hipMemcpyDeviceToHost, r.st));
+  GH_HIP(hipMemcpyAsync(r.h_back + 1, r.scal.d(), sizeof(double), hipMemcpyDeviceToHost, r.st));
+  GH_CHECK(mg_drain(h, r, r.st));
   long long info = 0;
-  double ld_part = 0.0;
-  GH_HIP(hipMemcpyAsync(&info, r.d_info, sizeof(long long), hipMemcpyDeviceToHost, r.st));
-  GH_HIP(hipMemcpyAsync(&ld_part, r.scal.d(), sizeof(double), hipMemcpyDeviceToHost, r.st));
-  for (hipStream_t q : {r.st, r.sp, r.sg}) GH_CHECK(mg_drain(h, r, q));
-  r.info = info; r.logdet = ld_part;
+  memcpy(&info, r.h_back, sizeof(long long));
+  r.info = info; r.logdet = r.h_back[1];
   return GH_OK;
 }
 

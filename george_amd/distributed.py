@@ -9,7 +9,7 @@ needs -> potrf(k+1): with whole tile rows per rank only two NB x NB tiles travel
 and the block-column update are split over ALL ranks, and the bulk of the panel (the all-gather every
 rank's trailing update needs) moves beside it on a communicator and a stream of its own.  A 2 x 4 grid
 puts (N - k NB) / 2 x NB doubles of row panel on one link inside the chain at every step
-(profiles/r04/scale_model.md prices both).  `grid=(Pr, Pc)` / GEORGE_AMD_DIST_GRID=PrxPc select any other
+(profiles/r04/scale_model.md prices both).  `grid=(Pr, Pc)` selects any other
 grid (then prow(I) = I mod Pr: plain 2-D block-cyclic).  Every rank BUILDS its own tiles on its own GPU
 from (kernel, x) -- nothing is scattered -- and the factorisation proceeds right-looking, one tile column
 per step:
@@ -116,11 +116,9 @@ _CHOL_CACHE_MAX = 2       # parked workspaces in total
 
 
 def grid_shape(world, grid=None):
-    """(Pr, Pc): `grid` if given, else GEORGE_AMD_DIST_GRID=PrxPc, else world x 1 (whole tile rows per rank: the
+    """(Pr, Pc): `grid` if given, else world x 1 (whole tile rows per rank: the
     module docstring says why); "square" asks for the grid a switched network would want (Pr <= Pc, as square as
     the world size allows: 1x2, 2x2, 2x4)."""
-    if grid is None:
-        grid = os.environ.get("GEORGE_AMD_DIST_GRID") or None
     if grid is None:
         return world, 1
     if isinstance(grid, str):
@@ -271,7 +269,7 @@ class HipTileOps(object):
 
 class BlockCyclicCholesky(object):
 
-    def __init__(self, ops, n, nb=512, rank=None, world=None, lookahead=None, grid=None, snake=None):
+    def __init__(self, ops, n, nb=512, rank=None, world=None, lookahead=True, grid=None, snake=True, chain_only=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.ops = torch, dist, ops
@@ -280,10 +278,8 @@ class BlockCyclicCholesky(object):
         self.rank = rank if rank is not None else (dist.get_rank() if self.live else 0)
         self.Pr, self.Pc = grid_shape(self.world, grid)
         self.pr, self.pc = divmod(self.rank, self.Pc)
-        if snake is None:
-            snake = os.environ.get("GEORGE_AMD_DIST_SNAKE", "1") != "0"
         self.snake = bool(snake) and self.Pc == 1 and self.Pr > 1
-        self.chain_only = os.environ.get("GEORGE_AMD_DIST_CHAIN_ONLY", "0") == "1"       # timing aid: no trailing update but block column k+1
+        self.chain_only = bool(chain_only)                                               # timing aid: no trailing update but block column k+1
         if nb % 128:
             raise ValueError("nb must be a multiple of 128")
         self.n, self.nb = int(n), int(nb)
@@ -292,8 +288,6 @@ class BlockCyclicCholesky(object):
         self.cols = [j for j in range(self.nt) if self.pcol(j) == self.pc]
         self.lrow = {i: li for li, i in enumerate(self.rows)}
         self.lcol = {j: lj for lj, j in enumerate(self.cols)}
-        if lookahead is None:
-            lookahead = os.environ.get("GEORGE_AMD_DIST_LOOKAHEAD", "1") != "0"
         self.lookahead = bool(lookahead) and getattr(ops, "has_streams", False)
         nbk, nlr = self.nb, max(len(self.rows), 1)
         self.A = ops.zeros(nlr * nbk, max(len(self.cols), 1) * nbk)
@@ -831,7 +825,7 @@ class DistributedBasicSolver(object):
     makes a new solver at every optimiser evaluation -- and sub-communicators are created once per
     process group."""
 
-    def __init__(self, kernel, nb=512, device=None, ops=None, lookahead=None, grid=None):
+    def __init__(self, kernel, nb=512, device=None, ops=None, lookahead=True, grid=None):
         self.kernel, self.nb = kernel, nb
         self._grid = grid
         self._ops = ops

@@ -95,10 +95,15 @@ typedef struct gh_hodlr  gh_hodlr;
 int         gh_device_count(void);
 const char* gh_last_error(void);
 const char* gh_version(void);
-/* Device memory the library keeps for re-use -- released transient blocks (up to 48 GB per device) -- is really freed.  The
+/* Device memory the library keeps for re-use -- released transient blocks (up to 128 GB per device, gh_set_cache_limit) -- is really freed.  The
  * library does this itself before it reports GH_ERR_NOMEM; an application that needs the memory for its own allocations
  * calls it directly (solver handles keep what they hold: gh_chol_trim / gh_chol_release_buffers / *_destroy). */
 void gh_release_caches(int32_t device);
+/* upper bound, per device, on the released device blocks the library keeps parked for its next allocation (default 128 GB of
+ * the 288; they are otherwise returned to the driver only when one of the library's OWN allocations fails).  A process that
+ * shares a GPU with another allocator (torch, RCCL buffers) lowers it; 0 = park nothing.  Blocks above the new bound are
+ * freed at once.  (No reference counterpart: NumPy's allocator, basic.py:58.) */
+void gh_set_cache_limit(int64_t bytes);
 /* ---------------------------------------------- kernel-function evaluator
  * Replaces the pybind11 class KernelInterface, src/george/kernel_interface.cpp:
  *   ctor + parse_kernel_spec  :12-14   -> gh_kernel_create

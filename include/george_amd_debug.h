@@ -21,13 +21,16 @@ int gh_microbench_mfma_f64(double* tflops_out);
  * (default); returns the previous setting. */
 int gh_debug_set_mfma(int mode);
 /* the k-major x k-major GEMM kernel with its slab loop software-pipelined by half a slab (gemm_f64_mfma_dma_sp): 1 on, 0 off,
- * -1 the build's default; returns the previous mode.  Same bits either way (tests/test_gpu_gemm.py).  GEORGE_AMD_GEMM_SP. */
+ * -1 the build's default; returns the previous mode.  Same bits either way (tests/test_gpu_gemm.py). */
 int gh_debug_set_gemm_sp(int mode);
 /* HODLR passes that serve two levels at once (round 5): bit 0 = the narrow solve (update of level l + chunk products of the
  * next level in one pass over the rows, "sum + core product" in one launch, symmetric leaf product), bit 1 = the factorisation
  * sweep's update of level l + reduce of the next level in one pass over U; -1: the default (both); returns the previous mask.
- * GEORGE_AMD_HODLR_PASSES. */
+ */
 int gh_debug_set_hodlr_passes(int mask);
+/* 1: HODLR leaves of 129 .. 256 rows through the in-place pivoted Gauss-Jordan (what leaves of more than 256 rows take) instead of
+ * the 2 x 2 blocked Cholesky; returns the previous setting (validation arm) */
+int gh_debug_set_hodlr_leaf_gj(int on);
 /* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */
@@ -36,29 +39,6 @@ int gh_debug_stream_overlap(gh_chol* s, double* out, int n);
  * 2^18 workgroups (~2 ms) on stream i: small = the two queues dispatch independently (same stream numbering) */
 int gh_debug_stream_dispatch(gh_chol* s, double* out, int n);
 int gh_microbench_hbm_copy(double* gbps_out);
-/* the dense factorisation as one persistent launch of tile tasks (gh_dflow.hip): 1 = always (Np >= 256), 0 = never (the
- * launch chain), -1 = by size (the default; GEORGE_AMD_DATAFLOW=0|1 overrides); returns the previous setting.  Both arms
- * give bit-identical factors. */
-int gh_debug_set_dataflow(int mode);
-/* the task queues of the dataflow factorisation of an nt x nt tile matrix (host only): counts[q] = tasks of queue q
- * (gh_dflow.hip: crit, next-block steps, hi, lo near, lo far; q < 5); out (nullable): rows of 10 ints {queue, i, j, k0, k1, half, fin, bucket,
- * gate word, gate value} in ticket order, at most max_rows (gate word: 0 = diagonal steps finished, 256 + 2 r + h = final L
- * tiles of half-row (r, h)) */
-int gh_debug_dflow_schedule(int32_t nt, int32_t* counts, int32_t* out, int64_t max_rows);
-/* the candidate lists of that schedule (queues 0 and 1 have no buckets: whoever finishes one of their tasks' inputs appends the
- * task to the queue's ready list): producers = all tasks in the order of gh_debug_dflow_schedule, then the diagonal worker's
- * sub-diagonal multiply of step j (total + j), then its 128 x 128 kernel of step j (total + nt + j); ptr (nullable): total +
- * 2 nt + 1 offsets into cand; cand (nullable): at most max_cand task indices (of queues 0, 1); *n_cand = entries in all */
-int gh_debug_dflow_candidates(int32_t nt, uint32_t* ptr, uint32_t* cand, int64_t max_cand, int64_t* n_cand);
-/* per-task trace of the dataflow factorisation (single-threaded debugging aid).  capacity >= 0: from now on record up to
- * `capacity` tasks per factorisation (0 = off); out != NULL: first copy the last factorisation's records (4 x uint64 each:
- * start and end in 10-ns ticks, i | j << 16 | k0 << 32 | k1 << 48, kind | half << 8 | fin << 16 | workgroup << 32; kind 0-3 =
- * queue, 8-11 = the diagonal worker's wait / multiply / update / 128 x 128 kernel) and their number to *n_out */
-int gh_debug_dflow_trace(int64_t capacity, uint64_t* out, int64_t max_records, int64_t* n_out);
-/* the first n counter words of the handle's dataflow factorisation (gh_dflow.hip: 0 = diagonal steps finished, 32 = abort word,
- * 64 = the diagonal worker runs, 96 + 32 q = first bucket of queue q that is not used up), read on a stream
- * of its own: answers while a factorisation is running */
-int gh_debug_dflow_peek(gh_chol* s, uint32_t* out, int32_t n);
 /* instruction-rate suite (n >= 16): out[0..2] = v_mfma_f64_16x16x4 TFLOP/s, cycles/instr, GHz at
  * 1 wave/SIMD; out[3..5] same at 2 waves/SIMD; out[6] TFLOP/s at 4 waves/SIMD; out[7..9] v_fma_f64
  * TFLOP/s, cycles/instr, GHz at 4 waves/SIMD; out[10] TFLOP/s at 8 waves/SIMD; out[11..12]

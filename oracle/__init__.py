@@ -14,6 +14,6 @@ Parity status:
   oracle/mini_eigen (the Eigen submodule is empty upstream) behind oracle/hodlr_ref_driver.cpp (oracle/_ref/_hodlr;
   goldens: oracle/gen_golden_hodlr.py, oracle/gen_golden_large.py C4 at N = 262144); the stand-in's LDLT / FullPivLU are
   checked against SciPy / NumPy (tests/test_oracle_hodlr.py).
-* oracle/_ref/george/: byte-code of the reference's Python package (oracle/Makefile: stage), loaded by
-  ref_loader.load_reference() where /root/reference is absent (the GPU box): tests/test_gpu_reference_suite.py.
+* the reference's Python package itself is imported only where /root/reference exists (ref_loader.load_reference());
+  nothing of it travels to the GPU box.
 """

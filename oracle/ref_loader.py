@@ -7,12 +7,12 @@ Loads the *real* reference (dfm/george) for oracle pinning:
   ``oracle/Makefile`` into ``oracle/_ref/``.  The shared object travels to the
   GPU box, so this works there too (it only needs a *spec object* exposing the
   attributes ``parser.h:14-35,344-403`` reads -- our own host classes do).
-* ``load_reference()`` -- the full reference Python package as ``george``: from
-  the sources where they lie under ``/root/reference`` in the build container,
-  else from ``oracle/_ref/george`` (byte-code compiled from those sources by
-  ``oracle/Makefile``'s ``stage`` target: a git-ignored build output that
-  travels to the GPU box like the shared objects), plus the compiled
-  ``kernel_interface`` / ``_hodlr``.  ``None`` when neither is there.
+* ``load_reference()`` -- the full reference Python package as ``george``, imported
+  from the sources where they lie under ``/root/reference`` (the build container
+  only), plus the compiled ``kernel_interface`` / ``_hodlr``.  ``None`` where
+  ``/root/reference`` does not exist (the GPU box): a Python reference does not
+  travel in any form -- rounds 4-5 staged its byte-code under ``oracle/_ref/george``,
+  round 6 removed that.
 
 * ``load_hodlr()`` -- the reference's HODLR solver: its unmodified
   ``include/george/hodlr.h`` compiled against ``oracle/mini_eigen`` behind
@@ -30,7 +30,6 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("GEORGE_REFERENCE", "/root/reference")
 REF_SRC = os.path.join(REF_ROOT, "src", "george")
-STAGED = os.path.join(HERE, "_ref", "george")          # byte-code of the reference package (oracle/Makefile: stage)
 
 
 def _so_path():
@@ -76,9 +75,6 @@ def load_reference():
         return sys.modules["george"]
     if os.path.isdir(REF_SRC):
         src, init = REF_SRC, os.path.join(REF_SRC, "__init__.py")
-    elif os.path.isfile(os.path.join(STAGED, "__init__.pyc")):
-        # the GPU box: /root/reference does not exist there, the compiled package travelled with the snapshot
-        src, init = STAGED, os.path.join(STAGED, "__init__.pyc")
     else:
         return None
     KI = load_kernel_interface()

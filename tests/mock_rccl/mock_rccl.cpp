@@ -31,6 +31,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -137,6 +138,22 @@ void match_pair(Set* s, int a, int b) {
     {
       DeviceGuard g(rv->comm->dev);
       e = hipStreamWaitEvent(rv->st, sd->posted, 0);
+      // fault injection (tests/test_gpu_mgpu_mock_rccl.py): MOCK_RCCL_STALL=<pair index>:<seconds> holds the receiver's
+      // stream for that long in front of the copy of the <pair index>-th matched pair -- a transfer that hangs on the
+      // device for a while, as two crossed communicators would, but ends by itself
+      {
+        static const char* const stall = getenv("MOCK_RCCL_STALL");
+        static long long stall_at = -1;
+        static double stall_s = 0.0;
+        if (stall && stall_at < 0) { stall_at = atoll(stall); const char* c = strchr(stall, ':'); stall_s = c ? atof(c + 1) : 3.0; }
+        if (stall && g_stat[1] == stall_at) {
+          double* secs = new double(stall_s);
+          (void)hipLaunchHostFunc(rv->st, [](void* p) {
+            std::this_thread::sleep_for(std::chrono::duration<double>(*(double*)p));
+            delete (double*)p;
+          }, secs);
+        }
+      }
       if (e == hipSuccess && bytes) {
         if (sd->comm->dev == rv->comm->dev) e = hipMemcpyAsync(rv->dst, sd->src, bytes, hipMemcpyDeviceToDevice, rv->st);
         else e = hipMemcpyPeerAsync(rv->dst, rv->comm->dev, sd->src, sd->comm->dev, bytes, rv->st);

@@ -17,6 +17,7 @@ import os
 
 from oracle import solver_np, hodlr_np, ref_loader
 from george_amd import kernels, GP, BasicSolver, HODLRSolver
+from george_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 
@@ -299,7 +300,7 @@ def test_hodlr_not_positive_definite_leaf(leaf_gj):
     k = kernels.CosineKernel(log_period=0.0)             # rank-2 kernel: every leaf is singular
     for env in ([None] if not leaf_gj else [None, "1"]):
         if env:
-            os.environ["GEORGE_AMD_HODLR_LEAF_GJ"] = env
+            N.lib.gh_debug_set_hodlr_leaf_gj(1)
         try:
             s = HODLRSolver(k, tol=1e-10)
             if env is None:
@@ -312,27 +313,27 @@ def test_hodlr_not_positive_definite_leaf(leaf_gj):
                 except (np.linalg.LinAlgError, RuntimeError):
                     assert not s.computed
         finally:
-            os.environ.pop("GEORGE_AMD_HODLR_LEAF_GJ", None)
+            N.lib.gh_debug_set_hodlr_leaf_gj(0)
 
 
 @pytest.mark.parametrize("n", [3000, 1560, 10000])
 def test_blocked_cholesky_leaves_match_gauss_jordan_and_dense(n):
     """leaves of 129 .. 256 rows (n = 3000: 187 / 188 rows; 1560: 195; 10000: 156 / 157): the 2 x 2 blocked Cholesky path on
-    256 x 256 slots (round 5) against the pivoted Gauss-Jordan it replaces (GEORGE_AMD_HODLR_LEAF_GJ=1) and the dense solver"""
+    256 x 256 slots (round 5) against the pivoted Gauss-Jordan it replaces (gh_debug_set_hodlr_leaf_gj(1)) and the dense solver"""
     x, yerr, y = zoo.bench_data(n)
     kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
     X = x[:, None]
     got = {}
     for env in (None, "1"):
         if env:
-            os.environ["GEORGE_AMD_HODLR_LEAF_GJ"] = env
+            N.lib.gh_debug_set_hodlr_leaf_gj(1)
         try:
             s = HODLRSolver(kernel, tol=1e-12)
             s.compute(X, yerr)
             wide = np.stack([np.cos((q + 1) * x) for q in range(20)], axis=1)      # 20 right-hand sides: the tile-kernel path, leaf pitch 256
             got[env] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(np.stack([y, np.cos(x)], axis=1)), s.apply_inverse(wide))
         finally:
-            os.environ.pop("GEORGE_AMD_HODLR_LEAF_GJ", None)
+            N.lib.gh_debug_set_hodlr_leaf_gj(0)
     a, b = got[None], got["1"]
     assert abs(a[0] - b[0]) <= 1e-11 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-9 * abs(b[1])
     np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8 * np.abs(b[2]).max())

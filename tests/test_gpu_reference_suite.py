@@ -1,9 +1,10 @@
 """The reference's OWN package (`george.GP`, `george.kernels`, `george.modeling`) with the HIP solver classes
 plugged in through its documented `solver=` slot -- INTEGRATION.md section 1's zero-change claim, executed.
 
-`george` here is dfm/george itself: byte-code of /root/reference/src/george compiled by `oracle/Makefile` (target
-`stage`) into the git-ignored `oracle/_ref/george`, which travels to the GPU box like `oracle/_ref/*.so`
-(`oracle/ref_loader.load_reference`).  Nothing of `george_amd`'s own GP facade is involved: the orchestration
+`george` here is dfm/george itself, imported from /root/reference (`oracle/ref_loader.load_reference`).  This module therefore
+runs only on a machine that has BOTH the reference checkout and an MI355X.  Rounds 4-5 shipped the reference's byte-code to
+the GPU box to make that true there (GPUTEST_r04 / r05: 28 tests of this file green); round 6 removed the staging -- a Python
+reference must not travel in any form -- so on the project's GPU box this module skips.  Nothing of `george_amd`'s own GP facade is involved: the orchestration
 (gp.py:303-337 compute, :369-397 log_likelihood, :406-468 grad_log_likelihood, :482-545 predict, :547-600 sample)
 is the reference's, and every solver call it makes (`solver_type(kernel, **kwargs)` gp.py:327, `.compute`,
 `.apply_inverse`, `.dot_solve`, `.get_inverse`, `.apply_sqrt`, `.log_determinant`, `.computed`) lands in
@@ -26,8 +27,8 @@ import george_amd
 pytestmark = pytest.mark.gpu
 
 george = ref_loader.load_reference()
-if george is None:                                           # (collection on a box where oracle/_ref was not built)
-    pytest.skip("oracle/_ref/george is not staged (make -C oracle)", allow_module_level=True)
+if george is None:                                           # (the GPU box of this project: /root/reference does not exist there)
+    pytest.skip("the reference package (/root/reference) is not on this machine: a Python reference does not travel", allow_module_level=True)
 kernels, GP = george.kernels, george.GP
 
 HIP = {"basic": george_amd.BasicSolver, "hodlr": george_amd.HODLRSolver}
