@@ -365,6 +365,80 @@ def c5_report(local_rank, n=32768, m=4096):
     return res
 
 
+def f1_kernel(kernels):
+    """docs/tutorials/hyper.rst:91-95 (the survey's f1 workload): k1 + k2 * ExpSine2 + k3 + k4, 11 kernel parameters"""
+    k1 = 66.0 ** 2 * kernels.ExpSquaredKernel(metric=67.0 ** 2)
+    k2 = 2.4 ** 2 * kernels.ExpSquaredKernel(90.0 ** 2) * kernels.ExpSine2Kernel(gamma=2.0 / 1.3 ** 2, log_period=0.0)
+    k3 = 0.66 ** 2 * kernels.RationalQuadraticKernel(log_alpha=np.log(0.78), metric=1.2 ** 2)
+    k4 = 0.18 ** 2 * kernels.ExpSquaredKernel(1.6 ** 2)
+    return k1 + k2 + k3 + k4
+
+
+def f1_data(n, seed=7):
+    """n 'monthly CO2' samples over 1958 .. 2010 shaped like the tutorial's Mauna Loa series (the data set itself is a download)"""
+    rng = np.random.RandomState(seed)
+    t = np.sort(1958.0 + 52.0 * (np.arange(n) + rng.uniform(0.0, 1.0, n)) / n)
+    y = 315.0 + 0.9 * (t - 1958.0) + 0.012 * (t - 1958.0) ** 2 + 3.0 * np.sin(2 * np.pi * t) + 0.8 * np.sin(4 * np.pi * t + 0.4)
+    return t, y + 0.25 * rng.randn(n)
+
+
+def f1_report(local_rank, sizes=(2048, 8192, 16384), cpu_n=2048):
+    """SURVEY 8(f).1 on the kernel it exists for (hyper.rst:91-152): the 13-parameter model (11 kernel parameters + white noise +
+    mean) -- compute()+log_likelihood(), grad_log_likelihood() and the fused nll_and_grad() per optimiser iterate, the kernel-matrix
+    build alone (HIP events inside compute()), and the reference CPU path (its C++ evaluator + LAPACK) at the smallest size."""
+    from george_amd import GP, kernels, BasicSolver
+    res = {"kernel": "66^2 ES(67^2) + 2.4^2 ES(90^2) ExpSine2(2/1.3^2, 0) + 0.66^2 RQ(log 0.78, 1.2^2) + 0.18^2 ES(1.6^2); "
+                     "mean and white noise fitted: 13 parameters (docs/tutorials/hyper.rst:91-104)", "sizes": {}}
+    for n in sizes:
+        t, y = f1_data(n)
+        gp = GP(f1_kernel(kernels), mean=float(np.mean(y)), fit_mean=True, white_noise=np.log(0.19 ** 2), fit_white_noise=True,
+                solver=BasicSolver, device=local_rank, profile=True)
+        r = {}
+        for rep in range(3):                                 # third pass is the measurement
+            t0 = time.perf_counter(); gp.compute(t); ll = gp.log_likelihood(y); r["compute_loglike_ms"] = (time.perf_counter() - t0) * 1e3
+            r["build_ms"] = float(gp.solver.profile().ms_build)
+            t0 = time.perf_counter(); g = gp.grad_log_likelihood(y); r["grad_ms"] = (time.perf_counter() - t0) * 1e3
+        p = gp.get_parameter_vector()
+        gp.grad_nll(p, y)
+        fused = []
+        for it in range(5):
+            t0 = time.perf_counter(); v, gg = gp.nll_and_grad(p + 1e-4 * (it + 1), y); fused.append((time.perf_counter() - t0) * 1e3)
+        r["fused_nll_and_grad_ms"] = min(fused[2:])
+        npd = -(-n // 128) * 128
+        tiles = (npd // 128) * (npd // 128 + 1) // 2
+        bytes_alg = tiles * 128 * 128 * 8 + 16 * n
+        r["build_GBs"] = bytes_alg / (r["build_ms"] * 1e-3) * 1e-9
+        r["build_frac_of_hbm"] = r["build_GBs"] / PEAK_HBM_GBS
+        r["build_elements_per_s"] = tiles * 128 * 128 / (r["build_ms"] * 1e-3)
+        r["log_likelihood"] = float(ll)
+        r["grad"] = [float(v_) for v_ in g]
+        res["sizes"]["N%d" % n] = r
+        del gp
+    if cpu_n:
+        # the reference's CPU path for the same iterate at the smallest size: its C++ evaluator (value + 11-parameter gradient) + LAPACK
+        from oracle import solver_np
+        t, y = f1_data(cpu_n)
+        kernel = f1_kernel(kernels)
+        mean, wn = float(np.mean(y)), np.log(0.19 ** 2)
+        d = solver_np.DenseOracle(kernel)
+        t0 = time.perf_counter()
+        ll_ref = solver_np.gp_log_likelihood(d, t[:, None], 0.0, y, mean=mean, white_noise=wn)
+        t_ll = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        kg, A = solver_np.gp_grad_log_likelihood(d, kernel, t[:, None], y, mean=mean)
+        t_g = time.perf_counter() - t0
+        alpha = d.apply_inverse(y - mean)
+        gref = np.concatenate([[alpha.sum()], [0.5 * np.exp(wn) * np.trace(A)], kg])       # gp.py:443-461 for a constant mean / white noise
+        mine = res["sizes"].get("N%d" % cpu_n)
+        res["cpu_reference"] = {"n": cpu_n, "kind": solver_np.evaluator_kind(), "compute_loglike_s": t_ll, "grad_s": t_g,
+                                "log_likelihood": float(ll_ref)}
+        if mine:
+            res["cpu_reference"]["rel_ll"] = abs(mine["log_likelihood"] - ll_ref) / abs(ll_ref)
+            res["cpu_reference"]["grad_rel_max"] = float(np.max(np.abs(np.asarray(mine["grad"]) - gref) / np.maximum(np.abs(gref), 1e-3 * np.abs(gref).max())))
+            res["cpu_reference"]["gpu_over_cpu_iterate"] = (t_ll + t_g) / (mine["fused_nll_and_grad_ms"] * 1e-3)
+    return res
+
+
 def mgpu_abi_report(local_rank, n=32768):
     """The sharded solver behind the C ABI (gh_mgpu_*: host threads + RCCL) as a world of ONE on the leased GPU:
     communicator creation, the all-reduce self-check and the block-cyclic driver end to end, against the
@@ -570,6 +644,17 @@ def compact_line(out):
     if a and "compute_loglike_s" in a:
         also["C5_N32768_3d"] = {"compute_loglike_s": a["compute_loglike_s"], "predict_var_s": a["predict_var_s"], "grad_s": a["grad_s"],
                                 "fused_nll_and_grad_s": a["fused_nll_and_grad_s"], "fused_frac": a["roofline"]["frac"]}
+    a = cfg.get("also_f1")
+    if a and "sizes" in a:
+        also["f1_hyper_kernel_13p"] = {k: {q: _r(v[q]) for q in ("compute_loglike_ms", "build_ms", "build_frac_of_hbm", "grad_ms", "fused_nll_and_grad_ms")}
+                                       for k, v in a["sizes"].items()}
+        cr = a.get("cpu_reference")
+        if cr:
+            also["f1_hyper_kernel_13p"]["cpu_ref_N%d_s" % cr["n"]] = [_r(cr["compute_loglike_s"]), _r(cr["grad_s"])]
+            if "gpu_over_cpu_iterate" in cr:
+                also["f1_hyper_kernel_13p"]["gpu_over_cpu_iterate"] = _r(cr["gpu_over_cpu_iterate"])
+    elif a:
+        also["f1_hyper_kernel_13p"] = a
     a = cfg.get("also_abi_multi_gpu_world_of_one")
     if a:
         also["abi_mgpu_world1_N32768"] = {"s": a.get("seconds_per_step"), "tflops": a.get("value_tflops")} if "error" not in a else {"error": a["error"][:120]}
@@ -1123,6 +1208,13 @@ def main():
                 if "parity_cpu_sample" in out["config"]["also_C4"]:
                     parity["C4_hodlr_cpu_sample"] = out["config"]["also_C4"]["parity_cpu_sample"]
                 out["config"]["also_C5"] = c5_report(local_rank)
+                try:
+                    out["config"]["also_f1"] = f1_report(local_rank, cpu_n=0 if args.no_cpu else 2048)
+                    cr = out["config"]["also_f1"].get("cpu_reference")
+                    if cr and "rel_ll" in cr:
+                        parity["f1_hyper_kernel_N2048"] = {"rel": cr["rel_ll"], "ll_ref": cr["log_likelihood"], "grad_rel_max": cr["grad_rel_max"]}
+                except Exception as e:
+                    out["config"]["also_f1"] = {"error": repr(e)[:200]}
                 try:
                     out["config"]["also_abi_multi_gpu_world_of_one"] = mgpu_abi_report(local_rank)
                     parity["abi_multi_gpu_world_of_one"] = out["config"]["also_abi_multi_gpu_world_of_one"]["parity"]

@@ -96,6 +96,12 @@ __device__ __forceinline__ void hw_block_argmax(double& val, int& idx, double* s
 // (Tcm[k*N + i]): for a node, entries at its first-half rows hold V(:,k) (the block's columns),
 // at its second-half rows U(:,k).
 #define ACA_THREADS 512
+#ifndef ACA_WAVES_PER_EU
+#define ACA_WAVES_PER_EU 4     // one-workgroup nodes: <= 128 registers per lane -- two of these workgroups, or one and 256 registers of other kernels, per SIMD
+#endif
+#ifndef ACA_WAVES_PER_EU_CL
+#define ACA_WAVES_PER_EU_CL 2  // the cooperative launch: the critical chain of phase 1 keeps the registers it wants (no spills)
+#endif
 #define ACA_MAXR 2048          // coefficient slots in LDS: rank <= 2048 (one-workgroup nodes) / 1024 (clusters)
 #define ACA_NC 64              // candidate rows tested per search pass once the search has started failing
 #define ACA_LIDX 4096          // row permutations of one-workgroup nodes live in LDS up to this many rows
@@ -178,12 +184,22 @@ struct AcaSeg {
   const LvlNode* nodes; double* Tcm; int* idx; int* ranks; unsigned* bars; double* part; int* sel; int* fail; int* trunc;
   int level, G, wg0, nwg;
 };
-template <bool FAST>
-__global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
+// CL: the CLUSTER instantiation (G > 1: the cooperative launch of the top levels) without the one-workgroup-only machinery --
+// batched candidate search, LDS mirrors, LDS row permutation; !CL: one workgroup per node (G == 1) without the cluster protocol.
+// One kernel for both needed 225 registers per lane: the cooperative launch -- one 512-thread workgroup on every CU for 1.4 ms,
+// two wavefronts per SIMD -- then held 464 of each SIMD's 512 registers, and nothing else of phase 1 (one-workgroup nodes 225,
+// leaf Cholesky 256, leaf build 127) could share a SIMD with it (profiles/r06/hodlr_phase1_registers.md).
+template <bool FAST, bool CL>
+__global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_PER_EU) void hodlr_aca_kernel(
     const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
-    int G, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc,
-    const AcaSeg* segs, int nseg, int capd) {
+    int G_, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc,
+    const AcaSeg* segs, int nseg, int capd_) {
+  int G = CL ? G_ : 1;
+  const int capd = CL ? 0 : capd_;
+#ifdef ACA_CL_SETPRIO
+  if (CL) __builtin_amdgcn_s_setprio(ACA_CL_SETPRIO);       // the critical chain of phase 1 first at every SIMD's arbiter
+#endif
   __shared__ AcaShared sh;
   extern __shared__ double aca_dyn[];                  // capd > 0: U mirror | V mirror | coordinates (ACA_DYN_BYTES)
   int bid = blockIdx.x;
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     while (q + 1 < nseg && bid >= segs[q].wg0 + segs[q].nwg) ++q;
     const AcaSeg sg = segs[q];
     nodes = sg.nodes; Tcm = sg.Tcm; idx = sg.idx; ranks = sg.ranks; bars = sg.bars; part = sg.part; sel = sg.sel;
-    fail = sg.fail; trunc = sg.trunc; level = sg.level; G = sg.G;
+    fail = sg.fail; trunc = sg.trunc; level = sg.level; G = CL ? sg.G : 1;
     bid -= sg.wg0;
   }
   const int node = bid / G, g = bid % G;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   if (max_rank > rcap) max_rank = rcap;
   // one-workgroup nodes keep the row permutation in LDS (the candidate draws are a serial chain of
   // dependent reads and writes: ~1 us each through HBM, 64 of them per search pass)
-  const bool lperm = (G == 1) && n_rows <= ACA_LIDX;
+  const bool lperm = !CL && (G == 1) && n_rows <= ACA_LIDX;
   // Small one-workgroup nodes (levels 8-10 of C4: 1792 of its 2047 blocks) are a chain of ~10 dependent global round trips
   // per ACA step -- 13 us per step for 128-entry vectors.  They mirror the first `kcap` rows of U and V (and, in 1-D, their
   // coordinates) in LDS: every read of a factor entry below comes from the mirror when its row is there, every write goes to
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
     // 0.75 + 0.6 ms; after the first pass without a hit the batch grows to 64.  Same result as the
     // one-by-one search: the candidates are drawn in the same order, the first that passes wins,
     // and the draws after it are undone (row permutation and generator state restored).
-    while ((multi & 1) && lperm && remaining > 0 && rank <= 32) {
+    while (!CL && (multi & 1) && lperm && remaining > 0 && rank <= 32) {
       int NC = remaining < batch ? remaining : batch;
       if (rank + NC > rcap) NC = rcap - rank;
       if (NC < 1) break;
@@ -514,14 +530,224 @@ __global__ __launch_bounds__(ACA_THREADS) void hodlr_aca_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ACA with ONE WAVEFRONT per node, for the deep levels whose blocks have at most 64 E rows and columns, E = 1, 2, 4 (levels
+// 9 and 10 of C4 -- 256 x 256 and 128 x 128 blocks, 1536 of its 2047 nodes; the workgroup kernel above spent 124 of its
+// 198 ms of workgroup time on them: a 512-thread workgroup, ~10 workgroup barriers and six block-wide reductions per ACA
+// step for vectors of 128 or 256 entries, and one thread drawing up to 64 candidate rows per search pass).  Four nodes per
+// 256-thread workgroup, no workgroup barrier anywhere.  Lane l owns rows and columns l + 64 e, e < E, and keeps ITS entries
+// of the factors found so far (rank <= AW_RW) in registers: U[k][e], V[k][e].  What another lane's entry is needed for --
+// the candidate row's coefficients U(i, :), the pivot column's V(j, :) -- travels by one shuffle per k.  LDS holds only the
+// node's coordinates (1-D) and its row permutation: 4.5 KiB per node at E = 4, so these workgroups find room beside the
+// cooperative launch, the leaf Cholesky and the one-workgroup nodes that share the chip with them in phase 1.
+//
+// SAME BITS as hodlr_aca_kernel with G = 1: the same generator and draws, candidates tested in drawing order (the first
+// whose largest residual entry reaches 1e-14 wins -- what the workgroup kernel's batched search returns), residuals formed by
+// the same expression with k ascending, and every sum reduced by the tree the workgroup kernel uses for <= 512 entries: there
+// thread t holds element t alone, wavefront q reduces elements 64 q .. 64 q + 63 with the shfl_down tree and the wavefront
+// results are added in order; here lane l holds elements l + 64 e, "virtual wavefront" e reduced by the same tree, then
+// added in order.  Ranks, factors, log-determinants do not change by a bit (tests/test_gpu_hodlr.py).
+// A node that needs more than AW_RW_OF(E) columns is NOT cut short: the launch raises the level's `trunc` word to 2 and the host
+// redoes the level with the workgroup kernel (and remembers it for the handle's next compute()).
+// rank capacity of the register mirrors: 8 columns, 6 where a lane holds four entries of each (256 x 256 blocks: 96 instead of 128
+// registers of mirrors -- with 8 the kernel spilled 560 bytes per lane)
+#define AW_RW_OF(E) ((E) >= 4 ? 6 : 8)
+#define AW_NODES 4              // nodes (wavefronts) per workgroup
+// (the lane's E entries of a vector as a clang extended vector, not an array: a run-time element index -- the candidate row's
+//  slot -- is then an extractelement the backend lowers to selects; on arrays, however the selects were spelt, the optimiser
+//  folded them back into a run-time array index and moved U and V to scratch memory)
+template <int E> struct AwVec { typedef double type __attribute__((ext_vector_type(E))); };
+template <> struct AwVec<1> { typedef double type __attribute__((ext_vector_type(2))); };      // (one entry used)
+template <int E>
+__device__ __forceinline__ double aw_sum(const typename AwVec<E>::type& x) {
+  // (hw_block_sum of the workgroup kernel for <= 64 E entries: t = 0 + wave0 + wave1 + ...)
+  double t = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) t += __shfl(hw_wave_sum(x[e]), 0, 64);
+  return t;
+}
+template <int E>
+__device__ __forceinline__ double aw_pick(const typename AwVec<E>::type& x, int slot) {      // x[slot], slot wave-uniform
+  return E == 1 ? x[0] : x[slot];
+}
+template <bool FAST, int E>
+__global__ __launch_bounds__(64 * AW_NODES) void hodlr_aca_wave_kernel(
+    const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, int n_nodes, double* Tcm, long N,
+    int rcap, int* ranks, double tol, unsigned long long seed, int level, int* trunc) {
+  constexpr int MR = 64 * E;                            // rows / columns capacity
+  constexpr int AW_RW = AW_RW_OF(E);
+  __shared__ double xs_all[AW_NODES][2 * MR];           // 1-D: [0, MR) row coordinates, [MR, 2 MR) column coordinates
+  __shared__ unsigned short lidx_all[AW_NODES][MR];     // row permutation
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int node = blockIdx.x * AW_NODES + wave;
+  if (node >= n_nodes) return;                          // (no workgroup barrier in this kernel)
+  double* const xs = xs_all[wave];
+  unsigned short* const lidx = lidx_all[wave];
+  const LvlNode nodev = nodes[node];
+  const int col0 = nodev.start, n_cols = nodev.half;
+  const int row0 = nodev.start + nodev.half, n_rows = nodev.size - nodev.half;
+  const bool xlds = nd == 1;
+  bool cm[E], rm[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { cm[e] = lane + 64 * e < n_cols; rm[e] = lane + 64 * e < n_rows; }
+  if (xlds) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (rm[e]) xs[lane + 64 * e] = x[row0 + lane + 64 * e];
+      if (cm[e]) xs[MR + lane + 64 * e] = x[col0 + lane + 64 * e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) if (rm[e]) lidx[lane + 64 * e] = (unsigned short)(lane + 64 * e);
+  auto xrow = [&](int m) -> const double* { return xlds ? (const double*)(xs + m) : x + (long)(row0 + m) * nd; };
+  auto xcol = [&](int n) -> const double* { return xlds ? (const double*)(xs + MR + n) : x + (long)(col0 + n) * nd; };
+  auto kval = [&](const double* a, const double* b) -> double { return FAST ? gh_fast_value(fast, a, b) : gh_eval_value(prog, n_prog, a, b); };
+  const int full_rank = n_rows < n_cols ? n_rows : n_cols;
+  int max_rank = full_rank;
+  if (max_rank > rcap) max_rank = rcap;
+  int remaining = n_rows, rank = 0;
+  double norm = 0.0;
+  const double tol2 = tol * tol;
+  bool converged = false;
+  unsigned long long st = seed ^ ((unsigned long long)(level + 1) << 40) ^ ((unsigned long long)(node + nodev.pad) * 0x9E3779B97F4A7C15ull);
+  typedef typename AwVec<E>::type VE;
+  VE U[AW_RW], V[AW_RW];
+#pragma unroll
+  for (int k = 0; k < AW_RW; ++k) { U[k] = (VE)(0.0); V[k] = (VE)(0.0); }
+  __builtin_amdgcn_s_waitcnt(0);                        // (the wavefront's own LDS writes above)
+  __builtin_amdgcn_wave_barrier();
+  while (rank < max_rank) {
+    if (rank >= AW_RW) {                                // more columns than the mirrors hold: the level goes to the workgroup kernel
+      if (lane == 0) atomicMax(trunc, 2);
+      return;
+    }
+    // ---- a random unused row with a non-negligible residual (hodlr.h:159-191): candidates one by one, in drawing order
+    bool got = false;
+    VE v = (VE)(0.0);
+    while (remaining > 0) {
+      st += 0x9E3779B97F4A7C15ull;
+      unsigned long long z = st;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      const int kk = (int)(z % (unsigned long long)remaining);
+      const int i = __builtin_amdgcn_readfirstlane((int)lidx[kk]);
+      __builtin_amdgcn_wave_barrier();                  // (every lane has read lidx[kk] before lane 0 overwrites it)
+      if (lane == 0) lidx[kk] = lidx[remaining - 1];
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      --remaining;
+      const int si = i >> 6, li = i & 63;
+      double cw[AW_RW];
+#pragma unroll
+      for (int k = 0; k < AW_RW; ++k) cw[k] = (k < rank) ? __shfl(aw_pick<E>(U[k], si), li, 64) : 0.0;       // U(i, k)
+      const double* xi = xrow(i);
+      bool hit = false;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        double t = cm[e] ? kval(xi, xcol(lane + 64 * e)) : 0.0;
+#pragma unroll
+        for (int k = 0; k < AW_RW; ++k) if (k < rank) t -= cw[k] * V[k][e];
+        v[e] = t;
+        hit = hit || (cm[e] && fabs(t) >= 1e-14);       // hodlr.h:191 on the row's largest entry
+      }
+      if (__any(hit)) { got = true; break; }
+    }
+    if (!got) { converged = true; break; }              // rows exhausted (see hodlr_aca_kernel)
+    // ---- pivot: largest |entry|, smallest column on ties
+    int j;
+    double pivot;
+    {
+      double best = -1.0;
+      int bestn = -1;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const double a = cm[e] ? fabs(v[e]) : -1.0; if (cm[e] && a > best) { best = a; bestn = lane + 64 * e; } }
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bestn, off, 64);
+        if (ov > best || (ov == best && oi >= 0 && (bestn < 0 || oi < bestn))) { best = ov; bestn = oi; }
+      }
+      j = __builtin_amdgcn_readfirstlane(bestn);
+      pivot = __shfl(aw_pick<E>(v, j >> 6), j & 63, 64);
+    }
+    // ---- normalise the row by its pivot, build the column (hodlr.h:194-199)
+    VE vn = (VE)(0.0), un = (VE)(0.0), u = (VE)(0.0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (cm[e]) { v[e] = v[e] / pivot; Tcm[(long)rank * N + col0 + lane + 64 * e] = v[e]; vn[e] = v[e] * v[e]; }
+    }
+    double cv[AW_RW];
+#pragma unroll
+    for (int k = 0; k < AW_RW; ++k) cv[k] = (k < rank) ? __shfl(aw_pick<E>(V[k], j >> 6), j & 63, 64) : 0.0;   // V(j, k)
+    const double* xj = xcol(j);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      double t = rm[e] ? kval(xrow(lane + 64 * e), xj) : 0.0;
+#pragma unroll
+      for (int k = 0; k < AW_RW; ++k) if (k < rank) t -= cv[k] * U[k][e];
+      u[e] = t;
+      if (rm[e]) { Tcm[(long)rank * N + row0 + lane + 64 * e] = t; un[e] = t * t; }
+    }
+    // (column `rank` of the mirrors: selects with constant register indices -- written as `if (k == rank) V[k][e] = ...` the
+    //  compiler turned the chain back into V[rank][e], a run-time index, and moved both arrays to scratch memory)
+#pragma unroll
+    for (int k = 0; k < AW_RW; ++k) {
+      const bool here = (k == rank);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        V[k][e] = here ? (cm[e] ? v[e] : 0.0) : V[k][e];
+        U[k][e] = here ? (rm[e] ? u[e] : 0.0) : U[k][e];
+      }
+    }
+    ++rank;
+    if (rank >= full_rank) { converged = true; break; }                                // hodlr.h:203
+    if (rank >= max_rank) break;                                                       // rank cap: NOT converged
+    const double un2 = aw_sum<E>(un), vn2 = aw_sum<E>(vn);
+    // cross terms |u_new . u_k|, |v_new . v_k|, k < rank - 1 (hodlr.h:210-214)
+    double maxu = 0.0, maxv = 0.0;
+#pragma unroll
+    for (int k = 0; k < AW_RW - 1; ++k)
+      if (k < rank - 1) {
+        VE pu = (VE)(0.0), pv = (VE)(0.0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { pu[e] = rm[e] ? U[k][e] * u[e] : 0.0; pv[e] = cm[e] ? V[k][e] * v[e] : 0.0; }
+        const double a = aw_sum<E>(pu), b = aw_sum<E>(pv);
+        if (fabs(a) > maxu) maxu = fabs(a);
+        if (fabs(b) > maxv) maxv = fabs(b);
+      }
+    const double rowcol = un2 * vn2;
+    if (rowcol < tol2 * norm) { converged = true; break; }                             // hodlr.h:206-207
+    norm += rowcol;
+    if (rank > 1) norm += 2.0 * maxu + 2.0 * maxv;
+  }
+  if (lane == 0) {
+    ranks[node] = rank;
+    if (!converged && rank < full_rank) atomicMax(trunc, 1);     // stopped by the caller's cap, not by the tolerance
+  }
+}
+
+// 1 (default): the deep levels whose blocks have <= 256 rows and columns through hodlr_aca_wave_kernel; 0: every level through the
+// workgroup kernel (A/B and the same-bits test)
+static int g_hodlr_coop_wgs = 256;      // workgroups of the cooperative ACA launch (<= CUs: every cluster resident)
+extern "C" int gh_debug_set_hodlr_coop_wgs(int n) {
+  const int prev = g_hodlr_coop_wgs;
+  g_hodlr_coop_wgs = n < 32 ? 32 : (n > 256 ? 256 : n);
+  return prev;
+}
+static int g_hodlr_wave_aca = 1;
+extern "C" int gh_debug_set_hodlr_wave_aca(int on) {
+  const int prev = g_hodlr_wave_aca;
+  g_hodlr_wave_aca = on ? 1 : 0;
+  return prev;
+}
 // (static + dynamic LDS of a launch with the mirrors is 67 KiB: above the 64 KiB a kernel gets without asking; per device)
 static int aca_lds_attr() {
   static thread_local unsigned long long done = 0;
   int dev = 0;
   GH_HIP(hipGetDevice(&dev));
   if (dev < 64 && (done >> dev & 1ull)) return GH_OK;
-  GH_HIP(hipFuncSetAttribute((const void*)hodlr_aca_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ACA_DYN_BYTES));
-  GH_HIP(hipFuncSetAttribute((const void*)hodlr_aca_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ACA_DYN_BYTES));
+  GH_HIP(hipFuncSetAttribute((const void*)hodlr_aca_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ACA_DYN_BYTES));
+  GH_HIP(hipFuncSetAttribute((const void*)hodlr_aca_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ACA_DYN_BYTES));
   if (dev < 64) done |= 1ull << dev;
   return GH_OK;
 }
@@ -1403,6 +1629,7 @@ struct gh_hodlr {
   hipEvent_t aca_fused_ev[2] = {nullptr, nullptr};
   bool aca_timed = false;
   std::vector<double> aca_ms;            // measured milliseconds: [0..nlev) levels, [nlev] fused launch, [nlev+1] leaf stage
+  std::vector<char> wave_bad;            // per level: a block needed more columns than the wavefront-per-node ACA holds (hodlr_aca_wave_kernel): the workgroup kernel from then on
   int64_t n = 0;
   int ndim = 0;
   bool computed = false;
@@ -1438,7 +1665,7 @@ struct gh_hodlr {
   int64_t tree_n = -1;
   int tree_min = -1;
   bool leaf_tab_up = false;
-  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); tree_n = -1; leaf_tab_up = false; col_Rtot = -1; col_sig.clear(); aca_ms.clear(); }
+  void reset_tree() { for (auto* l : levels) delete l; levels.clear(); nodes.clear(); leaves.clear(); tree_n = -1; leaf_tab_up = false; col_Rtot = -1; col_sig.clear(); aca_ms.clear(); wave_bad.clear(); }
 };
 
 extern "C" int gh_hodlr_create(const gh_hodlr_opts* opts, gh_hodlr** out) {
@@ -2437,7 +2664,16 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   std::vector<GhBuf*> levelB(nlev, nullptr);
   struct Cleanup { std::vector<GhBuf*>& v; ~Cleanup() { for (auto* b : v) delete b; } } cleanup{levelB};
   const int pstride = 8 + 2 * ACA_MAXR;
-  // enqueue the ACA of level l with column capacity rc on stream sx (no synchronisation)
+  // 0: level l goes through the workgroup kernel; 64 / 128 / 256: every block of the level has at most that many rows and
+  // columns and the level goes through hodlr_aca_wave_kernel
+  if ((int)h->wave_bad.size() != nlev) h->wave_bad.assign(nlev, 0);
+  auto wave_mr = [&](int l) -> int {
+    if (!g_hodlr_wave_aca || h->wave_bad[l] || h->levels[l]->top || al[l].G != 1) return 0;
+    int mx = 0;
+    for (int id : h->levels[l]->node_ids) { const HNode& nd = h->nodes[id]; mx = std::max(mx, std::max(nd.half, nd.size - nd.half)); }
+    // (the interpreter's registers beside 128 of mirrors would spill: kernels off the a + b F(r^2) form stop at 128 x 128)
+    return mx <= 64 ? 64 : mx <= 128 ? 128 : (mx <= 256 && k->fast.ok) ? 256 : 0;
+  };
   // buffers of level l for column capacity rc, counters cleared on stream sx
   auto prepare_level = [&](int l, int rc, hipStream_t sx) -> int {
     HLevel* L = h->levels[l];
@@ -2468,13 +2704,25 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     unsigned* d_bars = (unsigned*)a.syncp;
     int* d_sel = (int*)(d_bars + nn);
     int* d_fail = d_sel + nn;
-#define GH_ACA_LAUNCH(F)                                                                                          \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(nn * a.G), dim3(ACA_THREADS), a.G == 1 ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),  \
+    if (const int mr = wave_mr(l)) {                       // blocks of <= 256 x 256: a wavefront per node
+#define GH_ACA_WAVE(F, EE)                                                                                        \
+      hipLaunchKernelGGL((hodlr_aca_wave_kernel<F, EE>), dim3((nn + AW_NODES - 1) / AW_NODES), dim3(64 * AW_NODES), 0, sx, \
+                         k->d_nodes, (int)k->nodes.size(), k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, nn, T.d(), (long)n, rc, \
+                         (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l, d_fail + 1)
+      if (k->fast.ok) { if (mr == 64) GH_ACA_WAVE(true, 1); else if (mr == 128) GH_ACA_WAVE(true, 2); else GH_ACA_WAVE(true, 4); }
+      else            { if (mr == 64) GH_ACA_WAVE(false, 1); else GH_ACA_WAVE(false, 2); }
+#undef GH_ACA_WAVE
+      GH_HIP(hipGetLastError());
+      return GH_OK;
+    }
+#define GH_ACA_LAUNCH(F, CLU)                                                                                          \
+    hipLaunchKernelGGL((hodlr_aca_kernel<F, CLU>), dim3(nn * a.G), dim3(ACA_THREADS), a.G == 1 ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),  \
                        k->fast, ndim, h->x.d(), (const LvlNode*)L->d_nodes.p, T.d(), (long)n, rc, (int*)a.idx.p,     \
                        (int*)L->d_ranks.p, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, l,               \
                        a.G, d_bars, a.part.d(), pstride, d_sel, d_fail, aca_multi, aca_fence, d_fail + 1,            \
                        (const AcaSeg*)nullptr, 0, a.G == 1 ? ACA_CAPD : 0)
-    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+    if (a.G == 1) { if (k->fast.ok) GH_ACA_LAUNCH(true, false); else GH_ACA_LAUNCH(false, false); }
+    else          { if (k->fast.ok) GH_ACA_LAUNCH(true, true); else GH_ACA_LAUNCH(false, true); }
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
     return GH_OK;
@@ -2499,13 +2747,14 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       wg += nn * a.G;
     }
     GH_CHECK(upload(segbuf, segs, sx));
-#define GH_ACA_LAUNCH(F)                                                                                          \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(wg), dim3(threads), ones_only ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),    \
+#define GH_ACA_LAUNCH(F, CLU)                                                                                          \
+    hipLaunchKernelGGL((hodlr_aca_kernel<F, CLU>), dim3(wg), dim3(threads), ones_only ? ACA_DYN_BYTES : 0, sx, k->d_nodes, (int)k->nodes.size(),    \
                        k->fast, ndim, h->x.d(), (const LvlNode*)nullptr, (double*)nullptr, (long)n, rc, (int*)nullptr, \
                        (int*)nullptr, h->opts.tol, (unsigned long long)(unsigned)h->opts.seed, 0,                     \
                        1, (unsigned*)nullptr, (double*)nullptr, pstride, (int*)nullptr, (int*)nullptr, aca_multi, aca_fence, \
                        (int*)nullptr, (const AcaSeg*)segbuf.p, (int)segs.size(), ones_only ? ACA_CAPD : 0)
-    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+    if (ones_only) { if (k->fast.ok) GH_ACA_LAUNCH(true, false); else GH_ACA_LAUNCH(false, false); }
+    else           { if (k->fast.ok) GH_ACA_LAUNCH(true, true); else GH_ACA_LAUNCH(false, true); }
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
     return GH_OK;
@@ -2528,6 +2777,15 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     for (;;) {
       if (a.flags[0]) { gh_set_error("HODLR: cluster barrier of the ACA kernel timed out at level %d", l); return GH_ERR_HIP; }
       if (!a.flags[1]) return GH_OK;
+      if (a.flags[1] >= 2) {
+        // a block of this level asked the wavefront-per-node kernel for more than AW_RW_OF(E) columns: the level again, with the
+        // workgroup kernel (same draws, same results), and the handle remembers it for its next compute()
+        h->wave_bad[l] = 1;
+        GH_CHECK(enqueue_level(l, a.rcap, st));
+        GH_CHECK(fetch_level(l, st));
+        GH_HIP(hipStreamSynchronize(st));
+        continue;
+      }
       // hodlr.h:147 lets the rank grow to min(rows, cols); a cut-short block would be a silently wrong answer
       if (user_cap || a.rcap >= RANK_CAP) {
         gh_set_error("HODLR: an off-diagonal block of level %d needs a rank above %d to reach tol = %g (%s); "
@@ -2622,7 +2880,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         for (int id : h->levels[l]->node_ids) mh = std::min(mh, h->nodes[id].half);
         half[l] = mh;
         int G = 1;
-        while (G * 2 <= gmax[l] && nn * G * 2 <= 32) G *= 2;
+        while (G * 2 <= gmax[l] && nn * G * 2 <= g_hodlr_coop_wgs / 8) G *= 2;
         al[l].G = G;
         if (G > 1) total += nn * G;              // (a level left with one workgroup per node goes to the other stream)
       }
@@ -2631,7 +2889,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         double load = 0.0;
         for (int l : cl) {
           const int nn = (int)h->levels[l]->node_ids.size();
-          if (al[l].G < 2 || al[l].G * 2 > gmax[l] || total + nn * al[l].G > 256) continue;
+          if (al[l].G < 2 || al[l].G * 2 > gmax[l] || total + nn * al[l].G > g_hodlr_coop_wgs) continue;
           const double ld = (double)half[l] / al[l].G;
           if (ld > load) { load = ld; best = l; }
         }
@@ -2671,8 +2929,28 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       // compute()'s durations, and the queue that drew the two slowest levels ended 0.4 ms after the others.  One grid
       // leaves the balancing to the dispatcher: C4 5.36 -> 5.24 ms.  (EVERY level in one grid, clustered segments first, was
       // no better: 5.30.)
+      // the deep levels that take the wavefront-per-node kernel: launches of their own, first, on the fourth queue (the
+      // process-wide chain stream: high priority) where there is one
+      bool wave_on_d = false;
+      {
+        std::vector<int> keep;
+        hipStream_t sw = h->st_d ? h->st_d : h->st_b;
+        for (int l : ones) {
+          if (!wave_mr(l)) { keep.push_back(l); continue; }
+          if (sw == h->st_d && !wave_on_d) { GH_HIP(hipStreamWaitEvent(h->st_d, h->ev_b, 0)); wave_on_d = true; }
+          GH_CHECK(enqueue_level(l, rcap0, sw));
+        }
+        ones.swap(keep);
+        if (wave_on_d) { GH_HIP(hipEventRecord(h->ev_d, h->st_d)); GH_HIP(hipStreamWaitEvent(st, h->ev_d, 0)); }
+      }
       if (ones.size() >= 2 && h->st_c) {
         std::sort(ones.begin(), ones.end());
+#ifdef ACA_ONES_DEEPEST_FIRST
+        std::reverse(ones.begin(), ones.end());
+#endif
+#ifdef ACA_ONES_LAST_FIRST
+        std::rotate(ones.begin(), ones.end() - 1, ones.end());       // deepest level first, then by decreasing block size
+#endif
         GH_HIP(hipStreamWaitEvent(h->st_c, h->ev_b, 0));
         if (h->st_d) GH_HIP(hipStreamWaitEvent(h->st_d, h->ev_b, 0));
         // (round 5, measured and left out -- HISTORY.md: the leaf chain first and this launch behind it: +1.5 %; the levels with
@@ -3184,12 +3462,13 @@ int aca_top_node(gh_hodlr* h, gh_kernel* k, const double* x_dev, long N, int ndi
     unsigned* d_bars = (unsigned*)sync.p;
     int* d_sel = (int*)(d_bars + 1);
     int* d_fail = d_sel + 1;
-#define GH_ACA_LAUNCH(F)                                                                                               \
-    hipLaunchKernelGGL(hodlr_aca_kernel<F>, dim3(G), dim3(ACA_THREADS), G == 1 ? ACA_DYN_BYTES : 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, \
+#define GH_ACA_LAUNCH(F, CLU)                                                                                               \
+    hipLaunchKernelGGL((hodlr_aca_kernel<F, CLU>), dim3(G), dim3(ACA_THREADS), G == 1 ? ACA_DYN_BYTES : 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, \
                        ndim, x_dev, (const LvlNode*)d_node.p, Tcm.d(), N, rc, (int*)idx.p, (int*)d_rank.p, h->opts.tol,  \
                        (unsigned long long)(unsigned)h->opts.seed, level, G, d_bars, part.d(), pstride, d_sel, d_fail,   \
                        aca_multi, aca_fence, d_fail + 1, (const AcaSeg*)nullptr, 0, G == 1 ? ACA_CAPD : 0)
-    if (k->fast.ok) GH_ACA_LAUNCH(true); else GH_ACA_LAUNCH(false);
+    if (G == 1) { if (k->fast.ok) GH_ACA_LAUNCH(true, false); else GH_ACA_LAUNCH(false, false); }
+    else        { if (k->fast.ok) GH_ACA_LAUNCH(true, true); else GH_ACA_LAUNCH(false, true); }
 #undef GH_ACA_LAUNCH
     GH_HIP(hipGetLastError());
     int flags[2] = {0, 0};

@@ -31,6 +31,13 @@ int gh_debug_set_hodlr_passes(int mask);
 /* 1: HODLR leaves of 129 .. 256 rows through the in-place pivoted Gauss-Jordan (what leaves of more than 256 rows take) instead of
  * the 2 x 2 blocked Cholesky; returns the previous setting (validation arm) */
 int gh_debug_set_hodlr_leaf_gj(int on);
+/* 1 (default): the ACA of tree levels whose blocks have at most 128 rows and columns runs with one wavefront per node
+ * (hodlr_aca_wave_kernel); 0: every level with one workgroup per node.  Same ranks and factors, bit for bit; returns the
+ * previous setting. */
+int gh_debug_set_hodlr_wave_aca(int on);
+/* workgroups the cooperative ACA launch of the top tree levels may use (32 .. 256, default 256: one per CU); returns the previous
+ * value.  Same draws; the cluster sizes change the reduction trees, so results agree to rounding, not bit for bit. */
+int gh_debug_set_hodlr_coop_wgs(int n);
 /* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */

@@ -371,6 +371,46 @@ def test_shared_passes_match_separate_launches(n):
         np.testing.assert_allclose(got[m][2], got[0][2], rtol=0, atol=1e-9 * np.abs(got[0][2]).max())
 
 
+@pytest.mark.parametrize("case", ["c4_4096", "c4_16384", "c4_65536", "min50", "ragged_3000", "default_tol", "interp_sum", "overflow_3d", "matern_tight"])
+def test_wave_per_node_aca_gives_the_same_bits(case):
+    """hodlr_aca_wave_kernel (one wavefront per node for blocks of <= 256 x 256 -- 64 / 128 / 256: one, two, four entries per lane;
+    min50: 64 x 64 blocks -- four nodes per workgroup, no workgroup barrier)
+    against the one-workgroup-per-node kernel (gh_debug_set_hodlr_wave_aca(0)): same generator, same draws, the workgroup
+    kernel's reduction trees -- ranks, log-determinant, solves IDENTICAL.  overflow_3d / matern_tight: deep blocks that need more
+    than the wavefront kernel's eight (six for 256 x 256 blocks) columns -- the level is redone with the workgroup kernel (and on the handle's second
+    compute() goes there directly): still identical."""
+    if case == "overflow_3d":
+        x, yerr, y = zoo.bench_data(3000, ndim=3)
+        kernel = kernels.Matern52Kernel(0.5, ndim=3) + kernels.ConstantKernel(log_constant=np.log(0.1 / 3), ndim=3)
+        X, kw = np.ascontiguousarray(x), dict(tol=1e-6)
+    else:
+        n = {"c4_4096": 4096, "c4_16384": 16384, "c4_65536": 65536, "min50": 4096, "ragged_3000": 3000, "default_tol": 10000, "interp_sum": 5000, "matern_tight": 6000}[case]
+        x, yerr, y = zoo.bench_data(n)
+        X = x[:, None]
+        if case == "interp_sum":
+            kernel = 0.3 * kernels.ExpSquaredKernel(1.0) + 0.2 * kernels.Matern32Kernel(2.0)      # two stationary leaves: the interpreter
+        elif case == "matern_tight":
+            kernel = np.var(y) * kernels.Matern32Kernel(1.0)
+        else:
+            kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+        kw = dict(tol=0.1) if case == "default_tol" else dict(tol=1e-10, min_size=50) if case == "min50" else dict(tol=1e-10)
+    got = {}
+    try:
+        for mode in (0, 1):
+            N.lib.gh_debug_set_hodlr_wave_aca(mode)
+            s = HODLRSolver(kernel, **kw)
+            s.compute(X, yerr)
+            first = (s.log_determinant, s.dot_solve(y), s.apply_inverse(y), list(s.ranks()))
+            s.compute(X, yerr)                                     # (second compute() of the handle: overflowed levels remembered)
+            assert s.log_determinant == first[0] and s.dot_solve(y) == first[1]
+            got[mode] = first
+    finally:
+        N.lib.gh_debug_set_hodlr_wave_aca(1)
+    assert got[1][0] == got[0][0] and got[1][1] == got[0][1]
+    assert np.array_equal(got[1][2], got[0][2])
+    assert got[1][3] == got[0][3]
+
+
 def test_parked_handles_are_bounded_and_reused():
     """A dropped HODLRSolver parks its native handle for the next solver with the same options (GP makes a new solver
     per compute, gp.py:327): at most two per option set and four in all, oldest option set evicted first."""
