@@ -105,6 +105,7 @@ SIGNATURES = {
     "gh_microbench_hbm_copy": (C.c_int, [C.POINTER(C.c_double)]),
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
     "gh_debug_set_gemm_sp": (C.c_int, [C.c_int]),
+    "gh_debug_set_adaptive_panels": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_passes": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_leaf_gj": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_wave_aca": (C.c_int, [C.c_int]),

@@ -534,7 +534,7 @@ struct gh_chol {
   hipStream_t st3 = nullptr;             // second panel stream: rows-below TRSM beside the potf2 chain
   bool shared_streams = false;           // st, st2, st3, st4, st_mask belong to the process (gh_shared_streams): not destroyed here
   hipStream_t st4 = nullptr;             // third panel stream: in-panel rows >= j+2 (everything off the potf2 chain)
-  hipEvent_t ev_diag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_diag[32] = {};             // one per 128-column step of a panel (panels of up to 4096 columns)
   hipEvent_t ev_aux = nullptr, ev_aux2 = nullptr;
   std::vector<hipEvent_t> ev_p, ev_w, ev_nf;   // deep look-ahead: panel j factored / W(j) done / U(j, j+2) done
   hipStream_t st_mask = nullptr;         // main-stream stand-in that leaves CUs to the panel chain (small N)
@@ -924,6 +924,36 @@ static int64_t panel_width(const gh_chol* s) {
   //  1024 wins or ties everywhere -- 512 used to win between 4096 and 12288, when a chain link cost twice as much)
   return 1024;
 }
+// Start columns of the outer panels, pc[0] = 0 < pc[1] < ... < pc[P] = Np.  With the width left to the solver (opts.nb == 0) the
+// panels are 2048 columns wide while the trailing matrix behind them is larger than GH_WIDE_PANEL_MIN_TRAILING columns and 1024
+// after (round 6; round 5 measured a uniform 2048 at -1.4 % for N = 65536 and +3.6 % for N = 32768: the K = 2048 update runs its
+// tiles 2 % faster and halves the launches, but a 2048-column panel is sixteen chain links + a block-column update twice as
+// deep, which only a trailing update of more than ~20 ms hides -- at 66 TFLOP/s that is a trailing matrix of ~25 000 columns).
+#ifndef GH_WIDE_PANEL_MIN_TRAILING
+#define GH_WIDE_PANEL_MIN_TRAILING 25600
+#endif
+static int g_adaptive_panels = 1;        // 0: off; 1: on (GH_WIDE_PANEL_MIN_TRAILING); > 1: on with this many trailing columns as the bound
+extern "C" int gh_debug_set_adaptive_panels(int on) {
+  const int prev = g_adaptive_panels;
+  g_adaptive_panels = on < 0 ? 1 : on;
+  return prev;
+}
+static std::vector<int64_t> panel_starts(const gh_chol* s) {
+  std::vector<int64_t> pc;
+  const int64_t np = s->np, nb = panel_width(s);
+  const bool adaptive = s->opts.nb == 0 && g_adaptive_panels && !use_simple_potf2();
+  for (int64_t k0 = 0; k0 < np;) {
+    pc.push_back(k0);
+    const int64_t bound = g_adaptive_panels > 1 ? g_adaptive_panels : GH_WIDE_PANEL_MIN_TRAILING;
+    int64_t w = (adaptive && np - (k0 + 2 * nb) >= bound) ? 2 * nb : nb;
+#ifdef GH_WIDE_PANEL_TIER2
+    if (adaptive && np - (k0 + 4 * nb) >= GH_WIDE_PANEL_TIER2) w = 4 * nb;
+#endif
+    k0 += std::min<int64_t>(w, np - k0);
+  }
+  pc.push_back(np);
+  return pc;
+}
 
 // One panel step: factor the nb x nb diagonal block at k0, TRSM the rows below it.
 static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
@@ -935,7 +965,7 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   // (Retired arms, all measured and slower, sources under scripts/dev/arms/: only row block j+1 on the chain and the
   //  other in-panel rows on a third stream; the chain on CUs of its own; only the potf2 launches on reserved CUs; the
   //  whole panel as two persistent flag-driven launches.  DESIGN.md section 4, "Where N < 24k stands".)
-  if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 8 || use_simple_potf2()) {
+  if (!s->st3 || !on_panel_stream || m <= 0 || nb / T > 32 || use_simple_potf2()) {
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, dinv, s->d_info, k0));
     if (m > 0) {
       GH_CHECK(trsm_right(st, blk(A, ld, k0, k0), ld, dinv, blk(A, ld, k0 + nb, k0), ld, m, nb));
@@ -1042,18 +1072,19 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
 #ifndef GH_FULLCHIP_MS
 #define GH_FULLCHIP_MS 2.5
 #endif
+  const std::vector<int64_t> pc = panel_starts(s);
   auto wide_stream = [&](int j) -> hipStream_t {
     if (sm == s->st) return sm;
     const int cwj = j + depth + 1;
-    if (cwj > (int)((s->np + panel_width(s) - 1) / panel_width(s)) - 1) return sm;
-    const double m2 = (double)(s->np - (int64_t)cwj * panel_width(s));
-    const double ms = (m2 / T) * (m2 / T + 1.0) / 2.0 * 2.0 * T * T * (double)panel_width(s) / 60e12 * 1e3;
+    if (j < 0 || cwj > (int)pc.size() - 2) return sm;
+    const double m2 = (double)(s->np - pc[cwj]);
+    const double ms = (m2 / T) * (m2 / T + 1.0) / 2.0 * 2.0 * T * T * (double)(pc[j + 1] - pc[j]) / 60e12 * 1e3;
     return ms > GH_FULLCHIP_MS ? s->st : sm;
   };
   hipStream_t sw_prev = nullptr;
   double* A = s->A.d();
-  const int64_t np = s->np, ld = np, NB = panel_width(s);
-  const int P = (int)((np + NB - 1) / NB);
+  const int64_t np = s->np, ld = np;
+  const int P = (int)pc.size() - 1;
   // (measured at N = 16384, depth 1: whole block column on the chain 34.8 ms; diagonal block on the chain + rows
   //  below on the near stream 35.6; the same with the chain on CUs of its own 48.5 -- retired, scripts/dev/arms/)
   const bool prof = s->opts.profile != 0;
@@ -1062,8 +1093,8 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     for (auto& x : e) GH_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
     s->ev_p.push_back(e[0]); s->ev_w.push_back(e[1]); s->ev_nf.push_back(e[2]);
   }
-  auto c0 = [&](int c) { return (int64_t)c * NB; };
-  auto nbc = [&](int c) { return std::min<int64_t>(NB, np - c0(c)); };
+  auto c0 = [&](int c) { return pc[c]; };
+  auto nbc = [&](int c) { return pc[c + 1] - pc[c]; };
   auto narrow = [&](hipStream_t st, int j, int c) -> int {         // U(j, c)
     const double* Pj = blk(A, ld, c0(c), c0(j));
     const long eu = prof ? s->next_ev() : -1;
@@ -1184,7 +1215,7 @@ static int factor(gh_chol* s) {
       guard(s->opts.lookahead && s->st2 && trailing_stream(s) == s->st);       // no CUs kept free of the SYRK
   // (a matrix of ONE panel has nothing to look ahead to: on the main stream it saves the two cross-stream hand-overs,
   //  ~35 us each -- a tenth of the step at N = 1024)
-  if (s->opts.lookahead && s->st2 && s->st3 && s->st4 && s->np > panel_width(s)) return factor_lookahead_deep(s, lookahead_depth(s));
+  if (s->opts.lookahead && s->st2 && s->st3 && s->st4 && s->np > panel_width(s)) return factor_lookahead_deep(s, lookahead_depth(s));      // (panel widths: panel_starts())
   hipStream_t st = s->st;
   double* A = s->A.d();
   const int64_t np = s->np, ld = np, NB = panel_width(s);

@@ -23,6 +23,10 @@ int gh_debug_set_mfma(int mode);
 /* the k-major x k-major GEMM kernel with its slab loop software-pipelined by half a slab (gemm_f64_mfma_dma_sp): 1 on, 0 off,
  * -1 the build's default; returns the previous mode.  Same bits either way (tests/test_gpu_gemm.py). */
 int gh_debug_set_gemm_sp(int mode);
+/* 1 (default): with the panel width left to the solver (gh_chol_opts.nb == 0) the outer panels are 2048 columns wide while the
+ * trailing matrix behind them has more than 25 600 columns and 1024 after; 0: 1024 throughout; n > 1: the bound is n columns.
+ * Returns the previous setting.  Same bits whatever the widths (the update adds the same k in the same order). */
+int gh_debug_set_adaptive_panels(int on);
 /* HODLR passes that serve two levels at once (round 5): bit 0 = the narrow solve (update of level l + chunk products of the
  * next level in one pass over the rows, "sum + core product" in one launch, symmetric leaf product), bit 1 = the factorisation
  * sweep's update of level l + reduce of the next level in one pass over U; -1: the default (both); returns the previous mask.

@@ -541,6 +541,30 @@ def test_panel_width_does_not_change_result(nb):
     assert abs(gp.log_likelihood(y) - base.log_likelihood(y)) <= 1e-10 * abs(base.log_likelihood(y))
 
 
+def test_adaptive_panel_width_gives_the_same_bits():
+    """Round 6: with the panel width left to the solver, panels are 2048 columns wide while more than 25 600 columns of trailing
+    matrix lie behind them, 1024 after (gh_chol.hip, panel_starts).  A wide update adds the same k-steps in the same order as the
+    two narrow ones it replaces: the factor is IDENTICAL -- log-determinant, quadratic form and alpha bit for bit.  N = 30000:
+    three wide panels, then 1024s (and a ragged last panel)."""
+    from george_amd import _native as N
+    n = 30000
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    got = {}
+    try:
+        for mode in (0, 1, 8192):                       # off / default bound / wide panels far into the matrix
+            N.lib.gh_debug_set_adaptive_panels(mode)
+            s = BasicSolver(kernel)
+            s.compute(x[:, None], yerr)
+            got[mode] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(y))
+            del s
+    finally:
+        N.lib.gh_debug_set_adaptive_panels(1)
+    for mode in (1, 8192):
+        assert got[mode][0] == got[0][0] and got[mode][1] == got[0][1]
+        assert np.array_equal(got[mode][2], got[0][2])
+
+
 def test_full_size_c2_properties():
     """BASELINE config C2 (N=16384, 1-D ExpSquared): too slow for the CPU oracle inside a test
     (~30 s), so check size-independent properties: residual of the solve against an independent
