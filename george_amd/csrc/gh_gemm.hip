@@ -705,6 +705,13 @@ static int gemm_sp_mode() {
   if (g_gemm_sp < 0) g_gemm_sp = GH_GEMM_SP_DEFAULT;
   return g_gemm_sp;
 }
+// tile order of the launches without k clipping: -1 by size (above), 0 row-major, 1 the 8-row groups walked column-major
+static int g_gemm_grouped = -1;
+extern "C" int gh_debug_set_gemm_grouped(int mode) {
+  const int prev = g_gemm_grouped;
+  g_gemm_grouped = mode < 0 ? -1 : (mode != 0);
+  return prev;
+}
 extern "C" int gh_debug_set_gemm_sp(int mode) {
   const int prev = gemm_sp_mode();
   g_gemm_sp = mode < 0 ? GH_GEMM_SP_DEFAULT : (mode != 0);
@@ -735,6 +742,7 @@ int gh_launch_gemm(const GhGemm& h, hipStream_t st) {
   // (grouped tile order only once the column operand outgrows what the 256 MB MALL keeps between tile rows -- 128 MiB, N > 16384
   //  at K = 1024: below that a row-major walk already finds its slabs on chip and is 1 % faster, profiles/r04/gemm_tile_order_ab.md)
   g.grouped = (!(h.klo_max | h.khi_col | h.khi_row) && (long)h.N * h.K * 8 > (128L << 20)) ? 1 : 0;
+  if (g_gemm_grouped >= 0 && !(h.klo_max | h.khi_col | h.khi_row)) g.grouped = g_gemm_grouped;      // (A/B: gh_debug_set_gemm_grouped)
   g.preload = (h.beta != 0.0 && (h.beta == h.alpha || h.beta == -h.alpha)) ? 1 : 0;
   if (g.nblk > 0x7fffffffL) { gh_set_error("gemm: grid too large"); return GH_ERR_BAD_ARG; }
   const dim3 grid((unsigned)g.nblk), block(256);

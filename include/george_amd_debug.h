@@ -23,6 +23,10 @@ int gh_debug_set_mfma(int mode);
 /* the k-major x k-major GEMM kernel with its slab loop software-pipelined by half a slab (gemm_f64_mfma_dma_sp): 1 on, 0 off,
  * -1 the build's default; returns the previous mode.  Same bits either way (tests/test_gpu_gemm.py). */
 int gh_debug_set_gemm_sp(int mode);
+/* tile order of the GEMM launches without k clipping: -1 the library's rule (grouped when the column operand exceeds 128 MiB), 0
+ * row-major, 1 row groups of 8 walked column-major; returns the previous mode.  Same bits (a tile's arithmetic does not depend on
+ * when it runs).  For the traffic A/B of profiles/r06/syrk_traffic_ab.md. */
+int gh_debug_set_gemm_grouped(int mode);
 /* 1 (default): with the panel width left to the solver (gh_chol_opts.nb == 0) the outer panels are 2048 columns wide while the
  * trailing matrix behind them has more than 25 600 columns and 1024 after; 0: 1024 throughout; n > 1: the bound is n columns.
  * Returns the previous setting.  Same bits whatever the widths (the update adds the same k in the same order). */
