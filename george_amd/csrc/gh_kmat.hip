@@ -364,7 +364,7 @@ struct KmatArgs {
 // FAST: the kernel has the affine single-leaf form (a.fast): no interpreter in the instantiation
 // (half the registers), passes unrolled so that several exp() chains are in flight per lane.
 template <bool FAST>
-__device__ __forceinline__ void kmat_generic_tile(const KmatArgs& a, int ti, int tj, double* xr, double* xc) {
+__device__ __forceinline__ void kmat_generic_tile(const KmatArgs& a, const GhNode* __restrict__ prog, int ti, int tj, double* xr, double* xc) {
   const long r0 = (long)ti * KT, c0 = (long)tj * KT;
   const int nd = a.ndim;
   // stage the tile's points (coalesced: consecutive threads read consecutive doubles)
@@ -393,7 +393,7 @@ __device__ __forceinline__ void kmat_generic_tile(const KmatArgs& a, int ti, int
         // symmetric build: evaluate k(x_min, x_max) as kernel_interface.cpp:68-74 does
         const bool swap = a.sym && (gr > gc);
         double val = FAST ? gh_fast_value(a.fast, swap ? p2 : p1, swap ? p1 : p2)
-                          : gh_eval_value(a.prog, a.n_nodes, swap ? p2 : p1, swap ? p1 : p2);
+                          : gh_eval_value(prog, a.n_nodes, swap ? p2 : p1, swap ? p1 : p2);
         if (a.sym && a.yerr && gr == gc) { const double e2 = a.yerr[r]; val += e2 * e2; }   // basic.py:65
         v[e] = val;
       } else {
@@ -419,13 +419,19 @@ __device__ __forceinline__ void kmat_tile_of(const KmatArgs& a, int& ti, int& tj
     tj = TJ * 2 + (blockIdx.y & 1);
   } else { ti = blockIdx.x / a.tiles_n; tj = blockIdx.x % a.tiles_n; }
 }
+// (the program as a `const __restrict__` kernel parameter of its own: read-only and no alias of the output, so that the walker's
+//  node-field loads -- wave-uniform addresses -- become SCALAR loads.  As a member of KmatArgs they were vector loads, ~77 per
+//  element for the hyper.rst kernel, each a dependent round trip in front of a branch: -24 % on that build, profiles/r06/composite_kernel.md)
+#ifndef GH_KMAT_INTERP_WAVES
+#define GH_KMAT_INTERP_WAVES 4   // <= 128 registers: four wavefronts per SIMD hide the walker's dependent scalar loads (-13 %, profiles/r06/composite_kernel.md)
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs a) {
+__global__ __launch_bounds__(256, FAST ? 2 : GH_KMAT_INTERP_WAVES) void kmat_kernel(KmatArgs a, const GhNode* __restrict__ prog) {
   __shared__ double xr[KT * GH_MAX_NDIM];
   __shared__ double xc[KT * GH_MAX_NDIM];
   int ti, tj;
   kmat_tile_of(a, ti, tj);
-  kmat_generic_tile<FAST>(a, ti, tj, xr, xc);
+  kmat_generic_tile<FAST>(a, prog, ti, tj, xr, xc);
 }
 
 // Interior tiles of the stationary kernels a + b F(r^2) on ND <= 3 coordinates used as they come (axes =
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256) void kmat_interior_kernel(KmatArgs a) {
   const long gr0 = a.row0 + r0, gc0 = a.col0 + c0;
   const bool interior = r0 + KT <= a.n1 && c0 + KT <= a.n2 && r0 + KT <= a.rows_p && c0 + KT <= a.cols_p &&
                         (!a.sym || gr0 + KT <= gc0 || gc0 + KT <= gr0) && ((((size_t)a.out) | ((size_t)a.ldo * 8)) & 15) == 0;
-  if (!interior) { kmat_generic_tile<true>(a, ti, tj, xr, xc); return; }
+  if (!interior) { kmat_generic_tile<true>(a, a.prog, ti, tj, xr, xc); return; }
   for (int t = threadIdx.x; t < KT * ND; t += 256) xr[t] = a.x1[r0 * ND + t];
   __syncthreads();
   const int lc = (threadIdx.x & 31) * 2, lr = threadIdx.x >> 5;
@@ -523,13 +529,13 @@ int gh_launch_kmat(const gh_kernel* k, const double* x1, int64_t n1, const doubl
     }
 #undef GH_KMAT_ND
   }
-  else if (a.fast.ok) hipLaunchKernelGGL(kmat_kernel<true>, grid, block, 0, st, a);
-  else                hipLaunchKernelGGL(kmat_kernel<false>, grid, block, 0, st, a);
+  else if (a.fast.ok) hipLaunchKernelGGL(kmat_kernel<true>, grid, block, 0, st, a, (const GhNode*)k->d_nodes);
+  else                hipLaunchKernelGGL(kmat_kernel<false>, grid, block, 0, st, a, (const GhNode*)k->d_nodes);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
 
-__global__ void kdiag_kernel(const GhNode* prog, int n_nodes, int nd, const double* x1, const double* x2, long n, double* out) {
+__global__ void kdiag_kernel(const GhNode* __restrict__ prog, int n_nodes, int nd, const double* x1, const double* x2, long n, double* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = gh_eval_value(prog, n_nodes, x1 + i * nd, x2 + i * nd);
@@ -544,7 +550,7 @@ int gh_launch_kdiag(const gh_kernel* k, const double* x1, const double* x2, int6
 
 // full (n1, n2, P) parameter-gradient tensor -- API parity with gradient_general/symmetric
 // (kernel_interface.cpp:92-125).  HBM-write bound: 8*P bytes per pair.
-__global__ __launch_bounds__(256) void kgrad_kernel(const GhNode* prog, int n_nodes, int nd, int P,
+__global__ __launch_bounds__(256) void kgrad_kernel(const GhNode* __restrict__ prog, int n_nodes, int nd, int P,
                                                     const uint32_t* which, const double* x1, long n1,
                                                     const double* x2, long n2, int sym, double* out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -576,7 +582,7 @@ int gh_launch_kgrad(const gh_kernel* k, const uint32_t* which_host, const double
 }
 
 // (n1, n2, ndim) coordinate gradients (kernel_interface.cpp:127-157)
-__global__ __launch_bounds__(256) void kxgrad_kernel(const GhNode* prog, int n_nodes, int nd, int which_arg,
+__global__ __launch_bounds__(256) void kxgrad_kernel(const GhNode* __restrict__ prog, int n_nodes, int nd, int which_arg,
                                                      const double* x1, long n1, const double* x2, long n2, double* out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n1 * n2) return;
@@ -600,8 +606,11 @@ int gh_launch_kxgrad(const gh_kernel* k, int which_arg, const double* x1, int64_
 // One 64x64 tile of the LOWER triangle per workgroup; per-thread partial sums over its 16
 // elements, wavefront shuffle reduction, LDS cross-wave reduction, one partial row per
 // workgroup; a second kernel sums the partial rows in fixed order (deterministic).
+#ifndef GH_KGRAD_WAVES
+#define GH_KGRAD_WAVES 4
+#endif
 template <int PMAX>
-__global__ __launch_bounds__(256) void kgrad_reduce_kernel(const GhNode* prog, int n_nodes, int nd, int P,
+__global__ __launch_bounds__(256, PMAX <= 16 ? GH_KGRAD_WAVES : 1) void kgrad_reduce_kernel(const GhNode* __restrict__ prog, int n_nodes, int nd, int P,
                                                            const uint32_t* which, const double* x, long n,
                                                            const double* alpha, const double* kinv, long ld,
                                                            double* partial, double* diagA) {

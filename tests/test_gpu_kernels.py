@@ -197,3 +197,42 @@ def test_fast_affine_form_matches_interpreter(name, make, monkeypatch):
     ks = fast.value_symmetric(x)
     assert np.array_equal(ks, ks.T)
     assert np.allclose(ks, kernels_np.value_symmetric(kernel, x), rtol=1e-13, atol=1e-14)
+
+
+def _hyper_kernel():
+    """docs/tutorials/hyper.rst:91-95: k1 + k2 * ExpSine2 + k3 + k4, eleven parameters (the survey's f1 workload)"""
+    kernels = AK
+    k1 = 66.0 ** 2 * kernels.ExpSquaredKernel(metric=67.0 ** 2)
+    k2 = 2.4 ** 2 * kernels.ExpSquaredKernel(90.0 ** 2) * kernels.ExpSine2Kernel(gamma=2.0 / 1.3 ** 2, log_period=0.0)
+    k3 = 0.66 ** 2 * kernels.RationalQuadraticKernel(log_alpha=np.log(0.78), metric=1.2 ** 2)
+    k4 = 0.18 ** 2 * kernels.ExpSquaredKernel(1.6 ** 2)
+    return k1 + k2 + k3 + k4
+
+
+@pytest.mark.gpu
+def test_hyper_tutorial_kernel_against_the_oracle():
+    """The survey's f1 workload (docs/tutorials/hyper.rst:91-104): the 11-parameter kernel through the postfix walker -- kernel
+    matrix against the oracle (the reference's C++ evaluator where oracle/_ref travelled) at 2e-12 of the largest entry, and the
+    fused gradient reduction 1/2 sum A_ij dK_ij/dtheta against the reference formula (gp.py:465-466) on the oracle's tensors."""
+    from george_amd.kernel_interface import KernelInterface
+    from george_amd import BasicSolver
+    from oracle import solver_np
+    kernel = _hyper_kernel()
+    rng = np.random.default_rng(3)
+    n = 400
+    x = np.sort(1958.0 + 52.0 * rng.uniform(0, 1, n))[:, None]
+    ks = KernelInterface(kernel).value_symmetric(x)
+    ref = kernels_np.value_symmetric(kernel, x)
+    assert np.max(np.abs(ks - ref)) <= 2e-12 * np.max(np.abs(ref))
+    assert np.array_equal(ks, ks.T)
+    y = 340.0 + 3.0 * np.sin(2 * np.pi * x[:, 0]) - 345.0
+    yerr = 0.19 * np.ones(n)
+    s = BasicSolver(kernel)
+    s.compute(x, yerr)
+    which = np.ones(len(kernel.get_parameter_vector(include_frozen=True)), dtype=np.uint32)
+    g, alpha, diagA = s.grad(y, which)
+    d = solver_np.DenseOracle(kernel)
+    d.compute(x, yerr)
+    gref, A = solver_np.gp_grad_log_likelihood(d, kernel, x, y)
+    assert np.max(np.abs(g - gref) / np.maximum(np.abs(gref), 1e-6 * np.abs(gref).max())) <= 1e-7
+    assert np.allclose(diagA, np.diag(A), rtol=1e-7, atol=1e-9 * np.abs(np.diag(A)).max())
