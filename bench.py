@@ -165,6 +165,35 @@ class DenseJob(object):
         self.N.lib.gh_chol_destroy(self.h)
 
 
+def syrk_standalone(job, device, m=32768):
+    """The trailing-update kernel alone on the chip: C (m x m, lower tiles) -= A A^T for K = 1024 and 2048 through gh_dev_gemm,
+    best of 3 launches each by HIP events on the launch stream (torch's current stream = the one gh_dev_gemm(None) uses)."""
+    import torch
+    N = job.N
+    dp = C.POINTER(C.c_double)
+    res = {"M": m}
+    c = torch.zeros(m, m, dtype=torch.float64, device="cuda:%d" % device)
+    tiles = (m // 128) * (m // 128 + 1) / 2
+    for k in (1024, 2048):
+        a = torch.randn(m, k, dtype=torch.float64, device="cuda:%d" % device)
+        best = 1e30
+        for rep in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            N.check(N.lib.gh_dev_gemm(C.cast(c.data_ptr(), dp), c.stride(0), C.cast(a.data_ptr(), dp), a.stride(0),
+                                      C.cast(a.data_ptr(), dp), a.stride(0), m, m, k, -1.0, 1.0, 4, None))
+            e1.record()
+            torch.cuda.synchronize()
+            if rep:
+                best = min(best, e0.elapsed_time(e1))
+        tf = tiles * 2 * 128 * 128 * k / best * 1e-9
+        res["K%d" % k] = {"ms": best, "tflops": tf, "frac": tf / PEAK_FP64_MFMA_TFLOPS}
+        del a
+    del c
+    return res
+
+
 def pmc_traffic(n):
     """Per-launch traffic of the trailing SYRK from the committed rocprofv3 --pmc passes
     (profiles/*/traffic_N<n>.json, produced by scripts/profile.sh + scripts/traffic_from_pmc.py:
@@ -605,6 +634,9 @@ def compact_line(out):
                                                "traffic_algorithmic_bytes", "launches", "avg_launch_ms",
                                                "algorithmic_flops_per_launch", "peak_measured", "frac_of_measured",
                                                "scope") if k in rf}
+        sa = rf.get("standalone")
+        if sa and "K1024" in sa:
+            line["roofline"]["standalone_M%d" % sa["M"]] = {k: [_r(sa[k]["tflops"]), _r(sa[k]["frac"])] for k in ("K1024", "K2048")}
         line["roofline"]["kernel"] = line["roofline"]["kernel"][:96]
         w = rf.get("with_overlapped_block_column_launches")
         if w:
@@ -1143,6 +1175,13 @@ def main():
                                                              "%.1f / %.1f / %.1f TFLOP/s at 1 / 2 / 4 wavefronts per SIMD" % (mo[0], mo[1], mo[2]))
                 except Exception as e:
                     out["roofline"]["peak_measured_error"] = repr(e)
+                try:
+                    # the same kernel ALONE on the chip (after the timed region): one SYRK-shaped launch per panel width of the
+                    # factorisation, M = 32768.  `achieved` above is the kernel in place -- beside the panel chain of the next
+                    # panel, which with 2048-column panels (round 6) holds its share of the CUs twice as long
+                    out["roofline"]["standalone"] = syrk_standalone(job, local_rank)
+                except Exception as e:
+                    out["roofline"]["standalone"] = {"error": repr(e)[:160]}
                 # the launches behind `achieved`, so that the union can be re-derived from the line itself (and from
                 # profiles/<round>/update_intervals_N<n>.json, written by --dump-intervals)
                 iv = job.update_intervals()

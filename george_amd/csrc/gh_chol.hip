@@ -932,6 +932,7 @@ static int64_t panel_width(const gh_chol* s) {
 #ifndef GH_WIDE_PANEL_MIN_TRAILING
 #define GH_WIDE_PANEL_MIN_TRAILING 25600
 #endif
+
 static int g_adaptive_panels = 1;        // 0: off; 1: on (GH_WIDE_PANEL_MIN_TRAILING); > 1: on with this many trailing columns as the bound
 extern "C" int gh_debug_set_adaptive_panels(int on) {
   const int prev = g_adaptive_panels;

@@ -191,7 +191,7 @@ struct AcaSeg {
 // leaf Cholesky 256, leaf build 127) could share a SIMD with it (profiles/r06/hodlr_phase1_registers.md).
 template <bool FAST, bool CL>
 __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_PER_EU) void hodlr_aca_kernel(
-    const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
+    const GhNode* __restrict__ prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, double* Tcm, long N,
     int rcap, int* idx, int* ranks, double tol, unsigned long long seed, int level,
     int G_, unsigned* bars, double* part, int pstride, int* sel, int* fail, int multi, int fence, int* trunc,
     const AcaSeg* segs, int nseg, int capd_) {
@@ -572,7 +572,7 @@ __device__ __forceinline__ double aw_pick(const typename AwVec<E>::type& x, int 
 }
 template <bool FAST, int E>
 __global__ __launch_bounds__(64 * AW_NODES) void hodlr_aca_wave_kernel(
-    const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, int n_nodes, double* Tcm, long N,
+    const GhNode* __restrict__ prog, int n_prog, GhFast fast, int nd, const double* x, const LvlNode* nodes, int n_nodes, double* Tcm, long N,
     int rcap, int* ranks, double tol, unsigned long long seed, int level, int* trunc) {
   constexpr int MR = 64 * E;                            // rows / columns capacity
   constexpr int AW_RW = AW_RW_OF(E);
@@ -801,7 +801,7 @@ __global__ void hodlr_relayout_kernel(const double* UA, long n, int Rtot, const 
 // ======================================================================== leaves
 // pitch == 0: leaf b is stored size x size at leaves[b].off; pitch > 0: in a pitch x pitch slot at
 // b * pitch^2, identity-padded (the batched Cholesky path below wants 128 x 128 blocks)
-__global__ void hodlr_leaf_build_kernel(const GhNode* prog, int n_prog, GhFast fast, int nd, const double* x,
+__global__ void hodlr_leaf_build_kernel(const GhNode* __restrict__ prog, int n_prog, GhFast fast, int nd, const double* x,
                                         const double* yerr, const LeafDesc* leaves, double* Lf, int pitch) {
   const LeafDesc lf = leaves[blockIdx.x];
   if (pitch > 0) {

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """HBM/fabric traffic of the trailing-update (SYRK) launches from two rocprofv3 --pmc passes.
 
-usage: traffic_from_pmc.py <fetch.db> <write.db> <N> <nb> [<out.json>]
+usage: traffic_from_pmc.py <fetch.db> <write.db> <N> <nb> [<out.json>] [--uniform]
+(--uniform: panels of nb columns throughout; default: the solver's adaptive widths, round 6)
 
 Method (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
 passes (they do not fit one TCC pass); both are in KiB; on gfx950 FETCH_SIZE reports exactly half
@@ -17,20 +18,29 @@ import sqlite3
 import sys
 
 
-def trailing_grids(n, nb):
-    np_ = (n + 127) // 128 * 128
-    grids = {}
-    k0 = 0
+def panel_starts(np_, nb, adaptive=True, wide_min_trailing=25600):
+    """gh_chol.hip, panel_starts(): with the width left to the solver (nb = 1024 here, adaptive) the panels are 2 nb wide while
+    more than `wide_min_trailing` columns of trailing matrix lie behind them"""
+    pc, k0 = [], 0
     while k0 < np_:
-        b = min(nb, np_ - k0)
-        k1 = k0 + b
-        if k1 >= np_:
+        pc.append(k0)
+        w = 2 * nb if (adaptive and np_ - (k0 + 2 * nb) >= wide_min_trailing) else nb
+        k0 += min(w, np_ - k0)
+    pc.append(np_)
+    return pc
+
+
+def trailing_grids(n, nb, adaptive=True):
+    """{workgroups of a wide trailing launch: (tile rows m2, K of the launch)}: W(j) updates columns from panel j + 2 on"""
+    np_ = (n + 127) // 128 * 128
+    pc = panel_starts(np_, nb, adaptive)
+    grids = {}
+    for j in range(len(pc) - 1):
+        if j + 2 > len(pc) - 2:
             break
-        b1 = min(nb, np_ - k1)
-        m2 = (np_ - (k1 + b1)) // 128
+        m2 = (np_ - pc[j + 2]) // 128
         if m2 > 0:
-            grids[m2 * (m2 + 1) // 2] = (m2, b)
-        k0 = k1
+            grids[m2 * (m2 + 1) // 2] = (m2, pc[j + 1] - pc[j])
     return grids
 
 
@@ -51,7 +61,7 @@ def collect(db, counter, grids):
 
 def main():
     fdb, wdb, n, nb = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-    grids = trailing_grids(n, nb)
+    grids = trailing_grids(n, nb, adaptive="--uniform" not in sys.argv)
     f = collect(fdb, "FETCH_SIZE", grids)
     w = collect(wdb, "WRITE_SIZE", grids)
     nf, nw = len(f), len(w)
