@@ -47,6 +47,8 @@
 // gh_potf2.hip: batched 128x128 Cholesky + inverse of the factor (block b at A + b*stride_a)
 int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* dinv, int64_t stride_d, long long* info,
                             int nbatch, hipStream_t st);
+// ... and the leaf form: block b -> K_b^-1 (full symmetric, in place) and logdet[b] = log|K_b|, nothing else written
+int gh_launch_potf2_kinv_batched(double* A, int64_t lda, int64_t stride_a, double* logdet, long long* info, int nbatch, hipStream_t st);
 
 #define HCH 128          // rows per reduce/update chunk
 #define CPASS 256        // columns handled per pass of an apply
@@ -337,7 +339,41 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
       int chosen = -1;
       for (int c = 0; c < NC; ++c)
         if (sh.cand_best[c] >= 1e-14) { chosen = c; break; }                           // hodlr.h:191
-      if (chosen < 0) { remaining -= NC; batch = ACA_NC; __syncthreads(); continue; }
+      if (chosen < 0) {
+        remaining -= NC;
+        // (round 6) The first pass without a hit: before walking the rest of the rows 64 at a time, SCREEN them all -- thread t the
+        // rows lidx[t], lidx[t + 512], ..., a whole row each (no cross-lane reduction, V entries and column points as LDS
+        // broadcasts), leaving as soon as anybody has found an entry >= 1e-14.  If nobody has, every remaining row would fail
+        // its test: the search ends as it would after the walk (rows exhausted, same rank, same factors).  The walk of the one
+        // such node of C4's level 8 took 806 us -- twelve passes -- and was the tail of phase 1; its screen is ~50 us.
+        if (batch != ACA_NC && remaining > 0 && rank <= 8 && (long)n_rows * n_cols <= 512L * 512L) {    // (a thread walks whole rows: 512 entries here; 0.7 ms for a 2048 x 2048 block)
+          if (tid == 0) sh.s_i = 0;
+          __syncthreads();
+          const int kv = rank < kcap ? rank : kcap;
+          for (int q = tid; q < remaining && !*(volatile int*)&sh.s_i; q += nt) {
+            const int i = sh.lidx[q];
+            double cu[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cu[k] = k < rank ? (k < kcap ? uc[k * n_rows + i] : Tcm[(long)k * N + row0 + i]) : 0.0;
+            const double* xi = xrow(i);
+            bool hit = false;
+            for (int n = 0; n < n_cols && !hit; ++n) {
+              double v = FAST ? gh_fast_value(fast, xi, xcol(n)) : gh_eval_value(prog, n_prog, xi, xcol(n));
+#pragma unroll
+              for (int k = 0; k < 8; ++k) if (k < rank) v -= cu[k] * (k < kv ? vc[k * n_cols + n] : Tcm[(long)k * N + col0 + n]);
+              hit = fabs(v) >= 1e-14;
+              if ((n & 31) == 31 && *(volatile int*)&sh.s_i) break;
+            }
+            if (hit) *(volatile int*)&sh.s_i = 1;
+          }
+          __syncthreads();
+          if (!*(volatile int*)&sh.s_i) remaining = 0;
+          __syncthreads();
+        }
+        batch = ACA_NC;
+        __syncthreads();
+        continue;
+      }
       if (tid == 0) {                                 // undo the draws after the chosen one, last first
         for (int c = NC - 1; c > chosen; --c) {
           sh.lidx[sh.cand_k[c]] = (unsigned short)sh.cand_i[c];
@@ -728,6 +764,12 @@ __global__ __launch_bounds__(64 * AW_NODES) void hodlr_aca_wave_kernel(
 
 // 1 (default): the deep levels whose blocks have <= 256 rows and columns through hodlr_aca_wave_kernel; 0: every level through the
 // workgroup kernel (A/B and the same-bits test)
+static int g_hodlr_coop_singles = 1;    // clusterable levels that end up with one workgroup per node ride at the end of the cooperative launch
+extern "C" int gh_debug_set_hodlr_coop_singles(int on) {
+  const int prev = g_hodlr_coop_singles;
+  g_hodlr_coop_singles = on ? 1 : 0;
+  return prev;
+}
 static int g_hodlr_coop_wgs = 256;      // workgroups of the cooperative ACA launch (<= CUs: every cluster resident)
 extern "C" int gh_debug_set_hodlr_coop_wgs(int n) {
   const int prev = g_hodlr_coop_wgs;
@@ -2493,33 +2535,22 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     const int nl = (int)h->leaves.size();
     const size_t slot = (size_t)128 * 128;
     GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
-    GH_CHECK(linv.ensure(nl * slot * sizeof(double)));
     long long* d_info = (long long*)((int*)h->flags.p + 2);
     if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
     hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
                        h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
     GH_HIP(hipGetLastError());
-    GH_CHECK(gh_launch_potf2_batched(h->leaf_inv.d(), 128, (int64_t)slot, linv.d(), (int64_t)slot, d_info, nl, st));
-    hipLaunchKernelGGL(hodlr_leaf_logdet_kernel, dim3(nl), dim3(128), 0, st, h->leaf_inv.d(), h->ld_all.d() + ld_at);
+    // K_leaf^-1 = L^-T L^-1 (in place) and log|K_leaf| in ONE launch per batch: gh_potf2.hip, potf2_kinv_kernel (round 6; it was
+    // the batched factorisation + a log-det kernel + a batched transpose + a batched product: four launches, 1.8 GB through the L2s)
+    GH_CHECK(gh_launch_potf2_kinv_batched(h->leaf_inv.d(), 128, (int64_t)slot, h->ld_all.d() + ld_at, d_info, nl, st));
     ld_at += nl;
-    GH_HIP(hipGetLastError());
-    std::vector<MMJob> prod(nl), jobs(nl);
-    for (int i = 0; i < nl; ++i) {
-      prod[i] = {(long)(i * slot), i * 128, i * 128, 128, 128};                       // slot_i = Linv_i^T Linv_i
-      jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
-    }
-    if (!h->leaf_tab_up) {
-      GH_CHECK(upload(h->d_leaf_prod, prod, st));
-      GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
-      h->leaf_tab_up = true;
-    }
     {
-      // K^-1 = L^-T L^-1 = (L^-T)(L^-T)^T: the transposed inverse factors, then one tile product per leaf
-      GH_CHECK(lstk.ensure(nl * slot * sizeof(double)));
-      hipLaunchKernelGGL(hodlr_transpose128_kernel, dim3(nl, 16), dim3(256), 0, st, (const double*)linv.d(), 128L, (long)slot, lstk.d(), 128L, (long)slot);
-      hipLaunchKernelGGL(hodlr_bmm_nt_kernel<false>, dim3(nl), dim3(256), 0, st, h->leaf_inv.d(), 128L, (long)slot, (const double*)lstk.d(), 128L, (long)slot,
-                         (const double*)lstk.d(), 128L, (long)slot, 128L);
-      GH_HIP(hipGetLastError());
+      std::vector<MMJob> jobs(nl);
+      for (int i = 0; i < nl; ++i) jobs[i] = {(long)(i * slot), h->leaves[i].start, h->leaves[i].start, h->leaves[i].size, h->leaves[i].size};
+      if (!h->leaf_tab_up) {
+        GH_CHECK(upload(h->d_leaf_jobs, jobs, st));
+        h->leaf_tab_up = true;
+      }
     }
     h->leaf_pitch = 128;
   } else if (h->max_leaf <= 256 && !g_hodlr_leaf_gj) {
@@ -2882,7 +2913,11 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         int G = 1;
         while (G * 2 <= gmax[l] && nn * G * 2 <= g_hodlr_coop_wgs / 8) G *= 2;
         al[l].G = G;
-        if (G > 1) total += nn * G;              // (a level left with one workgroup per node goes to the other stream)
+        // (round 6: a clusterable level left with one workgroup per node -- level 5 of C4: 32 blocks of 4096 x 4096, 0.54 ms per
+        //  node -- stays in the cooperative launch as one-workgroup segments at its end while the launch still fits the chip: in
+        //  the one-workgroup launch its nodes found no SIMD with room beside a cooperative workgroup before ~0.5 ms and were the
+        //  tail of phase 1, profiles/r06/hodlr_phase1_registers.md)
+        if (G > 1 || (g_hodlr_coop_singles && nn <= g_hodlr_coop_wgs / 8)) total += nn * G;       // (reserved: the doubling below stays inside the budget)
       }
       for (;;) {
         int best = -1;
@@ -2898,7 +2933,16 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         al[best].G *= 2;
       }
       std::vector<int> fused, single;
-      for (int l : cl) (al[l].G > 1 ? fused : single).push_back(l);
+      {
+        int used = 0;
+        for (int l : cl) if (al[l].G > 1) used += (int)h->levels[l]->node_ids.size() * al[l].G;
+        for (int l : cl) {
+          const int nn = (int)h->levels[l]->node_ids.size();
+          if (al[l].G > 1) fused.push_back(l);
+          else if (g_hodlr_coop_singles && nn <= g_hodlr_coop_wgs / 8 && used + nn <= g_hodlr_coop_wgs) { fused.push_back(l); used += nn; }     // (G = 1 segments)
+          else single.push_back(l);
+        }
+      }
       if (h->aca_fused_ev[0] == nullptr) { GH_HIP(hipEventCreate(&h->aca_fused_ev[0])); GH_HIP(hipEventCreate(&h->aca_fused_ev[1])); }
       GH_HIP(hipEventRecord(h->aca_fused_ev[0], st));
       GH_CHECK(enqueue_fused(fused, rcap0, st, h->d_aca_segs));

@@ -50,3 +50,60 @@ int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, 
   GH_HIP(hipGetLastError());
   return GH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The HODLR leaf kernel (round 6): block b of a batch -> its INVERSE K_b^-1 = L^-T L^-1 (full symmetric 128 x 128, in place) and
+// log|K_b|, in ONE launch.  The HODLR solver needs nothing else of a leaf; as four launches -- this factorisation with L and L^-1
+// written out in full (zeros included), a read-back of L's diagonal for the log-determinant, a batched transpose of L^-1 and a batched
+// product -- the 2048 leaves of C4 moved 1.8 GB through the L2s (profiles/r06/traffic_C4_N262144.json: 0.69 + 0.03 + 0.54 + 0.54)
+// and held CUs for 0.27 ms of stream time in a phase that is bound by CU-time.  Here L^-1 never leaves LDS: potf2_body<false>
+// stops with its packed lower triangle in s; W = L^-T L^-1, W(ti, tj) = sum_{tk >= ti} Linv(tk, ti)^T Linv(tk, tj) over 16 x 16 tiles
+// (ti >= tj), is 480 matrix instructions shared by the four wavefronts (~4 us); log|K_b| = -2 sum_i log Linv(i, i).
+__global__ __launch_bounds__(256, 2) void potf2_kinv_kernel(double* A, long lda, long stride_a, double* logdet, long long* info) {
+  using namespace gh_potf2;
+  A += (long)blockIdx.x * stride_a;
+  __shared__ double s[GH_POTF2_S_DOUBLES];
+  __shared__ double dscr[GH_POTF2_D_DOUBLES];
+  __shared__ int fail_at;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (!potf2_body<false>(A, lda, nullptr, info, (long long)blockIdx.x * 128, s, dscr, &fail_at)) {
+    if (tid == 0) logdet[blockIdx.x] = 0.0;
+    return;
+  }
+  __syncthreads();
+  if (wave == 3) {                               // log|K| = 2 sum log L_ii = -2 sum log Linv_ii (fixed order: reproducible)
+    double v = log(s[rowbase(lane) + lane]) + log(s[rowbase(lane + 64) + lane + 64]);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) logdet[blockIdx.x] = -2.0 * v;
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  int e = 0;
+  for (int ti = 7; ti >= 0; --ti)                // (tile rows with the most k-tiles last: the short tiles fill the tail)
+    for (int tj = 0; tj <= ti; ++tj, ++e) {
+      if ((e & 3) != wave) continue;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      for (int tk = ti; tk < 8; ++tk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int R = 16 * tk + 4 * q + fq;    // the k index of this lane: row R of L^-1
+          const int ca = 16 * ti + fr, cb = 16 * tj + fr;
+          const double a = s[rowbase(R) + ca], b = s[rowbase(R) + cb];       // (a column beyond the diagonal: the next row's data, masked)
+          acc = mma(ca <= R ? a : 0.0, cb <= R ? b : 0.0, acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + fq + 4 * r, j = 16 * tj + fr;
+        A[(long)i * lda + j] = acc[r];
+        if (ti != tj) A[(long)j * lda + i] = acc[r];
+      }
+    }
+}
+// (every block's slot is read in full before it is overwritten: the loads of potf2_body precede its first barrier)
+int gh_launch_potf2_kinv_batched(double* A, int64_t lda, int64_t stride_a, double* logdet, long long* info, int nbatch, hipStream_t st) {
+  if (nbatch <= 0) return GH_OK;
+  hipLaunchKernelGGL(potf2_kinv_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, (long)stride_a, logdet, info);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+

@@ -113,6 +113,9 @@ __device__ __forceinline__ void diag16(double (&v)[16], double (&w)[16]) {
 
 // s: GH_POTF2_S_DOUBLES, dscr: GH_POTF2_D_DOUBLES doubles, fail_at_p: one int -- all LDS.
 // Returns false when the block is not positive definite (then *info is set) or an earlier one was not.
+// STORE = false (the HODLR leaf kernel, potf2_kinv_kernel): nothing is written to A or dinv -- on return the packed lower
+// triangle of L^-1 is in s, behind a workgroup barrier, and the caller goes on from there.
+template <bool STORE = true>
 __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, long long* info, long long base,
                                            double* s, double* dscr, int* fail_at_p) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,6 +230,7 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
   // addresses allow; all 130 KB of the first version at once kept them at the store queue for 4 us).
   const bool wide_ok = ((((unsigned long long)A | (unsigned long long)dinv) & 15ull) == 0) && ((lda & 1) == 0);
   auto zero_chunk = [&](int W, int c) {
+    if (!STORE) return;
     typedef double d2 __attribute__((ext_vector_type(2)));
     const d2 z2 = {0.0, 0.0};
     const int pr = lane & 31, sub = lane >> 5;  // column pair, row of the pair of rows
@@ -419,7 +423,7 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
   }
   // factor -> HBM: the half rows that hold part of the lower triangle, value or zero (no per-store
   // predicate); nothing waits for these stores
-  {
+  if (STORE) {
     // (a pointer the optimiser cannot relate to the one of the load phase: otherwise the 32 load
     // addresses are kept for these stores across the whole step loop, in scratch)
     double* Ast = A;
@@ -553,7 +557,7 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
   level(std::integral_constant<int, 2>());
   GH_POTF2_STAMP(5);
   // (c) L^-1 to HBM, likewise
-  {
+  if (STORE) {
     const int j = tid & 127, ih = wave >> 1;      // (ih scalar: the row addresses are SGPR arithmetic)
 #pragma unroll
     for (int q0 = 0; q0 < 64; q0 += 16) {
