@@ -1219,10 +1219,11 @@ static int factor(gh_chol* s) {
   if (s->opts.lookahead && s->st2 && s->st3 && s->st4 && s->np > panel_width(s)) return factor_lookahead_deep(s, lookahead_depth(s));      // (panel widths: panel_starts())
   hipStream_t st = s->st;
   double* A = s->A.d();
-  const int64_t np = s->np, ld = np, NB = panel_width(s);
+  const int64_t np = s->np, ld = np;
   const bool prof = s->opts.profile != 0;
-  for (int64_t k0 = 0; k0 < np; k0 += NB) {
-    const int64_t nb = std::min<int64_t>(NB, np - k0);
+  const std::vector<int64_t> pc = panel_starts(s);             // (the same panel widths as the look-ahead schedule)
+  for (size_t pj = 0; pj + 1 < pc.size(); ++pj) {
+    const int64_t k0 = pc[pj], nb = pc[pj + 1] - pc[pj];
     const long ep = prof ? s->next_ev() : -1;
     if (ep >= 0) { GH_HIP(hipEventRecord(s->ev_pool[ep].a, st)); s->ev_panel.push_back((size_t)ep); }
     GH_CHECK(potrf_block(st, blk(A, ld, k0, k0), ld, nb, s->dinv.d() + (k0 / T) * T * T, s->d_info, k0));

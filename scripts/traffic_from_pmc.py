@@ -30,15 +30,16 @@ def panel_starts(np_, nb, adaptive=True, wide_min_trailing=25600):
     return pc
 
 
-def trailing_grids(n, nb, adaptive=True):
+def trailing_grids(n, nb, adaptive=True, single_stream=True):
     """{workgroups of a wide trailing launch: (tile rows m2, K of the launch)}: W(j) updates columns from panel j + 2 on"""
     np_ = (n + 127) // 128 * 128
     pc = panel_starts(np_, nb, adaptive)
     grids = {}
+    ahead = 1 if single_stream else 2               # W(j) starts at panel j + 2 under look-ahead, at j + 1 without
     for j in range(len(pc) - 1):
-        if j + 2 > len(pc) - 2:
+        if j + ahead > len(pc) - 2:
             break
-        m2 = (np_ - pc[j + 2]) // 128
+        m2 = (np_ - pc[j + ahead]) // 128
         if m2 > 0:
             grids[m2 * (m2 + 1) // 2] = (m2, pc[j + 1] - pc[j])
     return grids
