@@ -49,6 +49,8 @@ int gh_launch_potf2_batched(double* A, int64_t lda, int64_t stride_a, double* di
                             int nbatch, hipStream_t st);
 // ... and the leaf form: block b -> K_b^-1 (full symmetric, in place) and logdet[b] = log|K_b|, nothing else written
 int gh_launch_potf2_kinv_batched(double* A, int64_t lda, int64_t stride_a, double* logdet, long long* info, int nbatch, hipStream_t st);
+int gh_launch_potf2_kinv_kernel_batched(double* A, int64_t lda, int64_t stride_a, double* logdet, long long* info, int nbatch,
+                                        const GhFast& fast, const double* x, const double* yerr, int nd, const void* leaves, hipStream_t st);
 
 #define HCH 128          // rows per reduce/update chunk
 #define CPASS 256        // columns handled per pass of an apply
@@ -764,6 +766,12 @@ __global__ __launch_bounds__(64 * AW_NODES) void hodlr_aca_wave_kernel(
 
 // 1 (default): the deep levels whose blocks have <= 256 rows and columns through hodlr_aca_wave_kernel; 0: every level through the
 // workgroup kernel (A/B and the same-bits test)
+static int g_hodlr_leaf_fused = 1;      // 128-row leaves of fast-form kernels: evaluated inside the factorisation kernel (0: a build launch first)
+extern "C" int gh_debug_set_hodlr_leaf_fused(int on) {
+  const int prev = g_hodlr_leaf_fused;
+  g_hodlr_leaf_fused = on ? 1 : 0;
+  return prev;
+}
 static int g_hodlr_coop_singles = 1;    // clusterable levels that end up with one workgroup per node ride at the end of the cooperative launch
 extern "C" int gh_debug_set_hodlr_coop_singles(int on) {
   const int prev = g_hodlr_coop_singles;
@@ -2537,12 +2545,19 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     GH_CHECK(h->leaf_inv.ensure(nl * slot * sizeof(double)));
     long long* d_info = (long long*)((int*)h->flags.p + 2);
     if (!h->leaf_tab_up) GH_CHECK(upload(h->d_leaves, h->leaves, st));
-    hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
-                       h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
-    GH_HIP(hipGetLastError());
-    // K_leaf^-1 = L^-T L^-1 (in place) and log|K_leaf| in ONE launch per batch: gh_potf2.hip, potf2_kinv_kernel (round 6; it was
-    // the batched factorisation + a log-det kernel + a batched transpose + a batched product: four launches, 1.8 GB through the L2s)
-    GH_CHECK(gh_launch_potf2_kinv_batched(h->leaf_inv.d(), 128, (int64_t)slot, h->ld_all.d() + ld_at, d_info, nl, st));
+    // K_leaf^-1 = L^-T L^-1 and log|K_leaf| in ONE launch per batch: gh_potf2.hip, potf2_kinv_kernel (round 6; it was the build + the
+    // batched factorisation + a log-det kernel + a batched transpose + a batched product: five launches, 2.3 GB through the L2s).
+    // Kernels of the a + b F(r^2) form are evaluated INSIDE that launch; the others keep the build launch in front of it.
+    static_assert(sizeof(LeafDesc) == 16, "potf2_kinv_kernel reads LeafDesc as {int start, size; long off}");
+    if (k->fast.ok && g_hodlr_leaf_fused) {
+      GH_CHECK(gh_launch_potf2_kinv_kernel_batched(h->leaf_inv.d(), 128, (int64_t)slot, h->ld_all.d() + ld_at, d_info, nl, k->fast,
+                                                   h->x.d(), h->yerr.d(), ndim, h->d_leaves.p, st));
+    } else {
+      hipLaunchKernelGGL(hodlr_leaf_build_kernel, dim3(nl, 8), dim3(256), 0, st, k->d_nodes, (int)k->nodes.size(), k->fast, ndim,
+                         h->x.d(), h->yerr.d(), (const LeafDesc*)h->d_leaves.p, h->leaf_inv.d(), 128);
+      GH_HIP(hipGetLastError());
+      GH_CHECK(gh_launch_potf2_kinv_batched(h->leaf_inv.d(), 128, (int64_t)slot, h->ld_all.d() + ld_at, d_info, nl, st));
+    }
     ld_at += nl;
     {
       std::vector<MMJob> jobs(nl);

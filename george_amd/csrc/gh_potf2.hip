@@ -59,14 +59,27 @@ int gh_launch_potf2_mfma(double* A, int64_t lda, double* dinv, long long* info, 
 // and held CUs for 0.27 ms of stream time in a phase that is bound by CU-time.  Here L^-1 never leaves LDS: potf2_body<false>
 // stops with its packed lower triangle in s; W = L^-T L^-1, W(ti, tj) = sum_{tk >= ti} Linv(tk, ti)^T Linv(tk, tj) over 16 x 16 tiles
 // (ti >= tj), is 480 matrix instructions shared by the four wavefronts (~4 us); log|K_b| = -2 sum_i log Linv(i, i).
-__global__ __launch_bounds__(256, 2) void potf2_kinv_kernel(double* A, long lda, long stride_a, double* logdet, long long* info) {
+// KERN: the block is not read from A but evaluated from the leaf's points (GhPotf2Kern): the HODLR leaf build -- a launch that wrote
+// 268 MB for the next one to read back -- disappears for kernels of the a + b F(r^2) form.
+struct GhLeafRange { int start, size; long off; };       // (= LeafDesc of gh_hodlr.hip)
+template <bool KERN>
+__global__ __launch_bounds__(256, 2) void potf2_kinv_kernel(double* A, long lda, long stride_a, double* logdet, long long* info,
+                                                            GhFast fast, const double* x, const double* yerr, int nd, const GhLeafRange* leaves) {
   using namespace gh_potf2;
   A += (long)blockIdx.x * stride_a;
   __shared__ double s[GH_POTF2_S_DOUBLES];
   __shared__ double dscr[GH_POTF2_D_DOUBLES];
   __shared__ int fail_at;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (!potf2_body<false>(A, lda, nullptr, info, (long long)blockIdx.x * 128, s, dscr, &fail_at)) {
+  bool ok;
+  if (KERN) {
+    const GhLeafRange lf = leaves[blockIdx.x];
+    const GhPotf2Kern src{fast, x + (long)lf.start * nd, yerr + lf.start, nd, lf.size};
+    ok = potf2_body<false, GhPotf2Kern>(A, lda, nullptr, info, (long long)blockIdx.x * 128, s, dscr, &fail_at, src);
+  } else {
+    ok = potf2_body<false>(A, lda, nullptr, info, (long long)blockIdx.x * 128, s, dscr, &fail_at);
+  }
+  if (!ok) {
     if (tid == 0) logdet[blockIdx.x] = 0.0;
     return;
   }
@@ -102,7 +115,20 @@ __global__ __launch_bounds__(256, 2) void potf2_kinv_kernel(double* A, long lda,
 // (every block's slot is read in full before it is overwritten: the loads of potf2_body precede its first barrier)
 int gh_launch_potf2_kinv_batched(double* A, int64_t lda, int64_t stride_a, double* logdet, long long* info, int nbatch, hipStream_t st) {
   if (nbatch <= 0) return GH_OK;
-  hipLaunchKernelGGL(potf2_kinv_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, (long)stride_a, logdet, info);
+  GhFast none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(potf2_kinv_kernel<false>, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, (long)stride_a, logdet, info,
+                     none, (const double*)nullptr, (const double*)nullptr, 0, (const GhLeafRange*)nullptr);
+  GH_HIP(hipGetLastError());
+  return GH_OK;
+}
+// ... with the blocks evaluated inside the kernel: block b = K(x[leaves[b].start ...], same) + diag(yerr^2), identity-padded to 128
+// (`leaves`: device array of {start, size, off}; fast.ok required)
+int gh_launch_potf2_kinv_kernel_batched(double* A, int64_t lda, int64_t stride_a, double* logdet, long long* info, int nbatch,
+                                        const GhFast& fast, const double* x, const double* yerr, int nd, const void* leaves, hipStream_t st) {
+  if (nbatch <= 0) return GH_OK;
+  hipLaunchKernelGGL(potf2_kinv_kernel<true>, dim3((unsigned)nbatch), dim3(256), 0, st, A, (long)lda, (long)stride_a, logdet, info,
+                     fast, x, yerr, nd, (const GhLeafRange*)leaves);
   GH_HIP(hipGetLastError());
   return GH_OK;
 }

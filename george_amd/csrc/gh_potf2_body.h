@@ -115,9 +115,28 @@ __device__ __forceinline__ void diag16(double (&v)[16], double (&w)[16]) {
 // Returns false when the block is not positive definite (then *info is set) or an earlier one was not.
 // STORE = false (the HODLR leaf kernel, potf2_kinv_kernel): nothing is written to A or dinv -- on return the packed lower
 // triangle of L^-1 is in s, behind a workgroup barrier, and the caller goes on from there.
-template <bool STORE = true>
+// SRC: where the block comes from.  The default reads A (row pitch lda); GhPotf2Kern (the HODLR leaf kernel) EVALUATES it --
+// K(x_c, x_r) + yerr_r^2 on the diagonal through the a + b F(r^2) fast form, identity padding beyond `size` -- so that the leaves'
+// covariance blocks are never written to memory at all.
+struct GhPotf2Mem {
+  static constexpr bool kLoadsInFlight = true;  // all 59 loads of a lane issued before the first is waited for
+  const double* A; long lda;
+  // element (row i, column c <= i); i wave-uniform in the bulk loads: the row address is SGPR arithmetic, the lane adds 32 bits
+  __device__ __forceinline__ double operator()(int i, int c) const { return *(const double*)((const char*)(A + (long)i * lda) + (unsigned)c * 8u); }
+};
+struct GhPotf2Kern {
+  static constexpr bool kLoadsInFlight = false;
+  GhFast fast; const double* x; const double* yerr; int nd, size;       // x, yerr: the leaf's first point
+  __device__ __forceinline__ double operator()(int i, int c) const {
+    if (i >= size || c >= size) return i == c ? 1.0 : 0.0;
+    double v = gh_fast_value(fast, x + (long)c * nd, x + (long)i * nd);   // ordered arguments (x_min, x_max): c <= i
+    if (i == c) { const double e = yerr[i]; v += e * e; }
+    return v;
+  }
+};
+template <bool STORE = true, class SRC = GhPotf2Mem>
 __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, long long* info, long long base,
-                                           double* s, double* dscr, int* fail_at_p) {
+                                           double* s, double* dscr, int* fail_at_p, const SRC& src) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (an SGPR: everything derived from it is scalar)
   const int fr = lane & 15, fq = lane >> 4;     // MFMA operand row / k sub-index of this lane
@@ -371,17 +390,28 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
     const int i = lane & 15;
     double t[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = A[(long)i * lda + (k < i ? k : i)];
+    for (int k = 0; k < 16; ++k) t[k] = src(i, k < i ? k : i);
     if (info_in != 0) return false;             // uniform over the workgroup: an earlier block already failed
 #pragma unroll
     for (int k = 15; k >= 0; --k) s[rowbase16(i) + (k < i ? k : i)] = t[k];
+  } else if (!SRC::kLoadsInFlight) {
+    // (an evaluated block: nothing to have in flight -- element by element straight into the image; 59 evaluated values held in
+    //  registers across the phase were 640 bytes of scratch per lane)
+    if (info_in != 0) return false;
+#pragma unroll 1
+    for (int m = 0; m < 59; ++m) {
+      const int q = (wave - 1) + 3 * m;
+      const int i = q < 112 ? 16 + q : (q < 176 ? q - 48 : 127), j = (q < 112 ? 0 : 64) + lane;
+      const double v = src(i, j < i ? j : i);
+      *((q < 176 && j <= i) ? &s[rowbase(i) + j] : dump) = v;
+    }
   } else {
     double v[59];
 #pragma unroll
     for (int m = 0; m < 59; ++m) {
       const int q = (wave - 1) + 3 * m;         // (scalar)
       const int i = q < 112 ? 16 + q : (q < 176 ? q - 48 : 127), j = (q < 112 ? 0 : 64) + lane;
-      v[m] = *(const double*)((const char*)(A + (long)i * lda) + (unsigned)(j < i ? j : i) * 8u);
+      v[m] = src(i, j < i ? j : i);
     }
     if (info_in != 0) return false;
 #pragma unroll
@@ -577,6 +607,13 @@ __device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, lo
   }
   GH_POTF2_STAMP(6);
   return true;
+}
+// (the dense solver's form: the block is read from A)
+template <bool STORE = true>
+__device__ __forceinline__ bool potf2_body(double* A, long lda, double* dinv, long long* info, long long base,
+                                           double* s, double* dscr, int* fail_at_p) {
+  const GhPotf2Mem src{A, lda};
+  return potf2_body<STORE, GhPotf2Mem>(A, lda, dinv, info, base, s, dscr, fail_at_p, src);
 }
 #undef GH_SB
 }  // namespace gh_potf2

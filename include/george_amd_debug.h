@@ -49,6 +49,9 @@ int gh_debug_set_hodlr_coop_wgs(int n);
 /* 1 (default): a level that could be clustered but is left with one workgroup per node by the launch's budget (level 5 of C4) is
  * appended to the cooperative launch as one-workgroup segments; 0: it goes to the one-workgroup launch.  Returns the previous setting. */
 int gh_debug_set_hodlr_coop_singles(int on);
+/* 1 (default): 128-row leaves of kernels with the a + b F(r^2) fast form are evaluated inside the leaf factorisation kernel
+ * (potf2_kinv_kernel<true>); 0: a build launch writes them first.  Same bits.  Returns the previous setting. */
+int gh_debug_set_hodlr_leaf_fused(int on);
 /* which of a dense handle's streams run concurrently (HIP maps streams onto few hardware queues):
  * out[i * 6 + j], i < j, n >= 36: milliseconds for two 300-us spin kernels launched together on
  * streams i and j (0 caller's null stream, 1 main, 2 chain, 3 rows-below, 4 near, 5 CU-masked); -1 = absent */

@@ -411,6 +411,29 @@ def test_wave_per_node_aca_gives_the_same_bits(case):
     assert got[1][3] == got[0][3]
 
 
+@pytest.mark.parametrize("n,ndim", [(4096, 1), (5000, 1), (6000, 3)])
+def test_leaf_blocks_evaluated_inside_the_factorisation_kernel(n, ndim):
+    """Round 6: 128-row leaves of fast-form kernels are evaluated inside potf2_kinv_kernel (no build launch, nothing written but
+    K_leaf^-1); with gh_debug_set_hodlr_leaf_fused(0) the build launch writes the blocks first.  Same evaluator, same ordered
+    arguments: identical log-determinant and solves.  n = 5000: ragged leaves (identity padding inside the kernel); 3-D inputs."""
+    x, yerr, y = zoo.bench_data(n, ndim=ndim)
+    X = x[:, None] if ndim == 1 else np.ascontiguousarray(x)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0) if ndim == 1 else 0.7 * kernels.Matern32Kernel(0.5, ndim=3)
+    got = {}
+    try:
+        for mode in (0, 1):
+            N.lib.gh_debug_set_hodlr_leaf_fused(mode)
+            s = HODLRSolver(kernel, tol=1e-8, min_size=64 if n != 5000 else 40)
+            s.compute(X, yerr)
+            got[mode] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(y))
+    finally:
+        N.lib.gh_debug_set_hodlr_leaf_fused(1)
+    assert got[1][0] == got[0][0] and got[1][1] == got[0][1] and np.array_equal(got[1][2], got[0][2])
+    d = BasicSolver(kernel)
+    d.compute(X, yerr)
+    assert abs(got[1][0] - d.log_determinant) <= 1e-6 * abs(d.log_determinant)
+
+
 def test_parked_handles_are_bounded_and_reused():
     """A dropped HODLRSolver parks its native handle for the next solver with the same options (GP makes a new solver
     per compute, gp.py:327): at most two per option set and four in all, oldest option set evicted first."""
