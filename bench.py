@@ -625,7 +625,7 @@ def compact_line(out):
             "vs_baseline", "dtype", "data", "log_likelihood", "frac_of_fp64_mfma_peak"]
     line = {k: out[k] for k in keep if k in out}
     cfg = out.get("config", {})
-    line["config"] = {k: cfg[k] for k in ("workload", "N", "kernel", "solver", "parallelism", "flops_model", "grid", "nb") if k in cfg}
+    line["config"] = {k: cfg[k] for k in ("workload", "N", "kernel", "solver", "parallelism", "flops_model", "grid", "nb", "panel_widths") if k in cfg}
     if "value_public_api" in out:
         line["value_public_api"] = out["value_public_api"]
     rf = out.get("roofline")
@@ -1084,6 +1084,9 @@ def main():
             "log_likelihood": ll,
             "frac_of_fp64_mfma_peak": value / (PEAK_FP64_MFMA_TFLOPS * world),
         }
+        if world == 1:
+            out["config"]["panel_widths"] = ("adaptive: 2048 while > 25600 trailing columns, then 1024 (gh_chol.hip panel_starts)"
+                                             if args.nb == 0 else "uniform %d" % args.nb)
         if world > 1:
             out["rccl"] = rccl
             out["rccl_ranks_seen"] = rccl["ranks_seen"]
