@@ -3234,15 +3234,20 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     L->tab_R = R; L->tab_off = L->off; L->tab_Rtot = Rtot;
   }
   mark("tables enqueued");
-  GH_HIP(hipStreamSynchronize(st));
-  mark("U, V assembled");
   // The ACA scratch (n x 256 doubles per level: 6 GB at C4, 12 GB for a 524288-row sub-tree) goes back to the block
-  // cache NOW, not when compute() returns: in a split tree the next sub-tree of this device starts while this one waits
+  // cache NOW, not when compute() returns, in a SPLIT tree: the next sub-tree of this device starts while this one waits
   // for the others in its top levels, and found the cache empty -- tens of GB of hipMalloc / hipFree per compute(),
-  // stalls of 1.4-2.8 s at N = 2M over four sub-trees on one GPU.  (Nothing is queued on them any more: just synchronised.)
-  for (auto& a : al) { a.Tcm.release(); a.idx.release(); a.sync.release(); a.part.release(); }
-  sync_all.release();
-  for (auto*& b : levelB) { delete b; b = nullptr; }
+  // stalls of 1.4-2.8 s at N = 2M over four sub-trees on one GPU.  That takes a host synchronisation (another handle may pick the
+  // blocks up on a stream of its own), 20 us in the middle of a 3.4-ms step: a handle that owns its whole tree keeps the scratch
+  // until the end of compute() instead -- the guard below synchronises before the buffers' destructors run on any path out.
+  struct SyncBeforeRelease { hipStream_t st; ~SyncBeforeRelease() { (void)hipStreamSynchronize(st); } } sync_before_release{st};
+  if (l0 > 0) {
+    GH_HIP(hipStreamSynchronize(st));
+    mark("U, V assembled");
+    for (auto& a : al) { a.Tcm.release(); a.idx.release(); a.sync.release(); a.part.release(); }
+    sync_all.release();
+    for (auto*& b : levelB) { delete b; b = nullptr; }
+  }
   {
     size_t maxnodes = 1;
     for (auto* L : h->levels) maxnodes = std::max(maxnodes, L->node_ids.size() * (size_t)std::max(L->R, 1));
