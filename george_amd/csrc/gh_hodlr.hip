@@ -778,6 +778,18 @@ extern "C" int gh_debug_set_hodlr_coop_singles(int on) {
   g_hodlr_coop_singles = on ? 1 : 0;
   return prev;
 }
+// The clusters BELOW the first clustered level get 1 / this of the workgroups the even-load rule deals them (never fewer than two).
+// Even load per thread makes every cluster as fast as the root's -- but only the root's chain of ~20 ACA steps is the critical path
+// of phase 1; the clusters below it finish earlier whatever they get, and every workgroup of a cluster holds its CU (registers:
+// nothing else fits beside it) mostly waiting at cluster barriers.  Half as wide they take longer, still end before the root,
+// and the CUs go to the one-workgroup nodes and the leaves: C4 3.48 -> 3.40 ms, 1 048 576 17.9 -> 17.4, never slower
+// (profiles/r06/hodlr_coop_lower_ab.md; a quarter: 4.02 ms -- then they outlast the root).
+static int g_hodlr_coop_lower = 2;
+extern "C" int gh_debug_set_hodlr_coop_lower(int div) {
+  const int prev = g_hodlr_coop_lower;
+  g_hodlr_coop_lower = div < 1 ? 2 : div;
+  return prev;
+}
 static int g_hodlr_coop_wgs = 256;      // workgroups of the cooperative ACA launch (<= CUs: every cluster resident)
 extern "C" int gh_debug_set_hodlr_coop_wgs(int n) {
   const int prev = g_hodlr_coop_wgs;
@@ -2947,6 +2959,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         total += (int)h->levels[best]->node_ids.size() * al[best].G;
         al[best].G *= 2;
       }
+      // (the clusters below the root at 1 / g_hodlr_coop_lower of that width: see there)
+      for (size_t q = 1; q < cl.size(); ++q) { int& G = al[cl[q]].G; int d = g_hodlr_coop_lower; while (d > 1 && G >= 4) { G /= 2; d /= 2; } }
       std::vector<int> fused, single;
       {
         int used = 0;
