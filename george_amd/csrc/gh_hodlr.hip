@@ -2968,7 +2968,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         for (int l : cl) {
           const int nn = (int)h->levels[l]->node_ids.size();
           if (al[l].G > 1) fused.push_back(l);
-          else if (g_hodlr_coop_singles && nn <= g_hodlr_coop_wgs / 8 && used + nn <= g_hodlr_coop_wgs) { fused.push_back(l); used += nn; }     // (G = 1 segments)
+          // (G = 1 segments.  With the clusters below the root at half width there is room for a second such level -- C4: level 6,
+          //  64 blocks of 2048 x 2048, which start at 0 instead of waiting ~0.24 ms for a CU: 3.40 -> 3.31 ms)
+          else if (g_hodlr_coop_singles && nn <= g_hodlr_coop_wgs / 4 && used + nn <= g_hodlr_coop_wgs) { fused.push_back(l); used += nn; }
           else single.push_back(l);
         }
       }
