@@ -486,13 +486,67 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
     ++rank;
     if (rank >= full_rank) { converged = true; break; }                                // hodlr.h:203
     if (rank >= max_rank) break;                                                       // rank cap: NOT converged
-    un2 = hw_block_sum(un2, sh.shd);
-    vn2 = hw_block_sum(vn2, sh.shd);
     // cross terms |u_new . u_k|, |v_new . v_k|, k < rank-1, of the norm estimate (hodlr.h:210-214):
     // this workgroup's share of each dot product, four at a time
     const double* ul = Tcm + (long)(rank - 1) * N + row0;
     const double* vl = Tcm + (long)(rank - 1) * N + col0;
     double maxu = 0.0, maxv = 0.0;
+    // (round 6, the cooperative launch) ONE workgroup barrier for all the block sums of a step instead of two per sum: the
+    // wavefronts' partial sums of the two squared norms and of the 2 (rank - 1) cross terms go to LDS (sh.coef is free between the
+    // column build and the next step), thread k then adds the eight wavefront sums of term k in hw_block_sum's order -- the same
+    // bits -- and publishes it.  The root of C4 (rank ~20) went through ~460 block sums, two barriers each.
+    const bool batched = CL && rank <= 120;
+    if (batched) {
+      const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+      double* const ws = sh.coef;                      // [(term * 2 + side) * 8 + wavefront]; term rank - 1 = the squared norms
+      __syncthreads();                                 // (every thread is done with the column build's coefficients)
+      {
+        const double a = hw_wave_sum(un2), b = hw_wave_sum(vn2);
+        if (lane == 0) { ws[((rank - 1) * 2) * 8 + wave] = a; ws[((rank - 1) * 2 + 1) * 8 + wave] = b; }
+      }
+      for (int k0 = 0; k0 < rank - 1; k0 += 4) {
+        double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
+        for (int m = t0; m < n_rows; m += ts) {
+          const double u = ul[m];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (k0 + q < rank - 1) du[q] += Tcm[(long)(k0 + q) * N + row0 + m] * u;
+        }
+        for (int n = t0; n < n_cols; n += ts) {
+          const double v = vl[n];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (k0 + q < rank - 1) dv[q] += Tcm[(long)(k0 + q) * N + col0 + n] * v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double a = hw_wave_sum(du[q]), b = hw_wave_sum(dv[q]);
+          if (lane == 0 && k0 + q < rank - 1) { ws[((k0 + q) * 2) * 8 + wave] = a; ws[((k0 + q) * 2 + 1) * 8 + wave] = b; }
+        }
+      }
+      __syncthreads();
+      double ta = 0.0, tb = 0.0;
+      if (tid < rank)
+        for (int w = 0; w < nw; ++w) { ta += ws[(tid * 2) * 8 + w]; tb += ws[(tid * 2 + 1) * 8 + w]; }
+      if (G > 1) {
+        if (tid < rank - 1) { aca_st(mypart + 6 + 2 * tid, ta, true); aca_st(mypart + 7 + 2 * tid, tb, true); }
+        if (tid == rank - 1) { sh.shd[0] = ta; sh.shd[1] = tb; }      // (published behind the next row's draw, below)
+        __syncthreads();
+        un2 = sh.shd[0]; vn2 = sh.shd[1];
+      } else {
+        __syncthreads();                               // (all partial sums read)
+        if (tid < rank) { ws[tid] = tid < rank - 1 ? fabs(ta) : ta; ws[1024 + tid] = tid < rank - 1 ? fabs(tb) : tb; }
+        __syncthreads();
+        for (int k = 0; k < rank - 1; ++k) {
+          if (ws[k] > maxu) maxu = ws[k];
+          if (ws[1024 + k] > maxv) maxv = ws[1024 + k];
+        }
+        un2 = ws[rank - 1]; vn2 = ws[1024 + rank - 1];
+        __syncthreads();                               // (coef is written again at the next step)
+      }
+    } else {
+    un2 = hw_block_sum(un2, sh.shd);
+    vn2 = hw_block_sum(vn2, sh.shd);
     for (int k0 = 0; k0 < rank - 1; k0 += 4) {
       double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
       for (int m = t0; m < n_rows; m += ts) {
@@ -518,6 +572,7 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
           if (fabs(b) > maxv) maxv = fabs(b);
         }
       }
+    }
     }
     if (G > 1) {
       // (round 5) the NEXT step's first candidate row is drawn here and published with this barrier: the draw depends on the
