@@ -187,6 +187,9 @@ __device__ __forceinline__ bool aca_barrier(unsigned* bar, int G, unsigned& epoc
 struct AcaSeg {
   const LvlNode* nodes; double* Tcm; int* idx; int* ranks; unsigned* bars; double* part; int* sel; int* fail; int* trunc;
   int level, G, wg0, nwg;
+  // one-workgroup segments: dur[node] <- how long the node took (10-ns ticks); order != nullptr: workgroup q of the segment takes
+  // node order[q] (the host's longest-first order from the previous compute() of the handle)
+  int* dur; const int* order;
 };
 // CL: the CLUSTER instantiation (G > 1: the cooperative launch of the top levels) without the one-workgroup-only machinery --
 // batched candidate search, LDS mirrors, LDS row permutation; !CL: one workgroup per node (G == 1) without the cluster protocol.
@@ -207,6 +210,8 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
   __shared__ AcaShared sh;
   extern __shared__ double aca_dyn[];                  // capd > 0: U mirror | V mirror | coordinates (ACA_DYN_BYTES)
   int bid = blockIdx.x;
+  int* dur = nullptr;
+  const int* order = nullptr;
   if (segs) {
     int q = 0;
     while (q + 1 < nseg && bid >= segs[q].wg0 + segs[q].nwg) ++q;
@@ -214,8 +219,10 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
     nodes = sg.nodes; Tcm = sg.Tcm; idx = sg.idx; ranks = sg.ranks; bars = sg.bars; part = sg.part; sel = sg.sel;
     fail = sg.fail; trunc = sg.trunc; level = sg.level; G = CL ? sg.G : 1;
     bid -= sg.wg0;
+    if (!CL) { dur = sg.dur; order = sg.order; }
   }
-  const int node = bid / G, g = bid % G;
+  const long long t_begin = dur ? wall_clock64() : 0;
+  const int node = order ? order[bid] : bid / G, g = order ? 0 : bid % G;
   const LvlNode nodev = nodes[node];
   const int col0 = nodev.start, n_cols = nodev.half;
   const int row0 = nodev.start + nodev.half, n_rows = nodev.size - nodev.half;
@@ -616,6 +623,7 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
   }
   if (g == 0 && tid == 0) {
     ranks[node] = rank;
+    if (dur) dur[node] = (int)(wall_clock64() - t_begin);
     if (!converged && rank < full_rank) atomicExch(trunc, 1);     // stopped by the cap, not by the tolerance
 #ifdef GH_ACA_TIMES                                                // (build-time debugging aid: per-node durations of one-workgroup nodes)
     if (G == 1) { mypart[0] = (double)(wall_clock64() - dbg_t0); mypart[1] = (double)rank; mypart[2] = (double)remaining; mypart[3] = (double)dbg_passes; mypart[4] = (double)dbg_t0; }
@@ -843,6 +851,12 @@ static int g_hodlr_coop_lower = 2;
 extern "C" int gh_debug_set_hodlr_coop_lower(int div) {
   const int prev = g_hodlr_coop_lower;
   g_hodlr_coop_lower = div < 1 ? 2 : div;
+  return prev;
+}
+static int g_hodlr_lpt = 1;             // the one-workgroup ACA launch takes a level's nodes longest first (durations of the handle's previous compute())
+extern "C" int gh_debug_set_hodlr_lpt(int on) {
+  const int prev = g_hodlr_lpt;
+  g_hodlr_lpt = on ? 1 : 0;
   return prev;
 }
 static int g_hodlr_coop_wgs = 256;      // workgroups of the cooperative ACA launch (<= CUs: every cluster resident)
@@ -1703,6 +1717,8 @@ struct HLevel {
   // host round trip) was ~1 ms of the 12 ms of a C4 compute.
   std::vector<int> chunk_geom;      // (row0, rows) of every chunk in order: two levels with the same list can share a pass over the rows
   bool nodes_up = false;
+  std::vector<int> aca_dur;         // per node: ticks its one-workgroup ACA took in the last compute() (empty: unknown)
+  GhPooledBuf d_order;              // the node order the next one-workgroup launch takes them in (longest first)
   int tab_R = -1, tab_off = -1, gj_R = -1;
   long tab_Rtot = -1;
 };
@@ -2770,7 +2786,8 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     if ((!h->shared_streams && hipStreamCreateWithFlags(&h->st_b, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->st_b = nullptr; }
   }
-  struct AcaLevel { GhPooledBuf Tcm, idx, sync, part; int G = 1, rcap = 0; int flags[2] = {0, 0}; char* syncp = nullptr; bool sync_cleared = false; };
+  struct AcaLevel { GhPooledBuf Tcm, idx, sync, part; int G = 1, rcap = 0; int flags[2] = {0, 0}; char* syncp = nullptr; bool sync_cleared = false;
+                    bool timed = false; };   // timed: its nodes wrote their durations behind the two flags (the one-workgroup launch)
   GhPooledBuf sync_all;                                  // the levels' barrier counters / selections / flags: one buffer, ONE memset
   std::vector<AcaLevel> al(nlev);
   GhPooledBuf shared_Tcm;
@@ -2800,9 +2817,9 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     if (a.sync_cleared) {                                  // (its slice of sync_all was cleared with all the others)
       a.sync_cleared = false;
     } else {
-      GH_CHECK(a.sync.ensure((size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)));
+      GH_CHECK(a.sync.ensure((size_t)nn * (sizeof(unsigned) + 2 * sizeof(int)) + 2 * sizeof(int)));
       a.syncp = (char*)a.sync.p;
-      GH_HIP(hipMemsetAsync(a.syncp, 0, (size_t)nn * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int), sx));
+      GH_HIP(hipMemsetAsync(a.syncp, 0, (size_t)nn * (sizeof(unsigned) + 2 * sizeof(int)) + 2 * sizeof(int), sx));
     }
     return GH_OK;
   };
@@ -2855,8 +2872,24 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       unsigned* d_bars = (unsigned*)a.syncp;
       int* d_sel = (int*)(d_bars + nn);
       int* d_fail = d_sel + nn;
+      int* d_dur = nullptr;
+      const int* d_order = nullptr;
+      if (ones_only && g_hodlr_lpt) {
+        // The nodes of a level differ in cost by 4x (C4, level 8: 205 us on average, ~800 us for the few whose search runs dry
+        // first), and a long one dispatched late is the end of phase 1: every node reports how long it took, and the next
+        // compute() of the handle launches the level longest first.  Inside an optimiser loop the costs hardly move.
+        d_dur = d_fail + 2;
+        a.timed = true;
+        if ((int)L->aca_dur.size() == nn) {
+          std::vector<int> ord(nn);
+          for (int q = 0; q < nn; ++q) ord[q] = q;
+          std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return L->aca_dur[x] > L->aca_dur[y]; });
+          GH_CHECK(upload(L->d_order, ord, sx));
+          d_order = (const int*)L->d_order.p;
+        }
+      }
       segs.push_back({(const LvlNode*)L->d_nodes.p, a.Tcm.d(), (int*)a.idx.p, (int*)L->d_ranks.p, d_bars, a.part.d(), d_sel,
-                      d_fail, d_fail + 1, l, a.G, wg, nn * a.G});
+                      d_fail, d_fail + 1, l, a.G, wg, nn * a.G, d_dur, d_order});
       wg += nn * a.G;
     }
     GH_CHECK(upload(segbuf, segs, sx));
@@ -2970,7 +3003,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       for (int l = l0; l < nlev; ++l) {
         if (h->levels[l]->top) continue;
         at[l] = off;
-        off += (size_t)gh_round_up((int64_t)(h->levels[l]->node_ids.size() * (sizeof(unsigned) + sizeof(int)) + 2 * sizeof(int)), 256);
+        off += (size_t)gh_round_up((int64_t)(h->levels[l]->node_ids.size() * (sizeof(unsigned) + 2 * sizeof(int)) + 2 * sizeof(int)), 256);   // bars | sel | fail, trunc | dur
       }
       GH_CHECK(sync_all.ensure(std::max<size_t>(off, 256)));
       GH_HIP(hipMemsetAsync(sync_all.p, 0, std::max<size_t>(off, 256), st));
@@ -3140,7 +3173,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         HLevel* L = h->levels[l];
         const int nn = (int)L->node_ids.size();
         items.push_back({(const int*)L->d_ranks.p, nn, tot}); tot += nn;
-        items.push_back({(const int*)((unsigned*)al[l].syncp + nn) + nn, 2, tot}); tot += 2;
+        items.push_back({(const int*)((unsigned*)al[l].syncp + nn) + nn, 2 + (al[l].timed ? nn : 0), tot}); tot += 2 + (al[l].timed ? nn : 0);
       }
       // (pinned host memory, read by the kernel in place: the item table needs no copy of its own)
       const size_t need = (size_t)tot + 4 + items.size() * (sizeof(GatherItem) / sizeof(int));
@@ -3163,6 +3196,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
         const int nn = (int)L->node_ids.size();
         L->ranks.assign(h->h_gather + at, h->h_gather + at + nn); at += nn;
         al[l].flags[0] = h->h_gather[at]; al[l].flags[1] = h->h_gather[at + 1]; at += 2;
+        if (al[l].timed) { L->aca_dur.assign(h->h_gather + at, h->h_gather + at + nn); at += nn; }
       }
     }
     if (h->aca_timed) {                                 // durations for the next compute()'s schedule

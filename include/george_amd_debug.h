@@ -49,6 +49,10 @@ int gh_debug_set_hodlr_coop_wgs(int n);
 /* the clusters below the first clustered level of that launch get 1 / div of the workgroups the even-load rule deals them (never
  * fewer than two): 2 (default; < 1 restores it), 1 = the even-load rule of rounds 3-5.  Returns the previous setting.  Same bits. */
 int gh_debug_set_hodlr_coop_lower(int div);
+/* 1 (default): the one-workgroup ACA launch takes each level's nodes longest first, by the durations the nodes reported in the
+ * handle's previous compute(); 0: in tree order.  Returns the previous setting.  Same bits (a node's arithmetic does not depend on
+ * when it runs). */
+int gh_debug_set_hodlr_lpt(int on);
 /* 1 (default): a level that could be clustered but is left with one workgroup per node by the launch's budget (level 5 of C4) is
  * appended to the cooperative launch as one-workgroup segments; 0: it goes to the one-workgroup launch.  Returns the previous setting. */
 int gh_debug_set_hodlr_coop_singles(int on);
