@@ -498,11 +498,14 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
     const double* ul = Tcm + (long)(rank - 1) * N + row0;
     const double* vl = Tcm + (long)(rank - 1) * N + col0;
     double maxu = 0.0, maxv = 0.0;
-    // (round 6, the cooperative launch) ONE workgroup barrier for all the block sums of a step instead of two per sum: the
+    // (round 6) ONE workgroup barrier for all the block sums of a step instead of two per sum: the
     // wavefronts' partial sums of the two squared norms and of the 2 (rank - 1) cross terms go to LDS (sh.coef is free between the
     // column build and the next step), thread k then adds the eight wavefront sums of term k in hw_block_sum's order -- the same
     // bits -- and publishes it.  The root of C4 (rank ~20) went through ~460 block sums, two barriers each.
-    const bool batched = CL && rank <= 120;
+#ifndef GH_ACA_BATCH_ONES
+#define GH_ACA_BATCH_ONES 1
+#endif
+    const bool batched = (CL || GH_ACA_BATCH_ONES) && rank <= 120;
     if (batched) {
       const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
       double* const ws = sh.coef;                      // [(term * 2 + side) * 8 + wavefront]; term rank - 1 = the squared norms
@@ -514,16 +517,16 @@ __global__ __launch_bounds__(ACA_THREADS, CL ? ACA_WAVES_PER_EU_CL : ACA_WAVES_P
       for (int k0 = 0; k0 < rank - 1; k0 += 4) {
         double du[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
         for (int m = t0; m < n_rows; m += ts) {
-          const double u = ul[m];
+          const double u = rank - 1 < kcap ? uc[(rank - 1) * n_rows + m] : ul[m];
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (k0 + q < rank - 1) du[q] += Tcm[(long)(k0 + q) * N + row0 + m] * u;
+            if (k0 + q < rank - 1) du[q] += (k0 + q < kcap ? uc[(k0 + q) * n_rows + m] : Tcm[(long)(k0 + q) * N + row0 + m]) * u;
         }
         for (int n = t0; n < n_cols; n += ts) {
-          const double v = vl[n];
+          const double v = rank - 1 < kcap ? vc[(rank - 1) * n_cols + n] : vl[n];
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (k0 + q < rank - 1) dv[q] += Tcm[(long)(k0 + q) * N + col0 + n] * v;
+            if (k0 + q < rank - 1) dv[q] += (k0 + q < kcap ? vc[(k0 + q) * n_cols + n] : Tcm[(long)(k0 + q) * N + col0 + n]) * v;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
