@@ -106,6 +106,7 @@ SIGNATURES = {
     "gh_debug_set_mfma": (C.c_int, [C.c_int]),
     "gh_debug_set_gemm_sp": (C.c_int, [C.c_int]),
     "gh_debug_set_adaptive_panels": (C.c_int, [C.c_int]),
+    "gh_debug_set_build_on_chain": (C.c_int, [C.c_int]),
     "gh_debug_set_gemm_grouped": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_passes": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_leaf_gj": (C.c_int, [C.c_int]),

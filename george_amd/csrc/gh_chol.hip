@@ -551,6 +551,7 @@ struct gh_chol {
   double logdet = 0.0;
   GhBuf A, dinv, x, yerr, v0, v1, v2, scal, rhs, work, work2, scratch, chain;
   long long* d_info = nullptr;           // = (long long*)(scal + 2): the failure word lives beside the scalars (set in compute_enqueue)
+  bool build_on_chain = false;           // this compute(): inputs + kernel-matrix build were enqueued on the chain stream (st2)
   gh_chol_profile prof;
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
@@ -933,6 +934,12 @@ static int64_t panel_width(const gh_chol* s) {
 #define GH_WIDE_PANEL_MIN_TRAILING 25600
 #endif
 
+static int g_build_on_chain = 1;
+extern "C" int gh_debug_set_build_on_chain(int on) {
+  const int prev = g_build_on_chain;
+  g_build_on_chain = on ? 1 : 0;
+  return prev;
+}
 static int g_adaptive_panels = 1;        // 0: off; 1: on (GH_WIDE_PANEL_MIN_TRAILING); > 1: on with this many trailing columns as the bound
 extern "C" int gh_debug_set_adaptive_panels(int on) {
   const int prev = g_adaptive_panels;
@@ -979,8 +986,8 @@ static int panel_step(gh_chol* s, hipStream_t st, int64_t k0, int64_t nb) {
   hipStream_t sa = s->st3;
   double* Ak = blk(A, ld, k0, k0);
   double* B = blk(A, ld, k0 + nb, k0);
-  GH_HIP(hipEventRecord(s->ev_aux, st));
-  GH_HIP(hipStreamWaitEvent(sa, s->ev_aux, 0));
+  // (the rows-below stream's first operation waits for ev_diag[0], recorded on `st` behind everything this panel needs: no event of
+  //  its own at the panel's start -- a record costs the recording stream ~6 us before its next kernel)
   for (int64_t j0 = 0; j0 < nb; j0 += T) {
     double* dj = dinv + (j0 / T) * T * T;
     GH_CHECK(gh_launch_potf2_mfma(blk(Ak, ld, j0, j0), ld, dj, s->d_info, k0 + j0, st));
@@ -1111,10 +1118,12 @@ static int factor_lookahead_deep(gh_chol* s, int depth) {
     return GH_OK;
   };
   // everything queued so far (the build, on s->st) before any of the three streams starts
-  GH_HIP(hipEventRecord(s->ev_sync[0], s->st));
-  GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
-  GH_HIP(hipStreamWaitEvent(sn, s->ev_sync[0], 0));
-  if (sm != s->st) GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[0], 0));
+  if (!s->build_on_chain) {
+    GH_HIP(hipEventRecord(s->ev_sync[0], s->st));
+    GH_HIP(hipStreamWaitEvent(sp, s->ev_sync[0], 0));
+    GH_HIP(hipStreamWaitEvent(sn, s->ev_sync[0], 0));
+    if (sm != s->st) GH_HIP(hipStreamWaitEvent(sm, s->ev_sync[0], 0));
+  }   // (else the build is the chain stream's own work: the rows-below stream follows ev_aux, the update streams ev_p[0])
   for (int j = 0; j < P; ++j) {
     // ---- chain: column j is complete once U(j-1, j) has run (issued at the end of the previous turn)
     {
@@ -1271,7 +1280,11 @@ static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n,
   GH_CHECK(s->x.ensure((size_t)n * ndim * sizeof(double)));
   GH_CHECK(s->yerr.ensure((size_t)n * sizeof(double)));
   GH_CHECK(s->scal.ensure(256 * sizeof(double)));      // [0] log-det, [1] quadratic form, [8..72) and [72..136) slice sums
-  hipStream_t st = s->st;
+  // With look-ahead the first thing that needs the matrix is the chain stream's first panel: inputs and kernel-matrix build go to
+  // THAT stream (everything else waits for panel events that follow them in its order) instead of the main stream + a
+  // cross-stream hand-over -- 19 us between the build and the first potf2 of every compute() (profiles/r06/: N = 2048 timeline).
+  s->build_on_chain = g_build_on_chain && s->opts.lookahead && s->st2 && s->st3 && s->st4 && np > panel_width(s);
+  hipStream_t st = s->build_on_chain ? s->st2 : s->st;
   memset(&s->prof, 0, sizeof(s->prof));
   s->ev_used = 0; s->ev_trailing.clear(); s->ev_panel.clear(); s->ev_update.clear(); s->ev_update_flops.clear();
   const bool prof = s->opts.profile != 0;
@@ -1292,7 +1305,7 @@ static int compute_enqueue(gh_chol* s, gh_kernel* k, const double* x, int64_t n,
   if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].a, st));
   GH_CHECK(gh_launch_kmat(k, s->x.d(), n, s->x.d(), n, s->yerr.d(), s->A.d(), np, np, np, 0, 0, true, true, st));
   if (c.e_build >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_build].b, st));
-  s->tail = st;
+  s->tail = s->st;
   GH_CHECK(factor(s));                                  // (may move s->tail to the chain stream)
   GH_CHECK(launch_logdet(s->A.d(), np, np, s->scal.d(), s->scal.d() + 8, s->tail));
   if (c.e_all >= 0) GH_HIP(hipEventRecord(s->ev_pool[c.e_all].b, s->tail));

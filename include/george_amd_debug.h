@@ -27,6 +27,9 @@ int gh_debug_set_gemm_sp(int mode);
  * row-major, 1 row groups of 8 walked column-major; returns the previous mode.  Same bits (a tile's arithmetic does not depend on
  * when it runs).  For the traffic A/B of profiles/r06/syrk_traffic_ab.md. */
 int gh_debug_set_gemm_grouped(int mode);
+/* 1 (default): with look-ahead, a compute()'s inputs and kernel-matrix build are enqueued on the chain stream (whose first panel is
+ * the first thing that needs them); 0: on the main stream with a cross-stream hand-over, as until round 6.  Returns the previous setting. */
+int gh_debug_set_build_on_chain(int on);
 /* 1 (default): with the panel width left to the solver (gh_chol_opts.nb == 0) the outer panels are 2048 columns wide while the
  * trailing matrix behind them has more than 25 600 columns and 1024 after; 0: 1024 throughout; n > 1: the bound is n columns.
  * Returns the previous setting.  Same bits whatever the widths (the update adds the same k in the same order). */
