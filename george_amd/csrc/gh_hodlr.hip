@@ -1162,7 +1162,10 @@ __global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long*
   }
   bool used = false, bad = false;
   int myk = 0, pc[NMAX];
-  double ld = 0.0;
+  // (round 6) log|det| = sum_k log|pivot_k| in pivot order -- but not INSIDE the pivot loop, where every lane evaluated the same
+  // f64 logarithm (~150 instructions) on the critical path of each of the n dependent steps: lane k keeps pivot k, all lanes take
+  // their logarithm at once after the loop, lane 0 adds them in the same order (the same bits)
+  double mypiv = 1.0;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     if (k < n && !bad) {                          // (uniform)
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long*
       else {
         pc[k] = p;
         if (lane == p) { used = true; myk = k; }
-        ld += log(fabs(pv));
+        if (lane == k) mypiv = pv;
         const double rinv = 1.0 / pv;
         const double f = m[k];
 #pragma unroll
@@ -1200,7 +1203,12 @@ __global__ __launch_bounds__(256) void gj_small_kernel(double* base, const long*
     for (int c = 0; c < NMAX; ++c)
       if (c < n) M[(long)myk * n + pc[c]] = m[c];
   }
-  if (lane == 0) logdet[b] = ld;
+  {
+    const double lg = log(fabs(mypiv));
+    double ld = 0.0;
+    for (int k = 0; k < n; ++k) ld += gj_bcast(lg, k);
+    if (lane == 0) logdet[b] = ld;
+  }
 }
 
 // The same inverse with ONE WORKGROUP per matrix, its columns dealt over the four wavefronts (column c on wavefront c & 3): for
@@ -1239,7 +1247,7 @@ __global__ __launch_bounds__(256) void gj_small4_kernel(double* base, const long
   }
   bool used = false, bad = false;
   int myk = 0, pcw[CW];
-  double ld = 0.0;
+  double mypiv = 1.0;                             // (lane k keeps pivot k: the logarithms are taken after the loop -- see gj_small_kernel)
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     if (k < n && !bad) {                          // (uniform over the workgroup: `bad` is set by all wavefronts together)
@@ -1262,7 +1270,7 @@ __global__ __launch_bounds__(256) void gj_small4_kernel(double* base, const long
         const double f = fcol[buf][lane];
         const double pv = fcol[buf][p];
         if (lane == p) { used = true; myk = k; }
-        ld += log(fabs(pv));
+        if (lane == k) mypiv = pv;
         const double rinv = 1.0 / pv;
 #pragma unroll
         for (int q = 0; q < CW; ++q) {
@@ -1288,7 +1296,12 @@ __global__ __launch_bounds__(256) void gj_small4_kernel(double* base, const long
       if (c < n) M[(long)myk * n + pcw[q]] = m[q];
     }
   }
-  if (threadIdx.x == 0) logdet[b] = ld;
+  if (w == 0) {
+    const double lg = log(fabs(mypiv));
+    double ld = 0.0;
+    for (int k = 0; k < n; ++k) ld += gj_bcast(lg, k);
+    if (lane == 0) logdet[b] = ld;
+  }
 }
 
 // =============================================================== batched small dense products
