@@ -411,6 +411,37 @@ def test_wave_per_node_aca_gives_the_same_bits(case):
     assert got[1][3] == got[0][3]
 
 
+@pytest.mark.parametrize("n", [65536, 131072])
+def test_phase_one_packing_gives_the_same_bits(n):
+    """Round 6, late: WHO GETS A CU WHEN in the ACA phase -- the clusters below the root at half the even-load width
+    (gh_debug_set_hodlr_coop_lower), a second level of one-workgroup nodes inside the cooperative launch, the one-workgroup launch
+    longest first by the durations the nodes reported in the handle's previous compute() (gh_debug_set_hodlr_lpt), one barrier for
+    all the block sums of an ACA step -- changes no arithmetic: ranks, log-determinant and solves IDENTICAL in every arm, and from
+    the first compute() of a handle (tree order) to its third (sorted by the second's durations)."""
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    got = {}
+    try:
+        for lower, lpt in ((1, 0), (2, 0), (2, 1), (4, 1)):
+            N.lib.gh_debug_set_hodlr_coop_lower(lower)
+            N.lib.gh_debug_set_hodlr_lpt(lpt)
+            s = HODLRSolver(kernel, tol=1e-10)
+            res = []
+            for rep in range(3):
+                s.compute(x[:, None], yerr)
+                res.append((s.log_determinant, s.dot_solve(y), list(s.ranks())))
+            assert res[1] == res[0] and res[2] == res[0]
+            got[(lower, lpt)] = (res[0], s.apply_inverse(y))
+            del s
+    finally:
+        N.lib.gh_debug_set_hodlr_coop_lower(-1)
+        N.lib.gh_debug_set_hodlr_lpt(1)
+    ref = got[(1, 0)]
+    for key, val in got.items():
+        assert val[0] == ref[0], key
+        assert np.array_equal(val[1], ref[1]), key
+
+
 @pytest.mark.parametrize("n,ndim", [(4096, 1), (5000, 1), (6000, 3)])
 def test_leaf_blocks_evaluated_inside_the_factorisation_kernel(n, ndim):
     """Round 6: 128-row leaves of fast-form kernels are evaluated inside potf2_kinv_kernel (no build launch, nothing written but

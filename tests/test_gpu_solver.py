@@ -565,6 +565,32 @@ def test_adaptive_panel_width_gives_the_same_bits():
         assert np.array_equal(got[mode][2], got[0][2])
 
 
+@pytest.mark.parametrize("n", [1500, 3000, 9000])
+def test_build_on_the_chain_stream_gives_the_same_bits(n):
+    """Round 6: with look-ahead, a compute()'s inputs and kernel-matrix build are enqueued on the chain stream (the first panel is the
+    first thing that needs them) instead of the main stream + a cross-stream hand-over (gh_debug_set_build_on_chain).  Where the
+    work is enqueued changes nothing it computes: identical log-determinant, quadratic form and alpha; a second compute() of the
+    same handle (the streams are re-used) and NumPy inputs (copies instead of the one-launch input staging) included."""
+    from george_amd import _native as N
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.Matern32Kernel(1.0)
+    got = {}
+    try:
+        for mode in (0, 1):
+            N.lib.gh_debug_set_build_on_chain(mode)
+            s = BasicSolver(kernel)
+            s.compute(x[:, None], yerr)
+            first = (s.log_determinant, s.dot_solve(y))
+            s.compute(x[:, None], yerr)
+            assert (s.log_determinant, s.dot_solve(y)) == first
+            got[mode] = first + (s.apply_inverse(y),)
+            del s
+    finally:
+        N.lib.gh_debug_set_build_on_chain(1)
+    assert got[1][0] == got[0][0] and got[1][1] == got[0][1]
+    assert np.array_equal(got[1][2], got[0][2])
+
+
 def test_full_size_c2_properties():
     """BASELINE config C2 (N=16384, 1-D ExpSquared): too slow for the CPU oracle inside a test
     (~30 s), so check size-independent properties: residual of the solve against an independent
