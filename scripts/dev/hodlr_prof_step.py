@@ -1,4 +1,4 @@
-"""five steps of bench.HodlrJob(N) for rocprofv3 --kernel-trace --stats (mask from GEORGE_AMD_HODLR_PASSES)"""
+"""five steps of bench.HodlrJob(N) for rocprofv3 --kernel-trace --stats (mask: gh_debug_set_hodlr_passes)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
