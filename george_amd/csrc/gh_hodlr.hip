@@ -856,6 +856,12 @@ extern "C" int gh_debug_set_hodlr_coop_lower(int div) {
   g_hodlr_coop_lower = div < 1 ? 2 : div;
   return prev;
 }
+static int g_hodlr_u_from_v = 1;        // the factorisation's leaf product reads the level-major V and writes U for the first time (no U from the compaction)
+extern "C" int gh_debug_set_hodlr_u_from_v(int on) {
+  const int prev = g_hodlr_u_from_v;
+  g_hodlr_u_from_v = on ? 1 : 0;
+  return prev;
+}
 static int g_hodlr_lpt = 1;             // the one-workgroup ACA launch takes a level's nodes longest first (durations of the handle's previous compute())
 extern "C" int gh_debug_set_hodlr_lpt(int on) {
   const int prev = g_hodlr_lpt;
@@ -902,7 +908,7 @@ __global__ void hodlr_compact_all_kernel(const CompactSeg* segs, int nseg, long 
     const int r = (int)(e / R), k = (int)(e % R);
     const long i = nd.start + r;
     const double v = (k < rk) ? sg.Tcm[(long)k * N + i] : 0.0;
-    UA[i * ld + sg.off + k] = v;
+    if (UA) UA[i * ld + sg.off + k] = v;          // (nullptr: the leaf product reads the level-major copy and writes U itself -- LeafSrc)
     VA[i * sg.ldv + sg.offv + k] = v;
   }
 }
@@ -1870,6 +1876,36 @@ __global__ void hodlr_gather_kernel(const GatherItem* items, int* out) {
 // rows [0, nrows) x columns [0, 16 ct) of a row-major block into LDS (pitch xp), zero where row >= nrows or
 // column >= C; eight independent loads in flight per thread (a rolled load-store loop waits for every load in turn:
 // 40 round trips per workgroup)
+// (round 6) The factorisation's leaf product takes its input -- the un-factored U, which is V: the compaction writes the same values
+// to both -- from the LEVEL-MAJOR copy VA (level l, row i, column k at VA[offv[l] + i R[l] + k]; a leaf's rows of a level are one
+// contiguous piece) and writes the row-major U for the first time: the compaction no longer writes U (157 MB at C4) for this
+// kernel to read back.  Same values in the same LDS image: the same bits.
+struct LeafSrc { const double* VA; int nlev; int off[24], R[24]; long offv[24]; };
+__device__ __forceinline__ void hodlr_stage_rows_va(double* Xs, int xp, const LeafSrc& ls, int row0, int nrows, int C, int ct) {
+  // column c of the image = column k of level l: element (r, c) at VA[colbase[c] + (row0 + r) colR[c]], colbase[c] = offv[l] + k.
+  // Lanes take consecutive COLUMNS (LDS writes free of bank conflicts at a pitch that is a multiple of 16 doubles; the reads are
+  // the levels' pieces of a row, 24-120 contiguous bytes each, whose neighbours the next row's loads find in the caches)
+  const int tid = threadIdx.x, w = 16 * ct;
+  const int c = tid & 127, rh = tid >> 7;            // two rows per step
+  const bool cok = c < C;
+  long cb = 0;                                       // (no table in LDS: the image is exactly half a CU's LDS at CT = 5)
+  int cr = 0;
+  for (int t = 0; t < ls.nlev; ++t)
+    if (cok && ls.R[t] > 0 && ls.off[t] <= c) { cb = ls.offv[t] + (c - ls.off[t]); cr = ls.R[t]; }
+  if (c < w) {
+#pragma unroll 1
+    for (int r0 = 0; r0 < 128; r0 += 16) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = r0 + 2 * q + rh;
+        v[q] = (cok && r < nrows) ? ls.VA[cb + (long)(row0 + r) * cr] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) Xs[(r0 + 2 * q + rh) * xp + c] = v[q];
+    }
+  }
+}
 __device__ __forceinline__ void hodlr_stage_rows(double* Xs, int xp, const double* src, long ld, int nrows, int C, int ct) {
   const int w = 16 * ct, tot = 128 * w;
   for (int e0 = threadIdx.x; e0 < tot; e0 += 8 * 256) {
@@ -1902,7 +1938,7 @@ template <int CT>
 __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __restrict__ jobs, const double* __restrict__ Kinv,
                                                                double* __restrict__ X, long ldx, long xcol0, int C,
                                                                const MMJob* __restrict__ rjobs = nullptr, const double* __restrict__ V2 = nullptr,
-                                                               int R2 = 0, double* __restrict__ P = nullptr, long ldp = 0) {
+                                                               int R2 = 0, double* __restrict__ P = nullptr, long ldp = 0, LeafSrc ls = LeafSrc()) {
   // (no padding column: at CT = 5 the image is then exactly 80 KiB and TWO workgroups share a CU's 160 KiB -- with 81 columns
   //  it was 83 KiB, one workgroup = one wavefront per SIMD and nothing to hide the A operand's HBM latency behind; the price is
   //  a two-way bank conflict between the lane groups fk and fk + 2 of a B fragment read)
@@ -1914,7 +1950,8 @@ __global__ __launch_bounds__(256) void hodlr_leaf_apply_kernel(const MMJob* __re
   const int fr = lane & 15, fk = lane >> 4;
   double* const xb = X + (long)job.b_row * ldx + xcol0;
   const int ct = (C + 15) >> 4;                   // column tiles that hold anything (uniform)
-  hodlr_stage_rows(Xs, XP, xb, ldx, job.m, C, ct);
+  if (ls.VA) hodlr_stage_rows_va(Xs, XP, ls, job.b_row, job.m, C, ct);      // (the factorisation's first pass: X is written here for the first time)
+  else hodlr_stage_rows(Xs, XP, xb, ldx, job.m, C, ct);
   __syncthreads();
   la_v4d acc[2][CT];
 #pragma unroll
@@ -2374,7 +2411,9 @@ static int apply_level(gh_hodlr* h, HLevel* L, double* X, long ldx, long xcol0, 
 // red / red_done: the sweep's first call -- form the chunk products of level `red` over the same columns in the same pass when
 // its chunks are the leaves (then *red_done = true and the caller skips that level's reduce)
 static int hodlr_passes();
-static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C, const HLevel* red = nullptr, bool* red_done = nullptr) {
+static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C, const HLevel* red = nullptr, bool* red_done = nullptr,
+                        const LeafSrc* src = nullptr) {
+  const LeafSrc ls = src ? *src : LeafSrc();         // (src: only on the 128-row-leaf path with ONE column pass -- leaf_src_possible())
   if (red_done) *red_done = false;
   if (C <= 0) return GH_OK;
   if (C <= MV_C && h->max_leaf <= 256) {
@@ -2394,9 +2433,9 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C, con
       const MMJob* rj = (const MMJob*)red->d_red_jobs.p;
       const double* V2 = h->VA.d() + (long)h->n * red->off;
       if (C <= 80) hipLaunchKernelGGL(hodlr_leaf_apply_kernel<5>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0, C,
-                                      rj, V2, red->R, h->P.d(), (long)h->cpass);
+                                      rj, V2, red->R, h->P.d(), (long)h->cpass, ls);
       else hipLaunchKernelGGL(hodlr_leaf_apply_kernel<8>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0, C,
-                              rj, V2, red->R, h->P.d(), (long)h->cpass);
+                              rj, V2, red->R, h->P.d(), (long)h->cpass, ls);
       GH_HIP(hipGetLastError());
       *red_done = true;
       return GH_OK;
@@ -2404,8 +2443,10 @@ static int apply_leaves(gh_hodlr* h, double* X, long ldx, long xcol0, int C, con
     for (int cp = 0; cp < C;) {
       const int cw = std::min(128, C - cp);
       const unsigned nl = (unsigned)h->leaves.size();
-      if (cw <= 80) hipLaunchKernelGGL(hodlr_leaf_apply_kernel<5>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0 + cp, cw);
-      else hipLaunchKernelGGL(hodlr_leaf_apply_kernel<8>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0 + cp, cw);
+      if (cw <= 80) hipLaunchKernelGGL(hodlr_leaf_apply_kernel<5>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0 + cp, cw,
+                                       (const MMJob*)nullptr, (const double*)nullptr, 0, (double*)nullptr, 0L, ls);
+      else hipLaunchKernelGGL(hodlr_leaf_apply_kernel<8>, dim3(nl), dim3(256), 0, h->st, (const MMJob*)h->d_leaf_jobs.p, h->leaf_inv.d(), X, ldx, xcol0 + cp, cw,
+                              (const MMJob*)nullptr, (const double*)nullptr, 0, (double*)nullptr, 0L, ls);
       GH_HIP(hipGetLastError());
       cp += cw;
     }
@@ -3280,6 +3321,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   for (int l = l0; l < nlev; ++l) if (h->levels[l]->node_ids.size() != ((size_t)1 << (l - l0))) complete = false;   // (a pseudo-level covers every local row)
   bool fused_compact = true;
   for (int l = 0; l < nlev; ++l) if (levelB[l]) fused_compact = false;
+  // (round 6) the compaction writes the level-major copy only and the leaf product -- the first thing that touches U -- reads that and
+  // writes the row-major U itself, where that product is ONE pass of the 128-row-leaf kernel over all columns (LeafSrc)
+  const bool u_from_v = g_hodlr_u_from_v && fused_compact && complete && l0 == 0 && nlev <= 24 && h->leaf_pitch == 128 && h->max_leaf <= 128 &&
+                        h->Rtot > MV_C && h->Rtot <= 128;
   if (!(complete && fused_compact)) {
     GH_HIP(hipMemsetAsync(h->UA.p, 0, (size_t)n * Rtot * sizeof(double), st));
     GH_HIP(hipMemsetAsync(h->VA.p, 0, (size_t)n * Rtot * sizeof(double), st));
@@ -3298,7 +3343,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     if (b0 > 0) {
       GH_CHECK(upload(h->d_compact_segs, segs, st));
       hipLaunchKernelGGL(hodlr_compact_all_kernel, dim3((unsigned)b0), dim3(256), 0, st, (const CompactSeg*)h->d_compact_segs.p, (int)segs.size(),
-                         (long)n, h->UA.d(), (long)Rtot, h->VA.d());
+                         (long)n, u_from_v ? (double*)nullptr : h->UA.d(), (long)Rtot, h->VA.d());
       GH_HIP(hipGetLastError());
     }
   }
@@ -3388,7 +3433,12 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   if (h->Rtot > 0) {
     const HLevel* deepest = nullptr;
     for (int q = nlev - 1; q >= 0 && !deepest; --q) if (h->levels[q]->R > 0) deepest = h->levels[q];
-    GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot, deepest, &red_ready));
+    LeafSrc ls;
+    if (u_from_v) {
+      ls.VA = h->VA.d(); ls.nlev = nlev;
+      for (int q = 0; q < nlev; ++q) { ls.off[q] = h->levels[q]->off; ls.R[q] = h->levels[q]->R; ls.offv[q] = (long)n * h->levels[q]->off; }
+    }
+    GH_CHECK(apply_leaves(h, h->UA.d(), Rtot, 0, h->Rtot, deepest, &red_ready, u_from_v ? &ls : nullptr));
   }
   std::vector<size_t> top_ld(l0, (size_t)-1);        // where in ld_all the core of pseudo-level l put its log|det|
   bool local_done = (l0 == 0);

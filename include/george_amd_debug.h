@@ -56,6 +56,10 @@ int gh_debug_set_hodlr_coop_lower(int div);
  * handle's previous compute(); 0: in tree order.  Returns the previous setting.  Same bits (a node's arithmetic does not depend on
  * when it runs). */
 int gh_debug_set_hodlr_lpt(int on);
+/* 1 (default): where the factorisation's leaf product is one pass of the 128-row-leaf kernel, the compaction of the ACA scratch
+ * writes the level-major copy V only and that product reads it and writes the row-major U for the first time; 0: the compaction
+ * writes both and the product works on U in place (rounds 3-5).  Returns the previous setting.  Same bits. */
+int gh_debug_set_hodlr_u_from_v(int on);
 /* 1 (default): a level that could be clustered but is left with one workgroup per node by the launch's budget (level 5 of C4) is
  * appended to the cooperative launch as one-workgroup segments; 0: it goes to the one-workgroup launch.  Returns the previous setting. */
 int gh_debug_set_hodlr_coop_singles(int on);

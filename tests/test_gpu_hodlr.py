@@ -411,6 +411,28 @@ def test_wave_per_node_aca_gives_the_same_bits(case):
     assert got[1][3] == got[0][3]
 
 
+@pytest.mark.parametrize("n, tol", [(4096, 1e-10), (16384, 1e-10), (65536, 1e-10), (5000, 1e-8), (20000, 1e-3)])
+def test_leaf_product_from_the_level_major_copy_gives_the_same_bits(n, tol):
+    """Round 6: the compaction writes the level-major copy V only; the factorisation's leaf product reads a leaf's rows from it
+    (a contiguous piece per level) and writes the row-major U for the first time (gh_debug_set_hodlr_u_from_v; LeafSrc in
+    gh_hodlr.hip).  The LDS image the product multiplies from holds the same doubles: identical ranks, log-determinant and solves.
+    n = 5000: ragged leaves (rows past a leaf's end are zeros in the image); tol = 1e-3: few columns, levels of rank zero."""
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    got = {}
+    try:
+        for mode in (0, 1):
+            N.lib.gh_debug_set_hodlr_u_from_v(mode)
+            s = HODLRSolver(kernel, tol=tol, min_size=64 if n != 5000 else 40)
+            s.compute(x[:, None], yerr)
+            got[mode] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(y), list(s.ranks()))
+            del s
+    finally:
+        N.lib.gh_debug_set_hodlr_u_from_v(1)
+    assert got[1][0] == got[0][0] and got[1][1] == got[0][1] and got[1][3] == got[0][3]
+    assert np.array_equal(got[1][2], got[0][2])
+
+
 @pytest.mark.parametrize("n", [65536, 131072])
 def test_phase_one_packing_gives_the_same_bits(n):
     """Round 6, late: WHO GETS A CU WHEN in the ACA phase -- the clusters below the root at half the even-load width
