@@ -115,6 +115,7 @@ SIGNATURES = {
     "gh_debug_set_hodlr_coop_lower": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_lpt": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_u_from_v": (C.c_int, [C.c_int]),
+    "gh_debug_set_hodlr_core_fused": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_coop_singles": (C.c_int, [C.c_int]),
     "gh_debug_set_hodlr_leaf_fused": (C.c_int, [C.c_int]),
     "gh_debug_stream_overlap": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),

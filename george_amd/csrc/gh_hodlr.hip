@@ -2537,6 +2537,148 @@ static int solve_all(gh_hodlr* h, double* X, long ldx, int C) {
 // (tables: device copies of offs / sizes / scratch offsets kept by the caller; *tables_valid says they
 //  already hold this batch's values)
 // tsum / tsum_R: see gj_small_kernel (the caller then skips hodlr_sbuild_kernel)
+// ---------------------------------------------------------------------------------------------------------------
+// (round 6) "sum + core inverse + core product" of one level in ONE launch, a workgroup per node, for the levels with many small
+// nodes (C4: levels 5-10, three launches of 5-15 us each per level for a few kFLOP per node):
+//   Tsum (2R x C, in LDS only) = the node's chunk partials added up -- hodlr_sum_kernel's order: eight slices of consecutive chunks,
+//        each summed from 0.0 in chunk order, then the slice sums in order;
+//   S^-1 = the pivoted Gauss-Jordan of gj_small4_kernel (columns over the four wavefronts; a column's arithmetic does not depend on
+//        which wavefront holds it), built from Tsum's own-level columns, written to `sinv` for the solves; log|det S| likewise;
+//   Tout = S^-1 Tsum[:, 0:Cmm] on the matrix pipe with hodlr_mm_kernel's tile and k order.
+// The same doubles through the same operations as the three launches: the same bits (tests/test_gpu_hodlr.py).
+template <int NMAX>
+__global__ __launch_bounds__(256) void hodlr_core_kernel(const double* __restrict__ P, const int* __restrict__ crange, int R, long Cp, int C,
+                                                         int coff, int Cmm, double* __restrict__ sinv, double* __restrict__ logdet,
+                                                         int* __restrict__ fail, double* __restrict__ Tout) {
+  constexpr int CW = NMAX / 4;
+  constexpr int TP = 129;                            // row pitch of the Tsum image (C <= 128)
+  __shared__ double ts[NMAX * TP];
+  __shared__ double ainv[NMAX * NMAX];
+  __shared__ double fcol[2][64];
+  __shared__ int sp[2];
+  const int node = blockIdx.x, n = 2 * R, tid = threadIdx.x;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- (1) Tsum
+  for (int e = tid; e < n * C; e += 256) {
+    const int row = e / C, c = e - row * C;
+    const int half = row < R ? 1 : 0, k = row < R ? row : row - R;
+    const int cb = crange[(node * 2 + half) * 2], ce = crange[(node * 2 + half) * 2 + 1];
+    const int per = (ce - cb + SUM_NS - 1) / SUM_NS;
+    double t = 0.0;
+    for (int q = 0; q < SUM_NS; ++q) {
+      const int lo = cb + q * per, hi = lo + per < ce ? lo + per : ce;
+      double v = 0.0;
+      for (int ch = lo; ch < hi; ++ch) v += P[((long)ch * R + k) * Cp + c];
+      t += v;
+    }
+    ts[row * TP + c] = t;
+  }
+  __syncthreads();
+  // ---- (2) S = [[I, V1^T U1], [V0^T U0, I]] (hodlr.h:229-232) and its inverse: gj_small4_kernel on the LDS image
+  const bool row = lane < n;
+  double m[CW];
+#pragma unroll
+  for (int q = 0; q < CW; ++q) {
+    const int c = 4 * q + w;
+    double v = (lane == c) ? 1.0 : 0.0;
+    if (row && c < n) {
+      if (lane < R && c >= R) v = ts[lane * TP + coff + c - R];
+      else if (lane >= R && c < R) v = ts[lane * TP + coff + c];
+    }
+    m[q] = (row && c < n) ? v : 0.0;
+  }
+  bool used = false, bad = false;
+  int myk = 0, pcw[CW];
+  double mypiv = 1.0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    if (k < n && !bad) {
+      const int buf = k & 1, own = k & 3, qk = k >> 2;
+      if (w == own) {
+        const bool cand = row && !used;
+        const unsigned key = cand ? (unsigned)__double2hiint(fabs(m[qk])) : 0u;
+        const unsigned rm = gj_row_max_u32(key);
+        const unsigned mx = max((unsigned)__builtin_amdgcn_readlane((int)rm, 0), (unsigned)__builtin_amdgcn_readlane((int)rm, 16));
+        const unsigned long long who = __builtin_amdgcn_ballot_w64(cand && key == mx);
+        const int p = (int)__builtin_ctzll(who | (1ull << 63));
+        const double pv = gj_bcast(m[qk], p);
+        fcol[buf][lane] = m[qk];
+        if (lane == 0) sp[buf] = (who == 0ull || !(fabs(pv) > 0.0)) ? -1 : p;
+      }
+      __syncthreads();
+      const int p = __builtin_amdgcn_readfirstlane(sp[buf]);
+      if (p < 0) { bad = true; }
+      else {
+        const double f = fcol[buf][lane];
+        const double pv = fcol[buf][p];
+        if (lane == p) { used = true; myk = k; }
+        if (lane == k) mypiv = pv;
+        const double rinv = 1.0 / pv;
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const int c = 4 * q + w;
+          if (c == k) pcw[q] = p;
+          if (c != k && c < n) {
+            const double pr = gj_bcast(m[q], p) * rinv;
+            m[q] = (lane == p) ? pr : fma(-f, pr, m[q]);
+          }
+        }
+        if (w == own) m[qk] = (lane == p) ? rinv : -f * rinv;
+      }
+    }
+  }
+  if (bad) {                                       // (uniform over the workgroup)
+    if (tid == 0) { atomicExch(fail, node + 1); logdet[node] = 0.0; }
+    return;
+  }
+  double* const M = sinv + (long)node * n * n;
+  if (row) {
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+      const int c = 4 * q + w;
+      if (c < n) { M[(long)myk * n + pcw[q]] = m[q]; ainv[myk * n + pcw[q]] = m[q]; }
+    }
+  }
+  if (w == 0) {
+    const double lg = log(fabs(mypiv));
+    double ld = 0.0;
+    for (int k = 0; k < n; ++k) ld += gj_bcast(lg, k);
+    if (lane == 0) logdet[node] = ld;
+  }
+  __syncthreads();
+  // ---- (3) Tout = S^-1 Tsum[:, 0:Cmm]: hodlr_mm_kernel's 32 x 64 tile (wavefront w: 16-row block w & 1, 16-column blocks
+  //          2 (w >> 1), 2 (w >> 1) + 1), one 32-deep k block (2R <= 32)
+  typedef double cm_v4d __attribute__((ext_vector_type(4)));
+  const int fr = lane & 15, fk = lane >> 4, bi = w & 1, bj = 2 * (w >> 1);
+  for (int c0 = 0; c0 < Cmm; c0 += 64) {
+    cm_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int ar = 16 * bi + fr, k = 4 * kk + fk;
+      const double av = (ar < n && k < n) ? ainv[ar * n + k] : 0.0;
+      const int cA = c0 + 16 * bj + fr, cB = cA + 16;
+      const double b0 = (k < n && cA < Cmm) ? ts[k * TP + cA] : 0.0;
+      const double b1 = (k < n && cB < Cmm) ? ts[k * TP + cB] : 0.0;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rw = 16 * bi + fk + 4 * r;
+      if (rw >= n) continue;
+      double* const o = Tout + ((long)node * n + rw) * Cp + c0 + 16 * bj + fr;
+      if (c0 + 16 * bj + fr < Cmm) o[0] = acc0[r];
+      if (c0 + 16 * bj + 16 + fr < Cmm) o[16] = acc1[r];
+    }
+  }
+}
+static int g_hodlr_core_fused = 1;
+extern "C" int gh_debug_set_hodlr_core_fused(int on) {
+  const int prev = g_hodlr_core_fused;
+  g_hodlr_core_fused = on ? 1 : 0;
+  return prev;
+}
+
 static int batched_inverse(gh_hodlr* h, double* base, const std::vector<long>& offs, const std::vector<int>& sizes,
                            double* d_logdet, GhBuf* const* tables = nullptr, bool tables_valid = false,
                            const double* tsum = nullptr, int tsum_R = 0) {
@@ -3478,6 +3620,33 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
     // rows: ONE reduce + sum over columns [0, off + R) serves both (two launches fewer per level).
     const int Call = L->off + R;
     const bool merged = Call <= h->cpass;
+    // (round 6) levels of many small nodes: sum + core inverse + core product in one launch (hodlr_core_kernel)
+    const bool core_fused = g_hodlr_core_fused && merged && L->off > 0 && nn >= 32 && 2 * R <= 32 && Call <= 128 &&
+                            L->nchunks <= 128 * nn;      // (a workgroup adds up ITS node's chunk partials: few chunks per node)
+    if (core_fused) {
+      if (!red_ready)
+        GH_CHECK(launch_red(h, (const MMJob*)L->d_red_jobs.p, L->nchunks, R, h->VA.d() + (long)n * L->off,
+                            h->UA.d(), Rtot, 0, h->P.d(), h->cpass, 0, Call));
+      red_ready = false;
+#define GH_CORE_LAUNCH(NM) hipLaunchKernelGGL(hodlr_core_kernel<NM>, dim3(nn), dim3(256), 0, st, h->P.d(), (const int*)L->d_crange.p, R, (long)h->cpass, Call, \
+                                              L->off, L->off, L->sinv.d(), h->ld_all.d() + ld_at, (int*)h->flags.p, h->Tout.d())
+      if (2 * R <= 8) GH_CORE_LAUNCH(8); else if (2 * R <= 16) GH_CORE_LAUNCH(16); else GH_CORE_LAUNCH(32);
+#undef GH_CORE_LAUNCH
+      GH_HIP(hipGetLastError());
+      L->gj_R = -1;                                    // (the separate launch's tables were not refreshed)
+      ld_at += nn;
+      const HLevel* nx = nullptr;
+      for (int q = l - 1; q >= 0 && !nx; --q) if (h->levels[q]->R > 0) nx = h->levels[q];
+      if (updred_possible(L, nx, L->off, h->cpass)) {
+        GH_CHECK(launch_updred(h, L, nx, h->UA.d() + L->off, Rtot, h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off,
+                               h->VA.d() + (long)n * nx->off, h->P.d(), h->cpass));
+        red_ready = true;
+      } else {
+        GH_CHECK(launch_upd(h, (const MMJob*)L->d_upd_jobs.p, L->nchunks, R, h->UA.d() + L->off, Rtot,
+                            h->Tout.d(), h->cpass, h->UA.d(), Rtot, L->off));
+      }
+      continue;
+    }
     if (merged) {
       // (red_ready: the deeper level's update pass has already formed this level's chunk products -- hodlr_updred_kernel)
       if (!red_ready)

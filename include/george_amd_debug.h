@@ -60,6 +60,10 @@ int gh_debug_set_hodlr_lpt(int on);
  * writes the level-major copy V only and that product reads it and writes the row-major U for the first time; 0: the compaction
  * writes both and the product works on U in place (rounds 3-5).  Returns the previous setting.  Same bits. */
 int gh_debug_set_hodlr_u_from_v(int on);
+/* 1 (default): for the levels with many small nodes (>= 32 nodes, cores of <= 32 rows) "sum of the chunk partials + core inverse +
+ * core product" is ONE launch with a workgroup per node (hodlr_core_kernel); 0: the three launches of rounds 2-5.  Returns the
+ * previous setting.  Same bits. */
+int gh_debug_set_hodlr_core_fused(int on);
 /* 1 (default): a level that could be clustered but is left with one workgroup per node by the launch's budget (level 5 of C4) is
  * appended to the cooperative launch as one-workgroup segments; 0: it goes to the one-workgroup launch.  Returns the previous setting. */
 int gh_debug_set_hodlr_coop_singles(int on);

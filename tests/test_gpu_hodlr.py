@@ -433,6 +433,30 @@ def test_leaf_product_from_the_level_major_copy_gives_the_same_bits(n, tol):
     assert np.array_equal(got[1][2], got[0][2])
 
 
+@pytest.mark.parametrize("n, tol, min_size", [(8192, 1e-10, 64), (65536, 1e-10, 64), (20000, 1e-6, 64), (30000, 1e-12, 40), (12000, 1e-3, 64)])
+def test_fused_core_launch_gives_the_same_bits(n, tol, min_size):
+    """Round 6: for the levels with many small nodes, the sum of the chunk partials, the core's pivoted Gauss-Jordan and the core
+    product are ONE launch with a workgroup per node (hodlr_core_kernel) instead of three (gh_debug_set_hodlr_core_fused(0)): the
+    same doubles through the same operations in the same order -- ranks, log-determinant and solves IDENTICAL.  tol = 1e-12: cores
+    of up to 32 rows (all three instantiations); min_size = 40: ragged chunks; tol = 1e-3: levels of rank zero or one."""
+    x, yerr, y = zoo.bench_data(n)
+    kernel = np.var(y) * kernels.ExpSquaredKernel(1.0)
+    got = {}
+    try:
+        for mode in (0, 1):
+            N.lib.gh_debug_set_hodlr_core_fused(mode)
+            s = HODLRSolver(kernel, tol=tol, min_size=min_size)
+            s.compute(x[:, None], yerr)
+            got[mode] = (s.log_determinant, s.dot_solve(y), s.apply_inverse(y), list(s.ranks()))
+            s.compute(x[:, None], yerr)
+            assert s.log_determinant == got[mode][0]
+            del s
+    finally:
+        N.lib.gh_debug_set_hodlr_core_fused(1)
+    assert got[1][0] == got[0][0] and got[1][1] == got[0][1] and got[1][3] == got[0][3]
+    assert np.array_equal(got[1][2], got[0][2])
+
+
 @pytest.mark.parametrize("n", [65536, 131072])
 def test_phase_one_packing_gives_the_same_bits(n):
     """Round 6, late: WHO GETS A CU WHEN in the ACA phase -- the clusters below the root at half the even-load width
