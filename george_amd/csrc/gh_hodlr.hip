@@ -896,10 +896,13 @@ static int aca_lds_attr() {
 // All levels in ONE launch (eleven launches of 10-38 us each at C4): workgroups [b0, b0 + nn * ny) belong to the
 // level described by a segment; inside it, workgroup (node, y) as in hodlr_compact_kernel below.
 struct CompactSeg { const double* Tcm; const LvlNode* nodes; const int* ranks; int R, ny; long off, offv, ldv; int b0, nblk; };
-__global__ void hodlr_compact_all_kernel(const CompactSeg* segs, int nseg, long N, double* UA, long ld, double* VA) {
+// (the segment table rides in the kernel arguments: uploading it was a copy from pageable memory -- staged and waited for -- between
+//  the ranks' arrival on the host and this launch, on the critical path of every compute())
+struct CompactSegs { int n; CompactSeg s[24]; };
+__global__ void hodlr_compact_all_kernel(const CompactSegs segs, long N, double* UA, long ld, double* VA) {
   int q = 0;
-  while (q + 1 < nseg && (int)blockIdx.x >= segs[q].b0 + segs[q].nblk) ++q;
-  const CompactSeg sg = segs[q];
+  while (q + 1 < segs.n && (int)blockIdx.x >= segs.s[q].b0 + segs.s[q].nblk) ++q;
+  const CompactSeg sg = segs.s[q];
   const int local = (int)blockIdx.x - sg.b0, node = local / sg.ny, by = local % sg.ny;
   const LvlNode nd = sg.nodes[node];
   const int rk = sg.ranks[node], R = sg.R;
@@ -1797,7 +1800,7 @@ struct gh_hodlr {
   int cpass = CPASS;             // columns per apply pass = row pitch of P / Tsum / Tout / Y (>= the largest level rank)
   GhBuf x, yerr, UA, VA, leaf_inv, d_leaves, d_leaf_jobs, P, Tsum, Tout, Y, rhs, scal, work, dotp;
   GhBuf d_leaf_prod;
-  GhBuf d_aca_segs, d_aca_segs1, d_compact_segs;
+  GhBuf d_aca_segs, d_aca_segs1;
   double* pin = nullptr;         // pinned host block for the results compute() brings back (log|det| of every block, flags)
   size_t pin_doubles = 0;
   GhBuf UL, d_colbase, d_colld;  // level-major copy of the final U (wide solves: ensure_ul) and its column map
@@ -3461,7 +3464,7 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
   // has 2^l internal nodes -- the case of C4); only then can the two memsets (157 MB each at C4) be skipped
   bool complete = true;
   for (int l = l0; l < nlev; ++l) if (h->levels[l]->node_ids.size() != ((size_t)1 << (l - l0))) complete = false;   // (a pseudo-level covers every local row)
-  bool fused_compact = true;
+  bool fused_compact = nlev <= 24;                     // (CompactSegs)
   for (int l = 0; l < nlev; ++l) if (levelB[l]) fused_compact = false;
   // (round 6) the compaction writes the level-major copy only and the leaf product -- the first thing that touches U -- reads that and
   // writes the row-major U itself, where that product is ONE pass of the 128-row-leaf kernel over all columns (LeafSrc)
@@ -3483,8 +3486,10 @@ extern "C" int gh_hodlr_compute(gh_hodlr* h, gh_kernel* k, const double* x, int6
       b0 += nn * ny;
     }
     if (b0 > 0) {
-      GH_CHECK(upload(h->d_compact_segs, segs, st));
-      hipLaunchKernelGGL(hodlr_compact_all_kernel, dim3((unsigned)b0), dim3(256), 0, st, (const CompactSeg*)h->d_compact_segs.p, (int)segs.size(),
+      CompactSegs cs;
+      cs.n = (int)segs.size();
+      for (int q = 0; q < cs.n; ++q) cs.s[q] = segs[q];
+      hipLaunchKernelGGL(hodlr_compact_all_kernel, dim3((unsigned)b0), dim3(256), 0, st, cs,
                          (long)n, u_from_v ? (double*)nullptr : h->UA.d(), (long)Rtot, h->VA.d());
       GH_HIP(hipGetLastError());
     }
